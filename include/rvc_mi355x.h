@@ -1,0 +1,114 @@
+/*
+ * rvc_mi355x.h -- C ABI of the MI355X-native RVC streaming inference engine.
+ *
+ * Drop-in boundary for the `rvc` crate of RVC-Project/obs-rvc: every entry point below
+ * replaces one method of `rvc::RvcInfer` (reference: rvc/src/rvc.rs:30-220) or one
+ * variant of `rvc_common::errors::RvcInferError` (rvc-common/src/errors.rs:2-8).  Plain
+ * pointers and sizes only; one handle = one engine bound to one GPU; a handle is NOT
+ * re-entrant (the reference methods take `&mut self`, rvc.rs:133-134).
+ *
+ * Reference method                                  -> C entry point
+ *   RvcInfer::new(data_path)            rvc.rs:30-44   rvc_create
+ *   (Drop)                                             rvc_destroy
+ *   load_contentvec(RvcModelVersion)    rvc.rs:46-54   rvc_load_contentvec
+ *   load_model(model_path)              rvc.rs:56-60   rvc_load_model
+ *   load_f0(PitchAlgorithm)             rvc.rs:62-75   rvc_load_f0
+ *   unload_model()                      rvc.rs:77-79   rvc_unload_model
+ *   hubert(input) -> (1,C,T)            rvc.rs:81-97   rvc_hubert
+ *   extract_feature(input) -> (1,2T+1,C) rvc.rs:99-109 rvc_extract_feature
+ *   pitch(input, shift, frame) -> f0    rvc.rs:111-131 rvc_pitch
+ *   infer(input, frame, shift, skip_head, return_length) rvc.rs:133-220  rvc_infer
+ *
+ * File naming follows rvc/src/models.rs:58-61,72 with the native extension:
+ *   <data>/contentvec/vec-{256,768}-layer-{9,12}.rvcw, <data>/f0/rmvpe.rvcw, <model>.rvcw
+ * (a path ending in ".onnx" is mapped to its ".rvcw" sibling).
+ */
+#ifndef RVC_MI355X_H
+#define RVC_MI355X_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* RvcInferError (rvc-common/src/errors.rs:2-8) + RVC_PANIC for inputs on which the reference
+ * panics instead of returning an error (e.g. rmvpe.rs:124 out-of-bounds gather). */
+typedef enum {
+    RVC_OK = 0,
+    RVC_MODEL_NOT_LOADED = 1,
+    RVC_CONTENTVEC_NOT_LOADED = 2,
+    RVC_F0_NOT_LOADED = 3,
+    RVC_BACKEND = 4,          /* Ort(..) in the reference: load / device / kernel failure */
+    RVC_SHAPE = 5,            /* NdarrayShapeError(..): bad sizes, output buffer too small */
+    RVC_PANIC = 6
+} rvc_status;
+
+/* RvcModelVersion / PitchAlgorithm as the i64 conversions of rvc-common/src/enums.rs:32-48,96-110 */
+#define RVC_VERSION_V1 1
+#define RVC_VERSION_V2 2
+#define RVC_PITCH_RMVPE 1
+
+typedef struct rvc_engine rvc_engine;
+
+/* RvcInfer::new.  device = HIP device ordinal (-1: current / LOCAL_RANK default 0). */
+rvc_status rvc_create(const char *data_path, int device, rvc_engine **out);
+void rvc_destroy(rvc_engine *e);
+rvc_status rvc_load_contentvec(rvc_engine *e, int model_version);
+rvc_status rvc_load_model(rvc_engine *e, const char *model_path);
+rvc_status rvc_load_f0(rvc_engine *e, int pitch_algorithm);
+void rvc_unload_model(rvc_engine *e);
+
+/* Caller-owned buffers.  On RVC_SHAPE the required element count is still written to dims / out_len. */
+rvc_status rvc_hubert(rvc_engine *e, const float *input, size_t n, float *out, size_t cap, size_t dims[3]);
+rvc_status rvc_extract_feature(rvc_engine *e, const float *input, size_t n, float *out, size_t cap, size_t dims[3]);
+rvc_status rvc_pitch(rvc_engine *e, const float *input, size_t n, int32_t pitch_shift, size_t sample_frame_16k_size,
+                     float *out, size_t cap, size_t *out_len);
+/* has_pitch_shift = 0 mirrors Option::None (rvc.rs:163) */
+rvc_status rvc_infer(rvc_engine *e, const float *input, size_t n, size_t sample_frame_16k_size, int has_pitch_shift,
+                     int32_t pitch_shift, uint32_t skip_head, uint32_t return_length, float *out, size_t cap, size_t *out_len);
+const char *rvc_last_error_message(rvc_engine *e);
+
+/* ---- capabilities the reference plumbs through but never implements / bakes into its export ---- */
+/* flat-L2 retrieval index (index_path / index_rate settings, obs-rvc/src/lib.rs:78,81; rvc.rs:159 TODO) */
+rvc_status rvc_load_index(rvc_engine *e, const float *vectors, size_t n, size_t dim);
+rvc_status rvc_load_index_device(rvc_engine *e, const void *d_vectors, size_t n, size_t dim);  /* already in HBM (RCCL-broadcast) */
+void rvc_set_index_rate(rvc_engine *e, float rate);
+/* kNN hits of the last infer: idx[rows][4], squared distances */
+rvc_status rvc_get_knn(rvc_engine *e, int32_t *idx, float *dist, size_t cap_rows, size_t *rows);
+/* the synthesizer's two noise inputs are explicit counter-based (Philox4x32-10) streams */
+void rvc_set_noise_seed(rvc_engine *e, uint32_t seed, uint32_t stream_id);
+void rvc_reset_state(rvc_engine *e);     /* zero the 1024-entry pitch cache and the chunk counter */
+
+/* ---- many concurrent streams on one GPU (BASELINE configs 4-5) ---- */
+/* The engine then holds n_streams independent stream states (pitch cache, noise counters) that share weights. */
+rvc_status rvc_set_streams(rvc_engine *e, int n_streams);
+/* input [n_streams][n], out [n_streams][cap_per_stream]; all streams use the same geometry */
+rvc_status rvc_infer_batch(rvc_engine *e, const float *input, size_t n, size_t sample_frame_16k_size, int32_t pitch_shift,
+                           uint32_t skip_head, uint32_t return_length, float *out, size_t cap_per_stream, size_t *out_len);
+/* device-resident variant (input/out are HIP device pointers on the engine's device; no host copy, no sync
+ * unless sync != 0).  Used by the throughput bench so that the timed region starts with inputs in HBM. */
+rvc_status rvc_infer_device(rvc_engine *e, const void *d_input, size_t n, size_t sample_frame_16k_size, int32_t pitch_shift,
+                            uint32_t skip_head, uint32_t return_length, void *d_out, size_t cap_per_stream, size_t *out_len, int sync);
+rvc_status rvc_synchronize(rvc_engine *e);
+void rvc_set_use_graph(rvc_engine *e, int on);    /* replay the per-chunk launch sequence from a hipGraph */
+
+/* ---- measurement / debugging ---- */
+/* total milliseconds of the last infer measured with HIP events on the engine's stream */
+float rvc_last_gpu_ms(rvc_engine *e);
+/* HIP-event timing of the dominant (implicit-GEMM) kernel class over the last infer call:
+ * number of launches, summed milliseconds, summed algorithmic FLOPs (2*M*N*K per launch) */
+rvc_status rvc_profile_last(rvc_engine *e, int *launches, double *kernel_ms, double *flops);
+void rvc_set_profile(rvc_engine *e, int on);
+/* named intermediate tensor of stream 0 of the last call, contiguous row-major (tests) */
+void rvc_enable_taps(rvc_engine *e, int on);
+rvc_status rvc_get_tap(rvc_engine *e, const char *name, float *out, size_t cap, size_t *n);
+void rvc_get_pitch_cache(rvc_engine *e, int stream, float *out1024);
+/* raw device pointer of the engine's weights/index for RCCL broadcast at load (config 5) */
+void *rvc_index_device_ptr(rvc_engine *e, size_t *bytes);
+int rvc_device(rvc_engine *e);
+const char *rvc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,98 @@
+"""Loader for the in-tree C-ABI library (csrc/librvc_mi355x.so).  No fallback: if the HIP
+extension is missing or no GPU is present the product path raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "librvc_mi355x.so")
+RPC_PATH = os.path.join(CSRC, "rvc-rpc")
+_LIB = None
+
+# every symbol include/rvc_mi355x.h declares
+SYMBOLS = [
+    "rvc_create", "rvc_destroy", "rvc_load_contentvec", "rvc_load_model", "rvc_load_f0", "rvc_unload_model",
+    "rvc_hubert", "rvc_extract_feature", "rvc_pitch", "rvc_infer", "rvc_last_error_message",
+    "rvc_load_index", "rvc_load_index_device", "rvc_set_index_rate", "rvc_get_knn", "rvc_set_noise_seed", "rvc_reset_state",
+    "rvc_set_streams", "rvc_infer_batch", "rvc_infer_device", "rvc_synchronize", "rvc_set_use_graph",
+    "rvc_last_gpu_ms", "rvc_profile_last", "rvc_set_profile", "rvc_enable_taps", "rvc_get_tap", "rvc_get_pitch_cache",
+    "rvc_index_device_ptr", "rvc_device", "rvc_version",
+]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950: the engine library and the rvc-rpc protocol-compatible executable."""
+    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "kernels.hip.h", "blob.h")] + \
+           [os.path.join(os.path.dirname(_HERE), "include", "rvc_mi355x.h")]
+    newest = max(os.path.getmtime(s) for s in srcs)
+    if force or not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < newest:
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               os.path.join(CSRC, "engine.hip"), "-o", SO_PATH]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    rpc_src = os.path.join(CSRC, "rvc_rpc.cpp")
+    if os.path.exists(rpc_src) and (force or not os.path.exists(RPC_PATH) or os.path.getmtime(RPC_PATH) < max(newest, os.path.getmtime(rpc_src))):
+        cmd = ["hipcc", "-O2", "-std=c++17", rpc_src, "-o", RPC_PATH, "-L" + CSRC, "-lrvc_mi355x", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return SO_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % SO_PATH)
+    L = C.CDLL(SO_PATH)
+    vp, fp, sz, i32, u32 = C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_int32, C.c_uint32
+    L.rvc_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.rvc_destroy.argtypes = [vp]
+    L.rvc_destroy.restype = None
+    L.rvc_load_contentvec.argtypes = [vp, C.c_int]
+    L.rvc_load_model.argtypes = [vp, C.c_char_p]
+    L.rvc_load_f0.argtypes = [vp, C.c_int]
+    L.rvc_unload_model.argtypes = [vp]
+    L.rvc_unload_model.restype = None
+    L.rvc_hubert.argtypes = [vp, fp, sz, fp, sz, C.POINTER(sz)]
+    L.rvc_extract_feature.argtypes = [vp, fp, sz, fp, sz, C.POINTER(sz)]
+    L.rvc_pitch.argtypes = [vp, fp, sz, i32, sz, fp, sz, C.POINTER(sz)]
+    L.rvc_infer.argtypes = [vp, fp, sz, sz, C.c_int, i32, u32, u32, fp, sz, C.POINTER(sz)]
+    L.rvc_last_error_message.argtypes = [vp]
+    L.rvc_last_error_message.restype = C.c_char_p
+    L.rvc_load_index.argtypes = [vp, fp, sz, sz]
+    L.rvc_load_index_device.argtypes = [vp, vp, sz, sz]
+    L.rvc_set_index_rate.argtypes = [vp, C.c_float]
+    L.rvc_set_index_rate.restype = None
+    L.rvc_get_knn.argtypes = [vp, C.POINTER(i32), fp, sz, C.POINTER(sz)]
+    L.rvc_set_noise_seed.argtypes = [vp, u32, u32]
+    L.rvc_set_noise_seed.restype = None
+    L.rvc_reset_state.argtypes = [vp]
+    L.rvc_reset_state.restype = None
+    L.rvc_set_streams.argtypes = [vp, C.c_int]
+    L.rvc_infer_batch.argtypes = [vp, fp, sz, sz, i32, u32, u32, fp, sz, C.POINTER(sz)]
+    L.rvc_infer_device.argtypes = [vp, vp, sz, sz, i32, u32, u32, vp, sz, C.POINTER(sz), C.c_int]
+    L.rvc_synchronize.argtypes = [vp]
+    L.rvc_set_use_graph.argtypes = [vp, C.c_int]
+    L.rvc_set_use_graph.restype = None
+    L.rvc_last_gpu_ms.argtypes = [vp]
+    L.rvc_last_gpu_ms.restype = C.c_float
+    L.rvc_profile_last.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.rvc_set_profile.argtypes = [vp, C.c_int]
+    L.rvc_set_profile.restype = None
+    L.rvc_enable_taps.argtypes = [vp, C.c_int]
+    L.rvc_enable_taps.restype = None
+    L.rvc_get_tap.argtypes = [vp, C.c_char_p, fp, sz, C.POINTER(sz)]
+    L.rvc_get_pitch_cache.argtypes = [vp, C.c_int, fp]
+    L.rvc_get_pitch_cache.restype = None
+    L.rvc_index_device_ptr.argtypes = [vp, C.POINTER(sz)]
+    L.rvc_index_device_ptr.restype = vp
+    L.rvc_device.argtypes = [vp]
+    L.rvc_version.restype = C.c_char_p
+    _LIB = L
+    return L

@@ -1,0 +1,1602 @@
+// engine.hip -- host side of the MI355X-native RVC streaming inference engine + its C ABI.
+//
+// Mirrors rvc::RvcInfer (reference: rvc/src/rvc.rs:18-220): model handles, the 1024-entry
+// pitch cache, and the per-chunk pipeline hubert -> (retrieval) -> pitch -> synthesizer.
+// All compute is launched as hand-written gfx950 kernels (kernels.hip.h); nothing here falls
+// back to a CPU path: without a HIP device every entry point returns RVC_BACKEND.
+#include "../../include/rvc_mi355x.h"
+#include "blob.h"
+#include "kernels.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstddef>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace rvc {
+
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+struct ShapeError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct PanicError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// ---------------------------------------------------------------------------------------
+// device memory
+// ---------------------------------------------------------------------------------------
+class Arena {
+public:
+    ~Arena() { for (void *c : chunks_) (void)hipFree(c); }
+    void *alloc(size_t bytes)
+    {
+        bytes = (bytes + 255) / 256 * 256;
+        if (bytes > left_) {
+            size_t sz = std::max(bytes, (size_t)64 << 20);
+            void *c;
+            HIPCHK(hipMalloc(&c, sz));
+            HIPCHK(hipMemset(c, 0, sz));
+            chunks_.push_back(c);
+            cur_ = (char *)c;
+            left_ = sz;
+            total_ += sz;
+        }
+        void *r = cur_;
+        cur_ += bytes;
+        left_ -= bytes;
+        return r;
+    }
+    float *floats(size_t n) { return (float *)alloc(n * sizeof(float)); }
+    template <typename T> T *upload(const std::vector<T> &v)
+    {
+        T *d = (T *)alloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+        if (!v.empty()) HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return d;
+    }
+    size_t total() const { return total_; }
+
+private:
+    std::vector<void *> chunks_;
+    char *cur_ = nullptr;
+    size_t left_ = 0, total_ = 0;
+};
+
+// 1-D activation [B][C][ld]: row = halo | T | halo (halo stays zero)
+struct T1 {
+    float *p = nullptr;   // -> [0][0][0]
+    int B = 1, C = 0, T = 0, ld = 0, halo = 0;
+    long long bs = 0;
+    T1 rows(int c0, int n) const { T1 r = *this; r.p = p + (long long)c0 * ld; r.C = n; return r; }
+};
+// 2-D activation [B][C][H+2][W+2]
+struct T2 {
+    float *p = nullptr;   // -> interior (0,0) of channel 0
+    int B = 1, C = 0, H = 0, W = 0, ld = 0, cs = 0;
+    long long bs = 0;
+    T2 chans(int c0, int n) const { T2 r = *this; r.p = p + (long long)c0 * cs; r.C = n; return r; }
+};
+
+static T1 make_t1(Arena &a, int B, int C, int T, int halo)
+{
+    T1 t;
+    t.B = B; t.C = C; t.T = T; t.halo = halo;
+    t.ld = (T + 2 * halo + 3) / 4 * 4;
+    t.bs = (long long)C * t.ld;
+    // guard rows in front and behind so clamped/garbage tail reads stay inside the allocation
+    size_t guard = (size_t)t.ld + 64;
+    float *base = a.floats((size_t)B * t.bs + 2 * guard);
+    t.p = base + guard + halo;
+    return t;
+}
+static T2 make_t2(Arena &a, int B, int C, int H, int W)
+{
+    T2 t;
+    t.B = B; t.C = C; t.H = H; t.W = W;
+    t.ld = W + 2;
+    t.cs = (H + 2) * t.ld;
+    t.bs = (long long)C * t.cs;
+    size_t guard = (size_t)t.ld * 2 + 64;
+    float *base = a.floats((size_t)B * t.bs + 2 * guard);
+    t.p = base + guard + t.ld + 1;
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------
+// prepared convolution weights: [nphase][M][Kp] panels (Kp = K rounded up to 16, zero padded)
+// ---------------------------------------------------------------------------------------
+struct ConvW {
+    float *w = nullptr, *bias = nullptr;
+    int M = 0, K = 0, Kp = 0, nphase = 1;
+    int Cin = 0, Cout = 0, KW = 1, groups = 1;
+    int S = 1, ntaps = 1;      // transposed convs
+    bool transposed = false;
+};
+
+static int round16(int k) { return (k + 15) / 16 * 16; }
+
+static float *upload_f(const std::vector<float> &v)
+{
+    float *d;
+    HIPCHK(hipMalloc(&d, std::max<size_t>(v.size(), 4) * sizeof(float)));
+    if (!v.empty()) HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return d;
+}
+static float *upload_f(const float *p, size_t n) { return upload_f(std::vector<float>(p, p + n)); }
+
+// Conv (any rank flattened to K = Cin/groups * KW taps): w [Cout][Cin/groups][KW]
+static ConvW prep_conv(const float *w, const float *bias, int Cout, int Cin, int KW, int groups)
+{
+    ConvW c;
+    c.Cin = Cin; c.Cout = Cout; c.KW = KW; c.groups = groups; c.nphase = groups;
+    int cig = Cin / groups, cog = Cout / groups;
+    c.M = cog; c.K = cig * KW; c.Kp = round16(c.K);
+    std::vector<float> panel((size_t)Cout * c.Kp, 0.f);
+    for (int co = 0; co < Cout; co++) memcpy(&panel[(size_t)co * c.Kp], w + (size_t)co * c.K, (size_t)c.K * sizeof(float));
+    c.w = upload_f(panel);
+    if (bias) c.bias = upload_f(bias, Cout);
+    return c;
+}
+// ConvTranspose1d: w [Cin][Cout][K], stride S -> S polyphase sub-convolutions with ntaps = ceil(K/S) taps:
+//   out[co][q*S + p - pad] = sum_ci sum_j w[ci][co][p + j*S] * in[ci][q - j]
+static ConvW prep_convT1d(const float *w, const float *bias, int Cin, int Cout, int K, int S)
+{
+    ConvW c;
+    c.transposed = true; c.Cin = Cin; c.Cout = Cout; c.KW = K; c.S = S; c.ntaps = (K + S - 1) / S; c.nphase = S;
+    c.M = Cout; c.K = Cin * c.ntaps; c.Kp = round16(c.K);
+    std::vector<float> panel((size_t)S * Cout * c.Kp, 0.f);
+    for (int p = 0; p < S; p++)
+        for (int co = 0; co < Cout; co++)
+            for (int ci = 0; ci < Cin; ci++)
+                for (int j = 0; j < c.ntaps; j++) {
+                    int k = p + j * S;
+                    if (k < K) panel[((size_t)p * Cout + co) * c.Kp + ci * c.ntaps + j] = w[((size_t)ci * Cout + co) * K + k];
+                }
+    c.w = upload_f(panel);
+    if (bias) c.bias = upload_f(bias, Cout);
+    return c;
+}
+// ConvTranspose2d 3x3 stride 2 pad 1 output_pad 1: w [Cin][Cout][3][3] -> 4 phases (oh&1, ow&1), 2x2 taps each
+//   out[2a+ph][2b+pw] = sum_ci sum_{jh,jw} Wp[ph,pw][co][ci][jh][jw] * in[a+jh][b+jw]
+//   even output row: kh = 1 (jh = 0); odd: kh = 2 (jh = 0), kh = 0 (jh = 1); same along w
+static ConvW prep_convT2d(const float *w, const float *bias, int Cin, int Cout)
+{
+    ConvW c;
+    c.transposed = true; c.Cin = Cin; c.Cout = Cout; c.KW = 9; c.S = 2; c.ntaps = 4; c.nphase = 4;
+    c.M = Cout; c.K = Cin * 4; c.Kp = round16(c.K);
+    std::vector<float> panel((size_t)4 * Cout * c.Kp, 0.f);
+    auto ktap = [](int par, int j) { return par == 0 ? (j == 0 ? 1 : -1) : (j == 0 ? 2 : 0); };
+    for (int ph = 0; ph < 2; ph++)
+        for (int pw = 0; pw < 2; pw++)
+            for (int co = 0; co < Cout; co++)
+                for (int ci = 0; ci < Cin; ci++)
+                    for (int jh = 0; jh < 2; jh++)
+                        for (int jw = 0; jw < 2; jw++) {
+                            int kh = ktap(ph, jh), kw = ktap(pw, jw);
+                            if (kh < 0 || kw < 0) continue;
+                            panel[((size_t)(ph * 2 + pw) * Cout + co) * c.Kp + ci * 4 + jh * 2 + jw] = w[(((size_t)ci * Cout + co) * 3 + kh) * 3 + kw];
+                        }
+    c.w = upload_f(panel);
+    if (bias) c.bias = upload_f(bias, Cout);
+    return c;
+}
+static void free_conv(ConvW &c)
+{
+    if (c.w) (void)hipFree(c.w);
+    if (c.bias) (void)hipFree(c.bias);
+    c.w = c.bias = nullptr;
+}
+
+// ---------------------------------------------------------------------------------------
+// op list ("plan") construction
+// ---------------------------------------------------------------------------------------
+struct ConvOpts {
+    int act = ACT_NONE; float slope = 0.f; float scale = 1.f; bool accumulate = false;
+    int pre_act = ACT_NONE; float pre_slope = 0.f;
+    const float *res = nullptr; int res_cs = 0; long long res_bs = 0;
+    int m_off = 0, m_cnt = -1;   // output-row sub-range of the weight panel
+    bool no_bias = false;
+};
+
+struct ProfEvent { hipEvent_t a, b; double flops; };
+
+struct Plan;
+typedef std::function<void(hipStream_t)> Op;
+
+struct TapRec { std::string name; int rank; T1 t1; T2 t2; };
+
+struct Plan {
+    Arena arena;
+    std::vector<Op> ops;
+    std::vector<TapRec> taps;
+    // geometry
+    int B = 1; size_t L = 0, frame16k = 0; uint32_t skip_head = 0, R = 0;
+    int T = 0, Tm = 0, C = 0; size_t N = 0;
+    bool with_index = false, with_taps = false;
+    int mode = 0;   // 0 infer, 1 hubert only, 2 pitch only
+    // I/O tensors
+    float *d_in = nullptr;  // [B][L]
+    T1 cv_out, audio;
+    float *d_f0 = nullptr;  // [B][Tm]
+    float *d_feat = nullptr; // extract_feature output (1,2T+1,C)
+    int *d_knn_idx = nullptr; float *d_knn_dist = nullptr;
+    // profiling
+    bool profile = false;
+    std::vector<ProfEvent> prof;
+    size_t prof_used = 0;
+    double igemm_flops = 0;
+    int n_igemm = 0;
+    // graph
+    hipGraphExec_t graph_exec = nullptr;
+    ~Plan()
+    {
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        for (auto &e : prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    }
+};
+
+template <int MF, int NF> static void launch_igemm_t(const IgemmP &p, dim3 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((igemm_kernel<MF, NF>), grid, dim3(256), 0, s, p);
+}
+
+static void launch_igemm(int cfg, const IgemmP &p, dim3 grid, hipStream_t s)
+{
+    switch (cfg) {
+    case 0: launch_igemm_t<1, 1>(p, grid, s); break;
+    case 1: launch_igemm_t<1, 2>(p, grid, s); break;
+    case 2: launch_igemm_t<1, 4>(p, grid, s); break;
+    case 3: launch_igemm_t<2, 2>(p, grid, s); break;
+    default: launch_igemm_t<2, 4>(p, grid, s); break;
+    }
+}
+
+// generic: the caller fills geometry (N, NW, strides, koff, phases); this picks the tile + split-K and queues the op
+static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases)
+{
+    p.koff = pl.arena.upload(koff);
+    p.ph = pl.arena.upload(phases);
+    p.nphase = (int)phases.size();
+    static const int MFs[5] = {1, 1, 1, 2, 2}, NFs[5] = {1, 2, 4, 2, 4};
+    auto waves = [&](int c) {
+        long long tm = (p.M + 16 * MFs[c] - 1) / (16 * MFs[c]), tn = (p.N + 16 * NFs[c] - 1) / (16 * NFs[c]);
+        return tm * tn * B * p.nphase;
+    };
+    int cfg;
+    if (p.M > 16) cfg = waves(4) >= 1024 ? 4 : (waves(3) >= 1024 ? 3 : 0);
+    else cfg = waves(2) >= 1024 ? 2 : (waves(1) >= 1024 ? 1 : 0);
+    const int nchunks = p.K / 16;
+    int ksplit = 1;
+    if (cfg == 0) {
+        long long w0 = waves(0);
+        if (w0 < 512 && nchunks >= 8) {
+            int want = (int)((1024 + w0 - 1) / w0);
+            ksplit = std::min(want, nchunks / 4);
+            if (ksplit < 1) ksplit = 1;
+        }
+    }
+    int cps = (nchunks + ksplit - 1) / ksplit;
+    ksplit = (nchunks + cps - 1) / cps;
+    p.ksplit = ksplit; p.chunks_per_split = cps;
+    p.ntm = (p.M + 16 * MFs[cfg] - 1) / (16 * MFs[cfg]);
+    p.ntn = (p.N + 16 * NFs[cfg] - 1) / (16 * NFs[cfg]);
+    if (ksplit > 1) p.part = pl.arena.floats((size_t)B * p.nphase * ksplit * p.M * p.N);
+    dim3 grid((p.ntm * p.ntn + 3) / 4, B * p.nphase * ksplit);
+    dim3 egrid((unsigned)(((long long)p.M * p.N + 255) / 256), B * p.nphase);
+    const double flops = 2.0 * p.M * (double)p.N * p.K * B * p.nphase;
+    pl.igemm_flops += flops;
+    pl.n_igemm++;
+    Plan *plp = &pl;
+    pl.ops.push_back([=](hipStream_t s) {
+        ProfEvent *pe = nullptr;
+        if (plp->profile) {
+            if (plp->prof_used == plp->prof.size()) {
+                ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; plp->prof.push_back(e);
+            }
+            pe = &plp->prof[plp->prof_used++];
+            pe->flops = flops;
+            HIPCHK(hipEventRecord(pe->a, s));
+        }
+        launch_igemm(cfg, p, grid, s);
+        if (ksplit > 1) hipLaunchKernelGGL(splitk_epilogue_kernel, egrid, dim3(256), 0, s, p);
+        if (pe) HIPCHK(hipEventRecord(pe->b, s));
+    });
+}
+
+static void fill_epilogue(IgemmP &p, const ConvW &cw, const ConvOpts &o)
+{
+    p.bias = (o.no_bias || !cw.bias) ? nullptr : cw.bias + o.m_off;
+    p.res = o.res; p.res_cs = o.res_cs; p.res_bs = o.res_bs;
+    p.act = o.act; p.slope = o.slope; p.scale = o.scale; p.accumulate = o.accumulate ? 1 : 0;
+    p.pre_act = o.pre_act; p.pre_slope = o.pre_slope;
+    p.part = nullptr;
+}
+
+// Conv1d (stride s, dilation d, symmetric zero padding pad, groups) on halo'd rows
+static void add_conv1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int stride, int pad, int dil, ConvOpts o = ConvOpts())
+{
+    if (cw.transposed) throw std::runtime_error("add_conv1d on transposed weights");
+    const int cig = cw.Cin / cw.groups, KW = cw.KW;
+    const int Tout = (x.T + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+    if (Tout != y.T && !(Tout == y.T + 1)) throw ShapeError("conv1d output length mismatch");
+    if (x.halo < pad || (y.T - 1) * stride + (KW - 1) * dil - pad > x.T - 1 + x.halo) throw ShapeError("conv1d halo too small");
+    IgemmP p{};
+    p.x = x.p; p.w = cw.w + (long long)o.m_off * cw.Kp; p.y = y.p;
+    p.M = o.m_cnt >= 0 ? o.m_cnt : cw.M; p.N = y.T; p.K = cw.Kp;
+    p.NW = y.T; p.x_hs = 0; p.x_ws = stride; p.y_hs = 0; p.y_ws = 1; p.OW = y.T;
+    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.ld;
+    fill_epilogue(p, cw, o);
+    if (cw.groups > 1 && (o.m_off != 0 || o.m_cnt >= 0)) throw std::runtime_error("row sub-range on grouped conv");
+    std::vector<int> koff(cw.Kp, 0);
+    for (int ci = 0; ci < cig; ci++) for (int k = 0; k < KW; k++) koff[ci * KW + k] = ci * x.ld + k * dil - pad;
+    std::vector<PhaseD> ph(cw.groups);
+    for (int g = 0; g < cw.groups; g++) {
+        ph[g] = PhaseD{};
+        ph[g].w_off = (long long)g * cw.M * cw.Kp;
+        ph[g].x_off = g * cig * x.ld;
+        ph[g].y_off = g * cw.M * y.ld;
+        ph[g].y_pos = 0;
+        ph[g].bias_off = g * cw.M;
+        ph[g].koff_off = 0;
+    }
+    queue_igemm(pl, p, x.B, koff, ph);
+}
+
+// ConvTranspose1d (polyphase), pad = (K - S) / 2 as in HiFiGAN
+static void add_convT1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int pad, ConvOpts o = ConvOpts())
+{
+    const int S = cw.S, nt = cw.ntaps;
+    const int Tout = (x.T - 1) * S - 2 * pad + cw.KW;
+    if (Tout != y.T) throw ShapeError("convT1d output length mismatch");
+    if (x.halo < nt) throw ShapeError("convT1d halo too small");
+    IgemmP p{};
+    p.x = x.p; p.w = cw.w; p.y = y.p;
+    p.M = cw.M; p.N = x.T + nt - 1; p.K = cw.Kp;
+    p.NW = p.N; p.x_hs = 0; p.x_ws = 1; p.y_hs = 0; p.y_ws = S; p.OW = y.T;
+    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.ld;
+    fill_epilogue(p, cw, o);
+    std::vector<int> koff(cw.Kp, 0);
+    for (int ci = 0; ci < cw.Cin; ci++) for (int j = 0; j < nt; j++) koff[ci * nt + j] = ci * x.ld - j;
+    std::vector<PhaseD> ph(S);
+    for (int q = 0; q < S; q++) {
+        ph[q] = PhaseD{};
+        ph[q].w_off = (long long)q * cw.M * cw.Kp;
+        ph[q].x_off = 0;
+        ph[q].y_off = q - pad;
+        ph[q].y_pos = q - pad;
+        ph[q].bias_off = 0;
+        ph[q].koff_off = 0;
+    }
+    queue_igemm(pl, p, x.B, koff, ph);
+}
+
+// Conv2d 3x3 pad 1 (KW = 9) or 1x1 (KW = 1) on halo'd images
+static void add_conv2d(Plan &pl, const ConvW &cw, const T2 &x, const T2 &y, ConvOpts o = ConvOpts())
+{
+    if (x.H != y.H || x.W != y.W) throw ShapeError("conv2d shape mismatch");
+    IgemmP p{};
+    p.x = x.p; p.w = cw.w; p.y = y.p;
+    p.M = cw.M; p.N = x.H * x.W; p.K = cw.Kp;
+    p.NW = x.W; p.x_hs = x.ld; p.x_ws = 1; p.y_hs = y.ld; p.y_ws = 1; p.OW = y.W;
+    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.cs;
+    fill_epilogue(p, cw, o);
+    std::vector<int> koff(cw.Kp, 0);
+    if (cw.KW == 9) { for (int ci = 0; ci < cw.Cin; ci++) for (int k = 0; k < 9; k++) koff[ci * 9 + k] = ci * x.cs + (k / 3 - 1) * x.ld + (k % 3 - 1); }
+    else { for (int ci = 0; ci < cw.Cin; ci++) koff[ci] = ci * x.cs; }
+    std::vector<PhaseD> ph(1);
+    ph[0] = PhaseD{};
+    queue_igemm(pl, p, x.B, koff, ph);
+}
+
+static void add_convT2d(Plan &pl, const ConvW &cw, const T2 &x, const T2 &y, ConvOpts o = ConvOpts())
+{
+    if (y.H != 2 * x.H || y.W != 2 * x.W) throw ShapeError("convT2d shape mismatch");
+    IgemmP p{};
+    p.x = x.p; p.w = cw.w; p.y = y.p;
+    p.M = cw.M; p.N = x.H * x.W; p.K = cw.Kp;
+    p.NW = x.W; p.x_hs = x.ld; p.x_ws = 1; p.y_hs = 2 * y.ld; p.y_ws = 2; p.OW = y.W;
+    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.cs;
+    fill_epilogue(p, cw, o);
+    std::vector<int> koff(cw.Kp, 0);
+    for (int ci = 0; ci < cw.Cin; ci++) for (int jh = 0; jh < 2; jh++) for (int jw = 0; jw < 2; jw++) koff[ci * 4 + jh * 2 + jw] = ci * x.cs + jh * x.ld + jw;
+    std::vector<PhaseD> ph(4);
+    for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) {
+        PhaseD d{};
+        d.w_off = (long long)(a * 2 + b) * cw.M * cw.Kp;
+        d.y_off = a * y.ld + b;
+        d.y_pos = b;
+        ph[a * 2 + b] = d;
+    }
+    queue_igemm(pl, p, x.B, koff, ph);
+}
+
+static void add_layernorm(Plan &pl, const T1 &x, const float *g, const float *b)
+{
+    dim3 grid((x.T + 31) / 32, x.B);
+    pl.ops.push_back([=](hipStream_t s) {
+        hipLaunchKernelGGL(layernorm_ct_kernel, grid, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
+    });
+}
+
+static void add_tap(Plan &pl, const char *name, const T1 &t)
+{
+    if (!pl.with_taps) return;
+    // snapshot into a private contiguous-row tensor so later in-place ops do not clobber it
+    T1 snap = make_t1(pl.arena, 1, t.C, t.T, 0);
+    pl.ops.push_back([=](hipStream_t s) {
+        HIPCHK(hipMemcpy2DAsync(snap.p, (size_t)snap.ld * 4, t.p, (size_t)t.ld * 4, (size_t)t.T * 4, t.C, hipMemcpyDeviceToDevice, s));
+    });
+    TapRec r; r.name = name; r.rank = 1; r.t1 = snap; pl.taps.push_back(r);
+}
+static void add_tap2(Plan &pl, const char *name, const T2 &t)
+{
+    if (!pl.with_taps) return;
+    TapRec r; r.name = name; r.rank = 2; r.t2 = t; pl.taps.push_back(r);   // RMVPE images are never overwritten
+}
+
+// ---------------------------------------------------------------------------------------
+// models
+// ---------------------------------------------------------------------------------------
+struct DevVec { float *p = nullptr; };
+static float *dv(const Blob &b, const std::string &name) { const BlobTensor &t = b.t(name); return upload_f(t.data, t.nelem); }
+
+struct ModelCV {
+    int conv_dim, embed, heads, ffn, run_layers, pos_k, pos_groups, out_dim;
+    int conv_k[7], conv_s[7];
+    ConvW conv[7], proj, pos, final_proj;
+    float *gn_g, *gn_b, *ln0_g, *ln0_b, *encln_g, *encln_b;
+    struct Layer { ConvW qkv, o, ff1, ff2; float *ln1_g, *ln1_b, *ln2_g, *ln2_b; };
+    std::vector<Layer> layers;
+    std::vector<float *> owned;
+    size_t weight_bytes = 0;
+    explicit ModelCV(const Blob &b)
+    {
+        conv_dim = b.icfg("conv_dim"); embed = b.icfg("embed"); heads = b.icfg("heads"); ffn = b.icfg("ffn");
+        run_layers = b.icfg("run_layers"); pos_k = b.icfg("pos_k"); pos_groups = b.icfg("pos_groups"); out_dim = b.icfg("out_dim");
+        int cin = 1;
+        for (int i = 0; i < 7; i++) {
+            conv_k[i] = b.icfg(fmt("conv_k%d", i)); conv_s[i] = b.icfg(fmt("conv_s%d", i));
+            conv[i] = prep_conv(b.w(fmt("cv.conv%d.w", i)), nullptr, conv_dim, cin, conv_k[i], 1);
+            cin = conv_dim;
+        }
+        auto own = [&](const std::string &n) { float *p = dv(b, n); owned.push_back(p); return p; };
+        gn_g = own("cv.gn.g"); gn_b = own("cv.gn.b"); ln0_g = own("cv.ln0.g"); ln0_b = own("cv.ln0.b");
+        proj = prep_conv(b.w("cv.proj.w"), b.w("cv.proj.b"), embed, conv_dim, 1, 1);
+        pos = prep_conv(b.w("cv.pos.w"), b.w("cv.pos.b"), embed, embed, pos_k, pos_groups);
+        encln_g = own("cv.enc_ln.g"); encln_b = own("cv.enc_ln.b");
+        const int E = embed;
+        for (int l = 0; l < run_layers; l++) {
+            Layer L;
+            std::vector<float> w((size_t)3 * E * E), bb((size_t)3 * E);
+            const char *nm[3] = {"q", "k", "v"};
+            for (int j = 0; j < 3; j++) {
+                memcpy(&w[(size_t)j * E * E], b.w(fmt("cv.l%d.", l) + nm[j] + ".w"), (size_t)E * E * 4);
+                memcpy(&bb[(size_t)j * E], b.w(fmt("cv.l%d.", l) + nm[j] + ".b"), (size_t)E * 4);
+            }
+            L.qkv = prep_conv(w.data(), bb.data(), 3 * E, E, 1, 1);
+            L.o = prep_conv(b.w(fmt("cv.l%d.o.w", l)), b.w(fmt("cv.l%d.o.b", l)), E, E, 1, 1);
+            L.ff1 = prep_conv(b.w(fmt("cv.l%d.ff1.w", l)), b.w(fmt("cv.l%d.ff1.b", l)), ffn, E, 1, 1);
+            L.ff2 = prep_conv(b.w(fmt("cv.l%d.ff2.w", l)), b.w(fmt("cv.l%d.ff2.b", l)), E, ffn, 1, 1);
+            L.ln1_g = own(fmt("cv.l%d.ln1.g", l)); L.ln1_b = own(fmt("cv.l%d.ln1.b", l));
+            L.ln2_g = own(fmt("cv.l%d.ln2.g", l)); L.ln2_b = own(fmt("cv.l%d.ln2.b", l));
+            layers.push_back(L);
+        }
+        if (out_dim != E) final_proj = prep_conv(b.w("cv.final_proj.w"), b.w("cv.final_proj.b"), out_dim, E, 1, 1);
+        weight_bytes = b.bytes();
+    }
+    ~ModelCV()
+    {
+        for (auto &c : conv) free_conv(c);
+        free_conv(proj); free_conv(pos); free_conv(final_proj);
+        for (auto &L : layers) { free_conv(L.qkv); free_conv(L.o); free_conv(L.ff1); free_conv(L.ff2); }
+        for (float *p : owned) (void)hipFree(p);
+    }
+    int out_frames(size_t L) const
+    {
+        long long T = (long long)L;
+        for (int i = 0; i < 7; i++) { if (T < conv_k[i]) return 0; T = (T - conv_k[i]) / conv_s[i] + 1; }
+        return (int)T;
+    }
+};
+
+struct ResBlockW { ConvW c1, c2, sc; bool has_sc = false; int ci = 0, co = 0; };
+struct ModelRM {
+    int en_out, levels, n_blocks, inter_layers, n_mels, gru_hidden, n_out;
+    float bn_scale, bn_shift;
+    std::vector<std::vector<ResBlockW>> enc, inter, dec;
+    std::vector<ConvW> up;
+    ConvW cnn, gru_ih, fc;
+    float *whhT = nullptr, *bhh = nullptr;
+    size_t weight_bytes = 0;
+    static ResBlockW block(const Blob &b, const std::string &pre, int ci, int co)
+    {
+        ResBlockW r; r.ci = ci; r.co = co;
+        r.c1 = prep_conv(b.w(pre + "c1.w"), b.w(pre + "c1.b"), co, ci, 9, 1);
+        r.c2 = prep_conv(b.w(pre + "c2.w"), b.w(pre + "c2.b"), co, co, 9, 1);
+        if (ci != co) { r.has_sc = true; r.sc = prep_conv(b.w(pre + "sc.w"), b.w(pre + "sc.b"), co, ci, 1, 1); }
+        return r;
+    }
+    explicit ModelRM(const Blob &b)
+    {
+        en_out = b.icfg("en_out"); levels = b.icfg("levels"); n_blocks = b.icfg("n_blocks"); inter_layers = b.icfg("inter_layers");
+        n_mels = b.icfg("n_mels"); gru_hidden = b.icfg("gru_hidden"); n_out = b.icfg("n_out");
+        bn_scale = b.w("rm.bn0")[0]; bn_shift = b.w("rm.bn0")[1];
+        int ci = 1, co = en_out;
+        for (int lv = 0; lv < levels; lv++) {
+            std::vector<ResBlockW> v;
+            for (int j = 0; j < n_blocks; j++) v.push_back(block(b, fmt("rm.enc%d.b%d.", lv, j), j == 0 ? ci : co, co));
+            enc.push_back(v);
+            ci = co; co *= 2;
+        }
+        for (int lv = 0; lv < inter_layers; lv++) {
+            std::vector<ResBlockW> v;
+            for (int j = 0; j < n_blocks; j++) v.push_back(block(b, fmt("rm.int%d.b%d.", lv, j), j == 0 ? (lv == 0 ? ci : co) : co, co));
+            inter.push_back(v);
+        }
+        ci = co;
+        for (int lv = 0; lv < levels; lv++) {
+            co = ci / 2;
+            up.push_back(prep_convT2d(b.w(fmt("rm.dec%d.up.w", lv)), b.w(fmt("rm.dec%d.up.b", lv)), ci, co));
+            std::vector<ResBlockW> v;
+            for (int j = 0; j < n_blocks; j++) v.push_back(block(b, fmt("rm.dec%d.b%d.", lv, j), j == 0 ? 2 * co : co, co));
+            dec.push_back(v);
+            ci = co;
+        }
+        cnn = prep_conv(b.w("rm.cnn.w"), b.w("rm.cnn.b"), 3, en_out, 9, 1);
+        const int H = gru_hidden, I = 3 * n_mels;
+        std::vector<float> wih((size_t)6 * H * I), bih((size_t)6 * H), wt((size_t)2 * H * 3 * H), bh((size_t)6 * H);
+        const char *sfx[2] = {"f", "b"};
+        for (int d = 0; d < 2; d++) {
+            memcpy(&wih[(size_t)d * 3 * H * I], b.w(std::string("rm.gru.w_ih_") + sfx[d]), (size_t)3 * H * I * 4);
+            memcpy(&bih[(size_t)d * 3 * H], b.w(std::string("rm.gru.b_ih_") + sfx[d]), (size_t)3 * H * 4);
+            memcpy(&bh[(size_t)d * 3 * H], b.w(std::string("rm.gru.b_hh_") + sfx[d]), (size_t)3 * H * 4);
+            const float *whh = b.w(std::string("rm.gru.w_hh_") + sfx[d]);
+            for (int r = 0; r < 3 * H; r++) for (int j = 0; j < H; j++) wt[((size_t)d * H + j) * 3 * H + r] = whh[(size_t)r * H + j];
+        }
+        gru_ih = prep_conv(wih.data(), bih.data(), 6 * H, I, 1, 1);
+        whhT = upload_f(wt); bhh = upload_f(bh);
+        fc = prep_conv(b.w("rm.fc.w"), b.w("rm.fc.b"), n_out, 2 * H, 1, 1);
+        weight_bytes = b.bytes();
+    }
+    ~ModelRM()
+    {
+        auto fb = [](std::vector<std::vector<ResBlockW>> &vv) { for (auto &v : vv) for (auto &r : v) { free_conv(r.c1); free_conv(r.c2); free_conv(r.sc); } };
+        fb(enc); fb(inter); fb(dec);
+        for (auto &u : up) free_conv(u);
+        free_conv(cnn); free_conv(gru_ih); free_conv(fc);
+        if (whhT) (void)hipFree(whhT);
+        if (bhh) (void)hipFree(bhh);
+    }
+};
+
+struct ModelSY {
+    int phone_dim, hidden, inter, filter, heads, enc_layers, enc_k, window, flow_n, wn_layers, wn_k, gin, up_init, n_ups, n_rb, n_rbd, sr;
+    int up_rate[8], up_kernel[8], rb_k[8], rb_d[8];
+    ConvW phone, proj;
+    float *pitch_emb = nullptr;
+    struct Layer { ConvW qkv, o, ff1, ff2; float *rel_k, *rel_v, *ln1_g, *ln1_b, *ln2_g, *ln2_b; };
+    std::vector<Layer> layers;
+    struct Flow { ConvW pre, post; std::vector<ConvW> in, rs; };
+    std::vector<Flow> flows;
+    ConvW dec_pre, dec_post;
+    std::vector<ConvW> ups, ncs;
+    std::vector<std::vector<std::vector<std::pair<ConvW, ConvW>>>> rbs;   // [stage][kernel][dilation] -> (c1, c2)
+    float src_w, src_b;
+    std::vector<float *> owned;
+    size_t weight_bytes = 0;
+    explicit ModelSY(const Blob &b)
+    {
+        phone_dim = b.icfg("phone_dim"); hidden = b.icfg("hidden"); inter = b.icfg("inter"); filter = b.icfg("filter"); heads = b.icfg("heads");
+        enc_layers = b.icfg("enc_layers"); enc_k = b.icfg("enc_k"); window = b.icfg("window"); flow_n = b.icfg("flow_n");
+        wn_layers = b.icfg("wn_layers"); wn_k = b.icfg("wn_k"); gin = b.icfg("gin"); up_init = b.icfg("up_init"); n_ups = b.icfg("n_ups");
+        n_rb = b.icfg("n_rb"); n_rbd = b.icfg("n_rbd"); sr = b.icfg("sr");
+        for (int i = 0; i < n_ups; i++) { up_rate[i] = b.icfg(fmt("up_rate%d", i)); up_kernel[i] = b.icfg(fmt("up_kernel%d", i)); }
+        for (int j = 0; j < n_rb; j++) rb_k[j] = b.icfg(fmt("rb_k%d", j));
+        for (int m = 0; m < n_rbd; m++) rb_d[m] = b.icfg(fmt("rb_d%d", m));
+        auto own = [&](const std::string &n) { float *p = dv(b, n); owned.push_back(p); return p; };
+        const int H = hidden, G = gin;
+        const float *g = b.w("sy.g");
+        phone = prep_conv(b.w("sy.enc.phone.w"), b.w("sy.enc.phone.b"), H, phone_dim, 1, 1);
+        pitch_emb = own("sy.enc.pitch_emb");
+        for (int l = 0; l < enc_layers; l++) {
+            Layer L;
+            std::vector<float> w((size_t)3 * H * H), bb((size_t)3 * H);
+            const char *nm[3] = {"q", "k", "v"};
+            for (int j = 0; j < 3; j++) {
+                memcpy(&w[(size_t)j * H * H], b.w(fmt("sy.enc.l%d.", l) + nm[j] + ".w"), (size_t)H * H * 4);
+                memcpy(&bb[(size_t)j * H], b.w(fmt("sy.enc.l%d.", l) + nm[j] + ".b"), (size_t)H * 4);
+            }
+            L.qkv = prep_conv(w.data(), bb.data(), 3 * H, H, 1, 1);
+            L.o = prep_conv(b.w(fmt("sy.enc.l%d.o.w", l)), b.w(fmt("sy.enc.l%d.o.b", l)), H, H, 1, 1);
+            L.ff1 = prep_conv(b.w(fmt("sy.enc.l%d.ff1.w", l)), b.w(fmt("sy.enc.l%d.ff1.b", l)), filter, H, enc_k, 1);
+            L.ff2 = prep_conv(b.w(fmt("sy.enc.l%d.ff2.w", l)), b.w(fmt("sy.enc.l%d.ff2.b", l)), H, filter, enc_k, 1);
+            L.rel_k = own(fmt("sy.enc.l%d.rel_k", l)); L.rel_v = own(fmt("sy.enc.l%d.rel_v", l));
+            L.ln1_g = own(fmt("sy.enc.l%d.ln1.g", l)); L.ln1_b = own(fmt("sy.enc.l%d.ln1.b", l));
+            L.ln2_g = own(fmt("sy.enc.l%d.ln2.g", l)); L.ln2_b = own(fmt("sy.enc.l%d.ln2.b", l));
+            layers.push_back(L);
+        }
+        proj = prep_conv(b.w("sy.enc.proj.w"), b.w("sy.enc.proj.b"), 2 * inter, H, 1, 1);
+        const int half = inter / 2;
+        for (int i = 0; i < flow_n; i++) {
+            Flow F;
+            F.pre = prep_conv(b.w(fmt("sy.flow%d.pre.w", i)), b.w(fmt("sy.flow%d.pre.b", i)), H, half, 1, 1);
+            // speaker conditioning is a load-time constant (sid baked, rvc.rs:186-187): fold cond(g) into the in-layer biases
+            const float *cw = b.w(fmt("sy.flow%d.cond.w", i)), *cb = b.w(fmt("sy.flow%d.cond.b", i));
+            for (int j = 0; j < wn_layers; j++) {
+                std::vector<float> bias(2 * H);
+                const float *ib = b.w(fmt("sy.flow%d.in%d.b", i, j));
+                for (int r = 0; r < 2 * H; r++) {
+                    float a = cb[j * 2 * H + r];
+                    for (int q = 0; q < G; q++) a += cw[(size_t)(j * 2 * H + r) * G + q] * g[q];
+                    bias[r] = ib[r] + a;
+                }
+                F.in.push_back(prep_conv(b.w(fmt("sy.flow%d.in%d.w", i, j)), bias.data(), 2 * H, H, wn_k, 1));
+                int rs_c = j < wn_layers - 1 ? 2 * H : H;
+                F.rs.push_back(prep_conv(b.w(fmt("sy.flow%d.rs%d.w", i, j)), b.w(fmt("sy.flow%d.rs%d.b", i, j)), rs_c, H, 1, 1));
+            }
+            F.post = prep_conv(b.w(fmt("sy.flow%d.post.w", i)), b.w(fmt("sy.flow%d.post.b", i)), half, H, 1, 1);
+            flows.push_back(F);
+        }
+        {
+            std::vector<float> bias(up_init);
+            const float *cw = b.w("sy.dec.cond.w"), *cb = b.w("sy.dec.cond.b"), *pb = b.w("sy.dec.pre.b");
+            for (int c = 0; c < up_init; c++) { float a = cb[c]; for (int q = 0; q < G; q++) a += cw[(size_t)c * G + q] * g[q]; bias[c] = pb[c] + a; }
+            dec_pre = prep_conv(b.w("sy.dec.pre.w"), bias.data(), up_init, inter, 7, 1);
+        }
+        int c = up_init;
+        for (int i = 0; i < n_ups; i++) {
+            int co = c / 2;
+            ups.push_back(prep_convT1d(b.w(fmt("sy.dec.up%d.w", i)), b.w(fmt("sy.dec.up%d.b", i)), c, co, up_kernel[i], up_rate[i]));
+            int sf = 1; for (int q = i + 1; q < n_ups; q++) sf *= up_rate[q];
+            int nk = i + 1 < n_ups ? 2 * sf : 1;
+            ncs.push_back(prep_conv(b.w(fmt("sy.dec.nc%d.w", i)), b.w(fmt("sy.dec.nc%d.b", i)), co, 1, nk, 1));
+            std::vector<std::vector<std::pair<ConvW, ConvW>>> stage;
+            for (int j = 0; j < n_rb; j++) {
+                std::vector<std::pair<ConvW, ConvW>> chain;
+                for (int m = 0; m < n_rbd; m++) {
+                    ConvW c1 = prep_conv(b.w(fmt("sy.dec.rb%d_%d.c1_%d.w", i, j, m)), b.w(fmt("sy.dec.rb%d_%d.c1_%d.b", i, j, m)), co, co, rb_k[j], 1);
+                    ConvW c2 = prep_conv(b.w(fmt("sy.dec.rb%d_%d.c2_%d.w", i, j, m)), b.w(fmt("sy.dec.rb%d_%d.c2_%d.b", i, j, m)), co, co, rb_k[j], 1);
+                    chain.push_back({c1, c2});
+                }
+                stage.push_back(chain);
+            }
+            rbs.push_back(stage);
+            c = co;
+        }
+        dec_post = prep_conv(b.w("sy.dec.post.w"), nullptr, 1, c, 7, 1);
+        src_w = b.w("sy.src")[0]; src_b = b.w("sy.src")[1];
+        weight_bytes = b.bytes();
+    }
+    ~ModelSY()
+    {
+        free_conv(phone); free_conv(proj); free_conv(dec_pre); free_conv(dec_post);
+        for (auto &L : layers) { free_conv(L.qkv); free_conv(L.o); free_conv(L.ff1); free_conv(L.ff2); }
+        for (auto &F : flows) { free_conv(F.pre); free_conv(F.post); for (auto &c : F.in) free_conv(c); for (auto &c : F.rs) free_conv(c); }
+        for (auto &c : ups) free_conv(c);
+        for (auto &c : ncs) free_conv(c);
+        for (auto &s : rbs) for (auto &ch : s) for (auto &pr : ch) { free_conv(pr.first); free_conv(pr.second); }
+        for (float *p : owned) (void)hipFree(p);
+    }
+    int upp() const { int u = 1; for (int i = 0; i < n_ups; i++) u *= up_rate[i]; return u; }
+};
+
+// ---------------------------------------------------------------------------------------
+// the engine
+// ---------------------------------------------------------------------------------------
+}  // namespace rvc
+
+using namespace rvc;
+
+struct rvc_engine {
+    std::string data_path, err;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::unique_ptr<ModelCV> cv;
+    std::unique_ptr<ModelRM> rm;
+    std::unique_ptr<ModelSY> sy;
+    // constants for the mel front end
+    float *d_window = nullptr, *d_twiddle = nullptr, *d_basis = nullptr;
+    // retrieval index
+    float *d_index = nullptr, *d_indexT = nullptr; size_t index_n = 0, index_dim = 0; bool index_owned = true;
+    float index_rate = 0.f;
+    // streams
+    int n_streams = 1;
+    StreamState *d_state = nullptr;
+    CallParams *d_cp = nullptr, *h_cp = nullptr;
+    uint32_t seed = 0, stream_id0 = 0;
+    // plans (keyed by geometry)
+    std::vector<std::unique_ptr<Plan>> plans;
+    Plan *last_plan = nullptr;
+    bool taps_on = false, profile_on = false, use_graph = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.f;
+    size_t last_knn_rows = 0;
+    std::vector<int> h_status;
+};
+
+namespace rvc {
+
+static void set_device(rvc_engine *e) { HIPCHK(hipSetDevice(e->device)); }
+
+static void init_constants(rvc_engine *e)
+{
+    // periodic Hann, f64 cosine cast to f32 then 0.5*(1-c) in f32 (rmvpe.rs:33-37, Q9)
+    std::vector<float> win(1024), tw(1024), basis((size_t)128 * 513);
+    for (int i = 0; i < 1024; i++) { float c = (float)cos(2.0 * M_PI * (double)i / 1024.0); win[i] = 0.5f * (1.0f - c); }
+    for (int j = 0; j < 512; j++) { double a = -2.0 * M_PI * (double)j / 1024.0; tw[2 * j] = (float)cos(a); tw[2 * j + 1] = (float)sin(a); }
+    // mel_spec::mel::mel(16000, 1024, 128, 30, 8000, htk=true, norm=true) (rmvpe.rs:146-148,220): HTK mel scale,
+    // triangular filters, Slaney area normalisation, computed in f64 then cast to f32
+    const int nb = 513, nm = 128;
+    const double sr = 16000.0, fmin = 30.0, fmax = 8000.0;
+    std::vector<double> melf(nm + 2);
+    double mlo = 2595.0 * log10(1.0 + fmin / 700.0), mhi = 2595.0 * log10(1.0 + fmax / 700.0);
+    for (int i = 0; i < nm + 2; i++) { double m = mlo + (mhi - mlo) * (double)i / (double)(nm + 1); melf[i] = 700.0 * (pow(10.0, m / 2595.0) - 1.0); }
+    for (int i = 0; i < nm; i++) {
+        double fd0 = melf[i + 1] - melf[i], fd1 = melf[i + 2] - melf[i + 1], enorm = 2.0 / (melf[i + 2] - melf[i]);
+        for (int j = 0; j < nb; j++) {
+            double f = (sr / 2.0) * (double)j / (double)(nb - 1);
+            double lower = -(melf[i] - f) / fd0, upper = (melf[i + 2] - f) / fd1;
+            double v = std::max(0.0, std::min(lower, upper));
+            basis[(size_t)i * nb + j] = (float)(v * enorm);
+        }
+    }
+    e->d_window = upload_f(win); e->d_twiddle = upload_f(tw); e->d_basis = upload_f(basis);
+}
+
+static void reset_state(rvc_engine *e)
+{
+    std::vector<StreamState> st(e->n_streams);
+    for (int b = 0; b < e->n_streams; b++) { memset(&st[b], 0, sizeof(StreamState)); st[b].stream_id = e->stream_id0 + (uint32_t)b; }
+    HIPCHK(hipMemcpy(e->d_state, st.data(), sizeof(StreamState) * e->n_streams, hipMemcpyHostToDevice));
+}
+
+static void alloc_state(rvc_engine *e)
+{
+    if (e->d_state) (void)hipFree(e->d_state);
+    HIPCHK(hipMalloc(&e->d_state, sizeof(StreamState) * e->n_streams));
+    reset_state(e);
+    e->plans.clear();
+    e->last_plan = nullptr;
+}
+
+// ------------------------------- ContentVec ------------------------------------------
+static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
+{
+    ModelCV &m = *e->cv;
+    Arena &A = pl.arena;
+    T1 x; x.p = pl.d_in; x.B = B; x.C = 1; x.T = (int)L; x.ld = (int)L; x.halo = 0; x.bs = (long long)L;
+    int T = (int)L;
+    for (int i = 0; i < 7; i++) {
+        int To = (T - m.conv_k[i]) / m.conv_s[i] + 1;
+        T1 y = make_t1(A, B, m.conv_dim, To, 0);
+        ConvOpts o; o.act = i == 0 ? ACT_NONE : ACT_GELU;
+        add_conv1d(pl, m.conv[i], x, y, m.conv_s[i], 0, 1, o);
+        if (i == 0) {
+            dim3 grid(m.conv_dim, B);
+            float *g = m.gn_g, *bb = m.gn_b;
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(groupnorm_gelu_kernel, grid, dim3(256), 0, s, y.p, g, bb, y.T, y.ld, y.bs); });
+            add_tap(pl, "cv.conv0", y);
+        }
+        x = y; T = To;
+    }
+    add_tap(pl, "cv.feat", x);
+    add_layernorm(pl, x, m.ln0_g, m.ln0_b);
+    const int E = m.embed;
+    T1 h = make_t1(A, B, E, T, m.pos_k / 2);
+    add_conv1d(pl, m.proj, x, h, 1, 0, 1);
+    add_tap(pl, "cv.proj", h);
+    T1 h2 = make_t1(A, B, E, T, 0);
+    { ConvOpts o; o.act = ACT_GELU; o.res = h.p; o.res_cs = h.ld; o.res_bs = h.bs; add_conv1d(pl, m.pos, h, h2, 1, m.pos_k / 2, 1, o); }
+    add_layernorm(pl, h2, m.encln_g, m.encln_b);
+    add_tap(pl, "cv.pos", h2);
+    T1 qkv = make_t1(A, B, 3 * E, T, 0), att = make_t1(A, B, E, T, 0), ff = make_t1(A, B, m.ffn, T, 0);
+    const int hd = E / m.heads, Tp = T | 1;
+    const size_t attn_lds = ((size_t)2 * hd * Tp + 4 * Tp + 4 * hd) * sizeof(float);
+    if (attn_lds > 160 * 1024) throw ShapeError("ContentVec attention: window too long for the LDS-resident kernel (T <= ~300)");
+    HIPCHK(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (int l = 0; l < m.run_layers; l++) {
+        ModelCV::Layer &Ly = m.layers[l];
+        add_conv1d(pl, Ly.qkv, h2, qkv, 1, 0, 1);
+        AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = E; ap.T = T; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;
+        ap.scale = 1.0f / sqrtf((float)hd); ap.rel_k = nullptr; ap.rel_v = nullptr; ap.window = 0;
+        dim3 ag(m.heads, B);
+        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(attention_kernel, ag, dim3(256), attn_lds, s, ap); });
+        { ConvOpts o; o.res = h2.p; o.res_cs = h2.ld; o.res_bs = h2.bs; add_conv1d(pl, Ly.o, att, h2, 1, 0, 1, o); }
+        add_layernorm(pl, h2, Ly.ln1_g, Ly.ln1_b);
+        { ConvOpts o; o.act = ACT_GELU; add_conv1d(pl, Ly.ff1, h2, ff, 1, 0, 1, o); }
+        { ConvOpts o; o.res = h2.p; o.res_cs = h2.ld; o.res_bs = h2.bs; add_conv1d(pl, Ly.ff2, ff, h2, 1, 0, 1, o); }
+        add_layernorm(pl, h2, Ly.ln2_g, Ly.ln2_b);
+        if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "cv.l%d", l); add_tap(pl, nm, h2); }
+    }
+    T1 out = h2;
+    if (m.out_dim != E) { out = make_t1(A, B, m.out_dim, T, 0); add_conv1d(pl, m.final_proj, h2, out, 1, 0, 1); }
+    add_tap(pl, "cv.out", out);
+    pl.T = T; pl.C = m.out_dim;
+    return out;
+}
+
+// ------------------------------- RMVPE ------------------------------------------------
+static T2 res_block(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &out)
+{
+    Arena &A = pl.arena;
+    T2 y1 = make_t2(A, x.B, w.co, x.H, x.W);
+    { ConvOpts o; o.act = ACT_RELU; add_conv2d(pl, w.c1, x, y1, o); }
+    if (w.has_sc) {
+        add_conv2d(pl, w.sc, x, out);
+        ConvOpts o; o.act = ACT_RELU; o.accumulate = true; add_conv2d(pl, w.c2, y1, out, o);
+    } else {
+        ConvOpts o; o.act = ACT_RELU; o.res = x.p; o.res_cs = x.cs; o.res_bs = x.bs; add_conv2d(pl, w.c2, y1, out, o);
+    }
+    return out;
+}
+
+static T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k, bool update_cache)
+{
+    ModelRM &m = *e->rm;
+    Arena &A = pl.arena;
+    const size_t fr = 5120 * ((frame16k + 800 - 1) / 5120 + 1) - 160;     // rmvpe.rs:256
+    if (fr > L) throw PanicError("input shorter than f0_extractor_frame");
+    const int Tm = (int)(1 + fr / 160);
+    if (Tm % 32 != 0) throw PanicError("mel frame count is not a multiple of 32 (rmvpe.rs:229-233 branch)");
+    if (Tm > 1024) throw ShapeError("f0 window too long");
+    pl.Tm = Tm;
+    const int H0 = Tm, W0 = m.n_mels;
+    if ((H0 >> m.levels) < 1 || (W0 >> m.levels) < 1) throw ShapeError("RMVPE: input too small for the U-Net depth");
+    T2 img = make_t2(A, B, 1, H0, W0);
+    float *d_mel = A.floats((size_t)B * 128 * Tm);
+    {
+        MelP mp{};
+        mp.audio = pl.d_in; mp.audio_bs = (long long)L; mp.n = (int)L; mp.frame = (int)fr; mp.Tm = Tm;
+        mp.window = e->d_window; mp.twiddle = e->d_twiddle; mp.basis = e->d_basis;
+        mp.mel = d_mel; mp.img = img.p; mp.img_bs = img.bs; mp.img_ld = img.ld; mp.bn_scale = m.bn_scale; mp.bn_shift = m.bn_shift;
+        dim3 grid(Tm, B);
+        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(mel_frontend_kernel, grid, dim3(256), 0, s, mp); });
+        if (pl.with_taps) { T1 t; t.p = d_mel; t.B = B; t.C = 128; t.T = Tm; t.ld = Tm; t.halo = 0; t.bs = 128LL * Tm; add_tap(pl, "rm.mel", t); }
+    }
+    // encoder; every level's pre-pool output is written straight into the second half of the decoder's concat buffer
+    std::vector<T2> cat(m.levels);
+    {
+        int H = H0, W = W0, co = m.en_out;
+        for (int lv = 0; lv < m.levels; lv++) { cat[lv] = make_t2(A, B, 2 * co, H, W); H /= 2; W /= 2; co *= 2; }
+    }
+    T2 x = img;
+    int H = H0, W = W0;
+    for (int lv = 0; lv < m.levels; lv++) {
+        const int co = m.enc[lv][0].co;
+        for (int j = 0; j < m.n_blocks; j++) {
+            T2 out = (j == m.n_blocks - 1) ? cat[lv].chans(co, co) : make_t2(A, B, co, H, W);
+            x = res_block(pl, m.enc[lv][j], x, out);
+        }
+        if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "rm.enc%d", lv); add_tap2(pl, nm, x); }
+        T2 p = make_t2(A, B, co, H / 2, W / 2);
+        {
+            T2 xi = x;
+            dim3 grid((co * (H / 2) * (W / 2) + 255) / 256, B);
+            pl.ops.push_back([=](hipStream_t s) {
+                hipLaunchKernelGGL(avgpool2_kernel, grid, dim3(256), 0, s, xi.p, xi.ld, xi.cs, xi.bs, p.p, p.ld, p.cs, p.bs, co, p.H, p.W);
+            });
+        }
+        x = p; H /= 2; W /= 2;
+    }
+    for (int lv = 0; lv < m.inter_layers; lv++)
+        for (int j = 0; j < m.n_blocks; j++) { T2 out = make_t2(A, B, m.inter[lv][j].co, H, W); x = res_block(pl, m.inter[lv][j], x, out); }
+    add_tap2(pl, "rm.int", x);
+    for (int lv = 0; lv < m.levels; lv++) {
+        const int sl = m.levels - 1 - lv, co = m.up[lv].Cout;
+        H *= 2; W *= 2;
+        { ConvOpts o; o.act = ACT_RELU; add_convT2d(pl, m.up[lv], x, cat[sl].chans(0, co), o); }
+        x = cat[sl];
+        for (int j = 0; j < m.n_blocks; j++) { T2 out = make_t2(A, B, co, H, W); x = res_block(pl, m.dec[lv][j], x, out); }
+        if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "rm.dec%d", lv); add_tap2(pl, nm, x); }
+    }
+    T2 cn = make_t2(A, B, 3, H, W);
+    add_conv2d(pl, m.cnn, x, cn);
+    const int Hg = m.gru_hidden, I = 3 * m.n_mels;
+    T1 feat = make_t1(A, B, I, Tm, 0), gi = make_t1(A, B, 6 * Hg, Tm, 0), gout = make_t1(A, B, 2 * Hg, Tm, 0), sal = make_t1(A, B, m.n_out, Tm, 0);
+    {
+        dim3 grid((3 * m.n_mels * Tm + 255) / 256, B); int nm = m.n_mels;
+        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(gru_input_kernel, grid, dim3(256), 0, s, cn.p, cn.ld, cn.cs, cn.bs, feat.p, feat.ld, feat.bs, Tm, nm); });
+    }
+    add_conv1d(pl, m.gru_ih, feat, gi, 1, 0, 1);
+    {
+        if (3 * Hg > 1024) throw ShapeError("GRU hidden size too large for the single-workgroup recurrence");
+        int threads = (3 * Hg + 63) / 64 * 64;
+        size_t lds = (size_t)4 * Hg * sizeof(float);
+        float *wt = m.whhT, *bh = m.bhh;
+        dim3 grid(2, B);
+        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(gru_kernel, grid, dim3(threads), lds, s, gi.p, gi.ld, gi.bs, wt, bh, gout.p, gout.ld, gout.bs, Hg, Tm); });
+    }
+    { ConvOpts o; o.act = ACT_SIGMOID; add_conv1d(pl, m.fc, gout, sal, 1, 0, 1, o); }
+    if (pl.with_taps) { add_tap(pl, "rm.sal_ct", sal); add_tap(pl, "rm.gru_ct", gout); add_tap(pl, "rm.cnn_ct", feat); }
+    return sal;
+}
+
+// decode + pitch shift + pitch cache + get_f0_post (rmvpe.rs:118-133,243-248; rvc.rs:121,167-180; f0/mod.rs:7-12)
+static void build_pitch_post(rvc_engine *e, Plan &pl, int B, const T1 &sal, bool update_cache, size_t frame16k, size_t hubert_length,
+                             float **pitchf_out, int **pitch_out)
+{
+    Arena &A = pl.arena;
+    const int Tm = pl.Tm;
+    pl.d_f0 = A.floats((size_t)B * Tm);
+    PitchP pp{};
+    pp.sal = sal.p; pp.sal_cs = sal.ld; pp.sal_bs = sal.bs; pp.Tm = Tm;
+    pp.st = e->d_state; pp.cp = e->d_cp; pp.f0 = pl.d_f0; pp.threshold = 0.03f;   // rvc.rs:122
+    if (update_cache) {
+        const int R = (int)pl.R;
+        const size_t shift = frame16k / 160;                                   // rvc.rs:168
+        if (shift > 1024 || Tm < 5) throw PanicError("pitch cache shift out of range");
+        const long long cache_start = 1024 + 4 - Tm;                            // rvc.rs:172
+        const long long read_start = 1024 - (long long)hubert_length + pl.skip_head;   // rvc.rs:176
+        if (cache_start < 0 || read_start < 0 || read_start + R > 1024) throw PanicError("pitch cache slice out of range");
+        pp.pitchf = A.floats((size_t)B * R);
+        pp.pitch = (int *)A.alloc((size_t)B * R * sizeof(int));
+        pp.shift = (int)shift; pp.cache_start = (int)cache_start; pp.read_start = (int)read_start; pp.R = R;
+        *pitchf_out = pp.pitchf; *pitch_out = pp.pitch;
+    } else {
+        pp.R = 0; pp.shift = 0; pp.cache_start = 1 << 30; pp.read_start = 0; pp.pitchf = nullptr; pp.pitch = nullptr;
+    }
+    pp.update = update_cache ? 1 : 0;
+    pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(pitch_post_kernel, dim3(B), dim3(1024), 0, s, pp); });
+}
+
+// ------------------------------- synthesizer ------------------------------------------
+static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, float *d_pitchf, int *d_pitch)
+{
+    ModelSY &m = *e->sy;
+    Arena &A = pl.arena;
+    const int R = (int)pl.R, H = m.hidden, I = m.inter, F = m.filter, half = I / 2;
+    const int HALO = 4;
+    if (m.enc_k / 2 > HALO || m.wn_k / 2 > HALO) throw ShapeError("synth kernel sizes exceed the halo");
+    T1 x = make_t1(A, B, H, R, HALO);
+    add_conv1d(pl, m.phone, phone, x, 1, 0, 1);
+    {
+        dim3 grid((H * R + 255) / 256, B); float *emb = m.pitch_emb; float sq = sqrtf((float)H);
+        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(embed_pitch_kernel, grid, dim3(256), 0, s, x.p, x.ld, x.bs, emb, d_pitch, H, R, sq); });
+    }
+    add_tap(pl, "sy.emb", x);
+    T1 qkv = make_t1(A, B, 3 * H, R, 0), att = make_t1(A, B, H, R, 0), ff = make_t1(A, B, F, R, HALO);
+    const int kc = H / m.heads, Tp = R | 1;
+    const size_t attn_lds = ((size_t)2 * kc * Tp + 4 * Tp + 4 * kc) * sizeof(float);
+    if (attn_lds > 160 * 1024) throw ShapeError("synth attention: return_length too long for the LDS-resident kernel");
+    for (int l = 0; l < m.enc_layers; l++) {
+        ModelSY::Layer &Ly = m.layers[l];
+        add_conv1d(pl, Ly.qkv, x, qkv, 1, 0, 1);
+        AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = H; ap.T = R; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;
+        ap.scale = 1.0f / sqrtf((float)kc); ap.rel_k = Ly.rel_k; ap.rel_v = Ly.rel_v; ap.window = m.window;
+        dim3 ag(m.heads, B);
+        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(attention_kernel, ag, dim3(256), attn_lds, s, ap); });
+        { ConvOpts o; o.res = x.p; o.res_cs = x.ld; o.res_bs = x.bs; add_conv1d(pl, Ly.o, att, x, 1, 0, 1, o); }
+        add_layernorm(pl, x, Ly.ln1_g, Ly.ln1_b);
+        { ConvOpts o; o.act = ACT_RELU; add_conv1d(pl, Ly.ff1, x, ff, 1, m.enc_k / 2, 1, o); }
+        { ConvOpts o; o.res = x.p; o.res_cs = x.ld; o.res_bs = x.bs; add_conv1d(pl, Ly.ff2, ff, x, 1, m.enc_k / 2, 1, o); }
+        add_layernorm(pl, x, Ly.ln2_g, Ly.ln2_b);
+    }
+    add_tap(pl, "sy.enc", x);
+    T1 stats = make_t1(A, B, 2 * I, R, 0);
+    add_conv1d(pl, m.proj, x, stats, 1, 0, 1);
+    add_tap(pl, "sy.stats", stats);
+    T1 z = make_t1(A, B, I, R, HALO), zf = make_t1(A, B, I, R, HALO);
+    {
+        dim3 grid(((I * R + 3) / 4 + 255) / 256, B); StreamState *st = e->d_state; CallParams *cp = e->d_cp;
+        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(prior_sample_kernel, grid, dim3(256), 0, s, stats.p, stats.ld, stats.bs, z.p, z.ld, z.bs, I, R, st, cp); });
+    }
+    add_tap(pl, "sy.zp", z);
+    T1 hh = make_t1(A, B, H, R, HALO), gate_in = make_t1(A, B, 2 * H, R, 0), acts = make_t1(A, B, H, R, 0), skip = make_t1(A, B, H, R, 0);
+    for (int fi = m.flow_n - 1; fi >= 0; fi--) {
+        ModelSY::Flow &Fw = m.flows[fi];
+        {
+            T1 zi = z, zo = zf; dim3 grid((I * R + 255) / 256, B);
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(flip_channels_kernel, grid, dim3(256), 0, s, zi.p, zo.p, I, R, zi.ld, zi.bs); });
+        }
+        std::swap(z, zf);   // z now holds the flipped tensor
+        add_conv1d(pl, Fw.pre, z.rows(0, half), hh, 1, 0, 1);
+        for (int j = 0; j < m.wn_layers; j++) {
+            add_conv1d(pl, Fw.in[j], hh, gate_in, 1, (m.wn_k - 1) / 2, 1);
+            {
+                dim3 grid((H * R + 255) / 256, B);
+                pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(gate_kernel, grid, dim3(256), 0, s, gate_in.p, gate_in.ld, gate_in.bs, acts.p, acts.ld, acts.bs, H, R); });
+            }
+            if (j < m.wn_layers - 1) {
+                { ConvOpts o; o.m_off = 0; o.m_cnt = H; o.accumulate = true; add_conv1d(pl, Fw.rs[j], acts, hh, 1, 0, 1, o); }
+                { ConvOpts o; o.m_off = H; o.m_cnt = H; o.accumulate = j > 0; add_conv1d(pl, Fw.rs[j], acts, skip, 1, 0, 1, o); }
+            } else {
+                ConvOpts o; o.accumulate = j > 0; add_conv1d(pl, Fw.rs[j], acts, skip, 1, 0, 1, o);
+            }
+        }
+        { ConvOpts o; o.scale = -1.f; o.accumulate = true; add_conv1d(pl, Fw.post, skip, z.rows(half, half), 1, 0, 1, o); }
+    }
+    add_tap(pl, "sy.z", z);
+    // NSF source
+    const int upp = m.upp();
+    const size_t N = (size_t)R * upp;
+    if (R > 512) throw ShapeError("return_length too long for the NSF source kernel");
+    int max_sf = 1; { int sf = 1; for (int i = m.n_ups - 1; i >= 1; i--) { sf *= m.up_rate[i]; max_sf = std::max(max_sf, sf); } }
+    T1 src = make_t1(A, B, 1, (int)N, max_sf + 2);
+    {
+        SrcP sp{}; sp.pitchf = d_pitchf; sp.src = src.p; sp.src_bs = src.bs; sp.T = R; sp.upp = upp; sp.sr = (float)m.sr;
+        sp.lin_w = m.src_w; sp.lin_b = m.src_b; sp.st = e->d_state; sp.cp = e->d_cp;
+        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(nsf_source_kernel, dim3(B), dim3(1024), 0, s, sp); });
+    }
+    add_tap(pl, "sy.src", src);
+    // decoder
+    int max_pad = 3;
+    for (int j = 0; j < m.n_rb; j++) for (int q = 0; q < m.n_rbd; q++) max_pad = std::max(max_pad, (m.rb_k[j] * m.rb_d[q] - m.rb_d[q]) / 2);
+    const int DH = (max_pad + 3) / 4 * 4;
+    int c = m.up_init, Tc = R;
+    T1 xd = make_t1(A, B, c, Tc, DH);
+    add_conv1d(pl, m.dec_pre, z, xd, 1, 3, 1);
+    add_tap(pl, "sy.pre", xd);
+    for (int i = 0; i < m.n_ups; i++) {
+        const int co = c / 2, K = m.up_kernel[i], S = m.up_rate[i], Tn = Tc * S;
+        if ((K - S) % 2 != 0) throw ShapeError("upsample kernel/stride parity not supported");
+        T1 u = make_t1(A, B, co, Tn, DH);
+        { ConvOpts o; o.pre_act = ACT_LRELU; o.pre_slope = 0.1f; add_convT1d(pl, m.ups[i], xd, u, (K - S) / 2, o); }
+        int sf = 1; for (int q = i + 1; q < m.n_ups; q++) sf *= m.up_rate[q];
+        { ConvOpts o; o.accumulate = true; if (i + 1 < m.n_ups) add_conv1d(pl, m.ncs[i], src, u, sf, sf / 2, 1, o); else add_conv1d(pl, m.ncs[i], src, u, 1, 0, 1, o); }
+        if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "sy.up%d", i); add_tap(pl, nm, u); }
+        T1 xs = make_t1(A, B, co, Tn, DH), ra = make_t1(A, B, co, Tn, DH), rb = make_t1(A, B, co, Tn, DH), tt = make_t1(A, B, co, Tn, DH);
+        for (int j = 0; j < m.n_rb; j++) {
+            const int k = m.rb_k[j];
+            T1 cur = u;
+            for (int q = 0; q < m.n_rbd; q++) {
+                const int d = m.rb_d[q];
+                { ConvOpts o; o.pre_act = ACT_LRELU; o.pre_slope = 0.1f; o.act = ACT_LRELU; o.slope = 0.1f; add_conv1d(pl, m.rbs[i][j][q].first, cur, tt, 1, (k * d - d) / 2, d, o); }
+                const bool last = q == m.n_rbd - 1;
+                T1 dst = last ? xs : (cur.p == ra.p ? rb : ra);
+                ConvOpts o; o.res = cur.p; o.res_cs = cur.ld; o.res_bs = cur.bs;
+                if (last) { o.scale = 1.0f / (float)m.n_rb; o.accumulate = j > 0; }
+                add_conv1d(pl, m.rbs[i][j][q].second, tt, dst, 1, (k - 1) / 2, 1, o);
+                cur = dst;
+            }
+        }
+        if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "sy.rb%d", i); add_tap(pl, nm, xs); }
+        xd = xs; c = co; Tc = Tn;
+    }
+    pl.audio = make_t1(A, B, 1, Tc, 0);
+    { ConvOpts o; o.pre_act = ACT_LRELU; o.pre_slope = 0.01f; o.act = ACT_TANH; o.no_bias = true; add_conv1d(pl, m.dec_post, xd, pl.audio, 1, 3, 1, o); }
+    pl.N = (size_t)Tc;
+    if (pl.audio.ld != Tc) {
+        // make the output rows contiguous [B][N] for the device-pointer API
+        T1 a2; a2.p = A.floats((size_t)B * Tc); a2.B = B; a2.C = 1; a2.T = Tc; a2.ld = Tc; a2.halo = 0; a2.bs = Tc;
+        T1 a1 = pl.audio;
+        pl.ops.push_back([=](hipStream_t s) { HIPCHK(hipMemcpy2DAsync(a2.p, (size_t)Tc * 4, a1.p, (size_t)a1.bs * 4, (size_t)Tc * 4, B, hipMemcpyDeviceToDevice, s)); });
+        pl.audio = a2;
+    }
+}
+
+// ------------------------------- plan -------------------------------------------------
+static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32_t skip_head, uint32_t R)
+{
+    const int B = e->n_streams;
+    const bool with_index = mode == 0 && e->d_index && e->index_rate > 0.f;
+    for (auto &p : e->plans)
+        if (p->mode == mode && p->L == L && p->frame16k == frame16k && p->skip_head == skip_head && p->R == R && p->B == B &&
+            p->with_index == with_index && p->with_taps == e->taps_on)
+            return p.get();
+    std::unique_ptr<Plan> up(new Plan());
+    Plan &pl = *up;
+    pl.mode = mode; pl.L = L; pl.frame16k = frame16k; pl.skip_head = skip_head; pl.R = R; pl.B = B; pl.with_index = with_index; pl.with_taps = e->taps_on;
+    pl.d_in = pl.arena.floats((size_t)B * L + 64);
+    if (mode == 0 || mode == 1) {
+        if (!e->cv) throw std::logic_error("contentvec");
+        if (e->cv->out_frames(L) < 1) throw ShapeError("input too short for ContentVec");
+        pl.cv_out = build_contentvec(e, pl, B, L);
+        if (mode == 1) {
+            const int T = pl.T, C = pl.C;
+            pl.d_feat = pl.arena.floats((size_t)(2 * T + 1) * C);
+            T1 cvo = pl.cv_out; float *df = pl.d_feat;
+            dim3 grid(((2 * T + 1) * C + 255) / 256);
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(extract_feature_kernel, grid, dim3(256), 0, s, cvo.p, cvo.ld, C, T, df); });
+        }
+    }
+    if (mode == 2) {
+        T1 sal = build_rmvpe(e, pl, B, L, frame16k, false);
+        float *pf; int *pi;
+        build_pitch_post(e, pl, B, sal, false, frame16k, 0, &pf, &pi);
+    }
+    if (mode == 0) {
+        const int T = pl.T, C = pl.C;
+        const size_t T2 = 2 * (size_t)T + 1;
+        const size_t hubert_length = std::min(L / 160, T2);                 // rvc.rs:153
+        if ((size_t)skip_head + R > T2) throw PanicError("feature slice out of range (rvc.rs:155)");
+        if (R < 1) throw ShapeError("return_length must be >= 1");
+        if (e->sy->phone_dim != C) throw std::runtime_error("synthesizer phone dimension does not match the ContentVec output");
+        T1 phone = make_t1(pl.arena, B, C, (int)R, 0);
+        {
+            T1 cvo = pl.cv_out; dim3 grid((C * (int)R + 255) / 256, B);
+            pl.ops.push_back([=](hipStream_t s) {
+                hipLaunchKernelGGL(gather_phone_kernel, grid, dim3(256), 0, s, cvo.p, cvo.ld, cvo.bs, C, T, (int)skip_head, (int)R, phone.p, phone.ld, phone.bs);
+            });
+        }
+        if (with_index) {
+            if (e->index_dim != (size_t)C) throw std::runtime_error("index dimension does not match the feature dimension");
+            // unique raw frames behind the sliced frames (Q2): first_raw .. last_raw
+            const int first_raw = std::min((int)skip_head / 2, T - 1), last_raw = std::min((int)(skip_head + R - 1) / 2, T - 1);
+            const int nq = last_raw - first_raw + 1;
+            float *d_q = pl.arena.floats((size_t)B * nq * C);
+            const int nblk = (int)((e->index_n + 255) / 256);
+            float *cand_d = pl.arena.floats((size_t)B * nq * nblk * KNN_K);
+            int *cand_i = (int *)pl.arena.alloc((size_t)B * nq * nblk * KNN_K * sizeof(int));
+            pl.d_knn_idx = (int *)pl.arena.alloc((size_t)B * R * KNN_K * sizeof(int));
+            pl.d_knn_dist = pl.arena.floats((size_t)B * R * KNN_K);
+            T1 cvo = pl.cv_out;
+            {
+                dim3 grid((nq * C + 255) / 256, B);
+                pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(knn_queries_kernel, grid, dim3(256), 0, s, cvo.p, cvo.ld, cvo.bs, C, first_raw, nq, d_q); });
+            }
+            if ((size_t)KNN_MAXQ * C * sizeof(float) > 64 * 1024) throw ShapeError("feature dimension too large for the kNN scan kernel");
+            for (int q0 = 0; q0 < nq; q0 += KNN_MAXQ) {
+                const int qn = std::min(KNN_MAXQ, nq - q0);
+                KnnP kp{}; kp.indexT = e->d_indexT; kp.index = e->d_index; kp.n = (int)e->index_n; kp.dim = C; kp.nblk = nblk;
+                // query sub-range: pointers offset so that [B][nq] strides stay those of the full arrays
+                kp.q = d_q + (size_t)q0 * C; kp.nq = qn; kp.cand_d = cand_d + (size_t)q0 * nblk * KNN_K; kp.cand_i = cand_i + (size_t)q0 * nblk * KNN_K;
+                const int nq_total = nq;
+                dim3 grid(nblk, B); size_t lds = (size_t)qn * C * sizeof(float);
+                pl.ops.push_back([=](hipStream_t s) {
+                    KnnP k2 = kp; k2.q_bs = (long long)nq_total * C; k2.cand_bs = (long long)nq_total * nblk * KNN_K;
+                    hipLaunchKernelGGL(knn_scan_kernel, grid, dim3(256), lds, s, k2);
+                });
+            }
+            KnnBlendP bp{}; bp.cand_d = cand_d; bp.cand_i = cand_i; bp.nblk = nblk; bp.nq = nq; bp.index = e->d_index; bp.dim = C; bp.q = d_q;
+            bp.skip_head = (int)skip_head; bp.T = T; bp.R = (int)R; bp.first_raw = first_raw; bp.rate = e->index_rate;
+            bp.phone = phone.p; bp.ph_cs = phone.ld; bp.ph_bs = phone.bs; bp.out_idx = pl.d_knn_idx; bp.out_dist = pl.d_knn_dist;
+            dim3 grid(nq, B);
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(knn_merge_blend_kernel, grid, dim3(256), 0, s, bp); });
+        }
+        add_tap(pl, "phone_ct", phone);
+        T1 sal = build_rmvpe(e, pl, B, L, frame16k, true);
+        float *d_pitchf = nullptr; int *d_pitch = nullptr;
+        build_pitch_post(e, pl, B, sal, true, frame16k, hubert_length, &d_pitchf, &d_pitch);
+        build_synth(e, pl, B, phone, d_pitchf, d_pitch);
+        StreamState *st = e->d_state;
+        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(advance_chunk_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, B); });
+    }
+    HIPCHK(hipDeviceSynchronize());
+    e->plans.push_back(std::move(up));
+    return e->plans.back().get();
+}
+
+static void run_plan(rvc_engine *e, Plan &pl)
+{
+    pl.profile = e->profile_on;
+    pl.prof_used = 0;
+    HIPCHK(hipEventRecord(e->ev0, e->stream));
+    if (e->use_graph && !e->profile_on) {
+        if (!pl.graph_exec) {
+            hipGraph_t g;
+            HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+            for (auto &op : pl.ops) op(e->stream);
+            HIPCHK(hipStreamEndCapture(e->stream, &g));
+            HIPCHK(hipGraphInstantiate(&pl.graph_exec, g, nullptr, nullptr, 0));
+            HIPCHK(hipGraphDestroy(g));
+        }
+        HIPCHK(hipGraphLaunch(pl.graph_exec, e->stream));
+    } else {
+        for (auto &op : pl.ops) op(e->stream);
+    }
+    HIPCHK(hipEventRecord(e->ev1, e->stream));
+    HIPCHK(hipGetLastError());
+    e->last_plan = &pl;
+}
+
+static float uppower(int32_t pitch_shift) { return ldexpf(1.0f, pitch_shift / 12); }   // rvc.rs:121, truncating division (Q1)
+
+static void push_call_params(rvc_engine *e, int32_t pitch_shift)
+{
+    e->h_cp->uppower = uppower(pitch_shift);
+    e->h_cp->seed = e->seed;
+    e->h_cp->chunk_base = 0;
+    HIPCHK(hipMemcpyAsync(e->d_cp, e->h_cp, sizeof(CallParams), hipMemcpyHostToDevice, e->stream));
+}
+
+static rvc_status check_status(rvc_engine *e)
+{
+    // the decode kernel raises status 6 where the reference would panic (rmvpe.rs:124)
+    e->h_status.resize(e->n_streams);
+    std::vector<StreamState> st(e->n_streams);
+    // only the small tail of each state is needed, but states are tiny (4 KB) -- copy the status words
+    for (int b = 0; b < e->n_streams; b++)
+        HIPCHK(hipMemcpy(&e->h_status[b], (char *)(e->d_state + b) + offsetof(StreamState, status), sizeof(int), hipMemcpyDeviceToHost));
+    for (int b = 0; b < e->n_streams; b++)
+        if (e->h_status[b] != 0) {
+            int zero = 0;
+            HIPCHK(hipMemcpy((char *)(e->d_state + b) + offsetof(StreamState, status), &zero, sizeof(int), hipMemcpyHostToDevice));
+            e->err = "to_local_average_cents: index out of bounds (argmax bin >= 348), the reference panics here";
+            return RVC_PANIC;
+        }
+    return RVC_OK;
+}
+
+template <typename Fn> static rvc_status guarded(rvc_engine *e, Fn fn)
+{
+    if (!e) return RVC_BACKEND;
+    try {
+        set_device(e);
+        return fn();
+    } catch (const ShapeError &x) { e->err = x.what(); return RVC_SHAPE; }
+    catch (const PanicError &x) { e->err = x.what(); return RVC_PANIC; }
+    catch (const std::exception &x) { e->err = x.what(); return RVC_BACKEND; }
+}
+
+static std::string native_path(const std::string &p)
+{
+    if (p.size() > 5 && p.substr(p.size() - 5) == ".onnx") return p.substr(0, p.size() - 5) + ".rvcw";
+    return p;
+}
+
+}  // namespace rvc
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+const char *rvc_version(void) { return "rvc-mi355x 0.1 (gfx950)"; }
+
+rvc_status rvc_create(const char *data_path, int device, rvc_engine **out)
+{
+    if (!out) return RVC_BACKEND;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return RVC_BACKEND;   // no CPU fallback, by design
+    rvc_engine *e = new rvc_engine();
+    e->data_path = data_path ? data_path : "";
+    if (device < 0) { const char *lr = getenv("LOCAL_RANK"); device = lr ? atoi(lr) % ndev : 0; }
+    e->device = device;
+    try {
+        set_device(e);
+        HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreate(&e->ev0)); HIPCHK(hipEventCreate(&e->ev1));
+        HIPCHK(hipMalloc(&e->d_cp, sizeof(CallParams)));
+        HIPCHK(hipHostMalloc((void **)&e->h_cp, sizeof(CallParams)));
+        init_constants(e);
+        alloc_state(e);
+    } catch (const std::exception &x) {
+        fprintf(stderr, "rvc_create: %s\n", x.what());
+        delete e;
+        return RVC_BACKEND;
+    }
+    *out = e;
+    return RVC_OK;
+}
+
+void rvc_destroy(rvc_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    e->plans.clear();
+    e->cv.reset(); e->rm.reset(); e->sy.reset();
+    if (e->d_window) (void)hipFree(e->d_window);
+    if (e->d_twiddle) (void)hipFree(e->d_twiddle);
+    if (e->d_basis) (void)hipFree(e->d_basis);
+    if (e->d_index && e->index_owned) (void)hipFree(e->d_index);
+    if (e->d_indexT) (void)hipFree(e->d_indexT);
+    if (e->d_state) (void)hipFree(e->d_state);
+    if (e->d_cp) (void)hipFree(e->d_cp);
+    if (e->h_cp) (void)hipHostFree(e->h_cp);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+const char *rvc_last_error_message(rvc_engine *e) { return e ? e->err.c_str() : "null engine"; }
+int rvc_device(rvc_engine *e) { return e ? e->device : -1; }
+
+// rvc.rs:46-54 + models.rs:52-64
+rvc_status rvc_load_contentvec(rvc_engine *e, int model_version)
+{
+    return guarded(e, [&]() {
+        const int dim = model_version == RVC_VERSION_V1 ? 256 : 768, layer = model_version == RVC_VERSION_V1 ? 9 : 12;   // enums.rs:10-23
+        char name[64]; snprintf(name, sizeof name, "vec-%d-layer-%d.rvcw", dim, layer);
+        Blob b(e->data_path + "/contentvec/" + name);
+        e->plans.clear(); e->last_plan = nullptr;
+        e->cv.reset(new ModelCV(b));
+        return RVC_OK;
+    });
+}
+// rvc.rs:56-60
+rvc_status rvc_load_model(rvc_engine *e, const char *model_path)
+{
+    return guarded(e, [&]() {
+        Blob b(native_path(model_path ? model_path : ""));
+        e->plans.clear(); e->last_plan = nullptr;
+        e->sy.reset(new ModelSY(b));
+        return RVC_OK;
+    });
+}
+// rvc.rs:62-75 + models.rs:66-76
+rvc_status rvc_load_f0(rvc_engine *e, int pitch_algorithm)
+{
+    (void)pitch_algorithm;   // only Rmvpe exists (enums.rs:26-28); unknown values map to it (enums.rs:96-103)
+    return guarded(e, [&]() {
+        Blob b(e->data_path + "/f0/rmvpe.rvcw");
+        e->plans.clear(); e->last_plan = nullptr;
+        e->rm.reset(new ModelRM(b));
+        return RVC_OK;
+    });
+}
+// rvc.rs:77-79
+void rvc_unload_model(rvc_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    e->plans.clear(); e->last_plan = nullptr;
+    e->sy.reset();
+}
+
+static rvc_status run_single_input(rvc_engine *e, Plan *pl, const float *input, size_t n, int32_t pitch_shift)
+{
+    HIPCHK(hipMemcpyAsync(pl->d_in, input, n * sizeof(float) * (size_t)pl->B, hipMemcpyHostToDevice, e->stream));
+    push_call_params(e, pitch_shift);
+    run_plan(e, *pl);
+    return RVC_OK;
+}
+
+// rvc.rs:81-97
+rvc_status rvc_hubert(rvc_engine *e, const float *input, size_t n, float *out, size_t cap, size_t dims[3])
+{
+    return guarded(e, [&]() {
+        if (!e->cv) return RVC_CONTENTVEC_NOT_LOADED;
+        if (e->n_streams != 1) throw ShapeError("hubert() is a single-stream call");
+        Plan *pl = get_plan(e, 1, n, 0, 0, 0);
+        dims[0] = 1; dims[1] = (size_t)pl->C; dims[2] = (size_t)pl->T;
+        if (cap < (size_t)pl->C * pl->T) return RVC_SHAPE;
+        run_single_input(e, pl, input, n, 0);
+        HIPCHK(hipMemcpy2DAsync(out, (size_t)pl->T * 4, pl->cv_out.p, (size_t)pl->cv_out.ld * 4, (size_t)pl->T * 4, pl->C, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        return RVC_OK;
+    });
+}
+// rvc.rs:99-109
+rvc_status rvc_extract_feature(rvc_engine *e, const float *input, size_t n, float *out, size_t cap, size_t dims[3])
+{
+    return guarded(e, [&]() {
+        if (!e->cv) return RVC_CONTENTVEC_NOT_LOADED;
+        if (e->n_streams != 1) throw ShapeError("extract_feature() is a single-stream call");
+        Plan *pl = get_plan(e, 1, n, 0, 0, 0);
+        const size_t T2 = 2 * (size_t)pl->T + 1;
+        dims[0] = 1; dims[1] = T2; dims[2] = (size_t)pl->C;
+        if (cap < T2 * pl->C) return RVC_SHAPE;
+        run_single_input(e, pl, input, n, 0);
+        HIPCHK(hipMemcpyAsync(out, pl->d_feat, T2 * pl->C * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        return RVC_OK;
+    });
+}
+// rvc.rs:111-131
+rvc_status rvc_pitch(rvc_engine *e, const float *input, size_t n, int32_t pitch_shift, size_t sample_frame_16k_size, float *out, size_t cap, size_t *out_len)
+{
+    return guarded(e, [&]() {
+        if (!e->rm) return RVC_F0_NOT_LOADED;   // the reference hits unreachable!() here (rvc.rs:125)
+        if (e->n_streams != 1) throw ShapeError("pitch() is a single-stream call");
+        Plan *pl = get_plan(e, 2, n, sample_frame_16k_size, 0, 0);
+        *out_len = (size_t)pl->Tm;
+        if (cap < (size_t)pl->Tm) return RVC_SHAPE;
+        run_single_input(e, pl, input, n, pitch_shift);
+        HIPCHK(hipMemcpyAsync(out, pl->d_f0, (size_t)pl->Tm * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        return check_status(e);
+    });
+}
+
+static rvc_status infer_common(rvc_engine *e, const void *input, bool input_on_device, size_t n, size_t frame16k, int32_t pitch_shift,
+                               uint32_t skip_head, uint32_t return_length, void *out, bool out_on_device, size_t cap, size_t *out_len, bool sync)
+{
+    if (!e->sy) return RVC_MODEL_NOT_LOADED;             // rvc.rs:141-143
+    if (!e->cv) return RVC_CONTENTVEC_NOT_LOADED;        // rvc.rs:85-88 (via extract_feature at rvc.rs:151)
+    if (!e->rm) return RVC_F0_NOT_LOADED;                // reference: unreachable!() at rvc.rs:125
+    Plan *pl = get_plan(e, 0, n, frame16k, skip_head, return_length);
+    if (out_len) *out_len = pl->N;
+    if (cap < pl->N) return RVC_SHAPE;
+    const int B = pl->B;
+    HIPCHK(hipMemcpyAsync(pl->d_in, input, (size_t)B * n * sizeof(float), input_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+    push_call_params(e, pitch_shift);
+    run_plan(e, *pl);
+    HIPCHK(hipMemcpy2DAsync(out, cap * sizeof(float), pl->audio.p, pl->N * sizeof(float), pl->N * sizeof(float), B,
+                            out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream));
+    e->last_knn_rows = pl->with_index ? return_length : 0;
+    if (!sync) return RVC_OK;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1));
+    return check_status(e);
+}
+
+// rvc.rs:133-220
+rvc_status rvc_infer(rvc_engine *e, const float *input, size_t n, size_t sample_frame_16k_size, int has_pitch_shift, int32_t pitch_shift,
+                     uint32_t skip_head, uint32_t return_length, float *out, size_t cap, size_t *out_len)
+{
+    return guarded(e, [&]() {
+        if (e->n_streams != 1) throw ShapeError("infer() is a single-stream call; use rvc_infer_batch");
+        return infer_common(e, input, false, n, sample_frame_16k_size, has_pitch_shift ? pitch_shift : 0, skip_head, return_length, out, false, cap, out_len, true);
+    });
+}
+
+rvc_status rvc_infer_batch(rvc_engine *e, const float *input, size_t n, size_t sample_frame_16k_size, int32_t pitch_shift, uint32_t skip_head,
+                           uint32_t return_length, float *out, size_t cap_per_stream, size_t *out_len)
+{
+    return guarded(e, [&]() { return infer_common(e, input, false, n, sample_frame_16k_size, pitch_shift, skip_head, return_length, out, false, cap_per_stream, out_len, true); });
+}
+
+rvc_status rvc_infer_device(rvc_engine *e, const void *d_input, size_t n, size_t sample_frame_16k_size, int32_t pitch_shift, uint32_t skip_head,
+                            uint32_t return_length, void *d_out, size_t cap_per_stream, size_t *out_len, int sync)
+{
+    return guarded(e, [&]() { return infer_common(e, d_input, true, n, sample_frame_16k_size, pitch_shift, skip_head, return_length, d_out, true, cap_per_stream, out_len, sync != 0); });
+}
+
+rvc_status rvc_synchronize(rvc_engine *e)
+{
+    return guarded(e, [&]() {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->ev0 && e->last_plan) (void)hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1);
+        return check_status(e);
+    });
+}
+
+rvc_status rvc_set_streams(rvc_engine *e, int n_streams)
+{
+    return guarded(e, [&]() {
+        if (n_streams < 1 || n_streams > 4096) throw ShapeError("n_streams out of range");
+        HIPCHK(hipDeviceSynchronize());
+        e->n_streams = n_streams;
+        alloc_state(e);
+        return RVC_OK;
+    });
+}
+
+void rvc_set_use_graph(rvc_engine *e, int on) { if (e) e->use_graph = on != 0; }
+void rvc_set_profile(rvc_engine *e, int on) { if (e) e->profile_on = on != 0; }
+void rvc_enable_taps(rvc_engine *e, int on) { if (e) e->taps_on = on != 0; }
+float rvc_last_gpu_ms(rvc_engine *e) { return e ? e->last_ms : 0.f; }
+void rvc_set_index_rate(rvc_engine *e, float rate) { if (e) e->index_rate = rate; }
+
+void rvc_set_noise_seed(rvc_engine *e, uint32_t seed, uint32_t stream_id)
+{
+    if (!e) return;
+    (void)guarded(e, [&]() {
+        HIPCHK(hipDeviceSynchronize());
+        e->seed = seed; e->stream_id0 = stream_id;
+        // keep pitch caches / chunk counters, only re-stamp the stream ids
+        std::vector<StreamState> st(e->n_streams);
+        HIPCHK(hipMemcpy(st.data(), e->d_state, sizeof(StreamState) * e->n_streams, hipMemcpyDeviceToHost));
+        for (int b = 0; b < e->n_streams; b++) st[b].stream_id = stream_id + (uint32_t)b;
+        HIPCHK(hipMemcpy(e->d_state, st.data(), sizeof(StreamState) * e->n_streams, hipMemcpyHostToDevice));
+        return RVC_OK;
+    });
+}
+
+void rvc_reset_state(rvc_engine *e)
+{
+    if (!e) return;
+    (void)guarded(e, [&]() { HIPCHK(hipDeviceSynchronize()); reset_state(e); return RVC_OK; });
+}
+
+void rvc_get_pitch_cache(rvc_engine *e, int stream, float *out1024)
+{
+    if (!e || stream < 0 || stream >= e->n_streams) return;
+    (void)guarded(e, [&]() {
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(out1024, e->d_state[stream].cache_pitchf, 1024 * sizeof(float), hipMemcpyDeviceToHost));
+        return RVC_OK;
+    });
+}
+
+static void build_index_transpose(rvc_engine *e)
+{
+    // [n][dim] -> [dim][n] on the host once at load (load path, not the per-chunk path)
+    std::vector<float> h(e->index_n * e->index_dim), t(e->index_n * e->index_dim);
+    HIPCHK(hipMemcpy(h.data(), e->d_index, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < e->index_n; i++) for (size_t d = 0; d < e->index_dim; d++) t[d * e->index_n + i] = h[i * e->index_dim + d];
+    if (e->d_indexT) (void)hipFree(e->d_indexT);
+    HIPCHK(hipMalloc(&e->d_indexT, t.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(e->d_indexT, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+}
+
+rvc_status rvc_load_index(rvc_engine *e, const float *vectors, size_t n, size_t dim)
+{
+    return guarded(e, [&]() {
+        if (n < KNN_K || dim < 1) throw ShapeError("index needs at least 4 vectors");
+        HIPCHK(hipDeviceSynchronize());
+        if (e->d_index && e->index_owned) (void)hipFree(e->d_index);
+        HIPCHK(hipMalloc(&e->d_index, n * dim * sizeof(float)));
+        e->index_owned = true;
+        HIPCHK(hipMemcpy(e->d_index, vectors, n * dim * sizeof(float), hipMemcpyHostToDevice));
+        e->index_n = n; e->index_dim = dim;
+        build_index_transpose(e);
+        e->plans.clear(); e->last_plan = nullptr;
+        return RVC_OK;
+    });
+}
+
+rvc_status rvc_load_index_device(rvc_engine *e, const void *d_vectors, size_t n, size_t dim)
+{
+    return guarded(e, [&]() {
+        if (n < KNN_K || dim < 1) throw ShapeError("index needs at least 4 vectors");
+        HIPCHK(hipDeviceSynchronize());
+        if (e->d_index && e->index_owned) (void)hipFree(e->d_index);
+        HIPCHK(hipMalloc(&e->d_index, n * dim * sizeof(float)));
+        e->index_owned = true;
+        HIPCHK(hipMemcpy(e->d_index, d_vectors, n * dim * sizeof(float), hipMemcpyDeviceToDevice));
+        e->index_n = n; e->index_dim = dim;
+        build_index_transpose(e);
+        e->plans.clear(); e->last_plan = nullptr;
+        return RVC_OK;
+    });
+}
+
+void *rvc_index_device_ptr(rvc_engine *e, size_t *bytes)
+{
+    if (!e || !e->d_index) { if (bytes) *bytes = 0; return nullptr; }
+    if (bytes) *bytes = e->index_n * e->index_dim * sizeof(float);
+    return e->d_index;
+}
+
+rvc_status rvc_get_knn(rvc_engine *e, int32_t *idx, float *dist, size_t cap_rows, size_t *rows)
+{
+    return guarded(e, [&]() {
+        Plan *pl = e->last_plan;
+        if (!pl || !pl->with_index) { if (rows) *rows = 0; return RVC_OK; }
+        const size_t r = pl->R;
+        if (rows) *rows = r;
+        if (cap_rows < r) return RVC_SHAPE;
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(idx, pl->d_knn_idx, r * KNN_K * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(dist, pl->d_knn_dist, r * KNN_K * sizeof(float), hipMemcpyDeviceToHost));
+        return RVC_OK;
+    });
+}
+
+rvc_status rvc_profile_last(rvc_engine *e, int *launches, double *kernel_ms, double *flops)
+{
+    return guarded(e, [&]() {
+        Plan *pl = e->last_plan;
+        if (!pl) return RVC_SHAPE;
+        HIPCHK(hipDeviceSynchronize());
+        double ms = 0, fl = 0;
+        for (size_t i = 0; i < pl->prof_used; i++) { float t; HIPCHK(hipEventElapsedTime(&t, pl->prof[i].a, pl->prof[i].b)); ms += t; fl += pl->prof[i].flops; }
+        if (launches) *launches = (int)pl->prof_used;
+        if (kernel_ms) *kernel_ms = ms;
+        if (flops) *flops = pl->prof_used ? fl : pl->igemm_flops;
+        return RVC_OK;
+    });
+}
+
+rvc_status rvc_get_tap(rvc_engine *e, const char *name, float *out, size_t cap, size_t *n)
+{
+    return guarded(e, [&]() {
+        Plan *pl = e->last_plan;
+        if (!pl) return RVC_SHAPE;
+        HIPCHK(hipDeviceSynchronize());
+        for (auto &t : pl->taps) {
+            if (t.name != name) continue;
+            if (t.rank == 1) {
+                size_t need = (size_t)t.t1.C * t.t1.T; if (n) *n = need;
+                if (cap < need) return RVC_SHAPE;
+                HIPCHK(hipMemcpy2D(out, (size_t)t.t1.T * 4, t.t1.p, (size_t)t.t1.ld * 4, (size_t)t.t1.T * 4, t.t1.C, hipMemcpyDeviceToHost));
+            } else {
+                size_t need = (size_t)t.t2.C * t.t2.H * t.t2.W; if (n) *n = need;
+                if (cap < need) return RVC_SHAPE;
+                for (int c = 0; c < t.t2.C; c++)
+                    HIPCHK(hipMemcpy2D(out + (size_t)c * t.t2.H * t.t2.W, (size_t)t.t2.W * 4, t.t2.p + (size_t)c * t.t2.cs, (size_t)t.t2.ld * 4, (size_t)t.t2.W * 4, t.t2.H, hipMemcpyDeviceToHost));
+            }
+            return RVC_OK;
+        }
+        if (!strcmp(name, "f0") && pl->d_f0) {
+            if (n) *n = (size_t)pl->Tm;
+            if (cap < (size_t)pl->Tm) return RVC_SHAPE;
+            HIPCHK(hipMemcpy(out, pl->d_f0, (size_t)pl->Tm * 4, hipMemcpyDeviceToHost));
+            return RVC_OK;
+        }
+        e->err = std::string("unknown tap ") + name;
+        return RVC_SHAPE;
+    });
+}
+
+}  // extern "C"

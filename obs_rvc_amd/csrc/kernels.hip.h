@@ -1,0 +1,906 @@
+// kernels.hip.h -- hand-written gfx950 (CDNA4) kernels for the RVC per-chunk hot path.
+//
+// Layout convention: every activation is channel-major [B][C][ld] with the time (or H*W)
+// axis contiguous and a zero halo on both sides of every row, so convolution taps never
+// need bounds checks (the halo is zeroed once at allocation and never written).
+//
+// The dense work (every Conv1d / ConvTranspose1d / Conv2d / ConvTranspose2d / Linear of
+// ContentVec, RMVPE and the NSF-HiFiGAN synthesizer) runs through ONE implicit-GEMM
+// kernel on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact f32, 157 TF peak):
+//   D[m][n] = sum_k W[m][k] * X[koff[k] + noff(n)]
+// where koff[] is a per-layer table of input offsets (channel stride, tap, dilation) and
+// noff(n) is the per-lane offset of output position n.  Transposed convolutions are run
+// as `stride` polyphase sub-convolutions ("phases"), grouped convolutions as one phase
+// per group.  64-wide wavefronts: one wave owns a (16*MF) x (16*NF) output tile.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rvc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_GELU = 3, ACT_TANH = 4, ACT_SIGMOID = 5 };
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope)
+{
+    switch (act) {
+    case ACT_RELU: return v > 0.f ? v : 0.f;
+    case ACT_LRELU: return v > 0.f ? v : v * slope;
+    case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case ACT_TANH: return tanhf(v);
+    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+    }
+}
+
+struct PhaseD {
+    long long w_off;   // element offset of this phase's [M][Kp] weight panel
+    int x_off;         // element offset added to the input base
+    int y_off;         // element offset added to the output base
+    int y_pos;         // output coordinate of nw = 0 on the w axis (for the OW range check)
+    int bias_off;      // offset into bias
+    int koff_off;      // offset into the koff table
+    int pad_;
+};
+
+struct IgemmP {
+    const float *x, *w, *bias, *res;
+    float *y, *part;
+    const int *koff;
+    const PhaseD *ph;
+    int M, N, K;             // K already padded to a multiple of 16
+    int NW;                  // n -> (nh, nw) = (n / NW, n % NW)
+    int x_hs, x_ws;          // input offset of position n  = nh*x_hs + nw*x_ws
+    int y_hs, y_ws;          // output offset of position n = nh*y_hs + nw*y_ws
+    int OW;                  // valid iff 0 <= nw*y_ws + y_pos < OW
+    long long x_bs, y_bs, res_bs;
+    int y_cs, res_cs;
+    int nphase, ksplit, chunks_per_split;
+    int act; float slope; float scale; int accumulate;
+    int pre_act; float pre_slope;
+    int ntn, ntm;
+};
+
+__device__ __forceinline__ void epilogue_store(const IgemmP &p, const PhaseD &ph, int b, int m, int n, float acc)
+{
+    if (m >= p.M || n >= p.N) return;
+    int nh = n / p.NW, nw = n - nh * p.NW;
+    int pos = nw * p.y_ws + ph.y_pos;
+    if (pos < 0 || pos >= p.OW) return;
+    long long o = (long long)ph.y_off + (long long)nh * p.y_hs + (long long)nw * p.y_ws;
+    float v = acc;
+    if (p.bias) v += p.bias[ph.bias_off + m];
+    v = apply_act(v, p.act, p.slope);
+    if (p.res) v += p.res[(long long)b * p.res_bs + (long long)m * p.res_cs + o];
+    v *= p.scale;
+    float *yp = p.y + (long long)b * p.y_bs + (long long)m * p.y_cs + o;
+    if (p.accumulate) v += *yp;
+    *yp = v;
+}
+
+// One wave = one (16*MF) x (16*NF) tile; 4 independent waves per workgroup (consecutive tiles
+// share the weight rows through the CU's L1).  No LDS, no barriers.
+template <int MF, int NF>
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmP p)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= p.ntn * p.ntm) return;
+    const int tn = tile % p.ntn, tm = tile / p.ntn;
+    int z = blockIdx.y;
+    const int ks = z % p.ksplit; z /= p.ksplit;
+    const int phase = z % p.nphase;
+    const int b = z / p.nphase;
+    const PhaseD ph = p.ph[phase];
+    const int li = lane & 15, kq = lane >> 4;
+
+    const float *xb = p.x + (long long)b * p.x_bs + ph.x_off;
+    int xo[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; nf++) {
+        int n = tn * 16 * NF + nf * 16 + li;
+        n = n < p.N ? n : p.N - 1;
+        int nh = n / p.NW, nw = n - nh * p.NW;
+        xo[nf] = nh * p.x_hs + nw * p.x_ws;
+    }
+    const float *wrow[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; mf++) {
+        int m = tm * 16 * MF + mf * 16 + li;
+        m = m < p.M ? m : p.M - 1;
+        wrow[mf] = p.w + ph.w_off + (long long)m * p.K + kq * 4;
+    }
+    const int *kofp = p.koff + ph.koff_off + kq * 4;
+    const int nchunks = p.K >> 4;
+    const int c0 = ks * p.chunks_per_split;
+    int c1 = c0 + p.chunks_per_split;
+    c1 = c1 < nchunks ? c1 : nchunks;
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+        for (int nf = 0; nf < NF; nf++) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (c0 < c1) {
+        f32x4 a_cur[MF], a_nxt[MF];
+        float b_cur[NF][4], b_nxt[NF][4];
+        int4 ko_nxt;
+        {
+            int4 ko = *reinterpret_cast<const int4 *>(kofp + c0 * 16);
+#pragma unroll
+            for (int mf = 0; mf < MF; mf++) a_cur[mf] = *reinterpret_cast<const f32x4 *>(wrow[mf] + c0 * 16);
+#pragma unroll
+            for (int nf = 0; nf < NF; nf++) {
+                b_cur[nf][0] = xb[xo[nf] + ko.x]; b_cur[nf][1] = xb[xo[nf] + ko.y];
+                b_cur[nf][2] = xb[xo[nf] + ko.z]; b_cur[nf][3] = xb[xo[nf] + ko.w];
+            }
+            int cn = c0 + 1 < c1 ? c0 + 1 : c1 - 1;
+            ko_nxt = *reinterpret_cast<const int4 *>(kofp + cn * 16);
+        }
+        for (int c = c0; c < c1; c++) {
+            const int cn = c + 1 < c1 ? c + 1 : c1 - 1;
+            const int cnn = c + 2 < c1 ? c + 2 : c1 - 1;
+            // prefetch chunk c+1 (weights + gathered activations) and the offsets of chunk c+2
+#pragma unroll
+            for (int mf = 0; mf < MF; mf++) a_nxt[mf] = *reinterpret_cast<const f32x4 *>(wrow[mf] + cn * 16);
+#pragma unroll
+            for (int nf = 0; nf < NF; nf++) {
+                b_nxt[nf][0] = xb[xo[nf] + ko_nxt.x]; b_nxt[nf][1] = xb[xo[nf] + ko_nxt.y];
+                b_nxt[nf][2] = xb[xo[nf] + ko_nxt.z]; b_nxt[nf][3] = xb[xo[nf] + ko_nxt.w];
+            }
+            ko_nxt = *reinterpret_cast<const int4 *>(kofp + cnn * 16);
+            if (p.pre_act) {
+#pragma unroll
+                for (int nf = 0; nf < NF; nf++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) b_cur[nf][j] = apply_act(b_cur[nf][j], p.pre_act, p.pre_slope);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+                    for (int nf = 0; nf < NF; nf++)
+                        acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mf][j], b_cur[nf][j], acc[mf][nf], 0, 0, 0);
+#pragma unroll
+            for (int mf = 0; mf < MF; mf++) a_cur[mf] = a_nxt[mf];
+#pragma unroll
+            for (int nf = 0; nf < NF; nf++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) b_cur[nf][j] = b_nxt[nf][j];
+        }
+    }
+
+    // D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
+    if (p.ksplit == 1) {
+#pragma unroll
+        for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+            for (int nf = 0; nf < NF; nf++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    epilogue_store(p, ph, b, tm * 16 * MF + mf * 16 + kq * 4 + r, tn * 16 * NF + nf * 16 + li, acc[mf][nf][r]);
+    } else {
+        // partial sums: part[((b*nphase + phase)*ksplit + ks)][M][N]
+        float *pp = p.part + ((long long)(b * p.nphase + phase) * p.ksplit + ks) * (long long)p.M * p.N;
+#pragma unroll
+        for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+            for (int nf = 0; nf < NF; nf++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int m = tm * 16 * MF + mf * 16 + kq * 4 + r, n = tn * 16 * NF + nf * 16 + li;
+                    if (m < p.M && n < p.N) pp[(long long)m * p.N + n] = acc[mf][nf][r];
+                }
+    }
+}
+
+// second stage of a split-K launch: fixed-order (deterministic) sum of the partials + epilogue
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(IgemmP p)
+{
+    long long total = (long long)p.M * p.N;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int z = blockIdx.y;
+    const int phase = z % p.nphase, b = z / p.nphase;
+    const PhaseD ph = p.ph[phase];
+    const float *pp = p.part + (long long)(b * p.nphase + phase) * p.ksplit * total + i;
+    float acc = 0.f;
+    for (int ks = 0; ks < p.ksplit; ks++) acc += pp[(long long)ks * total];
+    int m = (int)(i / p.N), n = (int)(i - (long long)m * p.N);
+    epilogue_store(p, ph, b, m, n, acc);
+}
+
+// ------------------------------------------------------------------------------------
+// wave / block reductions (64-wide wavefronts)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// blockDim.x must be a multiple of 64 and <= 1024; red must hold 16 floats
+__device__ __forceinline__ float block_sum(float v, float *red)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; i++) t += red[i];
+    return t;
+}
+
+// ------------------------------------------------------------------------------------
+// RMVPE front end: reflect pad + periodic Hann + 1024-pt FFT + magnitude + mel + log
+// (reference: rvc/src/f0/rmvpe.rs:80-116, 159-205).  One workgroup per frame, everything
+// LDS-resident; the mel reduction is a wavefront shuffle reduction.
+// Output goes straight into the RMVPE input image [1][Tm(+halo)][128(+halo)] with the
+// network's input BatchNorm affine applied; the raw log-mel is kept for taps.
+// ------------------------------------------------------------------------------------
+struct MelP {
+    const float *audio;     // [B][n] 16 kHz input (device)
+    long long audio_bs;
+    int n;                  // samples per stream
+    int frame;              // f0_extractor_frame: the last `frame` samples are analysed
+    int Tm;
+    const float *window;    // [1024]
+    const float *twiddle;   // [512][2] cos,sin of -2*pi*j/1024
+    const float *basis;     // [128][513]
+    float *mel;             // [B][128][Tm] raw log-mel (tap / parity)
+    float *img;             // RMVPE input image interior pointer
+    long long img_bs; int img_ld;
+    float bn_scale, bn_shift;
+};
+
+__global__ __launch_bounds__(256) void mel_frontend_kernel(MelP p)
+{
+    __shared__ float re[1024], im[1024], mag[516];
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float *sig = p.audio + (long long)b * p.audio_bs + (p.n - p.frame);
+    const int L = p.frame;
+    // frame t covers padded[t*160 .. t*160+1024), padded = reflect(sig, 512)
+    for (int j = tid; j < 1024; j += 256) {
+        int q = t * 160 + j - 512;            // index into the unpadded signal
+        if (q < 0) q = -q;                     // left reflect: padded[512-i-1] = sig[i+1]
+        if (q >= L) q = 2 * L - 2 - q;         // right reflect: padded[L+512+i] = sig[L-i-2]
+        float v = sig[q] * p.window[j];
+        // bit-reversed placement for the in-place radix-2 DIT
+        int r = __brev((unsigned)j) >> 22;
+        re[r] = v; im[r] = 0.f;
+    }
+    __syncthreads();
+    for (int len = 2; len <= 1024; len <<= 1) {
+        const int half = len >> 1, step = 1024 / len;
+        for (int i = tid; i < 512; i += 256) {
+            int grp = i / half, k = i - grp * half;
+            int i0 = grp * len + k, i1 = i0 + half;
+            float wr = p.twiddle[2 * k * step], wi = p.twiddle[2 * k * step + 1];
+            float ur = re[i0], ui = im[i0];
+            float xr = re[i1], xi = im[i1];
+            float vr = xr * wr - xi * wi, vi = xr * wi + xi * wr;
+            re[i0] = ur + vr; im[i0] = ui + vi; re[i1] = ur - vr; im[i1] = ui - vi;
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < 513; k += 256) mag[k] = sqrtf(re[k] * re[k] + im[k] * im[k]);
+    __syncthreads();
+    // 128 mel bins: each wave reduces 32 of them, lanes stride over the 513 magnitudes
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int m = wave * 32; m < wave * 32 + 32; m++) {
+        const float *br = p.basis + m * 513;
+        float s = 0.f;
+        for (int k = lane; k < 513; k += 64) s += br[k] * mag[k];
+        s = wave_sum(s);
+        if (lane == 0) {
+            float lm = logf(fmaxf(s, 1e-5f));
+            p.mel[((long long)b * 128 + m) * p.Tm + t] = lm;
+            p.img[(long long)b * p.img_bs + (long long)t * p.img_ld + m] = lm * p.bn_scale + p.bn_shift;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// normalisation kernels
+// ------------------------------------------------------------------------------------
+// LayerNorm over channels of x[B][C][ld] for each time step (eps 1e-5), optional in-place.
+// block (32 t, 8 channel lanes)
+__global__ __launch_bounds__(256) void layernorm_ct_kernel(const float *x, float *y, const float *g, const float *bta,
+                                                           int C, int T, int x_cs, long long x_bs, int y_cs, long long y_bs)
+{
+    __shared__ float red[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int t = blockIdx.x * 32 + tx, b = blockIdx.y;
+    const bool ok = t < T;
+    const float *xp = x + (long long)b * x_bs + (ok ? t : 0);
+    float s = 0.f;
+    if (ok) for (int c = ty; c < C; c += 8) s += xp[(long long)c * x_cs];
+    red[ty][tx] = s;
+    __syncthreads();
+    float mean = 0.f;
+    for (int i = 0; i < 8; i++) mean += red[i][tx];
+    mean /= (float)C;
+    __syncthreads();
+    float v = 0.f;
+    if (ok) for (int c = ty; c < C; c += 8) { float d = xp[(long long)c * x_cs] - mean; v += d * d; }
+    red[ty][tx] = v;
+    __syncthreads();
+    float var = 0.f;
+    for (int i = 0; i < 8; i++) var += red[i][tx];
+    var /= (float)C;
+    const float inv = 1.0f / sqrtf(var + 1e-5f);
+    if (ok) {
+        float *yp = y + (long long)b * y_bs + t;
+        for (int c = ty; c < C; c += 8) yp[(long long)c * y_cs] = (xp[(long long)c * x_cs] - mean) * inv * g[c] + bta[c];
+    }
+}
+
+// GroupNorm with one group per channel (= per-channel normalisation over time) + GELU, in place.
+__global__ __launch_bounds__(256) void groupnorm_gelu_kernel(float *x, const float *g, const float *bta, int T, int cs, long long bs)
+{
+    __shared__ float red[16];
+    const int c = blockIdx.x, b = blockIdx.y;
+    float *r = x + (long long)b * bs + (long long)c * cs;
+    float s = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) s += r[t];
+    const float mean = block_sum(s, red) / (float)T;
+    float v = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) { float d = r[t] - mean; v += d * d; }
+    const float var = block_sum(v, red) / (float)T;
+    const float inv = 1.0f / sqrtf(var + 1e-5f), gg = g[c], bb = bta[c];
+    for (int t = threadIdx.x; t < T; t += 256) r[t] = apply_act((r[t] - mean) * inv * gg + bb, ACT_GELU, 0.f);
+}
+
+// ------------------------------------------------------------------------------------
+// attention (fp32 VALU; T <= 256, head_dim <= 128).  K and V of one head live in LDS.
+// qkv: [B][3E][ld] (q rows 0..E, k rows E..2E, v rows 2E..3E), out: [B][E][ld]
+// Optional relative-position terms (synth TextEncoder): rel_k/rel_v [2*window+1][hd]
+// ------------------------------------------------------------------------------------
+struct AttnP {
+    const float *qkv; float *out;
+    int E, T, heads, cs; long long bs;
+    int o_cs; long long o_bs;
+    float scale;
+    const float *rel_k, *rel_v; int window;
+};
+
+__global__ __launch_bounds__(256) void attention_kernel(AttnP p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int hd = p.E / p.heads, T = p.T, Tp = T | 1;
+    float *Ks = smem;                    // [hd][Tp]
+    float *Vs = Ks + hd * Tp;            // [hd][Tp]
+    float *Ps = Vs + hd * Tp;            // [4 waves][Tp]
+    float *Qs = Ps + 4 * Tp;             // [4 waves][hd]
+    const float *base = p.qkv + (long long)b * p.bs;
+    for (int i = threadIdx.x; i < hd * T; i += 256) {
+        int d = i / T, t = i - d * T;
+        Ks[d * Tp + t] = base[(long long)(p.E + h * hd + d) * p.cs + t];
+        Vs[d * Tp + t] = base[(long long)(2 * p.E + h * hd + d) * p.cs + t];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *P = Ps + wave * Tp, *Q = Qs + wave * hd;
+    const int W = p.window;
+    for (int t1 = wave; t1 < T; t1 += 4) {
+        for (int d = lane; d < hd; d += 64) Q[d] = base[(long long)(h * hd + d) * p.cs + t1] * p.scale;
+        __builtin_amdgcn_wave_barrier();
+        float mx = -INFINITY;
+        for (int t2 = lane; t2 < T; t2 += 64) {
+            float a = 0.f;
+            for (int d = 0; d < hd; d++) a += Q[d] * Ks[d * Tp + t2];
+            if (p.rel_k) {
+                int r = t2 - t1;
+                if (r >= -W && r <= W) { float ra = 0.f; const float *rk = p.rel_k + (r + W) * hd; for (int d = 0; d < hd; d++) ra += Q[d] * rk[d]; a += ra; }
+            }
+            P[t2] = a;
+            mx = fmaxf(mx, a);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int t2 = lane; t2 < T; t2 += 64) { float e = expf(P[t2] - mx); P[t2] = e; sum += e; }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        __builtin_amdgcn_wave_barrier();
+        for (int d = lane; d < hd; d += 64) {
+            float a = 0.f;
+            if (p.rel_v) {
+                // oracle order: normalised probabilities, P.V first, then the relative-value term
+                for (int t2 = 0; t2 < T; t2++) a += (P[t2] * inv) * Vs[d * Tp + t2];
+                int lo = t1 - W < 0 ? 0 : t1 - W, hi = t1 + W >= T ? T - 1 : t1 + W;
+                for (int t2 = lo; t2 <= hi; t2++) a += (P[t2] * inv) * p.rel_v[(t2 - t1 + W) * hd + d];
+                p.out[(long long)b * p.o_bs + (long long)(h * hd + d) * p.o_cs + t1] = a;
+            } else {
+                for (int t2 = 0; t2 < T; t2++) a += P[t2] * Vs[d * Tp + t2];
+                p.out[(long long)b * p.o_bs + (long long)(h * hd + d) * p.o_cs + t1] = a * inv;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// RMVPE head: bidirectional GRU recurrence (input projections come from the implicit GEMM)
+// gi: [B][2*3H][ld] (forward gates rows 0..3H, backward rows 3H..6H; biases b_ih included)
+// whhT: [2][H][3H] (transposed so lanes read consecutive rows), bhh: [2][3H]
+// out: [B][2H][ld] (forward h rows 0..H, backward rows H..2H)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void gru_kernel(const float *gi, int gi_cs, long long gi_bs, const float *whhT, const float *bhh,
+                                                   float *out, int o_cs, long long o_bs, int H, int Tm)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *hs = smem;          // [H]
+    float *gh = smem + H;      // [3H]
+    const int dir = blockIdx.x, b = blockIdx.y, r = threadIdx.x;
+    const float *gib = gi + (long long)b * gi_bs + (long long)dir * 3 * H * gi_cs;
+    const float *wt = whhT + (long long)dir * H * 3 * H;
+    const float *bh = bhh + dir * 3 * H;
+    float *ob = out + (long long)b * o_bs + (long long)dir * H * o_cs;
+    if (r < H) hs[r] = 0.f;
+    __syncthreads();
+    for (int step = 0; step < Tm; step++) {
+        const int t = dir == 0 ? step : Tm - 1 - step;
+        if (r < 3 * H) {
+            float a = bh[r];
+            for (int j = 0; j < H; j++) a += wt[(long long)j * 3 * H + r] * hs[j];
+            gh[r] = a;
+        }
+        __syncthreads();
+        if (r < H) {
+            float ir = gib[(long long)r * gi_cs + t], iz = gib[(long long)(H + r) * gi_cs + t], in_ = gib[(long long)(2 * H + r) * gi_cs + t];
+            float rg = 1.0f / (1.0f + expf(-(ir + gh[r])));
+            float zg = 1.0f / (1.0f + expf(-(iz + gh[H + r])));
+            float ng = tanhf(in_ + rg * gh[2 * H + r]);
+            float hn = (1.f - zg) * ng + zg * hs[r];
+            hs[r] = hn;
+            ob[(long long)r * o_cs + t] = hn;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// per-stream state + per-call parameters
+// ------------------------------------------------------------------------------------
+struct CallParams {
+    float uppower;          // 2^(pitch_shift / 12) with truncating division (rvc.rs:121)
+    uint32_t seed;
+    uint32_t chunk_base;    // chunk counter of stream 0 is chunk[b] (kept per stream on device)
+    int pad_;
+};
+struct StreamState {        // one per stream
+    float cache_pitchf[1024];   // rvc.rs:42
+    uint32_t chunk;
+    uint32_t stream_id;
+    int status;             // 0 ok, 6 = the reference would have panicked (rmvpe.rs:124 out-of-bounds)
+    int pad_;
+};
+
+// RMVPE decode (rmvpe.rs:118-133, 243-248) + pitch shift (rvc.rs:121-122) + pitch cache update and
+// slice (rvc.rs:167-179) + get_f0_post (f0/mod.rs:7-12).  One workgroup per stream.
+struct PitchP {
+    const float *sal; int sal_cs; long long sal_bs;   // salience [B][360][ld] (channel-major)
+    int Tm;
+    StreamState *st; const CallParams *cp;
+    float *f0;            // [B][Tm] (shifted f0, tap)
+    float *pitchf;        // [B][R]
+    int *pitch;           // [B][R]
+    int shift, cache_start, read_start, R;
+    float threshold;
+    int update;           // 0: decode only (RvcInfer::pitch, rvc.rs:111-131), 1: also update + slice the cache (infer)
+};
+
+__global__ __launch_bounds__(1024) void pitch_post_kernel(PitchP p)
+{
+    __shared__ float f0s[1024];
+    __shared__ float cache[1024];
+    const int b = blockIdx.x, t = threadIdx.x;
+    StreamState *st = p.st + b;
+    const float up = p.cp->uppower;
+    if (t < p.Tm) {
+        const float *col = p.sal + (long long)b * p.sal_bs + t;
+        // argmax over the zero-padded row (368): first strictly greater wins; padded[0] = 0
+        int start = 0; float best = 0.f, mx = -INFINITY;
+        for (int i = 0; i < 360; i++) { float v = col[(long long)i * p.sal_cs]; if (v > best) { best = v; start = i + 4; } mx = fmaxf(mx, v); }
+        float hz = 0.f;
+        if (start + 8 >= 360) { st->status = 6; }
+        else {
+            float ps = 0.f, ws = 0.f;
+            for (int y = 0; y < 9; y++) { float s = col[(long long)(start + y) * p.sal_cs]; float cm = ((float)(start + y) - 4.f) * 20.f + 1997.3794084376191f; ps += s * cm; ws += s; }
+            float cents = ps / ws;
+            if (!(mx > p.threshold)) cents = 0.f;
+            hz = 10.0f * powf(2.0f, cents / 1200.0f);
+            if (hz == 10.0f) hz = 0.f;
+        }
+        hz *= up;
+        f0s[t] = hz;
+        p.f0[(long long)b * p.Tm + t] = hz;
+    }
+    if (!p.update) return;
+    cache[t] = st->cache_pitchf[t];
+    __syncthreads();
+    // copy_within(shift.., 0): cache[i] = cache[i+shift] for i < 1024-shift (tail keeps old values)
+    float v = (t + p.shift < 1024) ? cache[t + p.shift] : cache[t];
+    // cache[cache_start..] = pitchf[3..len-1]
+    if (t >= p.cache_start) v = f0s[3 + (t - p.cache_start)];
+    __syncthreads();
+    cache[t] = v;
+    st->cache_pitchf[t] = v;
+    __syncthreads();
+    if (t < p.R) {
+        float f = cache[p.read_start + t];
+        p.pitchf[(long long)b * p.R + t] = f;
+        const float mel_min = logf(50.0f / 700.0f + 1.f) * 1127.f, mel_max = logf(500.0f / 700.0f + 1.f) * 1127.f;
+        float x = logf(f / 700.0f + 1.f) * 1127.f;
+        if (!(x <= 0.f)) x = (x - mel_min) * 254.f / (mel_max - mel_min) + 1.f;
+        x = fminf(fmaxf(x, 1.f), 255.f);
+        p.pitch[(long long)b * p.R + t] = (int)roundf(x);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// small glue kernels
+// ------------------------------------------------------------------------------------
+// phone[c][r] = feats[min((skip_head + r) / 2, T - 1)][c]   (rvc.rs:99-109 + 155; Q2, Q8)
+__global__ void gather_phone_kernel(const float *cv, int cv_cs, long long cv_bs, int C, int T, int skip_head, int R,
+                                    float *phone, int ph_cs, long long ph_bs)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= C * R) return;
+    int c = i / R, r = i - c * R;
+    int s = (skip_head + r) / 2; s = s < T - 1 ? s : T - 1;
+    phone[(long long)b * ph_bs + (long long)c * ph_cs + r] = cv[(long long)b * cv_bs + (long long)c * cv_cs + s];
+}
+
+// (1, 2T+1, C) output of RvcInfer::extract_feature (rvc.rs:99-109), contiguous
+__global__ void extract_feature_kernel(const float *cv, int cv_cs, int C, int T, float *out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int T2 = 2 * T + 1;
+    if (i >= T2 * C) return;
+    int k = i / C, c = i - k * C;
+    int s = k / 2; s = s < T - 1 ? s : T - 1;
+    out[i] = cv[(long long)c * cv_cs + s];
+}
+
+// TextEncoder front: x = lrelu((lin + emb_pitch[pitch]) * sqrt(H), 0.1), in place on lin [B][H][ld]
+__global__ void embed_pitch_kernel(float *x, int cs, long long bs, const float *emb, const int *pitch, int H, int R, float sq)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= H * R) return;
+    int c = i / R, t = i - c * R;
+    float *xp = x + (long long)b * bs + (long long)c * cs + t;
+    float a = *xp + emb[(long long)pitch[(long long)b * R + t] * H + c];
+    a *= sq;
+    *xp = a > 0.f ? a : a * 0.1f;
+}
+
+// Philox4x32-10, the same counter layout as oracle/rvc_oracle.c (ora_philox_normal)
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ void philox_normal4(uint32_t seed, uint32_t stream, uint32_t chunk, uint32_t purpose, uint32_t blk, float z[4])
+{
+    uint32_t c[4] = {blk, 0u, chunk, purpose};
+    philox4x32_10(c, seed, stream);
+    float r0 = sqrtf(-2.0f * logf(u01(c[0]))), a0 = 6.28318530717958647692f * u01(c[1]);
+    float r1 = sqrtf(-2.0f * logf(u01(c[2]))), a1 = 6.28318530717958647692f * u01(c[3]);
+    z[0] = r0 * cosf(a0); z[1] = r0 * sinf(a0); z[2] = r1 * cosf(a1); z[3] = r1 * sinf(a1);
+}
+
+// z_p = m + exp(logs) * eps * 0.66666 ; stats [B][2I][ld] -> z [B][I][ld]; eps index = c*T + t
+__global__ void prior_sample_kernel(const float *stats, int s_cs, long long s_bs, float *z, int z_cs, long long z_bs, int I, int T,
+                                    const StreamState *st, const CallParams *cp)
+{
+    int blk = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    int total = I * T;
+    if (blk * 4 >= total) return;
+    float n4[4];
+    philox_normal4(cp->seed, st[b].stream_id, st[b].chunk, 0u, (uint32_t)blk, n4);
+    for (int j = 0; j < 4; j++) {
+        int i = blk * 4 + j;
+        if (i >= total) break;
+        int c = i / T, t = i - c * T;
+        float m = stats[(long long)b * s_bs + (long long)c * s_cs + t], lg = stats[(long long)b * s_bs + (long long)(I + c) * s_cs + t];
+        z[(long long)b * z_bs + (long long)c * z_cs + t] = m + expf(lg) * n4[j] * 0.66666f;
+    }
+}
+
+// channel flip (Flip flow): y[c] = x[C-1-c]
+__global__ void flip_channels_kernel(const float *x, float *y, int C, int T, int cs, long long bs)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= C * T) return;
+    int c = i / T, t = i - c * T;
+    y[(long long)b * bs + (long long)c * cs + t] = x[(long long)b * bs + (long long)(C - 1 - c) * cs + t];
+}
+
+// WaveNet gate: acts[c] = tanh(a[c]) * sigmoid(a[H + c])   (conditioning already folded into the conv bias)
+__global__ void gate_kernel(const float *a, int a_cs, long long a_bs, float *y, int y_cs, long long y_bs, int H, int T)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= H * T) return;
+    int c = i / T, t = i - c * T;
+    float ta = a[(long long)b * a_bs + (long long)c * a_cs + t], sa = a[(long long)b * a_bs + (long long)(H + c) * a_cs + t];
+    y[(long long)b * y_bs + (long long)c * y_cs + t] = tanhf(ta) * (1.0f / (1.0f + expf(-sa)));
+}
+
+// AvgPool2d(2,2): x [B][C][H(+2)][ld] -> y [B][C][H/2(+2)][ld2]
+__global__ void avgpool2_kernel(const float *x, int x_ld, int x_cs, long long x_bs, float *y, int y_ld, int y_cs, long long y_bs, int C, int H2, int W2)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= C * H2 * W2) return;
+    int c = i / (H2 * W2), r = i - c * H2 * W2, h = r / W2, w = r - h * W2;
+    const float *s = x + (long long)b * x_bs + (long long)c * x_cs + (long long)(2 * h) * x_ld + 2 * w;
+    y[(long long)b * y_bs + (long long)c * y_cs + (long long)h * y_ld + w] = (s[0] + s[1] + s[x_ld] + s[x_ld + 1]) * 0.25f;
+}
+
+// (3, Tm, n_mels) conv output image -> GRU input [B][3*n_mels][ld]: feat[c*n_mels + m][t] = img[c][t][m]
+__global__ void gru_input_kernel(const float *img, int i_ld, int i_cs, long long i_bs, float *feat, int f_cs, long long f_bs, int Tm, int n_mels)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= 3 * n_mels * Tm) return;
+    int row = i / Tm, t = i - row * Tm, c = row / n_mels, m = row - c * n_mels;
+    feat[(long long)b * f_bs + (long long)row * f_cs + t] = img[(long long)b * i_bs + (long long)c * i_cs + (long long)t * i_ld + m];
+}
+
+// ------------------------------------------------------------------------------------
+// NSF harmonic source (SineGen, harmonic_num = 0, + Linear(1,1) + tanh).  One workgroup of
+// 1024 threads per stream; the sample-rate phase cumsum is a block prefix scan.
+// ------------------------------------------------------------------------------------
+struct SrcP {
+    const float *pitchf;   // [B][T]
+    float *src;            // [B][1][ld] interior pointer
+    long long src_bs;
+    int T, upp; float sr;
+    float lin_w, lin_b;
+    const StreamState *st; const CallParams *cp;
+};
+
+__global__ __launch_bounds__(1024) void nsf_source_kernel(SrcP p)
+{
+    __shared__ float rad[512], cum[512];
+    __shared__ float part[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int T = p.T, upp = p.upp;
+    const long long N = (long long)T * upp;
+    const float *f0 = p.pitchf + (long long)b * T;
+    if (tid == 0) {
+        float c = 0.f;
+        for (int t = 0; t < T; t++) { float r = fmodf(f0[t] / p.sr, 1.0f); rad[t] = r; c += r; cum[t] = c * (float)upp; }
+    }
+    __syncthreads();
+    // each thread owns a contiguous segment whose length is a multiple of 4 (one Philox block = 4 samples)
+    long long seg = ((N + 1023) / 1024 + 3) / 4 * 4;
+    long long i0 = (long long)tid * seg, i1 = i0 + seg < N ? i0 + seg : N;
+    auto interp = [&](long long i) -> float {
+        float pos = (N > 1) ? (float)i * (float)(T - 1) / (float)(N - 1) : 0.f;
+        int j0 = (int)floorf(pos); if (j0 > T - 1) j0 = T - 1; int j1 = j0 + 1 < T ? j0 + 1 : T - 1;
+        float w = pos - (float)j0;
+        float v = cum[j0] * (1.0f - w) + cum[j1] * w;
+        return fmodf(v, 1.0f);
+    };
+    float local = 0.f;
+    if (i0 < N) {
+        float prev = i0 > 0 ? interp(i0 - 1) : 0.f;
+        for (long long i = i0; i < i1; i++) {
+            float cur = interp(i);
+            float shift = (i > 0 && (cur - prev) < 0.f) ? -1.0f : 0.f;
+            local += rad[(int)(i / upp)] + shift;
+            prev = cur;
+        }
+    }
+    part[tid] = local;
+    __syncthreads();
+    // inclusive scan over the 1024 partial sums (Hillis-Steele)
+    for (int o = 1; o < 1024; o <<= 1) {
+        float v = tid >= o ? part[tid - o] : 0.f;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    if (i0 < N) {
+        float phase = tid > 0 ? part[tid - 1] : 0.f;
+        float prev = i0 > 0 ? interp(i0 - 1) : 0.f;
+        float *out = p.src + (long long)b * p.src_bs;
+        const uint32_t seed = p.cp->seed, sid = p.st[b].stream_id, chunk = p.st[b].chunk;
+        float nz[4];
+        for (long long i = i0; i < i1; i++) {
+            if (((i - i0) & 3) == 0) philox_normal4(seed, sid, chunk, 1u, (uint32_t)(i >> 2), nz);
+            float cur = interp(i);
+            float shift = (i > 0 && (cur - prev) < 0.f) ? -1.0f : 0.f;
+            int t = (int)(i / upp);
+            phase += rad[t] + shift;
+            prev = cur;
+            float sine = sinf(phase * 6.28318530717958647692f) * 0.1f;
+            float uv = f0[t] > 0.f ? 1.f : 0.f;
+            float namp = uv * 0.003f + (1.f - uv) * 0.1f / 3.f;
+            float sw = sine * uv + namp * nz[(i - i0) & 3];
+            out[i] = tanhf(p.lin_w * sw + p.lin_b);
+        }
+    }
+}
+
+// bump the per-stream chunk counters after a call
+__global__ void advance_chunk_kernel(StreamState *st, int B)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) st[b].chunk += 1;
+}
+
+// ------------------------------------------------------------------------------------
+// flat-L2 retrieval (rvc.rs:159 is a TODO; definition in SURVEY.md Appendix A.4).
+// Stage 1: every thread owns one index vector (transposed index [dim][n] -> coalesced) and
+// accumulates exact sequential-fmaf distances to all queries of its stream; each workgroup
+// keeps its own top-4 per query.  Stage 2 merges the per-workgroup candidates
+// (ascending (distance, index)), forms w = (1/d)^2 and blends.
+// ------------------------------------------------------------------------------------
+#define KNN_K 4
+#define KNN_MAXQ 16
+struct KnnP {
+    const float *indexT;     // [dim][n]
+    const float *index;      // [n][dim]
+    int n, dim;
+    const float *q;          // unique queries, stream stride q_bs
+    long long q_bs, cand_bs;
+    int nq;
+    float *cand_d; int *cand_i;   // [B][nq][nblk][K]
+    int nblk;
+};
+
+__global__ __launch_bounds__(256) void knn_scan_kernel(KnnP p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // queries [nq][dim]
+    __shared__ float bd[KNN_MAXQ][4][KNN_K];
+    __shared__ int bi[KNN_MAXQ][4][KNN_K];
+    const int b = blockIdx.y;
+    const float *q = p.q + (long long)b * p.q_bs;
+    for (int i = threadIdx.x; i < p.nq * p.dim; i += 256) smem[i] = q[i];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float acc[KNN_MAXQ];
+#pragma unroll
+    for (int j = 0; j < KNN_MAXQ; j++) acc[j] = 0.f;
+    if (i < p.n) {
+        for (int d = 0; d < p.dim; d++) {
+            float v = p.indexT[(long long)d * p.n + i];
+#pragma unroll
+            for (int j = 0; j < KNN_MAXQ; j++) if (j < p.nq) { float df = smem[j * p.dim + d] - v; acc[j] = fmaf(df, df, acc[j]); }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // per query: wave-level top-4 by repeated argmin over (distance, index)
+    for (int j = 0; j < p.nq; j++) {
+        float d = i < p.n ? acc[j] : INFINITY; int id = i < p.n ? i : 0x7fffffff;
+        for (int k = 0; k < KNN_K; k++) {
+            float md = d; int mi = id;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                float od = __shfl_xor(md, o, 64); int oi = __shfl_xor(mi, o, 64);
+                if (od < md || (od == md && oi < mi)) { md = od; mi = oi; }
+            }
+            if (lane == 0) { bd[j][wave][k] = md; bi[j][wave][k] = mi; }
+            if (id == mi) { d = INFINITY; id = 0x7fffffff; }
+        }
+    }
+    __syncthreads();
+    // merge the 4 waves' lists: thread j (< nq) does a tiny selection
+    if (threadIdx.x < p.nq) {
+        const int j = threadIdx.x;
+        int pos[4] = {0, 0, 0, 0};
+        for (int k = 0; k < KNN_K; k++) {
+            float md = INFINITY; int mi = 0x7fffffff, mw = 0;
+            for (int w = 0; w < 4; w++) if (pos[w] < KNN_K) {
+                float od = bd[j][w][pos[w]]; int oi = bi[j][w][pos[w]];
+                if (od < md || (od == md && oi < mi)) { md = od; mi = oi; mw = w; }
+            }
+            pos[mw]++;
+            long long o = (long long)b * p.cand_bs + ((long long)j * p.nblk + blockIdx.x) * KNN_K + k;
+            p.cand_d[o] = md; p.cand_i[o] = mi;
+        }
+    }
+}
+
+struct KnnBlendP {
+    const float *cand_d; const int *cand_i; int nblk, nq;
+    const float *index; int dim;
+    const float *q;        // unique queries [B][nq][dim]
+    int skip_head, T, R, first_raw;   // sliced frame r uses unique query min((skip_head+r)/2, T-1) - first_raw
+    float rate;
+    float *phone; int ph_cs; long long ph_bs;
+    int *out_idx; float *out_dist;   // [B][R][K]
+};
+
+// one workgroup per (unique query, stream): merge candidates, then blend every sliced frame that maps to it
+__global__ __launch_bounds__(256) void knn_merge_blend_kernel(KnnBlendP p)
+{
+    __shared__ float sd[KNN_K]; __shared__ int si[KNN_K];
+    __shared__ float wd[4][KNN_K]; __shared__ int wi[4][KNN_K];
+    const int j = blockIdx.x, b = blockIdx.y;
+    const long long base = ((long long)b * p.nq + j) * p.nblk * KNN_K;
+    const int total = p.nblk * KNN_K;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // each thread keeps a sorted local top-4 of its strided candidates
+    float ld[KNN_K]; int li[KNN_K];
+    for (int k = 0; k < KNN_K; k++) { ld[k] = INFINITY; li[k] = 0x7fffffff; }
+    for (int c = threadIdx.x; c < total; c += 256) {
+        float d = p.cand_d[base + c]; int id = p.cand_i[base + c];
+        if (d < ld[KNN_K - 1] || (d == ld[KNN_K - 1] && id < li[KNN_K - 1])) {
+            int q = KNN_K - 1;
+            while (q > 0 && (d < ld[q - 1] || (d == ld[q - 1] && id < li[q - 1]))) { ld[q] = ld[q - 1]; li[q] = li[q - 1]; q--; }
+            ld[q] = d; li[q] = id;
+        }
+    }
+    int pos = 0;
+    for (int k = 0; k < KNN_K; k++) {
+        float md = pos < KNN_K ? ld[pos] : INFINITY; int mi = pos < KNN_K ? li[pos] : 0x7fffffff;
+        float d0 = md; int i0 = mi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float od = __shfl_xor(md, o, 64); int oi = __shfl_xor(mi, o, 64);
+            if (od < md || (od == md && oi < mi)) { md = od; mi = oi; }
+        }
+        if (d0 == md && i0 == mi && mi != 0x7fffffff) pos++;
+        if (lane == 0) { wd[wave][k] = md; wi[wave][k] = mi; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ps[4] = {0, 0, 0, 0};
+        for (int k = 0; k < KNN_K; k++) {
+            float md = INFINITY; int mi = 0x7fffffff, mw = 0;
+            for (int w = 0; w < 4; w++) if (ps[w] < KNN_K) {
+                float od = wd[w][ps[w]]; int oi = wi[w][ps[w]];
+                if (od < md || (od == md && oi < mi)) { md = od; mi = oi; mw = w; }
+            }
+            ps[mw]++;
+            sd[k] = md; si[k] = mi;
+        }
+    }
+    __syncthreads();
+    float w[KNN_K], ws = 0.f;
+    for (int k = 0; k < KNN_K; k++) { float inv = 1.0f / sd[k]; w[k] = inv * inv; ws += w[k]; }
+    const float *qv = p.q + ((long long)b * p.nq + j) * p.dim;
+    for (int r = 0; r < p.R; r++) {
+        int s = (p.skip_head + r) / 2; s = s < p.T - 1 ? s : p.T - 1;
+        if (s - p.first_raw != j) continue;
+        if (threadIdx.x < KNN_K) {
+            p.out_idx[((long long)b * p.R + r) * KNN_K + threadIdx.x] = si[threadIdx.x];
+            p.out_dist[((long long)b * p.R + r) * KNN_K + threadIdx.x] = sd[threadIdx.x];
+        }
+        for (int c = threadIdx.x; c < p.dim; c += 256) {
+            float acc = 0.f;
+            for (int k = 0; k < KNN_K; k++) acc += (w[k] / ws) * p.index[(long long)si[k] * p.dim + c];
+            p.phone[(long long)b * p.ph_bs + (long long)c * p.ph_cs + r] = p.rate * acc + (1.0f - p.rate) * qv[c];
+        }
+    }
+}
+
+// unique query rows for retrieval: q[j][c] = cv[c][first_raw + j]
+__global__ void knn_queries_kernel(const float *cv, int cv_cs, long long cv_bs, int C, int first_raw, int nq, float *q)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= nq * C) return;
+    int j = i / C, c = i - j * C;
+    q[(long long)b * nq * C + i] = cv[(long long)b * cv_bs + (long long)c * cv_cs + first_raw + j];
+}
+
+}  // namespace rvc

@@ -1,0 +1,177 @@
+"""Python mirror of the reference's `rvc` crate API (rvc/src/lib.rs:5, rvc/src/rvc.rs:18-220) on top of
+the C ABI (include/rvc_mi355x.h).  Same method names, argument meaning and error behaviour as
+`rvc::RvcInfer`; numpy arrays stand in for ndarray views.  All compute happens in the HIP library."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _native
+from .rvc_common import PitchAlgorithm, RvcInferError, RvcModelVersion
+
+_FP = C.POINTER(C.c_float)
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_FP)
+
+
+class RvcInfer:
+    def __init__(self, data_path, device: int = -1):
+        """RvcInfer::new (rvc.rs:30-44)."""
+        self._L = _native.lib()
+        h = C.c_void_p()
+        rc = self._L.rvc_create(os.fspath(data_path).encode(), int(device), C.byref(h))
+        if rc != 0:
+            raise RvcInferError(rc, "rvc_create failed (no HIP device?)")
+        self._h = h
+        self.n_streams = 1
+
+    # -- lifetime -----------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rvc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RvcInferError(rc, (self._L.rvc_last_error_message(self._h) or b"").decode())
+
+    # -- loading (rvc.rs:46-79) -------------------------------------------------------------
+    def load_contentvec(self, model_version=RvcModelVersion.V2):
+        self._chk(self._L.rvc_load_contentvec(self._h, int(RvcModelVersion.from_value(model_version))))
+
+    def load_model(self, model_path):
+        self._chk(self._L.rvc_load_model(self._h, os.fspath(model_path).encode()))
+
+    def load_f0(self, pitch_algorithm=PitchAlgorithm.Rmvpe):
+        self._chk(self._L.rvc_load_f0(self._h, int(PitchAlgorithm.from_value(pitch_algorithm))))
+
+    def unload_model(self):
+        self._L.rvc_unload_model(self._h)
+
+    # -- per-chunk API (rvc.rs:81-220) ----------------------------------------------------
+    def hubert(self, input):
+        """-> (1, C, T) float32 (rvc.rs:81-97)."""
+        x, xp = _f32(input)
+        dims = (C.c_size_t * 3)()
+        cap = 1024 * (len(x) // 320 + 8)
+        out = np.empty(cap, np.float32)
+        self._chk(self._L.rvc_hubert(self._h, xp, len(x), out.ctypes.data_as(_FP), cap, dims))
+        return out[: dims[0] * dims[1] * dims[2]].reshape(dims[0], dims[1], dims[2]).copy()
+
+    def extract_feature(self, input):
+        """-> (1, 2T+1, C) float32 (rvc.rs:99-109)."""
+        x, xp = _f32(input)
+        dims = (C.c_size_t * 3)()
+        cap = 1024 * (2 * (len(x) // 320) + 16)
+        out = np.empty(cap, np.float32)
+        self._chk(self._L.rvc_extract_feature(self._h, xp, len(x), out.ctypes.data_as(_FP), cap, dims))
+        return out[: dims[0] * dims[1] * dims[2]].reshape(dims[0], dims[1], dims[2]).copy()
+
+    def pitch(self, input, pitch_shift: int, sample_frame_16k_size: int):
+        """-> f0 in Hz, one value per RMVPE frame (rvc.rs:111-131)."""
+        x, xp = _f32(input)
+        n = C.c_size_t()
+        out = np.empty(4096, np.float32)
+        self._chk(self._L.rvc_pitch(self._h, xp, len(x), int(pitch_shift), int(sample_frame_16k_size), out.ctypes.data_as(_FP), 4096, C.byref(n)))
+        return out[: n.value].copy()
+
+    def infer(self, input, sample_frame_16k_size: int, pitch_shift, skip_head: int, return_length: int):
+        """-> float PCM at the model rate (rvc.rs:133-220).  pitch_shift=None mirrors Option::None."""
+        x, xp = _f32(input)
+        n = C.c_size_t()
+        cap = int(return_length) * 1024 + 16
+        out = np.empty(cap, np.float32)
+        self._chk(self._L.rvc_infer(self._h, xp, len(x), int(sample_frame_16k_size), 0 if pitch_shift is None else 1, int(pitch_shift or 0),
+                                    int(skip_head), int(return_length), out.ctypes.data_as(_FP), cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    # -- extensions ---------------------------------------------------------------------
+    def load_index(self, vectors):
+        v, vp = _f32(vectors)
+        self._chk(self._L.rvc_load_index(self._h, vp, v.shape[0], v.shape[1]))
+
+    def set_index_rate(self, rate: float):
+        self._L.rvc_set_index_rate(self._h, float(rate))
+
+    def knn(self, rows_cap: int = 4096):
+        idx = np.empty((rows_cap, 4), np.int32)
+        dist = np.empty((rows_cap, 4), np.float32)
+        rows = C.c_size_t()
+        self._chk(self._L.rvc_get_knn(self._h, idx.ctypes.data_as(C.POINTER(C.c_int32)), dist.ctypes.data_as(_FP), rows_cap, C.byref(rows)))
+        return idx[: rows.value].copy(), dist[: rows.value].copy()
+
+    def set_noise_seed(self, seed: int, stream_id: int = 0):
+        self._L.rvc_set_noise_seed(self._h, int(seed), int(stream_id))
+
+    def reset_state(self):
+        self._L.rvc_reset_state(self._h)
+
+    def set_streams(self, n: int):
+        self._chk(self._L.rvc_set_streams(self._h, int(n)))
+        self.n_streams = int(n)
+
+    def infer_batch(self, inputs, sample_frame_16k_size: int, pitch_shift: int, skip_head: int, return_length: int):
+        """inputs (n_streams, n) -> (n_streams, N)."""
+        x, xp = _f32(inputs)
+        assert x.ndim == 2 and x.shape[0] == self.n_streams
+        n = C.c_size_t()
+        cap = int(return_length) * 1024 + 16
+        out = np.empty((self.n_streams, cap), np.float32)
+        self._chk(self._L.rvc_infer_batch(self._h, xp, x.shape[1], int(sample_frame_16k_size), int(pitch_shift), int(skip_head),
+                                          int(return_length), out.ctypes.data_as(_FP), cap, C.byref(n)))
+        return out[:, : n.value].copy()
+
+    def infer_device(self, d_in_ptr: int, n: int, sample_frame_16k_size: int, pitch_shift: int, skip_head: int, return_length: int,
+                     d_out_ptr: int, cap_per_stream: int, sync: bool = False) -> int:
+        nn = C.c_size_t()
+        self._chk(self._L.rvc_infer_device(self._h, C.c_void_p(d_in_ptr), int(n), int(sample_frame_16k_size), int(pitch_shift), int(skip_head),
+                                           int(return_length), C.c_void_p(d_out_ptr), int(cap_per_stream), C.byref(nn), 1 if sync else 0))
+        return nn.value
+
+    def synchronize(self):
+        self._chk(self._L.rvc_synchronize(self._h))
+
+    def set_use_graph(self, on: bool = True):
+        self._L.rvc_set_use_graph(self._h, 1 if on else 0)
+
+    def set_profile(self, on: bool = True):
+        self._L.rvc_set_profile(self._h, 1 if on else 0)
+
+    def last_gpu_ms(self) -> float:
+        return float(self._L.rvc_last_gpu_ms(self._h))
+
+    def profile_last(self):
+        n, ms, fl = C.c_int(), C.c_double(), C.c_double()
+        self._chk(self._L.rvc_profile_last(self._h, C.byref(n), C.byref(ms), C.byref(fl)))
+        return n.value, ms.value, fl.value
+
+    def enable_taps(self, on: bool = True):
+        self._L.rvc_enable_taps(self._h, 1 if on else 0)
+
+    def tap(self, name: str):
+        n = C.c_size_t()
+        cap = 1 << 24
+        out = np.empty(cap, np.float32)
+        self._chk(self._L.rvc_get_tap(self._h, name.encode(), out.ctypes.data_as(_FP), cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def pitch_cache(self, stream: int = 0):
+        out = np.zeros(1024, np.float32)
+        self._L.rvc_get_pitch_cache(self._h, int(stream), out.ctypes.data_as(_FP))
+        return out
+
+    def index_device_ptr(self):
+        b = C.c_size_t()
+        p = self._L.rvc_index_device_ptr(self._h, C.byref(b))
+        return p, b.value

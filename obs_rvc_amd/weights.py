@@ -1,0 +1,356 @@
+"""Native weight-blob format ("RVCW") and the seeded synthetic model zoo.
+
+The reference loads three opaque ONNX graphs by file name
+(/root/reference/rvc/src/models.rs:48-76, rvc/src/rvc.rs:46-75).  None of those files
+exist in the reference tree, so this build defines an inference-ready blob format that the
+MI355X engine (csrc/engine.hip) and the CPU oracle (oracle/rvc_oracle.c) both read, plus
+seeded generators that emit weights of the public upstream architectures (SURVEY.md
+Appendix A).  Normalisation layers that the ONNX exporter would fold (BatchNorm,
+weight-norm) are already folded here.
+
+File layout (little endian):
+    char[8]  magic "RVCW0001"
+    u32 n_cfg, u32 n_tensors, u64 data_offset
+    n_cfg     x { char name[48]; f64 value }
+    n_tensors x { char name[96]; u32 ndim; u32 dims[5]; u64 byte_offset; u64 nelem }
+    (pad to data_offset, a multiple of 256)  f32 data, every tensor 64-byte aligned
+"""
+from __future__ import annotations
+
+import os
+import struct
+from typing import Dict, Tuple
+
+import numpy as np
+
+MAGIC = b"RVCW0001"
+_CFG_FMT = "<48sd"
+_TEN_FMT = "<96sI5IQQ"
+
+
+def write_blob(path: str, cfg: Dict[str, float], tensors: Dict[str, np.ndarray]) -> None:
+    cfg_items = list(cfg.items())
+    ten_items = list(tensors.items())
+    head = 8 + 4 + 4 + 8
+    table = head + struct.calcsize(_CFG_FMT) * len(cfg_items) + struct.calcsize(_TEN_FMT) * len(ten_items)
+    data_offset = (table + 255) // 256 * 256
+    offs = []
+    cur = 0
+    for _, a in ten_items:
+        offs.append(cur)
+        cur += (a.size * 4 + 63) // 64 * 64
+    tmp = path + ".tmp%d" % os.getpid()
+    with open(tmp, "wb") as f:
+        f.write(MAGIC)
+        f.write(struct.pack("<IIQ", len(cfg_items), len(ten_items), data_offset))
+        for k, v in cfg_items:
+            f.write(struct.pack(_CFG_FMT, k.encode()[:47], float(v)))
+        for (k, a), o in zip(ten_items, offs):
+            assert a.ndim <= 5 and len(k) < 96, k
+            dims = list(a.shape) + [1] * (5 - a.ndim)
+            f.write(struct.pack(_TEN_FMT, k.encode(), a.ndim, *dims, o, a.size))
+        f.write(b"\0" * (data_offset - table))
+        for (_, a), o in zip(ten_items, offs):
+            b = np.ascontiguousarray(a, dtype="<f4").tobytes()
+            f.write(b)
+            f.write(b"\0" * ((len(b) + 63) // 64 * 64 - len(b)))
+    os.replace(tmp, path)
+
+
+def read_blob(path: str) -> Tuple[Dict[str, float], Dict[str, np.ndarray]]:
+    with open(path, "rb") as f:
+        raw = f.read()
+    assert raw[:8] == MAGIC, "not an RVCW blob: %s" % path
+    n_cfg, n_ten, data_offset = struct.unpack_from("<IIQ", raw, 8)
+    p = 24
+    cfg = {}
+    for _ in range(n_cfg):
+        name, val = struct.unpack_from(_CFG_FMT, raw, p)
+        p += struct.calcsize(_CFG_FMT)
+        cfg[name.split(b"\0")[0].decode()] = val
+    tensors = {}
+    for _ in range(n_ten):
+        rec = struct.unpack_from(_TEN_FMT, raw, p)
+        p += struct.calcsize(_TEN_FMT)
+        name = rec[0].split(b"\0")[0].decode()
+        ndim = rec[1]
+        dims = rec[2:2 + ndim]
+        off, nelem = rec[7], rec[8]
+        tensors[name] = np.frombuffer(raw, dtype="<f4", count=nelem, offset=data_offset + off).reshape(dims)
+    return cfg, tensors
+
+
+# --------------------------------------------------------------------------------------
+# Synthetic model zoo.  Every generator is a pure function of (config, seed).
+# --------------------------------------------------------------------------------------
+class _Gen:
+    def __init__(self, seed: int):
+        self.rng = np.random.Generator(np.random.PCG64(seed))
+        self.t: Dict[str, np.ndarray] = {}
+
+    def normal(self, name, shape, std):
+        a = self.rng.standard_normal(size=shape, dtype=np.float32) * np.float32(std)
+        self.t[name] = a
+        return a
+
+    def fan(self, name, shape, fan_in, gain=1.0):
+        return self.normal(name, shape, gain / np.sqrt(float(fan_in)))
+
+    def affine(self, prefix, n):
+        """LayerNorm / GroupNorm gain and bias."""
+        self.t[prefix + ".g"] = (1.0 + 0.1 * self.rng.standard_normal(size=(n,), dtype=np.float32)).astype(np.float32)
+        self.normal(prefix + ".b", (n,), 0.05)
+
+
+CONTENTVEC_PRESETS = {
+    # ContentVec / HuBERT-base: SURVEY.md Appendix A.1.  v2 = 768-d layer 12, v1 = 256-d
+    # layer 9 with final_proj (rvc-common/src/enums.rs:10-23).
+    "full": dict(conv_dim=512, embed=768, heads=12, ffn=3072, layers=12, pos_k=128, pos_groups=16),
+    "tiny": dict(conv_dim=32, embed=48, heads=4, ffn=96, layers=2, pos_k=16, pos_groups=4),
+}
+CV_CONV_K = (10, 3, 3, 3, 3, 2, 2)
+CV_CONV_S = (5, 2, 2, 2, 2, 2, 2)
+
+
+def make_contentvec(preset: str = "full", version: int = 2, seed: int = 1234):
+    p = dict(CONTENTVEC_PRESETS[preset])
+    if version == 1:
+        # v1: layer-9 output through final_proj to 256 (tiny: layer 1 -> 16)
+        p["run_layers"] = 9 if preset == "full" else 1
+        p["out_dim"] = 256 if preset == "full" else 16
+    else:
+        p["run_layers"] = p["layers"]
+        p["out_dim"] = p["embed"]
+    g = _Gen(seed)
+    C, E = p["conv_dim"], p["embed"]
+    cin = 1
+    for i, k in enumerate(CV_CONV_K):
+        g.fan("cv.conv%d.w" % i, (C, cin, k), cin * k, 1.0 if i == 0 else 1.6)
+        cin = C
+    g.affine("cv.gn", C)
+    g.affine("cv.ln0", C)
+    g.fan("cv.proj.w", (E, C), C)
+    g.normal("cv.proj.b", (E,), 0.05)
+    gs = E // p["pos_groups"]
+    g.fan("cv.pos.w", (E, gs, p["pos_k"]), gs * p["pos_k"])
+    g.normal("cv.pos.b", (E,), 0.05)
+    g.affine("cv.enc_ln", E)
+    for i in range(p["run_layers"]):
+        pre = "cv.l%d." % i
+        for n in "qkvo":
+            g.fan(pre + n + ".w", (E, E), E)
+            g.normal(pre + n + ".b", (E,), 0.05)
+        g.affine(pre + "ln1", E)
+        g.fan(pre + "ff1.w", (p["ffn"], E), E, 1.4)
+        g.normal(pre + "ff1.b", (p["ffn"],), 0.05)
+        g.fan(pre + "ff2.w", (E, p["ffn"]), p["ffn"])
+        g.normal(pre + "ff2.b", (E,), 0.05)
+        g.affine(pre + "ln2", E)
+    if p["out_dim"] != E:
+        g.fan("cv.final_proj.w", (p["out_dim"], E), E)
+        g.normal("cv.final_proj.b", (p["out_dim"],), 0.05)
+    cfg = dict(kind=1, n_conv=7, **p)
+    for i in range(7):
+        cfg["conv_k%d" % i] = CV_CONV_K[i]
+        cfg["conv_s%d" % i] = CV_CONV_S[i]
+    return cfg, g.t
+
+
+RMVPE_PRESETS = {
+    # E2E(n_blocks=4, n_gru=1, kernel=(2,2), en_de_layers=5, inter_layers=4, in=1, en_out=16)
+    "full": dict(en_out=16, levels=5, n_blocks=4, inter_layers=4, n_mels=128, gru_hidden=256, n_out=360),
+    "tiny": dict(en_out=4, levels=5, n_blocks=1, inter_layers=1, n_mels=128, gru_hidden=32, n_out=360),
+}
+
+
+def _conv_block_res(g: _Gen, pre: str, ci: int, co: int):
+    # Conv3x3(no bias)+BN+ReLU twice, BN folded into (w, b); 1x1 shortcut with bias when ci != co.
+    g.fan(pre + "c1.w", (co, ci, 3, 3), ci * 9, 1.4)
+    g.normal(pre + "c1.b", (co,), 0.05)
+    g.fan(pre + "c2.w", (co, co, 3, 3), co * 9, 0.45)
+    g.normal(pre + "c2.b", (co,), 0.05)
+    if ci != co:
+        g.fan(pre + "sc.w", (co, ci), ci, 1.0)
+        g.normal(pre + "sc.b", (co,), 0.05)
+
+
+def make_rmvpe(preset: str = "full", seed: int = 4321):
+    from scipy.ndimage import gaussian_filter1d
+
+    p = dict(RMVPE_PRESETS[preset])
+    g = _Gen(seed)
+    # input BatchNorm2d(1) folded to (scale, shift); log-mel is roughly in [-12, 2]
+    g.t["rm.bn0"] = np.array([0.25, 1.2], dtype=np.float32)
+    ci, co = 1, p["en_out"]
+    for lv in range(p["levels"]):
+        for j in range(p["n_blocks"]):
+            _conv_block_res(g, "rm.enc%d.b%d." % (lv, j), ci if j == 0 else co, co)
+        ci, co = co, co * 2
+    # after the loop ci = en_out * 2^(levels-1) (256), co = 512
+    enc_out = ci
+    for lv in range(p["inter_layers"]):
+        for j in range(p["n_blocks"]):
+            _conv_block_res(g, "rm.int%d.b%d." % (lv, j), (enc_out if lv == 0 else co) if j == 0 else co, co)
+    ci = co
+    for lv in range(p["levels"]):
+        co = ci // 2
+        g.fan("rm.dec%d.up.w" % lv, (ci, co, 3, 3), ci * 9 / 4.0, 1.4)  # ConvTranspose2d layout [Cin][Cout][3][3]
+        g.normal("rm.dec%d.up.b" % lv, (co,), 0.05)
+        for j in range(p["n_blocks"]):
+            _conv_block_res(g, "rm.dec%d.b%d." % (lv, j), co * 2 if j == 0 else co, co)
+        ci = co
+    g.fan("rm.cnn.w", (3, p["en_out"], 3, 3), p["en_out"] * 9, 0.5)
+    g.normal("rm.cnn.b", (3,), 0.05)
+    H, I = p["gru_hidden"], 3 * p["n_mels"]
+    for d in "fb":
+        g.normal("rm.gru.w_ih_" + d, (3 * H, I), 1.0 / np.sqrt(I))
+        g.normal("rm.gru.w_hh_" + d, (3 * H, H), 1.0 / np.sqrt(H))
+        g.normal("rm.gru.b_ih_" + d, (3 * H,), 0.1)
+        g.normal("rm.gru.b_hh_" + d, (3 * H,), 0.1)
+    # Head: a smooth input-dependent salience bump well inside bins [60, 300] so the
+    # reference's out-of-range gather (argmax >= 348 panics) is never hit.
+    w = g.rng.standard_normal(size=(p["n_out"], 2 * H)).astype(np.float64)
+    w = gaussian_filter1d(w, sigma=10.0, axis=0, mode="nearest") * (6.0 / np.sqrt(2 * H))
+    g.t["rm.fc.w"] = w.astype(np.float32)
+    bins = np.arange(p["n_out"], dtype=np.float64)
+    g.t["rm.fc.b"] = (5.0 * np.exp(-0.5 * ((bins - 150.0) / 25.0) ** 2) - 3.0).astype(np.float32)
+    cfg = dict(kind=2, **p)
+    return cfg, g.t
+
+
+SYNTH_PRESETS = {
+    # SynthesizerTrnMs768NSFsid v2-48k: SURVEY.md Appendix A.3
+    "full": dict(inter=192, hidden=192, filter=768, heads=2, enc_layers=6, enc_k=3, window=10,
+                 flow_n=4, wn_layers=3, wn_k=5, gin=256, up_init=512, n_ups=4,
+                 up_rates=(12, 10, 2, 2), up_kernels=(24, 20, 4, 4),
+                 rb_k=(3, 7, 11), rb_d=(1, 3, 5), sr=48000),
+    "full40k": dict(inter=192, hidden=192, filter=768, heads=2, enc_layers=6, enc_k=3, window=10,
+                    flow_n=4, wn_layers=3, wn_k=5, gin=256, up_init=512, n_ups=4,
+                    up_rates=(10, 10, 2, 2), up_kernels=(16, 16, 4, 4),
+                    rb_k=(3, 7, 11), rb_d=(1, 3, 5), sr=40000),
+    "tiny": dict(inter=16, hidden=16, filter=32, heads=2, enc_layers=2, enc_k=3, window=4,
+                 flow_n=2, wn_layers=2, wn_k=5, gin=8, up_init=32, n_ups=4,
+                 up_rates=(4, 3, 2, 2), up_kernels=(8, 7, 4, 4),
+                 rb_k=(3, 5), rb_d=(1, 3), sr=4800),
+}
+
+
+def make_synth(preset: str = "full", phone_dim: int = 768, seed: int = 777):
+    p = dict(SYNTH_PRESETS[preset])
+    up_rates, up_kernels = p.pop("up_rates"), p.pop("up_kernels")
+    rb_k, rb_d = p.pop("rb_k"), p.pop("rb_d")
+    g = _Gen(seed)
+    Hd, I, F, G = p["hidden"], p["inter"], p["filter"], p["gin"]
+    kc = Hd // p["heads"]
+    g.normal("sy.g", (G,), 1.0)  # emb_g[sid], baked as in the reference's export (rvc.rs:186-187)
+    g.normal("sy.enc.phone.w", (Hd, phone_dim), 1.0 / np.sqrt(phone_dim) / np.sqrt(Hd))
+    g.normal("sy.enc.phone.b", (Hd,), 0.02 / np.sqrt(Hd))
+    g.normal("sy.enc.pitch_emb", (256, Hd), 1.0 / np.sqrt(Hd))
+    for i in range(p["enc_layers"]):
+        pre = "sy.enc.l%d." % i
+        for n in "qkvo":
+            g.fan(pre + n + ".w", (Hd, Hd), Hd)
+            g.normal(pre + n + ".b", (Hd,), 0.05)
+        g.normal(pre + "rel_k", (2 * p["window"] + 1, kc), kc ** -0.5)
+        g.normal(pre + "rel_v", (2 * p["window"] + 1, kc), kc ** -0.5)
+        g.affine(pre + "ln1", Hd)
+        g.fan(pre + "ff1.w", (F, Hd, p["enc_k"]), Hd * p["enc_k"], 1.4)
+        g.normal(pre + "ff1.b", (F,), 0.05)
+        g.fan(pre + "ff2.w", (Hd, F, p["enc_k"]), F * p["enc_k"])
+        g.normal(pre + "ff2.b", (Hd,), 0.05)
+        g.affine(pre + "ln2", Hd)
+    g.fan("sy.enc.proj.w", (2 * I, Hd), Hd, 0.5)
+    g.normal("sy.enc.proj.b", (2 * I,), 0.05)
+    half = I // 2
+    for i in range(p["flow_n"]):
+        pre = "sy.flow%d." % i
+        g.fan(pre + "pre.w", (Hd, half), half)
+        g.normal(pre + "pre.b", (Hd,), 0.05)
+        g.fan(pre + "cond.w", (2 * Hd * p["wn_layers"], G), G, 0.5)
+        g.normal(pre + "cond.b", (2 * Hd * p["wn_layers"],), 0.05)
+        for j in range(p["wn_layers"]):
+            g.fan(pre + "in%d.w" % j, (2 * Hd, Hd, p["wn_k"]), Hd * p["wn_k"])
+            g.normal(pre + "in%d.b" % j, (2 * Hd,), 0.05)
+            rs = 2 * Hd if j < p["wn_layers"] - 1 else Hd
+            g.fan(pre + "rs%d.w" % j, (rs, Hd), Hd, 0.7)
+            g.normal(pre + "rs%d.b" % j, (rs,), 0.05)
+        g.fan(pre + "post.w", (half, Hd), Hd, 0.5)
+        g.normal(pre + "post.b", (half,), 0.05)
+    C0 = p["up_init"]
+    g.fan("sy.dec.pre.w", (C0, I, 7), I * 7)
+    g.normal("sy.dec.pre.b", (C0,), 0.05)
+    g.fan("sy.dec.cond.w", (C0, G), G, 0.3)
+    g.normal("sy.dec.cond.b", (C0,), 0.05)
+    g.t["sy.src"] = np.array([2.5, 0.01], dtype=np.float32)  # SourceModuleHnNSF l_linear (1,1): w, b
+    c = C0
+    for i in range(p["n_ups"]):
+        co = c // 2
+        K, S = up_kernels[i], up_rates[i]
+        g.fan("sy.dec.up%d.w" % i, (c, co, K), c * K / float(S), 1.4)  # ConvTranspose1d layout [Cin][Cout][K]
+        g.normal("sy.dec.up%d.b" % i, (co,), 0.05)
+        sf = int(np.prod(up_rates[i + 1:])) if i + 1 < p["n_ups"] else 1
+        nk = sf * 2 if i + 1 < p["n_ups"] else 1
+        g.fan("sy.dec.nc%d.w" % i, (co, 1, nk), nk, 2.0)
+        g.normal("sy.dec.nc%d.b" % i, (co,), 0.05)
+        for j, k in enumerate(rb_k):
+            for m in range(len(rb_d)):
+                pre = "sy.dec.rb%d_%d." % (i, j)
+                g.fan(pre + "c1_%d.w" % m, (co, co, k), co * k, 1.4)
+                g.normal(pre + "c1_%d.b" % m, (co,), 0.05)
+                g.fan(pre + "c2_%d.w" % m, (co, co, k), co * k, 0.5)
+                g.normal(pre + "c2_%d.b" % m, (co,), 0.05)
+        c = co
+    g.fan("sy.dec.post.w", (1, c, 7), c * 7, 0.6)
+    cfg = dict(kind=3, phone_dim=phone_dim, n_rb=len(rb_k), n_rbd=len(rb_d), **p)
+    for i in range(p["n_ups"]):
+        cfg["up_rate%d" % i] = up_rates[i]
+        cfg["up_kernel%d" % i] = up_kernels[i]
+    for j, k in enumerate(rb_k):
+        cfg["rb_k%d" % j] = k
+    for m, d in enumerate(rb_d):
+        cfg["rb_d%d" % m] = d
+    return cfg, g.t
+
+
+def make_index(n: int = 100000, dim: int = 768, seed: int = 7) -> np.ndarray:
+    """BASELINE config 3: n x dim fp32 vectors ~ N(0,1)*0.35."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.standard_normal(size=(n, dim), dtype=np.float32) * np.float32(0.35)
+
+
+def cv_blob_name(version: int, preset: str = "full") -> str:
+    """File naming convention of /root/reference/rvc/src/models.rs:58-61 with the native extension."""
+    dim, layer = (256, 9) if version == 1 else (768, 12)
+    return "vec-%d-layer-%d.rvcw" % (dim, layer)
+
+
+def build_model_zoo(root: str, preset: str = "full", version: int = 2, synth_preset: str | None = None,
+                    force: bool = False) -> Dict[str, str]:
+    """Lay out <root> as the reference's data dir: contentvec/, f0/, plus a synth model file.
+
+    Returns {"data": data_path, "model": model_path}.  Idempotent (re-uses existing files).
+    """
+    data = os.path.join(root, "data")
+    os.makedirs(os.path.join(data, "contentvec"), exist_ok=True)
+    os.makedirs(os.path.join(data, "f0"), exist_ok=True)
+    cvp = os.path.join(data, "contentvec", cv_blob_name(version, preset))
+    if force or not os.path.exists(cvp):
+        write_blob(cvp, *make_contentvec(preset, version))
+    rmp = os.path.join(data, "f0", "rmvpe.rvcw")
+    if force or not os.path.exists(rmp):
+        write_blob(rmp, *make_rmvpe(preset))
+    sp = synth_preset or preset
+    cv_cfg = CONTENTVEC_PRESETS[preset]
+    if version == 1:
+        phone_dim = 256 if preset == "full" else 16
+    else:
+        phone_dim = cv_cfg["embed"]
+    mp = os.path.join(root, "model-%s-v%d.rvcw" % (sp, version))
+    if force or not os.path.exists(mp):
+        write_blob(mp, *make_synth(sp, phone_dim))
+    return {"data": data, "model": mp}
+
+
+def default_zoo_root(preset: str) -> str:
+    base = os.environ.get("RVC_ZOO_DIR", os.path.join("/tmp", "rvc_zoo_%d" % os.getuid()))
+    return os.path.join(base, preset)

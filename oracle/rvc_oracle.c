@@ -1,0 +1,1014 @@
+/*
+ * rvc_oracle.c -- CPU restatement of the RVC per-chunk hot path.  TEST INFRASTRUCTURE ONLY
+ * (see rvc_oracle.h for who may load it and for the "parity unpinned" statement on the
+ * three opaque ONNX graphs).  Plain C11 + OpenMP, fp32 arithmetic as in the reference.
+ *
+ * Reference files restated here (paths relative to /root/reference):
+ *   rvc/src/rvc.rs:30-220            RvcInfer::{new, hubert, extract_feature, pitch, infer}
+ *   rvc/src/f0/rmvpe.rs:33-37        get_hann_window_periodic
+ *   rvc/src/f0/rmvpe.rs:47-68        pad_reflect
+ *   rvc/src/f0/rmvpe.rs:80-116       stft
+ *   rvc/src/f0/rmvpe.rs:118-133      to_local_average_cents
+ *   rvc/src/f0/rmvpe.rs:136-157      MelSpectrogram::new (mel_spec 0.2.2 filterbank, restated
+ *                                    as the librosa HTK/Slaney construction; source not vendored)
+ *   rvc/src/f0/rmvpe.rs:159-205      mel_extract
+ *   rvc/src/f0/rmvpe.rs:211-261      Rmvpe::{new, mel2hidden, decode, pitch}
+ *   rvc/src/f0/mod.rs:7-12           get_f0_post
+ *   rvc/src/ndarray_ext.rs:5-32      CopyWithin (pitch cache shift)
+ *   rvc-common/src/enums.rs:10-23    (dim, layer) per model version
+ * Network definitions: SURVEY.md Appendix A (public upstream architectures).
+ */
+#define _GNU_SOURCE
+#include "rvc_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------ */
+/* blob reader (format: obs_rvc_amd/weights.py)                                          */
+/* ------------------------------------------------------------------------------------ */
+typedef struct { char name[96]; uint32_t ndim; uint32_t dims[5]; uint64_t off; uint64_t nelem; } ten_rec;
+typedef struct { char name[48]; double val; } cfg_rec;
+typedef struct {
+    unsigned char *raw; size_t raw_len;
+    uint32_t n_cfg, n_ten; uint64_t data_off;
+    cfg_rec *cfg; ten_rec *ten;
+} blob;
+
+static blob *blob_open(const char *path, char *err, size_t errn)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) { snprintf(err, errn, "cannot open %s", path); return NULL; }
+    fseek(f, 0, SEEK_END); long len = ftell(f); fseek(f, 0, SEEK_SET);
+    blob *b = (blob *)calloc(1, sizeof(blob));
+    b->raw = (unsigned char *)malloc((size_t)len); b->raw_len = (size_t)len;
+    if (fread(b->raw, 1, (size_t)len, f) != (size_t)len) { fclose(f); snprintf(err, errn, "short read %s", path); free(b->raw); free(b); return NULL; }
+    fclose(f);
+    if (len < 24 || memcmp(b->raw, "RVCW0001", 8) != 0) { snprintf(err, errn, "bad magic in %s", path); free(b->raw); free(b); return NULL; }
+    memcpy(&b->n_cfg, b->raw + 8, 4); memcpy(&b->n_ten, b->raw + 12, 4); memcpy(&b->data_off, b->raw + 16, 8);
+    b->cfg = (cfg_rec *)calloc(b->n_cfg, sizeof(cfg_rec));
+    b->ten = (ten_rec *)calloc(b->n_ten, sizeof(ten_rec));
+    size_t p = 24;
+    for (uint32_t i = 0; i < b->n_cfg; i++) { memcpy(b->cfg[i].name, b->raw + p, 48); memcpy(&b->cfg[i].val, b->raw + p + 48, 8); p += 56; }
+    for (uint32_t i = 0; i < b->n_ten; i++) {
+        memcpy(b->ten[i].name, b->raw + p, 96); memcpy(&b->ten[i].ndim, b->raw + p + 96, 4);
+        memcpy(b->ten[i].dims, b->raw + p + 100, 20); memcpy(&b->ten[i].off, b->raw + p + 120, 8);
+        memcpy(&b->ten[i].nelem, b->raw + p + 128, 8); p += 136;
+    }
+    return b;
+}
+static void blob_close(blob *b) { if (!b) return; free(b->raw); free(b->cfg); free(b->ten); free(b); }
+static int blob_has_cfg(const blob *b, const char *n) { for (uint32_t i = 0; i < b->n_cfg; i++) if (!strcmp(b->cfg[i].name, n)) return 1; return 0; }
+static int icfg(const blob *b, const char *n)
+{
+    for (uint32_t i = 0; i < b->n_cfg; i++) if (!strcmp(b->cfg[i].name, n)) return (int)b->cfg[i].val;
+    fprintf(stderr, "oracle: missing cfg %s\n", n); abort();
+}
+static int icfgf(const blob *b, const char *fmt, int i) { char n[64]; snprintf(n, sizeof n, fmt, i); return icfg(b, n); }
+static const float *W(const blob *b, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+#include <stdarg.h>
+static const float *W(const blob *b, const char *fmt, ...)
+{
+    char n[128]; va_list ap; va_start(ap, fmt); vsnprintf(n, sizeof n, fmt, ap); va_end(ap);
+    for (uint32_t i = 0; i < b->n_ten; i++) if (!strcmp(b->ten[i].name, n)) return (const float *)(b->raw + b->data_off + b->ten[i].off);
+    fprintf(stderr, "oracle: missing tensor %s\n", n); abort();
+}
+static int has_tensor(const blob *b, const char *n) { for (uint32_t i = 0; i < b->n_ten; i++) if (!strcmp(b->ten[i].name, n)) return 1; return 0; }
+
+/* ------------------------------------------------------------------------------------ */
+/* small dense kernels                                                                   */
+/* ------------------------------------------------------------------------------------ */
+static float *falloc(size_t n) { float *p = (float *)calloc(n ? n : 1, sizeof(float)); if (!p) { fprintf(stderr, "oracle: oom\n"); abort(); } return p; }
+
+void ora_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* C[M][N] = A[M][K] * B[K][N] (+ bias[m]) ; row-major, leading dims given */
+static void sgemm(int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc, const float *bias)
+{
+    enum { MB = 4, NB = 256 };
+    int mt = (M + MB - 1) / MB, nt = (N + NB - 1) / NB;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int mi = 0; mi < mt; mi++)
+        for (int ni = 0; ni < nt; ni++) {
+            int m0 = mi * MB, n0 = ni * NB;
+            int mb = M - m0 < MB ? M - m0 : MB, nb = N - n0 < NB ? N - n0 : NB;
+            float acc[MB][NB];
+            for (int r = 0; r < MB; r++) { float bv = (bias && r < mb) ? bias[m0 + r] : 0.f; for (int j = 0; j < NB; j++) acc[r][j] = bv; }
+            if (mb == MB) {
+                for (int k = 0; k < K; k++) {
+                    const float *br = B + (size_t)k * ldb + n0;
+                    float a0 = A[(size_t)(m0 + 0) * lda + k], a1 = A[(size_t)(m0 + 1) * lda + k];
+                    float a2 = A[(size_t)(m0 + 2) * lda + k], a3 = A[(size_t)(m0 + 3) * lda + k];
+                    for (int j = 0; j < nb; j++) { float bv = br[j]; acc[0][j] += a0 * bv; acc[1][j] += a1 * bv; acc[2][j] += a2 * bv; acc[3][j] += a3 * bv; }
+                }
+            } else {
+                for (int k = 0; k < K; k++) {
+                    const float *br = B + (size_t)k * ldb + n0;
+                    for (int r = 0; r < mb; r++) { float a = A[(size_t)(m0 + r) * lda + k]; for (int j = 0; j < nb; j++) acc[r][j] += a * br[j]; }
+                }
+            }
+            for (int r = 0; r < mb; r++) memcpy(C + (size_t)(m0 + r) * ldc + n0, acc[r], (size_t)nb * sizeof(float));
+        }
+}
+
+/* Conv1d: x[Cin][Tin] -> y[Cout][Tout], weight [Cout][Cin/groups][K], via im2col + sgemm */
+static int conv1d_out_len(int Tin, int K, int s, int pad, int dil) { return (Tin + 2 * pad - dil * (K - 1) - 1) / s + 1; }
+static float *conv1d(const float *x, int Cin, int Tin, const float *w, const float *bias, int Cout, int K, int s, int pad, int dil, int groups, int *Tout_)
+{
+    int Tout = conv1d_out_len(Tin, K, s, pad, dil);
+    *Tout_ = Tout;
+    float *y = falloc((size_t)Cout * Tout);
+    int cig = Cin / groups, cog = Cout / groups;
+    if (K == 1 && s == 1 && pad == 0 && groups == 1) { sgemm(Cout, Tout, Cin, w, Cin, x, Tin, y, Tout, bias); return y; }
+    float *col = falloc((size_t)cig * K * Tout);
+    for (int g = 0; g < groups; g++) {
+#pragma omp parallel for collapse(2)
+        for (int ci = 0; ci < cig; ci++)
+            for (int k = 0; k < K; k++) {
+                float *cr = col + ((size_t)ci * K + k) * Tout;
+                const float *xr = x + (size_t)(g * cig + ci) * Tin;
+                for (int t = 0; t < Tout; t++) { int p = t * s + k * dil - pad; cr[t] = (p >= 0 && p < Tin) ? xr[p] : 0.f; }
+            }
+        sgemm(cog, Tout, cig * K, w + (size_t)g * cog * cig * K, cig * K, col, Tout, y + (size_t)g * cog * Tout, Tout, bias ? bias + g * cog : NULL);
+    }
+    free(col);
+    return y;
+}
+
+/* ConvTranspose1d, literal scatter definition: weight [Cin][Cout][K]; Tout = (Tin-1)*S - 2*pad + K */
+static float *conv_transpose1d(const float *x, int Cin, int Tin, const float *w, const float *bias, int Cout, int K, int S, int pad, int *Tout_)
+{
+    int Tout = (Tin - 1) * S - 2 * pad + K;
+    *Tout_ = Tout;
+    float *y = falloc((size_t)Cout * Tout);
+    for (int co = 0; co < Cout; co++) for (int t = 0; t < Tout; t++) y[(size_t)co * Tout + t] = bias ? bias[co] : 0.f;
+    float *wt = falloc((size_t)Cout * Cin), *z = falloc((size_t)Cout * Tin);
+    for (int k = 0; k < K; k++) {
+        for (int co = 0; co < Cout; co++) for (int ci = 0; ci < Cin; ci++) wt[(size_t)co * Cin + ci] = w[((size_t)ci * Cout + co) * K + k];
+        sgemm(Cout, Tin, Cin, wt, Cin, x, Tin, z, Tin, NULL);
+#pragma omp parallel for
+        for (int co = 0; co < Cout; co++)
+            for (int t = 0; t < Tin; t++) { int o = t * S + k - pad; if (o >= 0 && o < Tout) y[(size_t)co * Tout + o] += z[(size_t)co * Tin + t]; }
+    }
+    free(wt); free(z);
+    return y;
+}
+
+/* Conv2d 3x3 pad 1 stride 1: x[Cin][H][W] -> y[Cout][H][W]; weight [Cout][Cin][3][3] */
+static float *conv2d3(const float *x, int Cin, int H, int Wd, const float *w, const float *bias, int Cout)
+{
+    size_t HW = (size_t)H * Wd;
+    float *col = falloc((size_t)Cin * 9 * HW);
+#pragma omp parallel for collapse(2)
+    for (int ci = 0; ci < Cin; ci++)
+        for (int k = 0; k < 9; k++) {
+            int kh = k / 3, kw = k % 3;
+            float *cr = col + ((size_t)ci * 9 + k) * HW;
+            for (int h = 0; h < H; h++) for (int v = 0; v < Wd; v++) {
+                int hh = h + kh - 1, ww = v + kw - 1;
+                cr[(size_t)h * Wd + v] = (hh >= 0 && hh < H && ww >= 0 && ww < Wd) ? x[((size_t)ci * H + hh) * Wd + ww] : 0.f;
+            }
+        }
+    float *y = falloc((size_t)Cout * HW);
+    sgemm(Cout, (int)HW, Cin * 9, w, Cin * 9, col, (int)HW, y, (int)HW, bias);
+    free(col);
+    return y;
+}
+
+/* ConvTranspose2d 3x3 stride 2 pad 1 output_pad 1, literal scatter: weight [Cin][Cout][3][3]; out (2H, 2W) */
+static float *conv_transpose2d3(const float *x, int Cin, int H, int Wd, const float *w, const float *bias, int Cout)
+{
+    int Ho = 2 * H, Wo = 2 * Wd; size_t HW = (size_t)H * Wd, HWo = (size_t)Ho * Wo;
+    float *y = falloc((size_t)Cout * HWo);
+    for (int co = 0; co < Cout; co++) for (size_t i = 0; i < HWo; i++) y[(size_t)co * HWo + i] = bias ? bias[co] : 0.f;
+    float *wt = falloc((size_t)Cout * Cin), *z = falloc((size_t)Cout * HW);
+    for (int k = 0; k < 9; k++) {
+        int kh = k / 3, kw = k % 3;
+        for (int co = 0; co < Cout; co++) for (int ci = 0; ci < Cin; ci++) wt[(size_t)co * Cin + ci] = w[((size_t)ci * Cout + co) * 9 + k];
+        sgemm(Cout, (int)HW, Cin, wt, Cin, x, (int)HW, z, (int)HW, NULL);
+#pragma omp parallel for
+        for (int co = 0; co < Cout; co++)
+            for (int h = 0; h < H; h++) for (int v = 0; v < Wd; v++) {
+                int oh = 2 * h - 1 + kh, ow = 2 * v - 1 + kw;
+                if (oh >= 0 && oh < Ho && ow >= 0 && ow < Wo) y[(size_t)co * HWo + (size_t)oh * Wo + ow] += z[(size_t)co * HW + (size_t)h * Wd + v];
+            }
+    }
+    free(wt); free(z);
+    return y;
+}
+
+static inline float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+static inline float lrelu_f(float x, float s) { return x > 0.f ? x : x * s; }
+static inline float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+/* LayerNorm over channels of x[C][T] (per time step), eps 1e-5, in place */
+static void layernorm_ct(float *x, int C, int T, const float *g, const float *b)
+{
+#pragma omp parallel for
+    for (int t = 0; t < T; t++) {
+        float mean = 0.f; for (int c = 0; c < C; c++) mean += x[(size_t)c * T + t]; mean /= (float)C;
+        float var = 0.f; for (int c = 0; c < C; c++) { float d = x[(size_t)c * T + t] - mean; var += d * d; } var /= (float)C;
+        float inv = 1.0f / sqrtf(var + 1e-5f);
+        for (int c = 0; c < C; c++) x[(size_t)c * T + t] = (x[(size_t)c * T + t] - mean) * inv * g[c] + b[c];
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Philox4x32-10 + Box-Muller (shared definition with csrc/kernels.hip)                  */
+/* ------------------------------------------------------------------------------------ */
+static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+static inline float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+/* element i of the stream = lane (i&3) of block (i>>2): counter = (block, 0, chunk, purpose), key = (seed, stream) */
+void ora_philox_normal(uint32_t seed, uint32_t stream, uint32_t chunk, uint32_t purpose, size_t n, float *out)
+{
+    size_t nb = (n + 3) / 4;
+#pragma omp parallel for
+    for (size_t blk = 0; blk < nb; blk++) {
+        uint32_t c[4] = { (uint32_t)blk, 0u, chunk, purpose };
+        philox4x32_10(c, seed, stream);
+        float z[4];
+        float r0 = sqrtf(-2.0f * logf(u01(c[0]))), a0 = 6.28318530717958647692f * u01(c[1]);
+        float r1 = sqrtf(-2.0f * logf(u01(c[2]))), a1 = 6.28318530717958647692f * u01(c[3]);
+        z[0] = r0 * cosf(a0); z[1] = r0 * sinf(a0); z[2] = r1 * cosf(a1); z[3] = r1 * sinf(a1);
+        for (int j = 0; j < 4; j++) if (blk * 4 + j < n) out[blk * 4 + j] = z[j];
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* RMVPE front / back end (rvc/src/f0/rmvpe.rs)                                          */
+/* ------------------------------------------------------------------------------------ */
+/* rmvpe.rs:33-37: f64 cosine cast to f32, then 0.5*(1-c) in f32 (Q9) */
+void ora_hann_periodic(size_t n, float *out)
+{
+    for (size_t i = 0; i < n; i++) {
+        float c = (float)cos(2.0 * 3.14159265358979323846 * (double)i / (((double)(n + 1)) - 1.0));
+        out[i] = 0.5f * (1.0f - c);
+    }
+}
+
+/* rmvpe.rs:47-68 */
+void ora_pad_reflect(const float *in, size_t n, size_t pad, float *out)
+{
+    memcpy(out + pad, in, n * sizeof(float));
+    for (size_t i = 0; i < pad; i++) out[pad - i - 1] = in[i + 1];
+    for (size_t i = 0; i < pad; i++) out[n + pad + i] = in[n - i - 2];
+}
+
+/* in-place complex f32 FFT, radix-2 for powers of two, naive DFT otherwise (rustfft stand-in) */
+static void fft_c32(float *re, float *im, size_t n)
+{
+    if ((n & (n - 1)) == 0) {
+        for (size_t i = 1, j = 0; i < n; i++) { size_t bit = n >> 1; for (; j & bit; bit >>= 1) j ^= bit; j ^= bit; if (i < j) { float t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; } }
+        for (size_t len = 2; len <= n; len <<= 1) {
+            for (size_t i = 0; i < n; i += len)
+                for (size_t k = 0; k < len / 2; k++) {
+                    double ang = -2.0 * 3.14159265358979323846 * (double)k / (double)len;
+                    float wr = (float)cos(ang), wi = (float)sin(ang);
+                    float ur = re[i + k], ui = im[i + k];
+                    float vr = re[i + k + len / 2] * wr - im[i + k + len / 2] * wi, vi = re[i + k + len / 2] * wi + im[i + k + len / 2] * wr;
+                    re[i + k] = ur + vr; im[i + k] = ui + vi; re[i + k + len / 2] = ur - vr; im[i + k + len / 2] = ui - vi;
+                }
+        }
+    } else {
+        float *or_ = falloc(n), *oi = falloc(n);
+        for (size_t k = 0; k < n; k++) { float sr = 0, si = 0; for (size_t j = 0; j < n; j++) { double a = -2.0 * 3.14159265358979323846 * (double)((k * j) % n) / (double)n; float c = (float)cos(a), s = (float)sin(a); sr += re[j] * c - im[j] * s; si += re[j] * s + im[j] * c; } or_[k] = sr; oi[k] = si; }
+        memcpy(re, or_, n * sizeof(float)); memcpy(im, oi, n * sizeof(float)); free(or_); free(oi);
+    }
+}
+
+/* rmvpe.rs:80-116: T = 1 + L/hop with L the UNPADDED length; magnitude sqrt(re^2+im^2); out (N, T) */
+size_t ora_stft(const float *sig, size_t n, size_t fft_size, size_t hop, const float *window, int center, float *out)
+{
+    size_t N = fft_size / 2 + 1, T = 1 + n / hop;
+    size_t plen = center ? n + 2 * (fft_size / 2) : n;
+    float *padded = falloc(plen + fft_size);
+    if (center) ora_pad_reflect(sig, n, fft_size / 2, padded); else memcpy(padded, sig, n * sizeof(float));
+#pragma omp parallel for
+    for (size_t t = 0; t < T; t++) {
+        float re[4096], im[4096];
+        float *pre = fft_size <= 4096 ? re : falloc(fft_size), *pim = fft_size <= 4096 ? im : falloc(fft_size);
+        for (size_t j = 0; j < fft_size; j++) { pre[j] = padded[t * hop + j] * window[j]; pim[j] = 0.f; }
+        fft_c32(pre, pim, fft_size);
+        for (size_t k = 0; k < N; k++) out[k * T + t] = sqrtf(pre[k] * pre[k] + pim[k] * pim[k]);
+        if (fft_size > 4096) { free(pre); free(pim); }
+    }
+    free(padded);
+    return T;
+}
+
+/* rmvpe.rs:146-148: mel_spec::mel::mel(sr, n_fft, n_mels, fmin, fmax, htk=true, norm=true), f64 -> f32 */
+void ora_mel_filterbank(double sr, size_t n_fft, size_t n_mels, double fmin, double fmax, float *out)
+{
+    size_t nb = n_fft / 2 + 1;
+    double *fftf = (double *)malloc(nb * sizeof(double)), *melf = (double *)malloc((n_mels + 2) * sizeof(double));
+    for (size_t i = 0; i < nb; i++) fftf[i] = (sr / 2.0) * (double)i / (double)(nb - 1);
+    double mlo = 2595.0 * log10(1.0 + fmin / 700.0), mhi = 2595.0 * log10(1.0 + fmax / 700.0);
+    for (size_t i = 0; i < n_mels + 2; i++) { double m = mlo + (mhi - mlo) * (double)i / (double)(n_mels + 1); melf[i] = 700.0 * (pow(10.0, m / 2595.0) - 1.0); }
+    for (size_t i = 0; i < n_mels; i++) {
+        double fd0 = melf[i + 1] - melf[i], fd1 = melf[i + 2] - melf[i + 1], enorm = 2.0 / (melf[i + 2] - melf[i]);
+        for (size_t j = 0; j < nb; j++) {
+            double lower = -(melf[i] - fftf[j]) / fd0, upper = (melf[i + 2] - fftf[j]) / fd1;
+            double v = lower < upper ? lower : upper; if (v < 0.0) v = 0.0;
+            out[i * nb + j] = (float)(v * enorm);
+        }
+    }
+    free(fftf); free(melf);
+}
+
+/* rmvpe.rs:159-205 with keyshift=0, speed=1, center=true (the only path taken, rmvpe.rs:258);
+ * MelSpectrogram::new(1024,16000,128,1024,160,30,8000,1e-5) at rmvpe.rs:220 */
+size_t ora_mel_extract(const float *sig, size_t n, float *out)
+{
+    static float basis[128 * 513]; static float win[1024]; static int init = 0;
+#pragma omp critical(ora_mel_init)
+    if (!init) { ora_mel_filterbank(16000.0, 1024, 128, 30.0, 8000.0, basis); ora_hann_periodic(1024, win); init = 1; }
+    size_t T = 1 + n / 160;
+    float *mag = falloc(513 * T);
+    ora_stft(sig, n, 1024, 160, win, 1, mag);
+    sgemm(128, (int)T, 513, basis, 513, mag, (int)T, out, (int)T, NULL);
+    for (size_t i = 0; i < 128 * T; i++) out[i] = logf(out[i] > 1e-5f ? out[i] : 1e-5f);
+    free(mag);
+    return T;
+}
+
+/* rmvpe.rs:118-133 (to_local_average_cents) + 243-248 (decode).  Q3: `starts` is the argmax
+ * in PADDED coordinates (first maximum), but salience is gathered from the UNPADDED array at
+ * starts..starts+9, cents from cents_mapping[starts..starts+9]; out-of-bounds (argmax bin >= 348)
+ * panics in the reference -> ORA_PANIC.  Q4: threshold on the row max, then 10*2^(c/1200), 10 -> 0. */
+int ora_decode(const float *sal, size_t T, float threshold, float *f0)
+{
+    float cents_mapping[368];
+    for (int i = 0; i < 368; i++) cents_mapping[i] = ((float)i - 4.f) * 20.f + 1997.3794084376191f;  /* rmvpe.rs:212-216 */
+    int rc = ORA_OK;
+    for (size_t t = 0; t < T; t++) {
+        const float *row = sal + t * 360;
+        /* argmax over the zero-padded row of 368: first strictly-greater wins (ndarray-stats 0.5.1) */
+        int start = 0; float best = 0.f;  /* padded[0] = 0 */
+        for (int i = 1; i < 368; i++) { float v = (i >= 4 && i < 364) ? row[i - 4] : 0.f; if (v > best) { best = v; start = i; } }
+        if (start + 8 >= 360) { rc = ORA_PANIC; f0[t] = 0.f; continue; }
+        float ps = 0.f, ws = 0.f;
+        for (int y = 0; y < 9; y++) { float s = row[start + y]; ps += s * cents_mapping[start + y]; ws += s; }
+        float cents = ps / ws;
+        float mx = row[0]; for (int i = 1; i < 360; i++) if (row[i] > mx) mx = row[i];
+        if (!(mx > threshold)) cents = 0.f;
+        float hz = 10.0f * powf(2.0f, cents / 1200.0f);
+        f0[t] = (hz == 10.0f) ? 0.f : hz;
+    }
+    return rc;
+}
+
+/* f0/mod.rs:7-12 (Q7: round half away from zero, clamp [1,255]) */
+void ora_get_f0_post(const float *f0, size_t n, int32_t *coarse)
+{
+    const float f0_mel_min = logf(50.0f / 700.0f + 1.f) * 1127.f, f0_mel_max = logf(500.0f / 700.0f + 1.f) * 1127.f; /* rvc.rs:31-34 */
+    for (size_t i = 0; i < n; i++) {
+        float x = logf(f0[i] / 700.0f + 1.f) * 1127.f;
+        if (!(x <= 0.f)) x = (x - f0_mel_min) * 254.f / (f0_mel_max - f0_mel_min) + 1.f;
+        x = x < 1.f ? 1.f : (x > 255.f ? 255.f : x);
+        coarse[i] = (int32_t)roundf(x);
+    }
+}
+
+/* rvc.rs:121: 2.0f32.powi(pitch_shift / 12) with truncating integer division (Q1) */
+float ora_uppower(int pitch_shift) { int e = pitch_shift / 12; return ldexpf(1.0f, e); }
+/* rmvpe.rs:256 */
+size_t ora_f0_extractor_frame(size_t sf) { return 5120 * ((sf + 800 - 1) / 5120 + 1) - 160; }
+
+/* flat-L2 top-k (rvc.rs:159 is a TODO; definition: SURVEY.md Appendix A.4).  Distances are a
+ * sequential fmaf chain over ascending dimension; ties broken by ascending index. */
+void ora_knn_search(const float *index, size_t n, size_t dim, const float *q, size_t nq, int k, int32_t *idx, float *dist)
+{
+#pragma omp parallel for
+    for (size_t qi = 0; qi < nq; qi++) {
+        float bd[16]; int32_t bi[16];
+        for (int j = 0; j < k; j++) { bd[j] = INFINITY; bi[j] = -1; }
+        const float *qv = q + qi * dim;
+        for (size_t i = 0; i < n; i++) {
+            const float *v = index + i * dim; float acc = 0.f;
+            for (size_t d = 0; d < dim; d++) { float df = qv[d] - v[d]; acc = fmaf(df, df, acc); }
+            if (acc < bd[k - 1]) { int p = k - 1; while (p > 0 && acc < bd[p - 1]) { bd[p] = bd[p - 1]; bi[p] = bi[p - 1]; p--; } bd[p] = acc; bi[p] = (int32_t)i; }
+        }
+        for (int j = 0; j < k; j++) { idx[qi * k + j] = bi[j]; dist[qi * k + j] = bd[j]; }
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* engine state                                                                          */
+/* ------------------------------------------------------------------------------------ */
+typedef struct { char name[48]; float *data; size_t n; } tap_rec;
+struct ora_engine {
+    char data_path[1024];
+    blob *cv, *rm, *sy;                 /* contentvec_session / f0_algorithm / session (rvc.rs:18-27) */
+    float cache_pitchf[1024];           /* rvc.rs:42 */
+    float *index; size_t index_n, index_dim; float index_rate;
+    uint32_t seed, stream, chunk;
+    int32_t *knn_idx; float *knn_dist; size_t knn_rows;
+    tap_rec *taps; size_t n_taps; int taps_on;
+    char err[512];
+};
+
+static void tap(ora_engine *e, const char *name, const float *d, size_t n)
+{
+    if (!e->taps_on) return;
+    for (size_t i = 0; i < e->n_taps; i++) if (!strcmp(e->taps[i].name, name)) { free(e->taps[i].data); e->taps[i].data = falloc(n); memcpy(e->taps[i].data, d, n * sizeof(float)); e->taps[i].n = n; return; }
+    e->taps = (tap_rec *)realloc(e->taps, (e->n_taps + 1) * sizeof(tap_rec));
+    tap_rec *t = &e->taps[e->n_taps++]; snprintf(t->name, sizeof t->name, "%s", name); t->data = falloc(n); memcpy(t->data, d, n * sizeof(float)); t->n = n;
+}
+static void tapf(ora_engine *e, const float *d, size_t n, const char *fmt, int i) { char nm[48]; snprintf(nm, sizeof nm, fmt, i); tap(e, nm, d, n); }
+
+ora_engine *ora_new(const char *data_path)
+{
+    ora_engine *e = (ora_engine *)calloc(1, sizeof(ora_engine));
+    snprintf(e->data_path, sizeof e->data_path, "%s", data_path);
+    e->index_rate = 0.f; e->seed = 0; e->stream = 0; e->chunk = 0;
+    return e;
+}
+void ora_free(ora_engine *e)
+{
+    if (!e) return;
+    blob_close(e->cv); blob_close(e->rm); blob_close(e->sy); free(e->index); free(e->knn_idx); free(e->knn_dist);
+    for (size_t i = 0; i < e->n_taps; i++) free(e->taps[i].data);
+    free(e->taps); free(e);
+}
+const char *ora_last_error(ora_engine *e) { return e->err; }
+void ora_enable_taps(ora_engine *e, int on) { e->taps_on = on; }
+int ora_get_tap(ora_engine *e, const char *name, const float **data, size_t *n)
+{
+    for (size_t i = 0; i < e->n_taps; i++) if (!strcmp(e->taps[i].name, name)) { *data = e->taps[i].data; *n = e->taps[i].n; return ORA_OK; }
+    return ORA_SHAPE;
+}
+/* rvc.rs:46-54 + models.rs:52-64 (file naming) */
+int ora_load_contentvec(ora_engine *e, int version)
+{
+    char p[1200]; int dim = version == 1 ? 256 : 768, layer = version == 1 ? 9 : 12;   /* enums.rs:10-23 */
+    snprintf(p, sizeof p, "%s/contentvec/vec-%d-layer-%d.rvcw", e->data_path, dim, layer);
+    blob *b = blob_open(p, e->err, sizeof e->err); if (!b) return ORA_BACKEND;
+    blob_close(e->cv); e->cv = b; return ORA_OK;
+}
+int ora_load_model(ora_engine *e, const char *model_path)
+{
+    blob *b = blob_open(model_path, e->err, sizeof e->err); if (!b) return ORA_BACKEND;
+    blob_close(e->sy); e->sy = b; return ORA_OK;
+}
+int ora_load_f0(ora_engine *e, int algorithm)
+{
+    (void)algorithm; char p[1200]; snprintf(p, sizeof p, "%s/f0/rmvpe.rvcw", e->data_path);   /* models.rs:66-76 */
+    blob *b = blob_open(p, e->err, sizeof e->err); if (!b) return ORA_BACKEND;
+    blob_close(e->rm); e->rm = b; return ORA_OK;
+}
+void ora_unload_model(ora_engine *e) { blob_close(e->sy); e->sy = NULL; }
+int ora_load_index(ora_engine *e, const float *vecs, size_t n, size_t dim)
+{
+    free(e->index); e->index = (float *)malloc(n * dim * sizeof(float)); memcpy(e->index, vecs, n * dim * sizeof(float));
+    e->index_n = n; e->index_dim = dim; return ORA_OK;
+}
+void ora_set_index_rate(ora_engine *e, float r) { e->index_rate = r; }
+void ora_set_noise_seed(ora_engine *e, uint32_t seed, uint32_t stream) { e->seed = seed; e->stream = stream; }
+void ora_reset_state(ora_engine *e) { memset(e->cache_pitchf, 0, sizeof e->cache_pitchf); e->chunk = 0; }
+void ora_get_pitch_cache(ora_engine *e, float *out) { memcpy(out, e->cache_pitchf, sizeof e->cache_pitchf); }
+int ora_get_knn(ora_engine *e, int32_t *idx, float *dist, size_t cap_rows, size_t *rows)
+{
+    *rows = e->knn_rows; if (cap_rows < e->knn_rows) return ORA_SHAPE;
+    memcpy(idx, e->knn_idx, e->knn_rows * 4 * sizeof(int32_t)); memcpy(dist, e->knn_dist, e->knn_rows * 4 * sizeof(float)); return ORA_OK;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* ContentVec: x[L] -> [out_dim][T]                             */
+/* ------------------------------------------------------------------------------------ */
+static void mha_ct(const float *q, const float *k, const float *v, float *o, int E, int T, int heads)
+{
+    int hd = E / heads;
+#pragma omp parallel for collapse(2)
+    for (int h = 0; h < heads; h++)
+        for (int t1 = 0; t1 < T; t1++) {
+            float *s = (float *)malloc((size_t)T * sizeof(float));
+            float mx = -INFINITY;
+            for (int t2 = 0; t2 < T; t2++) { float a = 0.f; for (int d = 0; d < hd; d++) a += q[(size_t)(h * hd + d) * T + t1] * k[(size_t)(h * hd + d) * T + t2]; s[t2] = a; if (a > mx) mx = a; }
+            float sum = 0.f; for (int t2 = 0; t2 < T; t2++) { s[t2] = expf(s[t2] - mx); sum += s[t2]; }
+            float inv = 1.0f / sum;
+            for (int d = 0; d < hd; d++) { float a = 0.f; for (int t2 = 0; t2 < T; t2++) a += s[t2] * v[(size_t)(h * hd + d) * T + t2]; o[(size_t)(h * hd + d) * T + t1] = a * inv; }
+            free(s);
+        }
+}
+
+static float *contentvec_forward(ora_engine *e, const float *x, size_t L, int *C_out, int *T_out)
+{
+    const blob *b = e->cv;
+    int C = icfg(b, "conv_dim"), E = icfg(b, "embed"), heads = icfg(b, "heads"), F = icfg(b, "ffn");
+    int run_layers = icfg(b, "run_layers"), pos_k = icfg(b, "pos_k"), pos_g = icfg(b, "pos_groups"), out_dim = icfg(b, "out_dim");
+    int T = (int)L, cin = 1;
+    float *cur = falloc(L); memcpy(cur, x, L * sizeof(float));
+    for (int i = 0; i < 7; i++) {
+        int k = icfgf(b, "conv_k%d", i), s = icfgf(b, "conv_s%d", i), To;
+        if (T < k) { free(cur); snprintf(e->err, sizeof e->err, "input too short for ContentVec"); return NULL; }
+        float *y = conv1d(cur, cin, T, W(b, "cv.conv%d.w", i), NULL, C, k, s, 0, 1, 1, &To);
+        free(cur); cur = y; T = To; cin = C;
+        if (i == 0) {   /* GroupNorm(num_groups = C): per-channel normalisation over time, eps 1e-5 */
+            const float *g = W(b, "cv.gn.g"), *bb = W(b, "cv.gn.b");
+#pragma omp parallel for
+            for (int c = 0; c < C; c++) {
+                float *r = cur + (size_t)c * T; double m = 0; for (int t = 0; t < T; t++) m += r[t]; m /= T;
+                double vv = 0; for (int t = 0; t < T; t++) { double d = r[t] - m; vv += d * d; } vv /= T;
+                float inv = 1.0f / sqrtf((float)vv + 1e-5f), mf = (float)m;
+                for (int t = 0; t < T; t++) r[t] = (r[t] - mf) * inv * g[c] + bb[c];
+            }
+        }
+        for (size_t j = 0; j < (size_t)C * T; j++) cur[j] = gelu_f(cur[j]);
+        if (i == 0) tap(e, "cv.conv0", cur, (size_t)C * T);
+    }
+    tap(e, "cv.feat", cur, (size_t)C * T);
+    layernorm_ct(cur, C, T, W(b, "cv.ln0.g"), W(b, "cv.ln0.b"));
+    int To;
+    float *h = conv1d(cur, C, T, W(b, "cv.proj.w"), W(b, "cv.proj.b"), E, 1, 1, 0, 1, 1, &To);
+    free(cur);
+    tap(e, "cv.proj", h, (size_t)E * T);
+    /* positional conv: k even -> pad k/2 gives T+1 frames, the last is dropped */
+    float *pc = conv1d(h, E, T, W(b, "cv.pos.w"), W(b, "cv.pos.b"), E, pos_k, 1, pos_k / 2, 1, pos_g, &To);
+    for (int c = 0; c < E; c++) for (int t = 0; t < T; t++) h[(size_t)c * T + t] += gelu_f(pc[(size_t)c * To + t]);
+    free(pc);
+    layernorm_ct(h, E, T, W(b, "cv.enc_ln.g"), W(b, "cv.enc_ln.b"));
+    tap(e, "cv.pos", h, (size_t)E * T);
+    float scale = 1.0f / sqrtf((float)(E / heads));
+    for (int l = 0; l < run_layers; l++) {
+        float *q = conv1d(h, E, T, W(b, "cv.l%d.q.w", l), W(b, "cv.l%d.q.b", l), E, 1, 1, 0, 1, 1, &To);
+        float *k = conv1d(h, E, T, W(b, "cv.l%d.k.w", l), W(b, "cv.l%d.k.b", l), E, 1, 1, 0, 1, 1, &To);
+        float *v = conv1d(h, E, T, W(b, "cv.l%d.v.w", l), W(b, "cv.l%d.v.b", l), E, 1, 1, 0, 1, 1, &To);
+        for (size_t j = 0; j < (size_t)E * T; j++) q[j] *= scale;
+        float *a = falloc((size_t)E * T);
+        mha_ct(q, k, v, a, E, T, heads);
+        float *o = conv1d(a, E, T, W(b, "cv.l%d.o.w", l), W(b, "cv.l%d.o.b", l), E, 1, 1, 0, 1, 1, &To);
+        for (size_t j = 0; j < (size_t)E * T; j++) h[j] += o[j];
+        layernorm_ct(h, E, T, W(b, "cv.l%d.ln1.g", l), W(b, "cv.l%d.ln1.b", l));
+        float *f1 = conv1d(h, E, T, W(b, "cv.l%d.ff1.w", l), W(b, "cv.l%d.ff1.b", l), F, 1, 1, 0, 1, 1, &To);
+        for (size_t j = 0; j < (size_t)F * T; j++) f1[j] = gelu_f(f1[j]);
+        float *f2 = conv1d(f1, F, T, W(b, "cv.l%d.ff2.w", l), W(b, "cv.l%d.ff2.b", l), E, 1, 1, 0, 1, 1, &To);
+        for (size_t j = 0; j < (size_t)E * T; j++) h[j] += f2[j];
+        layernorm_ct(h, E, T, W(b, "cv.l%d.ln2.g", l), W(b, "cv.l%d.ln2.b", l));
+        free(q); free(k); free(v); free(a); free(o); free(f1); free(f2);
+        tapf(e, h, (size_t)E * T, "cv.l%d", l);
+    }
+    if (out_dim != E) { float *fp = conv1d(h, E, T, W(b, "cv.final_proj.w"), W(b, "cv.final_proj.b"), out_dim, 1, 1, 0, 1, 1, &To); free(h); h = fp; }
+    tap(e, "cv.out", h, (size_t)out_dim * T);
+    *C_out = out_dim; *T_out = T;
+    return h;
+}
+
+/* rvc.rs:81-97: returns (1, C, T) */
+int ora_hubert(ora_engine *e, const float *in, size_t n, float *out, size_t cap, size_t dims[3])
+{
+    if (!e->cv) return ORA_CONTENTVEC_NOT_LOADED;
+    int C, T; float *h = contentvec_forward(e, in, n, &C, &T);
+    if (!h) return ORA_SHAPE;
+    dims[0] = 1; dims[1] = (size_t)C; dims[2] = (size_t)T;
+    if (cap < (size_t)C * T) { free(h); return ORA_SHAPE; }
+    memcpy(out, h, (size_t)C * T * sizeof(float)); free(h); return ORA_OK;
+}
+/* rvc.rs:99-109: out[k] = raw[min(k/2, T-1)], 2T+1 frames, returned as (1, 2T+1, C) (Q2) */
+int ora_extract_feature(ora_engine *e, const float *in, size_t n, float *out, size_t cap, size_t dims[3])
+{
+    if (!e->cv) return ORA_CONTENTVEC_NOT_LOADED;
+    int C, T; float *h = contentvec_forward(e, in, n, &C, &T);
+    if (!h) return ORA_SHAPE;
+    size_t T2 = 2 * (size_t)T + 1;
+    dims[0] = 1; dims[1] = T2; dims[2] = (size_t)C;
+    if (cap < T2 * C) { free(h); return ORA_SHAPE; }
+    for (size_t k = 0; k < T2; k++) { size_t src = k / 2 < (size_t)T - 1 ? k / 2 : (size_t)T - 1; for (int c = 0; c < C; c++) out[k * C + c] = h[(size_t)c * T + src]; }
+    free(h); return ORA_OK;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* RMVPE network: mel (128, Tm) -> salience (Tm, 360)            */
+/* ------------------------------------------------------------------------------------ */
+static float *conv_block_res(const blob *b, const char *pre, const float *x, int ci, int co, int H, int Wd)
+{
+    size_t HW = (size_t)H * Wd; char n1[128];
+    float *y1 = conv2d3(x, ci, H, Wd, W(b, "%sc1.w", pre), W(b, "%sc1.b", pre), co);
+    for (size_t i = 0; i < co * HW; i++) y1[i] = y1[i] > 0.f ? y1[i] : 0.f;
+    float *y2 = conv2d3(y1, co, H, Wd, W(b, "%sc2.w", pre), W(b, "%sc2.b", pre), co);
+    free(y1);
+    for (size_t i = 0; i < co * HW; i++) y2[i] = y2[i] > 0.f ? y2[i] : 0.f;
+    snprintf(n1, sizeof n1, "%ssc.w", pre);
+    if (ci != co) {
+        float *sc = falloc(co * HW);
+        sgemm(co, (int)HW, ci, W(b, "%ssc.w", pre), ci, x, (int)HW, sc, (int)HW, W(b, "%ssc.b", pre));
+        for (size_t i = 0; i < co * HW; i++) y2[i] += sc[i];
+        free(sc);
+    } else {
+        for (size_t i = 0; i < co * HW; i++) y2[i] += x[i];
+    }
+    return y2;
+}
+
+static float *rmvpe_forward(ora_engine *e, const float *mel, int Tm)
+{
+    const blob *b = e->rm;
+    int en_out = icfg(b, "en_out"), levels = icfg(b, "levels"), nb = icfg(b, "n_blocks"), inter = icfg(b, "inter_layers");
+    int n_mels = icfg(b, "n_mels"), Hg = icfg(b, "gru_hidden"), n_out = icfg(b, "n_out");
+    int H = Tm, Wd = n_mels; char pre[64];
+    const float *bn0 = W(b, "rm.bn0");
+    float *x = falloc((size_t)H * Wd);
+    for (int t = 0; t < H; t++) for (int m = 0; m < Wd; m++) x[(size_t)t * Wd + m] = mel[(size_t)m * Tm + t] * bn0[0] + bn0[1];
+    float *skips[8]; int skipC[8], skipH[8], skipW[8];
+    int ci = 1, co = en_out;
+    for (int lv = 0; lv < levels; lv++) {
+        for (int j = 0; j < nb; j++) { snprintf(pre, sizeof pre, "rm.enc%d.b%d.", lv, j); float *y = conv_block_res(b, pre, x, j == 0 ? ci : co, co, H, Wd); free(x); x = y; }
+        skips[lv] = x; skipC[lv] = co; skipH[lv] = H; skipW[lv] = Wd;
+        tapf(e, x, (size_t)co * H * Wd, "rm.enc%d", lv);
+        int H2 = H / 2, W2 = Wd / 2; float *p = falloc((size_t)co * H2 * W2);   /* AvgPool2d(2,2) */
+        for (int c = 0; c < co; c++) for (int h = 0; h < H2; h++) for (int v = 0; v < W2; v++) {
+            const float *s = x + ((size_t)c * H + 2 * h) * Wd + 2 * v;
+            p[((size_t)c * H2 + h) * W2 + v] = (s[0] + s[1] + s[Wd] + s[Wd + 1]) * 0.25f;
+        }
+        x = p; H = H2; Wd = W2; ci = co; co *= 2;
+    }
+    /* ci = encoder output channels (256), co = 512 */
+    for (int lv = 0; lv < inter; lv++)
+        for (int j = 0; j < nb; j++) { snprintf(pre, sizeof pre, "rm.int%d.b%d.", lv, j); int cin = (j == 0) ? (lv == 0 ? ci : co) : co; float *y = conv_block_res(b, pre, x, cin, co, H, Wd); free(x); x = y; }
+    tap(e, "rm.int", x, (size_t)co * H * Wd);
+    ci = co;
+    for (int lv = 0; lv < levels; lv++) {
+        co = ci / 2;
+        float *u = conv_transpose2d3(x, ci, H, Wd, W(b, "rm.dec%d.up.w", lv), W(b, "rm.dec%d.up.b", lv), co);
+        free(x); H *= 2; Wd *= 2; size_t HW = (size_t)H * Wd;
+        for (size_t i = 0; i < co * HW; i++) u[i] = u[i] > 0.f ? u[i] : 0.f;
+        int sl = levels - 1 - lv;
+        if (skipC[sl] != co || skipH[sl] != H || skipW[sl] != Wd) { fprintf(stderr, "oracle: rmvpe skip shape mismatch\n"); abort(); }
+        float *cat = falloc(2 * co * HW);
+        memcpy(cat, u, co * HW * sizeof(float)); memcpy(cat + co * HW, skips[sl], co * HW * sizeof(float));
+        free(u); free(skips[sl]);
+        x = cat;
+        for (int j = 0; j < nb; j++) { snprintf(pre, sizeof pre, "rm.dec%d.b%d.", lv, j); float *y = conv_block_res(b, pre, x, j == 0 ? 2 * co : co, co, H, Wd); free(x); x = y; }
+        tapf(e, x, (size_t)co * H * Wd, "rm.dec%d", lv);
+        ci = co;
+    }
+    float *cn = conv2d3(x, ci, H, Wd, W(b, "rm.cnn.w"), W(b, "rm.cnn.b"), 3);
+    free(x);
+    /* (3, Tm, n_mels) -> transpose(1,2).flatten(-2) -> feat[t][c*n_mels + m] */
+    int I = 3 * n_mels;
+    float *feat = falloc((size_t)Tm * I);
+    for (int t = 0; t < Tm; t++) for (int c = 0; c < 3; c++) for (int m = 0; m < n_mels; m++) feat[(size_t)t * I + c * n_mels + m] = cn[((size_t)c * Tm + t) * n_mels + m];
+    free(cn);
+    tap(e, "rm.cnn", feat, (size_t)Tm * I);
+    /* BiGRU, PyTorch gate order (r, z, n): n = tanh(W_in x + b_in + r * (W_hn h + b_hn)) */
+    float *gout = falloc((size_t)Tm * 2 * Hg);
+    for (int dir = 0; dir < 2; dir++) {
+        const char *sfx = dir == 0 ? "f" : "b";
+        const float *wih = W(b, "rm.gru.w_ih_%s", sfx), *whh = W(b, "rm.gru.w_hh_%s", sfx), *bih = W(b, "rm.gru.b_ih_%s", sfx), *bhh = W(b, "rm.gru.b_hh_%s", sfx);
+        float *h = falloc(Hg), *gi = falloc(3 * Hg), *gh = falloc(3 * Hg);
+        for (int step = 0; step < Tm; step++) {
+            int t = dir == 0 ? step : Tm - 1 - step;
+            const float *xt = feat + (size_t)t * I;
+#pragma omp parallel for
+            for (int r = 0; r < 3 * Hg; r++) {
+                float a = bih[r]; for (int j = 0; j < I; j++) a += wih[(size_t)r * I + j] * xt[j]; gi[r] = a;
+                float c = bhh[r]; for (int j = 0; j < Hg; j++) c += whh[(size_t)r * Hg + j] * h[j]; gh[r] = c;
+            }
+            for (int j = 0; j < Hg; j++) {
+                float r = sigmoid_f(gi[j] + gh[j]), z = sigmoid_f(gi[Hg + j] + gh[Hg + j]);
+                float nn = tanhf(gi[2 * Hg + j] + r * gh[2 * Hg + j]);
+                h[j] = (1.f - z) * nn + z * h[j];
+                gout[(size_t)t * 2 * Hg + dir * Hg + j] = h[j];
+            }
+        }
+        free(h); free(gi); free(gh);
+    }
+    free(feat);
+    tap(e, "rm.gru", gout, (size_t)Tm * 2 * Hg);
+    float *sal = falloc((size_t)Tm * n_out);
+    const float *fw = W(b, "rm.fc.w"), *fb = W(b, "rm.fc.b");
+#pragma omp parallel for
+    for (int t = 0; t < Tm; t++) for (int o = 0; o < n_out; o++) {
+        float a = fb[o]; for (int j = 0; j < 2 * Hg; j++) a += fw[(size_t)o * 2 * Hg + j] * gout[(size_t)t * 2 * Hg + j];
+        sal[(size_t)t * n_out + o] = sigmoid_f(a);
+    }
+    free(gout);
+    tap(e, "rm.sal", sal, (size_t)Tm * n_out);
+    return sal;
+}
+
+/* rmvpe.rs:250-261 (Rmvpe::pitch) + rmvpe.rs:225-241 (mel2hidden; Q5: the pad branch is unreachable
+ * because f0_extractor_frame = 5120k-160 gives Tm = 32k) */
+static int rmvpe_pitch(ora_engine *e, const float *in, size_t n, size_t sample_frame_16k, float threshold, float **f0_out, size_t *len)
+{
+    size_t fr = ora_f0_extractor_frame(sample_frame_16k);
+    if (fr > n) { snprintf(e->err, sizeof e->err, "input (%zu) shorter than f0_extractor_frame (%zu)", n, fr); return ORA_PANIC; }
+    const float *tail = in + (n - fr);
+    size_t Tm = 1 + fr / 160;
+    float *mel = falloc(128 * Tm);
+    ora_mel_extract(tail, fr, mel);
+    tap(e, "rm.mel", mel, 128 * Tm);
+    if (Tm % 32 != 0) { free(mel); snprintf(e->err, sizeof e->err, "Tm=%zu not a multiple of 32 (Q5 branch)", Tm); return ORA_PANIC; }
+    float *sal = rmvpe_forward(e, mel, (int)Tm);
+    free(mel);
+    float *f0 = falloc(Tm);
+    int rc = ora_decode(sal, Tm, threshold, f0);
+    free(sal);
+    if (rc != ORA_OK) { free(f0); snprintf(e->err, sizeof e->err, "to_local_average_cents: index out of bounds (Q3)"); return rc; }
+    *f0_out = f0; *len = Tm;
+    return ORA_OK;
+}
+
+/* rvc.rs:111-131 */
+int ora_pitch(ora_engine *e, const float *in, size_t n, int pitch_shift, size_t sample_frame_16k, float *out, size_t cap, size_t *out_len)
+{
+    if (!e->rm) return ORA_F0_NOT_LOADED;   /* reference: unreachable!() at rvc.rs:125 */
+    float *f0; size_t len; int rc = rmvpe_pitch(e, in, n, sample_frame_16k, 0.03f, &f0, &len);
+    if (rc != ORA_OK) return rc;
+    float up = ora_uppower(pitch_shift);
+    *out_len = len;
+    if (cap < len) { free(f0); return ORA_SHAPE; }
+    for (size_t i = 0; i < len; i++) out[i] = f0[i] * up;
+    free(f0); return ORA_OK;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Synthesizer                                                   */
+/* ------------------------------------------------------------------------------------ */
+static void relpos_mha(const blob *b, int l, const float *x, float *out, int Hd, int T, int heads, int window)
+{
+    int kc = Hd / heads, To; char nm[64];
+    (void)nm;
+    float *q = conv1d(x, Hd, T, W(b, "sy.enc.l%d.q.w", l), W(b, "sy.enc.l%d.q.b", l), Hd, 1, 1, 0, 1, 1, &To);
+    float *k = conv1d(x, Hd, T, W(b, "sy.enc.l%d.k.w", l), W(b, "sy.enc.l%d.k.b", l), Hd, 1, 1, 0, 1, 1, &To);
+    float *v = conv1d(x, Hd, T, W(b, "sy.enc.l%d.v.w", l), W(b, "sy.enc.l%d.v.b", l), Hd, 1, 1, 0, 1, 1, &To);
+    const float *rk = W(b, "sy.enc.l%d.rel_k", l), *rv = W(b, "sy.enc.l%d.rel_v", l);
+    float *a = falloc((size_t)Hd * T);
+    float scale = 1.0f / sqrtf((float)kc);
+    for (int h = 0; h < heads; h++)
+        for (int i = 0; i < T; i++) {
+            float s[4096]; float mx = -INFINITY;
+            for (int j = 0; j < T; j++) {
+                float acc = 0.f;
+                for (int d = 0; d < kc; d++) acc += (q[(size_t)(h * kc + d) * T + i] * scale) * k[(size_t)(h * kc + d) * T + j];
+                int r = j - i;
+                if (r >= -window && r <= window) { float ra = 0.f; for (int d = 0; d < kc; d++) ra += (q[(size_t)(h * kc + d) * T + i] * scale) * rk[(size_t)(r + window) * kc + d]; acc += ra; }
+                s[j] = acc; if (acc > mx) mx = acc;
+            }
+            float sum = 0.f; for (int j = 0; j < T; j++) { s[j] = expf(s[j] - mx); sum += s[j]; }
+            float inv = 1.0f / sum;
+            for (int j = 0; j < T; j++) s[j] *= inv;
+            for (int d = 0; d < kc; d++) {
+                float acc = 0.f;
+                for (int j = 0; j < T; j++) acc += s[j] * v[(size_t)(h * kc + d) * T + j];
+                for (int j = 0; j < T; j++) { int r = j - i; if (r >= -window && r <= window) acc += s[j] * rv[(size_t)(r + window) * kc + d]; }
+                a[(size_t)(h * kc + d) * T + i] = acc;
+            }
+        }
+    float *o = conv1d(a, Hd, T, W(b, "sy.enc.l%d.o.w", l), W(b, "sy.enc.l%d.o.b", l), Hd, 1, 1, 0, 1, 1, &To);
+    memcpy(out, o, (size_t)Hd * T * sizeof(float));
+    free(q); free(k); free(v); free(a); free(o);
+}
+
+/* NSF harmonic source: SineGen (harmonic_num = 0) + SourceModuleHnNSF linear + tanh */
+static float *nsf_source(ora_engine *e, const blob *b, const float *f0, int T, int upp, int sr)
+{
+    size_t N = (size_t)T * upp;
+    float *rad = falloc(T), *cum = falloc(T);
+    double acc = 0.0; (void)acc;
+    float c = 0.f;
+    for (int t = 0; t < T; t++) { rad[t] = fmodf(f0[t] / (float)sr, 1.0f); c += rad[t]; cum[t] = c * (float)upp; }
+    float *tmp = falloc(N), *src = falloc(N), *noise = falloc(N);
+    /* F.interpolate(..., scale_factor=upp, mode="linear", align_corners=True) of the frame-rate cumsum, then % 1 */
+    for (size_t i = 0; i < N; i++) {
+        float pos = (N > 1) ? (float)i * (float)(T - 1) / (float)(N - 1) : 0.f;
+        int i0 = (int)floorf(pos); if (i0 > T - 1) i0 = T - 1; int i1 = i0 + 1 < T ? i0 + 1 : T - 1;
+        float w = pos - (float)i0;
+        float v = cum[i0] * (1.0f - w) + cum[i1] * w;
+        tmp[i] = fmodf(v, 1.0f);
+    }
+    ora_philox_normal(e->seed, e->stream, e->chunk, 1u, N, noise);
+    const float *lin = W(b, "sy.src");
+    float phase = 0.f;
+    for (size_t i = 0; i < N; i++) {
+        int t = (int)(i / (size_t)upp);
+        float shift = (i > 0 && (tmp[i] - tmp[i - 1]) < 0.f) ? -1.0f : 0.f;
+        phase += rad[t] + shift;
+        float sine = sinf(phase * 6.28318530717958647692f) * 0.1f;
+        float uv = f0[t] > 0.f ? 1.f : 0.f;
+        float namp = uv * 0.003f + (1.f - uv) * 0.1f / 3.f;
+        float sw = sine * uv + namp * noise[i];
+        src[i] = tanhf(lin[0] * sw + lin[1]);
+    }
+    free(rad); free(cum); free(tmp); free(noise);
+    return src;
+}
+
+static float *synth_forward(ora_engine *e, const float *phone /* [R][Cin] */, const int32_t *pitch, const float *pitchf, int R, size_t *n_out)
+{
+    const blob *b = e->sy;
+    int Cin = icfg(b, "phone_dim"), Hd = icfg(b, "hidden"), I = icfg(b, "inter"), F = icfg(b, "filter"), heads = icfg(b, "heads");
+    int nl = icfg(b, "enc_layers"), ek = icfg(b, "enc_k"), window = icfg(b, "window"), flow_n = icfg(b, "flow_n"), wn_l = icfg(b, "wn_layers"), wn_k = icfg(b, "wn_k");
+    int G = icfg(b, "gin"), C0 = icfg(b, "up_init"), n_ups = icfg(b, "n_ups"), n_rb = icfg(b, "n_rb"), n_rbd = icfg(b, "n_rbd"), sr = icfg(b, "sr");
+    int T = R, To;
+    const float *g = W(b, "sy.g");
+    /* --- TextEncoder --- */
+    float *x = falloc((size_t)Hd * T);
+    {
+        const float *pw = W(b, "sy.enc.phone.w"), *pb = W(b, "sy.enc.phone.b"), *emb = W(b, "sy.enc.pitch_emb");
+        float sq = sqrtf((float)Hd);
+        for (int t = 0; t < T; t++) for (int c = 0; c < Hd; c++) {
+            float a = pb[c]; for (int j = 0; j < Cin; j++) a += pw[(size_t)c * Cin + j] * phone[(size_t)t * Cin + j];
+            a += emb[(size_t)pitch[t] * Hd + c];
+            x[(size_t)c * T + t] = lrelu_f(a * sq, 0.1f);
+        }
+    }
+    tap(e, "sy.emb", x, (size_t)Hd * T);
+    float *y = falloc((size_t)Hd * T);
+    for (int l = 0; l < nl; l++) {
+        relpos_mha(b, l, x, y, Hd, T, heads, window);
+        for (size_t j = 0; j < (size_t)Hd * T; j++) x[j] += y[j];
+        layernorm_ct(x, Hd, T, W(b, "sy.enc.l%d.ln1.g", l), W(b, "sy.enc.l%d.ln1.b", l));
+        float *f1 = conv1d(x, Hd, T, W(b, "sy.enc.l%d.ff1.w", l), W(b, "sy.enc.l%d.ff1.b", l), F, ek, 1, ek / 2, 1, 1, &To);
+        for (size_t j = 0; j < (size_t)F * T; j++) f1[j] = f1[j] > 0.f ? f1[j] : 0.f;
+        float *f2 = conv1d(f1, F, T, W(b, "sy.enc.l%d.ff2.w", l), W(b, "sy.enc.l%d.ff2.b", l), Hd, ek, 1, ek / 2, 1, 1, &To);
+        for (size_t j = 0; j < (size_t)Hd * T; j++) x[j] += f2[j];
+        layernorm_ct(x, Hd, T, W(b, "sy.enc.l%d.ln2.g", l), W(b, "sy.enc.l%d.ln2.b", l));
+        free(f1); free(f2);
+    }
+    free(y);
+    tap(e, "sy.enc", x, (size_t)Hd * T);
+    float *stats = conv1d(x, Hd, T, W(b, "sy.enc.proj.w"), W(b, "sy.enc.proj.b"), 2 * I, 1, 1, 0, 1, 1, &To);
+    free(x);
+    /* --- prior sample: z_p = m + exp(logs) * eps * 0.66666 --- */
+    float *z = falloc((size_t)I * T), *eps = falloc((size_t)I * T);
+    ora_philox_normal(e->seed, e->stream, e->chunk, 0u, (size_t)I * T, eps);
+    for (size_t j = 0; j < (size_t)I * T; j++) z[j] = stats[j] + expf(stats[(size_t)I * T + j]) * eps[j] * 0.66666f;
+    tap(e, "sy.stats", stats, (size_t)2 * I * T);
+    free(stats); free(eps);
+    tap(e, "sy.zp", z, (size_t)I * T);
+    /* --- flow, reverse: for i = flow_n-1 .. 0: Flip, then coupling_i reverse --- */
+    int half = I / 2;
+    float *tmpz = falloc((size_t)I * T);
+    for (int fi = flow_n - 1; fi >= 0; fi--) {
+        for (int c = 0; c < I; c++) memcpy(tmpz + (size_t)c * T, z + (size_t)(I - 1 - c) * T, T * sizeof(float));
+        memcpy(z, tmpz, (size_t)I * T * sizeof(float));
+        float *h = conv1d(z, half, T, W(b, "sy.flow%d.pre.w", fi), W(b, "sy.flow%d.pre.b", fi), Hd, 1, 1, 0, 1, 1, &To);
+        float *cond = falloc((size_t)2 * Hd * wn_l);
+        { const float *cw = W(b, "sy.flow%d.cond.w", fi), *cb = W(b, "sy.flow%d.cond.b", fi);
+          for (int r = 0; r < 2 * Hd * wn_l; r++) { float a = cb[r]; for (int j = 0; j < G; j++) a += cw[(size_t)r * G + j] * g[j]; cond[r] = a; } }
+        float *skip = falloc((size_t)Hd * T);
+        for (int j = 0; j < wn_l; j++) {
+            char nm[64]; snprintf(nm, sizeof nm, "sy.flow%d.in%d", fi, j);
+            float *a = conv1d(h, Hd, T, W(b, "%s.w", nm), W(b, "%s.b", nm), 2 * Hd, wn_k, 1, (wn_k - 1) / 2, 1, 1, &To);
+            float *acts = falloc((size_t)Hd * T);
+            for (int c = 0; c < Hd; c++) for (int t = 0; t < T; t++) {
+                float ta = a[(size_t)c * T + t] + cond[j * 2 * Hd + c], sa = a[(size_t)(Hd + c) * T + t] + cond[j * 2 * Hd + Hd + c];
+                acts[(size_t)c * T + t] = tanhf(ta) * sigmoid_f(sa);
+            }
+            int rs_c = j < wn_l - 1 ? 2 * Hd : Hd;
+            snprintf(nm, sizeof nm, "sy.flow%d.rs%d", fi, j);
+            float *rs = conv1d(acts, Hd, T, W(b, "%s.w", nm), W(b, "%s.b", nm), rs_c, 1, 1, 0, 1, 1, &To);
+            if (j < wn_l - 1) { for (size_t q = 0; q < (size_t)Hd * T; q++) { h[q] += rs[q]; skip[q] += rs[(size_t)Hd * T + q]; } }
+            else { for (size_t q = 0; q < (size_t)Hd * T; q++) skip[q] += rs[q]; }
+            free(a); free(acts); free(rs);
+        }
+        float *m = conv1d(skip, Hd, T, W(b, "sy.flow%d.post.w", fi), W(b, "sy.flow%d.post.b", fi), half, 1, 1, 0, 1, 1, &To);
+        for (size_t q = 0; q < (size_t)half * T; q++) z[(size_t)half * T + q] -= m[q];
+        free(h); free(cond); free(skip); free(m);
+    }
+    free(tmpz);
+    tap(e, "sy.z", z, (size_t)I * T);
+    /* --- NSF-HiFiGAN decoder --- */
+    int upp = 1; for (int i = 0; i < n_ups; i++) upp *= icfgf(b, "up_rate%d", i);
+    float *src = nsf_source(e, b, pitchf, T, upp, sr);
+    size_t N = (size_t)T * upp;
+    tap(e, "sy.src", src, N);
+    float *xd = conv1d(z, I, T, W(b, "sy.dec.pre.w"), W(b, "sy.dec.pre.b"), C0, 7, 1, 3, 1, 1, &To);
+    free(z);
+    { const float *cw = W(b, "sy.dec.cond.w"), *cb = W(b, "sy.dec.cond.b");
+      for (int c = 0; c < C0; c++) { float a = cb[c]; for (int j = 0; j < G; j++) a += cw[(size_t)c * G + j] * g[j]; for (int t = 0; t < T; t++) xd[(size_t)c * T + t] += a; } }
+    tap(e, "sy.pre", xd, (size_t)C0 * T);
+    int c = C0, Tc = T;
+    for (int i = 0; i < n_ups; i++) {
+        int co = c / 2, K = icfgf(b, "up_kernel%d", i), S = icfgf(b, "up_rate%d", i), Tn;
+        for (size_t q = 0; q < (size_t)c * Tc; q++) xd[q] = lrelu_f(xd[q], 0.1f);
+        float *u = conv_transpose1d(xd, c, Tc, W(b, "sy.dec.up%d.w", i), W(b, "sy.dec.up%d.b", i), co, K, S, (K - S) / 2, &Tn);
+        free(xd);
+        int sf = 1; for (int q = i + 1; q < n_ups; q++) sf *= icfgf(b, "up_rate%d", q);
+        int Tsrc; float *ns;
+        if (i + 1 < n_ups) ns = conv1d(src, 1, (int)N, W(b, "sy.dec.nc%d.w", i), W(b, "sy.dec.nc%d.b", i), co, sf * 2, sf, sf / 2, 1, 1, &Tsrc);
+        else ns = conv1d(src, 1, (int)N, W(b, "sy.dec.nc%d.w", i), W(b, "sy.dec.nc%d.b", i), co, 1, 1, 0, 1, 1, &Tsrc);
+        if (Tsrc != Tn) { fprintf(stderr, "oracle: noise conv length %d != upsampled length %d\n", Tsrc, Tn); abort(); }
+        for (size_t q = 0; q < (size_t)co * Tn; q++) u[q] += ns[q];
+        free(ns);
+        tapf(e, u, (size_t)co * Tn, "sy.up%d", i);
+        float *xs = falloc((size_t)co * Tn);
+        for (int j = 0; j < n_rb; j++) {
+            int k = icfgf(b, "rb_k%d", j);
+            float *r = falloc((size_t)co * Tn); memcpy(r, u, (size_t)co * Tn * sizeof(float));
+            for (int m = 0; m < n_rbd; m++) {
+                int d = icfgf(b, "rb_d%d", m);
+                float *xt = falloc((size_t)co * Tn);
+                for (size_t q = 0; q < (size_t)co * Tn; q++) xt[q] = lrelu_f(r[q], 0.1f);
+                float *y1 = conv1d(xt, co, Tn, W(b, "sy.dec.rb%d_%d.c1_%d.w", i, j, m), W(b, "sy.dec.rb%d_%d.c1_%d.b", i, j, m), co, k, 1, (k * d - d) / 2, d, 1, &To);
+                for (size_t q = 0; q < (size_t)co * Tn; q++) y1[q] = lrelu_f(y1[q], 0.1f);
+                float *y2 = conv1d(y1, co, Tn, W(b, "sy.dec.rb%d_%d.c2_%d.w", i, j, m), W(b, "sy.dec.rb%d_%d.c2_%d.b", i, j, m), co, k, 1, (k - 1) / 2, 1, 1, &To);
+                for (size_t q = 0; q < (size_t)co * Tn; q++) r[q] += y2[q];
+                free(xt); free(y1); free(y2);
+            }
+            for (size_t q = 0; q < (size_t)co * Tn; q++) xs[q] += r[q];
+            free(r);
+        }
+        float invn = 1.0f / (float)n_rb;
+        for (size_t q = 0; q < (size_t)co * Tn; q++) xs[q] *= invn;
+        free(u);
+        tapf(e, xs, (size_t)co * Tn, "sy.rb%d", i);
+        xd = xs; c = co; Tc = Tn;
+    }
+    free(src);
+    for (size_t q = 0; q < (size_t)c * Tc; q++) xd[q] = lrelu_f(xd[q], 0.01f);
+    float *au = conv1d(xd, c, Tc, W(b, "sy.dec.post.w"), NULL, 1, 7, 1, 3, 1, 1, &To);
+    free(xd);
+    for (int t = 0; t < To; t++) au[t] = tanhf(au[t]);
+    *n_out = (size_t)To;
+    return au;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* RvcInfer::infer (rvc/src/rvc.rs:133-220)                                               */
+/* ------------------------------------------------------------------------------------ */
+int ora_infer(ora_engine *e, const float *in, size_t n, size_t sample_frame_16k, int has_pitch_shift, int pitch_shift,
+              uint32_t skip_head_, uint32_t return_length_, float *out, size_t cap, size_t *out_len)
+{
+    if (!e->sy) return ORA_MODEL_NOT_LOADED;                       /* rvc.rs:141-143 */
+    if (!e->cv) return ORA_CONTENTVEC_NOT_LOADED;                  /* rvc.rs:85-88 via extract_feature */
+    size_t skip_head = skip_head_, return_length = return_length_;
+    int C, T;
+    float *h = contentvec_forward(e, in, n, &C, &T);              /* rvc.rs:151 */
+    if (!h) return ORA_SHAPE;
+    size_t T2 = 2 * (size_t)T + 1;
+    size_t hubert_length = n / 160 < T2 ? n / 160 : T2;             /* rvc.rs:153 */
+    if (skip_head + return_length > T2) { free(h); snprintf(e->err, sizeof e->err, "slice %zu..%zu out of %zu frames", skip_head, skip_head + return_length, T2); return ORA_PANIC; }
+    if (icfg(e->sy, "phone_dim") != C) { free(h); snprintf(e->err, sizeof e->err, "phone dim mismatch"); return ORA_BACKEND; }
+    /* rvc.rs:155: phone[r] = feats[skip_head + r] = raw[min((skip_head+r)/2, T-1)]  (Q2, Q8) */
+    float *phone = falloc(return_length * C);
+    for (size_t r = 0; r < return_length; r++) { size_t k = skip_head + r, s = k / 2 < (size_t)T - 1 ? k / 2 : (size_t)T - 1; for (int c = 0; c < C; c++) phone[r * C + c] = h[(size_t)c * T + s]; }
+    free(h);
+    /* rvc.rs:159 TODO -> flat-L2 retrieval */
+    free(e->knn_idx); free(e->knn_dist); e->knn_idx = NULL; e->knn_dist = NULL; e->knn_rows = 0;
+    if (e->index && e->index_rate > 0.f && e->index_dim == (size_t)C) {
+        const int k = 4;
+        e->knn_idx = (int32_t *)malloc(return_length * k * sizeof(int32_t)); e->knn_dist = falloc(return_length * k); e->knn_rows = return_length;
+        ora_knn_search(e->index, e->index_n, e->index_dim, phone, return_length, k, e->knn_idx, e->knn_dist);
+        for (size_t r = 0; r < return_length; r++) {
+            float w[4], ws = 0.f;
+            for (int j = 0; j < k; j++) { float inv = 1.0f / e->knn_dist[r * k + j]; w[j] = inv * inv; ws += w[j]; }
+            for (int c = 0; c < C; c++) {
+                float acc = 0.f; for (int j = 0; j < k; j++) acc += (w[j] / ws) * e->index[(size_t)e->knn_idx[r * k + j] * C + c];
+                phone[r * C + c] = e->index_rate * acc + (1.0f - e->index_rate) * phone[r * C + c];
+            }
+        }
+    }
+    tap(e, "phone", phone, return_length * C);
+    /* rvc.rs:163-182 */
+    if (!e->rm) { free(phone); return ORA_F0_NOT_LOADED; }
+    int ps = has_pitch_shift ? pitch_shift : 0;
+    float *f0; size_t pitch_len;
+    int rc = rmvpe_pitch(e, in, n, sample_frame_16k, 0.03f, &f0, &pitch_len);
+    if (rc != ORA_OK) { free(phone); return rc; }
+    float up = ora_uppower(ps);
+    for (size_t i = 0; i < pitch_len; i++) f0[i] *= up;
+    tap(e, "f0", f0, pitch_len);
+    size_t shift = sample_frame_16k / 160;                           /* rvc.rs:168 */
+    if (shift > 1024 || pitch_len < 5 || pitch_len - 4 > 1024) { free(phone); free(f0); return ORA_PANIC; }
+    memmove(e->cache_pitchf, e->cache_pitchf + shift, (1024 - shift) * sizeof(float));   /* rvc.rs:170, ndarray_ext.rs:5-32 */
+    size_t cache_start = 1024 + 4 - pitch_len;                       /* rvc.rs:172 */
+    memcpy(e->cache_pitchf + cache_start, f0 + 3, (pitch_len - 4) * sizeof(float));      /* rvc.rs:174: pitchf[3..len-1] */
+    free(f0);
+    if (hubert_length > 1024 + skip_head || 1024 - hubert_length + skip_head + return_length > 1024) { free(phone); snprintf(e->err, sizeof e->err, "pitch cache slice out of range"); return ORA_PANIC; }
+    size_t rs = 1024 - hubert_length + skip_head;                    /* rvc.rs:176 */
+    float *pitchf = falloc(return_length); int32_t *pitch = (int32_t *)malloc(return_length * sizeof(int32_t));
+    memcpy(pitchf, e->cache_pitchf + rs, return_length * sizeof(float));
+    ora_get_f0_post(pitchf, return_length, pitch);                   /* rvc.rs:180 */
+    tap(e, "pitchf", pitchf, return_length);
+    { float *pf = falloc(return_length); for (size_t i = 0; i < return_length; i++) pf[i] = (float)pitch[i]; tap(e, "pitch", pf, return_length); free(pf); }
+    /* rvc.rs:193-214 */
+    size_t N; float *au = synth_forward(e, phone, pitch, pitchf, (int)return_length, &N);
+    free(phone); free(pitchf); free(pitch);
+    e->chunk++;
+    *out_len = N;
+    if (cap < N) { free(au); return ORA_SHAPE; }
+    memcpy(out, au, N * sizeof(float));
+    tap(e, "audio", au, N);
+    free(au);
+    return ORA_OK;
+}
