@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""bench.py -- streaming-inference benchmark of the MI355X-native RVC engine.
+
+Metric (BASELINE.json): audio frames/s (+ p99 per-chunk latency), 160 ms chunks @16 kHz.
+A "step" is one 160 ms chunk of every stream of this rank through the whole per-chunk hot path
+(ContentVec -> RMVPE f0 -> [retrieval] -> NSF-HiFiGAN); one chunk = 16 new 10 ms frames.
+Workload at N=1: BASELINE configs[1] (1 stream, v2/768 ContentVec + RMVPE + v2-48k synthesizer,
+retrieval off).  With --gpus N every rank runs its own stream(s) (streams are independent, no per-chunk
+collective; RCCL is used only for the barrier/max and, with --index, the index broadcast at load).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--index] [--no-graph] [--no-cpu]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+FRAMES_PER_CHUNK = 16              # 160 ms chunk = 16 hops of 10 ms
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=1, help="concurrent streams per GPU (BASELINE config 4: 64)")
+    ap.add_argument("--index", action="store_true", help="BASELINE config 3: 100k x 768 flat-L2 retrieval, k=4, rate 0.75")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--preset", default="full")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from common import BASELINE_160MS as g, chunk_stream, voice_signal, zoo
+    from obs_rvc_amd import weights as W
+    from obs_rvc_amd.rvc import RvcInfer
+
+    if rank == 0:
+        z = zoo(args.preset)
+    if world > 1:
+        dist.barrier()
+    z = zoo(args.preset)
+
+    S = args.streams
+    eng = RvcInfer(z["data"], device=local_rank)
+    eng.load_contentvec(2); eng.load_f0(1); eng.load_model(z["model"])
+    eng.set_streams(S)
+    eng.set_noise_seed(1234, rank * S)
+    if args.index:
+        from obs_rvc_amd import dist as rdist
+        rdist.load_shared_index(eng, W.make_index() if rank == 0 else None, 100000, 768, rank, world)
+        eng.set_index_rate(0.75)
+    eng.set_use_graph(not args.no_graph)
+
+    # synthetic 16 kHz input: stream s of rank r uses audio seed r*S + s; the ring states are precomputed and
+    # made resident in HBM before the timed region (the chunk's H2D is outside `value`)
+    L, chunk = g.input_buffer_16k_size, g.sample_frame_16k
+    n_rings = 8
+    rings = np.zeros((n_rings, S, L), np.float32)
+    for s in range(S):
+        audio = voice_signal(chunk * (n_rings + 14), seed=rank * S + s)
+        rs = list(chunk_stream(audio, L, chunk))[-n_rings:]
+        for i in range(n_rings):
+            rings[i, s] = rs[i]
+    d_rings = torch.from_numpy(rings).cuda()
+    N = g.model_return_size
+    d_out = torch.empty((S, N), dtype=torch.float32, device="cuda")
+
+    def step(i, sync):
+        eng.infer_device(d_rings[i % n_rings].data_ptr(), L, chunk, 12, g.skip_head, g.model_return_length, d_out.data_ptr(), N, sync=sync)
+
+    for i in range(args.warmup):
+        step(i, True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # timed region: exactly K steps; each step is synchronised so that per-chunk latency is observed
+    barrier()
+    lat = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        t1 = time.perf_counter()
+        step(i, True)
+        lat.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        lt = torch.tensor(sorted(lat), dtype=torch.float64, device="cuda")
+        gl = [torch.empty_like(lt) for _ in range(world)]
+        dist.all_gather(gl, lt)
+        lat = torch.cat(gl).cpu().numpy().tolist()
+    lat = np.array(lat)
+
+    # roofline of the dominant kernel class (implicit-GEMM on the fp32 matrix cores): per-launch HIP events
+    # on the engine's own stream over a few chunks, eager launches (same kernels, same shapes)
+    roof = None
+    if rank == 0:
+        eng.set_profile(True)
+        tot_ms = tot_fl = 0.0
+        n_l = 0
+        reps = 5
+        for i in range(reps):
+            step(i, True)
+            nl, ms, fl = eng.profile_last()
+            tot_ms += ms; tot_fl += fl; n_l += nl
+        eng.set_profile(False)
+        achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": None,
+                "kernel": "rvc::igemm_kernel<MF,NF> (all instantiations)", "launches_per_step": n_l // reps,
+                "avg_launch_us": round(tot_ms * 1e3 / max(n_l, 1), 3), "flops_per_step": tot_fl / reps}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        # CPU baseline: the C oracle (a port of the reference's path; the reference itself -- Rust + ONNX Runtime -- cannot
+        # run here) on this node's host cores, bounded sample of the same workload
+        from oracle import oracle as O
+        threads = min(os.cpu_count() or 1, 32)
+        O.set_threads(threads)
+        ora = O.OracleRvcInfer(z["data"])
+        ora.load_contentvec(2); ora.load_f0(1); ora.load_model(z["model"]); ora.set_noise_seed(1234, 0)
+        if args.index:
+            ora.load_index(W.make_index()); ora.set_index_rate(0.75)
+        n_cpu = 24
+        ora.infer(rings[0, 0], chunk, 12, g.skip_head, g.model_return_length)
+        c0 = time.perf_counter()
+        for i in range(n_cpu):
+            ora.infer(rings[i % n_rings, 0], chunk, 12, g.skip_head, g.model_return_length)
+        ct = time.perf_counter() - c0
+        cpu = {"value": round(FRAMES_PER_CHUNK * n_cpu / ct, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+               "sample": "%d chunks of stream 0 (same rings, same weights), C oracle with OpenMP, %.1f s" % (n_cpu, ct),
+               "ms_per_chunk": round(ct / n_cpu * 1e3, 2)}
+
+    if rank == 0:
+        total_streams = S * world
+        value = FRAMES_PER_CHUNK * args.steps * total_streams / elapsed
+        out = {
+            "metric": "audio frames/sec (10 ms hops of new input, 160 ms chunks @16 kHz)", "value": round(value, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[%d]: %d stream(s)/GPU, ContentVec v2-768 + RMVPE + NSF-HiFiGAN v2-48k, retrieval %s, preset %s"
+                                   % (2 if args.index else (1 if S == 1 else 3), S, "100k x768 flat-L2 k=4" if args.index else "off", args.preset),
+                       "streams_per_gpu": S, "chunk_ms": 160, "input_samples_16k": L, "output_samples": N, "hip_graph": not args.no_graph},
+            "latency_ms": {"p50": round(float(np.percentile(lat, 50)) * 1e3, 4), "p99": round(float(np.percentile(lat, 99)) * 1e3, 4),
+                           "max": round(float(lat.max()) * 1e3, 4)},
+            "rtf": round(float(np.percentile(lat, 99)) / 0.160, 5),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

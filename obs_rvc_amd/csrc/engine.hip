@@ -198,7 +198,7 @@ static void free_conv(ConvW &c)
 struct ConvOpts {
     int act = ACT_NONE; float slope = 0.f; float scale = 1.f; bool accumulate = false;
     int pre_act = ACT_NONE; float pre_slope = 0.f;
-    const float *res = nullptr; int res_cs = 0; long long res_bs = 0;
+    const float *res = nullptr; int res_cs = 0; long long res_bs = 0; int res_rs = 0;
     int m_off = 0, m_cnt = -1;   // output-row sub-range of the weight panel
     bool no_bias = false;
 };
@@ -311,7 +311,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
 static void fill_epilogue(IgemmP &p, const ConvW &cw, const ConvOpts &o)
 {
     p.bias = (o.no_bias || !cw.bias) ? nullptr : cw.bias + o.m_off;
-    p.res = o.res; p.res_cs = o.res_cs; p.res_bs = o.res_bs;
+    p.res = o.res; p.res_cs = o.res_cs; p.res_bs = o.res_bs; p.res_rs = o.res_rs;
     p.act = o.act; p.slope = o.slope; p.scale = o.scale; p.accumulate = o.accumulate ? 1 : 0;
     p.pre_act = o.pre_act; p.pre_slope = o.pre_slope;
     p.part = nullptr;
@@ -328,8 +328,8 @@ static void add_conv1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int 
     IgemmP p{};
     p.x = x.p; p.w = cw.w + (long long)o.m_off * cw.Kp; p.y = y.p;
     p.M = o.m_cnt >= 0 ? o.m_cnt : cw.M; p.N = y.T; p.K = cw.Kp;
-    p.NW = y.T; p.x_hs = 0; p.x_ws = stride; p.y_hs = 0; p.y_ws = 1; p.OW = y.T;
-    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.ld;
+    p.NW = y.T; p.x_hs = 0; p.x_ws = stride; p.y_hm = 0; p.y_ws = 1; p.OW = y.T;
+    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.ld; p.y_rs = 0;
     fill_epilogue(p, cw, o);
     if (cw.groups > 1 && (o.m_off != 0 || o.m_cnt >= 0)) throw std::runtime_error("row sub-range on grouped conv");
     std::vector<int> koff(cw.Kp, 0);
@@ -339,7 +339,7 @@ static void add_conv1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int 
         ph[g] = PhaseD{};
         ph[g].w_off = (long long)g * cw.M * cw.Kp;
         ph[g].x_off = g * cig * x.ld;
-        ph[g].y_off = g * cw.M * y.ld;
+        ph[g].y_c0 = g * cw.M;
         ph[g].y_pos = 0;
         ph[g].bias_off = g * cw.M;
         ph[g].koff_off = 0;
@@ -357,8 +357,8 @@ static void add_convT1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int
     IgemmP p{};
     p.x = x.p; p.w = cw.w; p.y = y.p;
     p.M = cw.M; p.N = x.T + nt - 1; p.K = cw.Kp;
-    p.NW = p.N; p.x_hs = 0; p.x_ws = 1; p.y_hs = 0; p.y_ws = S; p.OW = y.T;
-    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.ld;
+    p.NW = p.N; p.x_hs = 0; p.x_ws = 1; p.y_hm = 0; p.y_ws = S; p.OW = y.T;
+    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.ld; p.y_rs = 0;
     fill_epilogue(p, cw, o);
     std::vector<int> koff(cw.Kp, 0);
     for (int ci = 0; ci < cw.Cin; ci++) for (int j = 0; j < nt; j++) koff[ci * nt + j] = ci * x.ld - j;
@@ -367,7 +367,6 @@ static void add_convT1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int
         ph[q] = PhaseD{};
         ph[q].w_off = (long long)q * cw.M * cw.Kp;
         ph[q].x_off = 0;
-        ph[q].y_off = q - pad;
         ph[q].y_pos = q - pad;
         ph[q].bias_off = 0;
         ph[q].koff_off = 0;
@@ -382,8 +381,8 @@ static void add_conv2d(Plan &pl, const ConvW &cw, const T2 &x, const T2 &y, Conv
     IgemmP p{};
     p.x = x.p; p.w = cw.w; p.y = y.p;
     p.M = cw.M; p.N = x.H * x.W; p.K = cw.Kp;
-    p.NW = x.W; p.x_hs = x.ld; p.x_ws = 1; p.y_hs = y.ld; p.y_ws = 1; p.OW = y.W;
-    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.cs;
+    p.NW = x.W; p.x_hs = x.ld; p.x_ws = 1; p.y_hm = 1; p.y_ws = 1; p.OW = y.W;
+    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.cs; p.y_rs = y.ld;
     fill_epilogue(p, cw, o);
     std::vector<int> koff(cw.Kp, 0);
     if (cw.KW == 9) { for (int ci = 0; ci < cw.Cin; ci++) for (int k = 0; k < 9; k++) koff[ci * 9 + k] = ci * x.cs + (k / 3 - 1) * x.ld + (k % 3 - 1); }
@@ -399,8 +398,8 @@ static void add_convT2d(Plan &pl, const ConvW &cw, const T2 &x, const T2 &y, Con
     IgemmP p{};
     p.x = x.p; p.w = cw.w; p.y = y.p;
     p.M = cw.M; p.N = x.H * x.W; p.K = cw.Kp;
-    p.NW = x.W; p.x_hs = x.ld; p.x_ws = 1; p.y_hs = 2 * y.ld; p.y_ws = 2; p.OW = y.W;
-    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.cs;
+    p.NW = x.W; p.x_hs = x.ld; p.x_ws = 1; p.y_hm = 2; p.y_ws = 2; p.OW = y.W;
+    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.cs; p.y_rs = y.ld;
     fill_epilogue(p, cw, o);
     std::vector<int> koff(cw.Kp, 0);
     for (int ci = 0; ci < cw.Cin; ci++) for (int jh = 0; jh < 2; jh++) for (int jw = 0; jw < 2; jw++) koff[ci * 4 + jh * 2 + jw] = ci * x.cs + jh * x.ld + jw;
@@ -408,7 +407,7 @@ static void add_convT2d(Plan &pl, const ConvW &cw, const T2 &x, const T2 &y, Con
     for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) {
         PhaseD d{};
         d.w_off = (long long)(a * 2 + b) * cw.M * cw.Kp;
-        d.y_off = a * y.ld + b;
+        d.y_h0 = a;
         d.y_pos = b;
         ph[a * 2 + b] = d;
     }
@@ -830,7 +829,7 @@ static T2 res_block(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &out)
         add_conv2d(pl, w.sc, x, out);
         ConvOpts o; o.act = ACT_RELU; o.accumulate = true; add_conv2d(pl, w.c2, y1, out, o);
     } else {
-        ConvOpts o; o.act = ACT_RELU; o.res = x.p; o.res_cs = x.cs; o.res_bs = x.bs; add_conv2d(pl, w.c2, y1, out, o);
+        ConvOpts o; o.act = ACT_RELU; o.res = x.p; o.res_cs = x.cs; o.res_bs = x.bs; o.res_rs = x.ld; add_conv2d(pl, w.c2, y1, out, o);
     }
     return out;
 }

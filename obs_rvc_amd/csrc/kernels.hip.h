@@ -37,11 +37,11 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope)
 struct PhaseD {
     long long w_off;   // element offset of this phase's [M][Kp] weight panel
     int x_off;         // element offset added to the input base
-    int y_off;         // element offset added to the output base
-    int y_pos;         // output coordinate of nw = 0 on the w axis (for the OW range check)
+    int y_c0;          // first output channel of this phase (grouped convs)
+    int y_h0;          // output row of nh = 0 (polyphase 2-D transposed convs)
+    int y_pos;         // output column of nw = 0 (polyphase transposed convs); checked against [0, OW)
     int bias_off;      // offset into bias
     int koff_off;      // offset into the koff table
-    int pad_;
 };
 
 struct IgemmP {
@@ -52,10 +52,11 @@ struct IgemmP {
     int M, N, K;             // K already padded to a multiple of 16
     int NW;                  // n -> (nh, nw) = (n / NW, n % NW)
     int x_hs, x_ws;          // input offset of position n  = nh*x_hs + nw*x_ws
-    int y_hs, y_ws;          // output offset of position n = nh*y_hs + nw*y_ws
-    int OW;                  // valid iff 0 <= nw*y_ws + y_pos < OW
+    int y_hm, y_ws;          // output coordinates of position n: row = nh*y_hm + y_h0, col = nw*y_ws + y_pos
+    int OW;                  // valid iff 0 <= col < OW
     long long x_bs, y_bs, res_bs;
-    int y_cs, res_cs;
+    int y_cs, res_cs;        // channel strides of the output / residual tensors
+    int y_rs, res_rs;        // row strides (0 for 1-D tensors)
     int nphase, ksplit, chunks_per_split;
     int act; float slope; float scale; int accumulate;
     int pre_act; float pre_slope;
@@ -66,15 +67,15 @@ __device__ __forceinline__ void epilogue_store(const IgemmP &p, const PhaseD &ph
 {
     if (m >= p.M || n >= p.N) return;
     int nh = n / p.NW, nw = n - nh * p.NW;
-    int pos = nw * p.y_ws + ph.y_pos;
-    if (pos < 0 || pos >= p.OW) return;
-    long long o = (long long)ph.y_off + (long long)nh * p.y_hs + (long long)nw * p.y_ws;
+    const int ow = nw * p.y_ws + ph.y_pos, oh = nh * p.y_hm + ph.y_h0;
+    if (ow < 0 || ow >= p.OW) return;
+    const int ch = m + ph.y_c0;
     float v = acc;
     if (p.bias) v += p.bias[ph.bias_off + m];
     v = apply_act(v, p.act, p.slope);
-    if (p.res) v += p.res[(long long)b * p.res_bs + (long long)m * p.res_cs + o];
+    if (p.res) v += p.res[(long long)b * p.res_bs + (long long)ch * p.res_cs + (long long)oh * p.res_rs + ow];
     v *= p.scale;
-    float *yp = p.y + (long long)b * p.y_bs + (long long)m * p.y_cs + o;
+    float *yp = p.y + (long long)b * p.y_bs + (long long)ch * p.y_cs + (long long)oh * p.y_rs + ow;
     if (p.accumulate) v += *yp;
     *yp = v;
 }

@@ -75,6 +75,7 @@ def lib():
         L.ora_f0_extractor_frame.argtypes = [sz]
         L.ora_knn_search.argtypes = [fp, sz, sz, fp, sz, C.c_int, i32p, fp]
         L.ora_philox_normal.argtypes = [u32, u32, u32, u32, sz, fp]
+        L.ora_set_threads(max(1, min(int(os.environ.get('RVC_ORACLE_THREADS', '16')), os.cpu_count() or 1)))
         _LIB = L
     return _LIB
 
