@@ -1,0 +1,98 @@
+"""Host-side checks that need no GPU: the C-ABI library loads and exports every symbol the header declares;
+rvc-common mirror; geometry formulas; blob round trip; stream sharding."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from common import ROOT
+from obs_rvc_amd import _native, dist, geometry, weights as W
+from obs_rvc_amd.rvc_common import PitchAlgorithm, RvcInferError, RvcModelVersion
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "rvc_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(rvc_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_exported():
+    names = _declared()
+    assert "rvc_infer" in names and "rvc_create" in names and len(names) >= 30
+    assert sorted(_native.SYMBOLS) == names
+    if not os.path.exists(_native.SO_PATH):
+        _native.build()
+    lib = ctypes.CDLL(_native.SO_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    lib.rvc_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.rvc_version()
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from obs_rvc_amd.rvc import RvcInfer
+    with pytest.raises(RvcInferError) as e:
+        RvcInfer("/nonexistent")
+    assert e.value.kind == "Backend"
+
+
+def test_product_does_not_touch_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "obs_rvc_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                # no import / link / dlopen / include of anything under oracle/
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "librvc_oracle" not in src and not re.search(r"#include\s*[<\"].*oracle", src), f
+
+
+def test_enums_mirror_rvc_common():
+    assert RvcModelVersion.V1.text_encoder_in_channels() == 256 and RvcModelVersion.V1.output_layers() == 9
+    assert RvcModelVersion.V2.text_encoder_in_channels() == 768 and RvcModelVersion.V2.output_layers() == 12
+    assert RvcModelVersion.from_value("v1") is RvcModelVersion.V1 and RvcModelVersion.from_value("bogus") is RvcModelVersion.V2
+    assert RvcModelVersion.from_value(1) is RvcModelVersion.V1 and RvcModelVersion.from_value(7) is RvcModelVersion.V2
+    assert str(RvcModelVersion.V2) == "v2" and int(RvcModelVersion.V1) == 1
+    assert RvcModelVersion.is_valid(2) and not RvcModelVersion.is_valid(3)
+    assert PitchAlgorithm.from_value("anything") is PitchAlgorithm.Rmvpe and str(PitchAlgorithm.Rmvpe) == "rmvpe"
+    assert PitchAlgorithm.is_valid(1) and not PitchAlgorithm.is_valid(2)
+    assert RvcInferError(1).kind == "ModelNotLoaded" and RvcInferError(5).kind == "NdarrayShapeError"
+
+
+def test_geometry_matches_plugin_formulas():
+    g = geometry.BASELINE_160MS      # SURVEY.md section 8 header
+    assert (g.sample_frame_16k, g.input_buffer_16k_size, g.skip_head, g.model_return_length, g.model_return_size) == (2560, 35840, 200, 21, 10080)
+    d = geometry.derive()            # plugin defaults: 0.30 s, 40 k
+    assert (d.sample_frame_16k, d.input_buffer_16k_size, d.model_return_length, d.model_return_size) == (4800, 38080, 35, 14000)
+    assert d.sola_buffer_frame_size == 1920 and d.sola_search_frame_size == 480
+
+
+def test_blob_roundtrip(tmp_path):
+    t = {"a.w": np.arange(24, dtype=np.float32).reshape(2, 3, 4), "b": np.array([1.5], np.float32)}
+    p = str(tmp_path / "x.rvcw")
+    W.write_blob(p, {"k": 3, "f": 0.5}, t)
+    cfg, tens = W.read_blob(p)
+    assert cfg == {"k": 3.0, "f": 0.5}
+    assert np.array_equal(tens["a.w"], t["a.w"]) and tens["a.w"].shape == (2, 3, 4) and tens["b"][0] == 1.5
+
+
+def test_model_zoo_is_deterministic_and_sized():
+    c1, t1 = W.make_synth("tiny", 48, seed=5)
+    c2, t2 = W.make_synth("tiny", 48, seed=5)
+    assert all(np.array_equal(t1[k], t2[k]) for k in t1)
+    cfg, t = W.make_contentvec("full", 2)
+    n = sum(v.size for v in t.values())
+    assert 94e6 < n < 95e6                       # ContentVec-base ~94.4 M parameters
+    cfg, t = W.make_rmvpe("full")
+    assert 90e6 < sum(v.size for v in t.values()) < 91e6   # RMVPE 90.4 M (BN folded)
+
+
+def test_shard_streams_round_robin():
+    sh = dist.shard_streams(512, 8)
+    assert [len(s) for s in sh] == [64] * 8 and sh[3][:3] == [3, 11, 19]
+    assert sorted(sum(dist.shard_streams(13, 4), [])) == list(range(13))
+    assert dist.local_streams(5, 1, 2) == [1, 3]

@@ -1,0 +1,244 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle and the committed
+golden vectors.  Tolerance (BASELINE.json north_star): +-1e-3 RMS on the float PCM output, bit-exact kNN hits.
+Per-stage relative RMS tolerances are tighter (1e-4) so that a wrong sub-stage cannot hide in the total."""
+import os
+
+import numpy as np
+import pytest
+
+from common import BASELINE_160MS as g, GOLDEN, chunk_stream, compare_taps, derive, rel_rms, rms, voice_signal, zoo
+from obs_rvc_amd import weights as W
+from obs_rvc_amd.rvc_common import RvcInferError, RvcModelVersion
+
+pytestmark = pytest.mark.gpu
+PCM_TOL = 1e-3
+
+
+def _pair(preset="tiny", version=2, seed=(1234, 0), taps=False):
+    from oracle import oracle as O
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo(preset, version)
+    ora = O.OracleRvcInfer(z["data"]); ora.load_contentvec(version); ora.load_f0(1); ora.load_model(z["model"]); ora.set_noise_seed(*seed)
+    eng = RvcInfer(z["data"]); eng.load_contentvec(RvcModelVersion.from_value(version)); eng.load_f0(); eng.load_model(z["model"]); eng.set_noise_seed(*seed)
+    if taps:
+        ora.enable_taps(True); eng.enable_taps(True)
+    return z, ora, eng
+
+
+@pytest.mark.parametrize("preset", ["tiny", "full"])
+def test_stage_by_stage(preset):
+    z, ora, eng = _pair(preset, taps=True)
+    x = voice_signal(g.input_buffer_16k_size, seed=3)
+    yo = ora.infer(x, g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+    ye = eng.infer(x, g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+    hints = {"rm.cnn": 32, "rm.gru": 32, "rm.sal": 32, "phone": g.model_return_length}
+    worst = {}
+    for name, e, n in compare_taps(ora, eng, hints):
+        worst[name] = e
+        assert e < (5e-4 if name.startswith("sy.") else 1e-4), (name, e)
+    assert len(worst) >= 25
+    assert ye.shape == yo.shape == ((g.model_return_size,) if preset == "full" else (g.model_return_length * 48,))
+    assert rms(ye - yo) < PCM_TOL
+
+
+@pytest.mark.parametrize("preset,version", [("tiny", 2), ("tiny", 1), ("full", 2)])
+def test_stream_of_chunks(preset, version):
+    # BASELINE configs[0]/[1]: a 16 kHz stream fed as 160 ms chunks through the 35 840-sample ring; state (pitch cache,
+    # noise counters) carries across calls
+    z, ora, eng = _pair(preset, version)
+    n_chunks = 12 if preset == "tiny" else 5
+    audio = voice_signal(g.sample_frame_16k * (n_chunks + 14), seed=1)
+    rings = list(chunk_stream(audio, g.input_buffer_16k_size, g.sample_frame_16k))[-n_chunks:]
+    for i, r in enumerate(rings):
+        shift = [12, 0, -12, 7, 13][i % 5]
+        yo = ora.infer(r, g.sample_frame_16k, shift, g.skip_head, g.model_return_length)
+        ye = eng.infer(r, g.sample_frame_16k, shift, g.skip_head, g.model_return_length)
+        assert rms(ye - yo) < PCM_TOL, (i, rms(ye - yo))
+        assert np.abs(ye).max() <= 1.0
+    assert np.allclose(eng.pitch_cache(), ora.pitch_cache(), rtol=1e-5, atol=1e-3)
+
+
+def test_committed_golden_chain():
+    d = np.load(os.path.join(GOLDEN, "tiny_chain.npz"))
+    z, ora, eng = _pair("tiny", seed=(99, 5))
+    rings = list(chunk_stream(d["audio"], g.input_buffer_16k_size, g.sample_frame_16k))[-4:]
+    assert rel_rms(eng.extract_feature(rings[0]), d["feat"]) < 1e-4
+    assert np.allclose(eng.pitch(rings[0], 12, g.sample_frame_16k), d["f0"], rtol=1e-5)
+    for i, r in enumerate(rings):
+        y = eng.infer(r, g.sample_frame_16k, 7 if i % 2 else -12, g.skip_head, g.model_return_length)
+        assert rms(y - d["outs"][i]) < PCM_TOL
+    assert np.allclose(eng.pitch_cache(), d["cache"], rtol=1e-5, atol=1e-3)
+
+
+def test_api_surface_matches_rvcinfer():
+    z, ora, eng = _pair("tiny")
+    wav = np.load(os.path.join(GOLDEN, "ref_input_wav2.npy"))          # rvc/src/tests/input_wav2.npy (38240 samples)
+    h = eng.hubert(wav)
+    assert h.shape == (1, 48, 119) and rel_rms(h, ora.hubert(wav)) < 1e-4
+    f = eng.extract_feature(wav)
+    assert f.shape == (1, 239, 48)                                     # 2T+1 frames (Q2), as rvc/src/tests/feats.npy (1,239,768)
+    assert np.array_equal(f[0, 0:238:2], f[0, 1:238:2]) and np.array_equal(f[0, 238], f[0, 236])
+    assert rel_rms(f, ora.extract_feature(wav)) < 1e-4
+    # rvc/src/tests/pitch.rs:19-30: pitch(input_wav2, 13, 4800); pitch() must not touch the cache
+    p = eng.pitch(wav, 13, 4800)
+    po = ora.pitch(wav, 13, 4800)
+    assert p.shape == po.shape == (64,) and np.allclose(p, po, rtol=1e-5)
+    assert not eng.pitch_cache().any()
+    # Option::None pitch shift (rvc.rs:163)
+    x = voice_signal(g.input_buffer_16k_size, seed=9)
+    assert rms(eng.infer(x, 2560, None, 200, 21) - ora.infer(x, 2560, None, 200, 21)) < PCM_TOL
+
+
+def test_error_behaviour_matches_reference():
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("tiny")
+    eng = RvcInfer(z["data"])
+    x = np.zeros(g.input_buffer_16k_size, np.float32)
+    with pytest.raises(RvcInferError) as e:
+        eng.infer(x, 2560, 12, 200, 21)
+    assert e.value.kind == "ModelNotLoaded"                          # rvc.rs:141-143
+    eng.load_model(z["model"])
+    with pytest.raises(RvcInferError) as e:
+        eng.infer(x, 2560, 12, 200, 21)
+    assert e.value.kind == "ContentvecNotLoaded"                     # rvc.rs:85-88
+    with pytest.raises(RvcInferError) as e:
+        eng.hubert(x)
+    assert e.value.kind == "ContentvecNotLoaded"
+    eng.load_contentvec(RvcModelVersion.V2)
+    with pytest.raises(RvcInferError) as e:
+        eng.infer(x, 2560, 12, 200, 21)
+    assert e.value.kind == "F0NotLoaded"
+    eng.load_f0()
+    assert eng.infer(x, 2560, 12, 200, 21).shape == (1008,)
+    eng.unload_model()
+    with pytest.raises(RvcInferError) as e:
+        eng.infer(x, 2560, 12, 200, 21)
+    assert e.value.kind == "ModelNotLoaded"
+    with pytest.raises(RvcInferError) as e:
+        eng.load_model("/nonexistent/model.onnx")
+    assert e.value.kind == "Backend"
+    eng.load_model(z["model"])
+    with pytest.raises(RvcInferError) as e:                          # slice past the 2T+1 frames -> the reference panics
+        eng.infer(x, 2560, 12, 220, 21)
+    assert e.value.kind == "Panic"
+    with pytest.raises(RvcInferError):                               # ragged / too-short input
+        eng.infer(x[:300], 2560, 12, 0, 1)
+    assert eng.infer(x, 2560, 12, 200, 21).shape == (1008,)          # the engine survives errors
+
+
+def test_other_geometries():
+    # plugin default 0.30 s chunks (R=35, Tm=64), a short-context geometry and the minimum return length
+    for gg in (derive(48000, 0.30, 0.07, 2.0, 48000), derive(48000, 0.10, 0.05, 0.5, 48000)):
+        z, ora, eng = _pair("tiny")
+        x = voice_signal(gg.input_buffer_16k_size, seed=4)
+        for _ in range(2):
+            yo = ora.infer(x, gg.sample_frame_16k, 12, gg.skip_head, gg.model_return_length)
+            ye = eng.infer(x, gg.sample_frame_16k, 12, gg.skip_head, gg.model_return_length)
+            assert ye.shape == yo.shape and rms(ye - yo) < PCM_TOL
+    z, ora, eng = _pair("tiny")
+    x = voice_signal(g.input_buffer_16k_size, seed=4)
+    assert rms(eng.infer(x, 2560, 0, 222, 1) - ora.infer(x, 2560, 0, 222, 1)) < PCM_TOL   # last frame of the 2T+1 (Q2 clamp)
+
+
+def test_silence_and_loud_inputs():
+    z, ora, eng = _pair("tiny")
+    for x in (np.zeros(g.input_buffer_16k_size, np.float32), np.load(os.path.join(GOLDEN, "ref_input_wav.npy"))[:g.input_buffer_16k_size],
+              np.clip(voice_signal(g.input_buffer_16k_size, seed=6) * 20, -1, 1)):
+        yo = ora.infer(x, 2560, 12, 200, 21)
+        ye = eng.infer(x, 2560, 12, 200, 21)
+        assert np.isfinite(ye).all() and rms(ye - yo) < PCM_TOL
+
+
+@pytest.mark.parametrize("preset", ["tiny", "full"])
+def test_retrieval_hits_bit_exact(preset):
+    # BASELINE configs[2]: flat-L2, k=4, index_rate 0.75 (100k x 768 at full size)
+    z, ora, eng = _pair(preset, taps=True)
+    dim = 48 if preset == "tiny" else 768
+    index = W.make_index(5000 if preset == "tiny" else 100000, dim, seed=7)
+    ora.load_index(index); ora.set_index_rate(0.75)
+    eng.load_index(index); eng.set_index_rate(0.75)
+    x = voice_signal(g.input_buffer_16k_size, seed=3)
+    for _ in range(2):
+        yo = ora.infer(x, 2560, 12, 200, 21)
+        ye = eng.infer(x, 2560, 12, 200, 21)
+        io, do = ora.knn()
+        ie, de = eng.knn()
+        assert ie.shape == io.shape == (21, 4)
+        # the queries come out of the ContentVec stack at ~1e-6 relative, so a hit could only flip on a ~1e-6 tie;
+        # demand identical index arrays and distances to fp32 round-off of the query
+        assert np.array_equal(ie, io)
+        assert np.allclose(de, do, rtol=1e-4)
+        assert rel_rms(eng.tap("phone_ct").reshape(dim, 21).T, ora.tap("phone").reshape(21, dim)) < 1e-4
+        assert rms(ye - yo) < PCM_TOL
+
+
+def test_retrieval_scan_exact_on_identical_queries():
+    # feed the GPU's own queries to the oracle's search: indices AND distances must be bit-identical
+    # (same sequential-fmaf distance, same (distance, index) ordering)
+    from oracle import oracle as O
+    z, ora, eng = _pair("tiny", taps=True)
+    index = W.make_index(7777, 48, seed=9)
+    index[100] = index[50]; index[2000] = index[50]                   # exact ties
+    eng.load_index(index); eng.set_index_rate(0.5)
+    x = voice_signal(g.input_buffer_16k_size, seed=3)
+    eng.set_index_rate(0.0)
+    eng.infer(x, 2560, 12, 200, 21)
+    q = eng.tap("phone_ct").reshape(48, 21).T.copy()                  # un-blended queries
+    eng.reset_state(); eng.set_index_rate(0.5)
+    eng.infer(x, 2560, 12, 200, 21)
+    ie, de = eng.knn()
+    io, do = O.knn_search(index, q, 4)
+    assert np.array_equal(ie, io) and np.array_equal(de, do)
+    # query equal to an index row: distance 0 hits, ties by ascending index
+    io2, do2 = O.knn_search(index, index[50:51], 4)
+    assert io2[0, :3].tolist() == [50, 100, 2000]
+
+
+def test_batched_streams_match_single_stream_oracles():
+    # BASELINE config 4 in miniature: S concurrent streams batched per stage, each with its own state
+    from oracle import oracle as O
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("tiny")
+    S = 5
+    eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"])
+    eng.set_streams(S); eng.set_noise_seed(42, 10)
+    oras = []
+    for s in range(S):
+        o = O.OracleRvcInfer(z["data"]); o.load_contentvec(2); o.load_f0(1); o.load_model(z["model"]); o.set_noise_seed(42, 10 + s)
+        oras.append(o)
+    streams = [list(chunk_stream(voice_signal(g.sample_frame_16k * 17, seed=30 + s), g.input_buffer_16k_size, g.sample_frame_16k))[-3:] for s in range(S)]
+    for c in range(3):
+        xin = np.stack([streams[s][c] for s in range(S)])
+        ye = eng.infer_batch(xin, g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+        for s in range(S):
+            yo = oras[s].infer(xin[s], g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+            assert rms(ye[s] - yo) < PCM_TOL, (c, s)
+    for s in range(S):
+        assert np.allclose(eng.pitch_cache(s), oras[s].pitch_cache(), rtol=1e-5, atol=1e-3)
+
+
+def test_graph_replay_equals_eager_and_device_api():
+    import torch
+    z, ora, eng = _pair("tiny")
+    z2, ora2, eng2 = _pair("tiny")
+    eng2.set_use_graph(True)
+    x = voice_signal(g.input_buffer_16k_size, seed=8)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros(g.model_return_length * 48, device="cuda")
+    for i in range(4):
+        ya = eng.infer(x, 2560, 12 if i < 2 else -12, 200, 21)
+        n = eng2.infer_device(d_in.data_ptr(), len(x), 2560, 12 if i < 2 else -12, 200, 21, d_out.data_ptr(), d_out.numel(), sync=True)
+        assert n == len(ya)
+        assert np.array_equal(d_out.cpu().numpy(), ya)                 # same kernels, same order -> bitwise equal
+    assert eng2.last_gpu_ms() > 0
+
+
+def test_linearity_of_retrieval_free_feature_path_properties():
+    # size-independent properties at BASELINE's full size: determinism across engines and chunk-counter dependence
+    z, ora, eng = _pair("full")
+    z2, ora2, eng2 = _pair("full")
+    x = voice_signal(g.input_buffer_16k_size, seed=12)
+    a1 = eng.infer(x, 2560, 12, 200, 21); a2 = eng.infer(x, 2560, 12, 200, 21)
+    b1 = eng2.infer(x, 2560, 12, 200, 21)
+    assert a1.shape == (10080,) and np.array_equal(a1, b1) and not np.array_equal(a1, a2)
+    assert np.abs(a1).max() <= 1.0 and np.isfinite(a1).all()
