@@ -210,9 +210,19 @@ typedef std::function<void(hipStream_t)> Op;
 
 struct TapRec { std::string name; int rank; T1 t1; T2 t2; };
 
+// ops are tagged with the HIP stream they run on: 0 = main, 1 = auxiliary (the RMVPE branch runs
+// concurrently with ContentVec; fork/join through events, captured as parallel branches of the hipGraph)
+struct OpList {
+    std::vector<Op> v;
+    std::vector<int> sid;
+    int cur = 0;
+    long join_at = -1;   // index of the first op that consumes both branches
+    void push_back(Op o) { v.push_back(std::move(o)); sid.push_back(cur); }
+};
+
 struct Plan {
     Arena arena;
-    std::vector<Op> ops;
+    OpList ops;
     std::vector<TapRec> taps;
     // geometry
     int B = 1; size_t L = 0, frame16k = 0; uint32_t skip_head = 0, R = 0;
@@ -240,19 +250,29 @@ struct Plan {
     }
 };
 
-template <int MF, int NF> static void launch_igemm_t(const IgemmP &p, dim3 grid, hipStream_t s)
+template <int MF, int NF, int D> static void launch_igemm_t(const IgemmP &p, dim3 grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((igemm_kernel<MF, NF>), grid, dim3(256), 0, s, p);
+    const size_t lds = (size_t)p.chunks_per_split * 16 * sizeof(int);   // this workgroup's slice of the koff table
+    hipLaunchKernelGGL((igemm_kernel<MF, NF, D>), grid, dim3(256), lds, s, p);
+}
+
+template <int KS> static void launch_wgsplit_t(const IgemmP &p, dim3 grid, hipStream_t s)
+{
+    const size_t lds = (size_t)(p.K / 16) * 16 * sizeof(int) + (size_t)KS * 256 * sizeof(float);
+    hipLaunchKernelGGL((igemm_wgsplit_kernel<KS>), grid, dim3(KS * 64), lds, s, p);
 }
 
 static void launch_igemm(int cfg, const IgemmP &p, dim3 grid, hipStream_t s)
 {
     switch (cfg) {
-    case 0: launch_igemm_t<1, 1>(p, grid, s); break;
-    case 1: launch_igemm_t<1, 2>(p, grid, s); break;
-    case 2: launch_igemm_t<1, 4>(p, grid, s); break;
-    case 3: launch_igemm_t<2, 2>(p, grid, s); break;
-    default: launch_igemm_t<2, 4>(p, grid, s); break;
+    case -4: launch_wgsplit_t<4>(p, grid, s); break;
+    case -8: launch_wgsplit_t<8>(p, grid, s); break;
+    case -16: launch_wgsplit_t<16>(p, grid, s); break;
+    case 0: launch_igemm_t<1, 1, 4>(p, grid, s); break;
+    case 1: launch_igemm_t<1, 2, 4>(p, grid, s); break;
+    case 2: launch_igemm_t<1, 4, 3>(p, grid, s); break;
+    case 3: launch_igemm_t<2, 2, 4>(p, grid, s); break;
+    default: launch_igemm_t<2, 4, 3>(p, grid, s); break;
     }
 }
 
@@ -271,10 +291,14 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     if (p.M > 16) cfg = waves(4) >= 1024 ? 4 : (waves(3) >= 1024 ? 3 : 0);
     else cfg = waves(2) >= 1024 ? 2 : (waves(1) >= 1024 ? 1 : 0);
     const int nchunks = p.K / 16;
-    int ksplit = 1;
+    int ksplit = 1, wg_ks = 0;
     if (cfg == 0) {
-        long long w0 = waves(0);
-        if (w0 < 512 && nchunks >= 8) {
+        const long long w0 = waves(0);
+        if (w0 <= 512 && nchunks >= 8 && (size_t)nchunks * 64 + 16 * 1024 <= 64 * 1024) {
+            // few tiles, long K: split K over the waves of one workgroup per tile (in-kernel LDS reduction)
+            wg_ks = 4;
+            while (wg_ks < 16 && w0 * wg_ks < 1024 && nchunks / (wg_ks * 2) >= 4) wg_ks *= 2;
+        } else if (w0 < 512 && nchunks >= 8) {
             int want = (int)((1024 + w0 - 1) / w0);
             ksplit = std::min(want, nchunks / 4);
             if (ksplit < 1) ksplit = 1;
@@ -287,6 +311,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     p.ntn = (p.N + 16 * NFs[cfg] - 1) / (16 * NFs[cfg]);
     if (ksplit > 1) p.part = pl.arena.floats((size_t)B * p.nphase * ksplit * p.M * p.N);
     dim3 grid((p.ntm * p.ntn + 3) / 4, B * p.nphase * ksplit);
+    if (wg_ks) { grid = dim3(p.ntm * p.ntn, B * p.nphase); cfg = -wg_ks; }
     dim3 egrid((unsigned)(((long long)p.M * p.N + 255) / 256), B * p.nphase);
     const double flops = 2.0 * p.M * (double)p.N * p.K * B * p.nphase;
     pl.igemm_flops += flops;
@@ -313,7 +338,8 @@ static void fill_epilogue(IgemmP &p, const ConvW &cw, const ConvOpts &o)
     p.bias = (o.no_bias || !cw.bias) ? nullptr : cw.bias + o.m_off;
     p.res = o.res; p.res_cs = o.res_cs; p.res_bs = o.res_bs; p.res_rs = o.res_rs;
     p.act = o.act; p.slope = o.slope; p.scale = o.scale; p.accumulate = o.accumulate ? 1 : 0;
-    p.pre_act = o.pre_act; p.pre_slope = o.pre_slope;
+    if (o.pre_act != ACT_NONE && o.pre_act != ACT_LRELU) throw std::runtime_error("only LeakyReLU can be fused on the input side");
+    p.pre_act = o.pre_act; p.pre_slope = o.pre_act == ACT_LRELU ? o.pre_slope : 1.0f;
     p.part = nullptr;
 }
 
@@ -416,9 +442,12 @@ static void add_convT2d(Plan &pl, const ConvW &cw, const T2 &x, const T2 &y, Con
 
 static void add_layernorm(Plan &pl, const T1 &x, const float *g, const float *b)
 {
-    dim3 grid((x.T + 31) / 32, x.B);
+    dim3 grid((x.T + 15) / 16, x.B);
+    if (x.C > 1024) throw ShapeError("layernorm: more than 1024 channels");
+    const bool small = x.C <= 256;
     pl.ops.push_back([=](hipStream_t s) {
-        hipLaunchKernelGGL(layernorm_ct_kernel, grid, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
+        if (small) hipLaunchKernelGGL((layernorm_ct_kernel<16>), grid, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
+        else hipLaunchKernelGGL((layernorm_ct_kernel<64>), grid, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
     });
 }
 
@@ -694,7 +723,8 @@ using namespace rvc;
 struct rvc_engine {
     std::string data_path, err;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::unique_ptr<ModelCV> cv;
     std::unique_ptr<ModelRM> rm;
     std::unique_ptr<ModelSY> sy;
@@ -795,7 +825,7 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
     add_tap(pl, "cv.pos", h2);
     T1 qkv = make_t1(A, B, 3 * E, T, 0), att = make_t1(A, B, E, T, 0), ff = make_t1(A, B, m.ffn, T, 0);
     const int hd = E / m.heads, Tp = T | 1;
-    const size_t attn_lds = ((size_t)2 * hd * Tp + 4 * Tp + 4 * hd) * sizeof(float);
+    const size_t attn_lds = ((size_t)((2 * hd * Tp + 3) & ~3) + 16 * Tp + 16 * hd) * sizeof(float);
     if (attn_lds > 160 * 1024) throw ShapeError("ContentVec attention: window too long for the LDS-resident kernel (T <= ~300)");
     HIPCHK(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     for (int l = 0; l < m.run_layers; l++) {
@@ -803,7 +833,7 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
         add_conv1d(pl, Ly.qkv, h2, qkv, 1, 0, 1);
         AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = E; ap.T = T; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;
         ap.scale = 1.0f / sqrtf((float)hd); ap.rel_k = nullptr; ap.rel_v = nullptr; ap.window = 0;
-        dim3 ag(m.heads, B);
+        dim3 ag(m.heads * ((T + 15) / 16), B);
         pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(attention_kernel, ag, dim3(256), attn_lds, s, ap); });
         { ConvOpts o; o.res = h2.p; o.res_cs = h2.ld; o.res_bs = h2.bs; add_conv1d(pl, Ly.o, att, h2, 1, 0, 1, o); }
         add_layernorm(pl, h2, Ly.ln1_g, Ly.ln1_b);
@@ -960,14 +990,14 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, float *
     add_tap(pl, "sy.emb", x);
     T1 qkv = make_t1(A, B, 3 * H, R, 0), att = make_t1(A, B, H, R, 0), ff = make_t1(A, B, F, R, HALO);
     const int kc = H / m.heads, Tp = R | 1;
-    const size_t attn_lds = ((size_t)2 * kc * Tp + 4 * Tp + 4 * kc) * sizeof(float);
+    const size_t attn_lds = ((size_t)((2 * kc * Tp + 3) & ~3) + 16 * Tp + 16 * kc) * sizeof(float);
     if (attn_lds > 160 * 1024) throw ShapeError("synth attention: return_length too long for the LDS-resident kernel");
     for (int l = 0; l < m.enc_layers; l++) {
         ModelSY::Layer &Ly = m.layers[l];
         add_conv1d(pl, Ly.qkv, x, qkv, 1, 0, 1);
         AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = H; ap.T = R; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;
         ap.scale = 1.0f / sqrtf((float)kc); ap.rel_k = Ly.rel_k; ap.rel_v = Ly.rel_v; ap.window = m.window;
-        dim3 ag(m.heads, B);
+        dim3 ag(m.heads * ((R + 15) / 16), B);
         pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(attention_kernel, ag, dim3(256), attn_lds, s, ap); });
         { ConvOpts o; o.res = x.p; o.res_cs = x.ld; o.res_bs = x.bs; add_conv1d(pl, Ly.o, att, x, 1, 0, 1, o); }
         add_layernorm(pl, x, Ly.ln1_g, Ly.ln1_b);
@@ -1081,6 +1111,17 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
     Plan &pl = *up;
     pl.mode = mode; pl.L = L; pl.frame16k = frame16k; pl.skip_head = skip_head; pl.R = R; pl.B = B; pl.with_index = with_index; pl.with_taps = e->taps_on;
     pl.d_in = pl.arena.floats((size_t)B * L + 64);
+    T1 sal0; float *d_pitchf0 = nullptr; int *d_pitch0 = nullptr;
+    if (mode == 0) {
+        // f0 branch first (auxiliary stream): independent of ContentVec until the synthesizer
+        const int Tcv = e->cv->out_frames(L);
+        if (Tcv < 1) throw ShapeError("input too short for ContentVec");
+        const size_t hubert_length0 = std::min(L / 160, 2 * (size_t)Tcv + 1);   // rvc.rs:153
+        pl.ops.cur = 1;
+        sal0 = build_rmvpe(e, pl, B, L, frame16k, true);
+        build_pitch_post(e, pl, B, sal0, true, frame16k, hubert_length0, &d_pitchf0, &d_pitch0);
+        pl.ops.cur = 0;
+    }
     if (mode == 0 || mode == 1) {
         if (!e->cv) throw std::logic_error("contentvec");
         if (e->cv->out_frames(L) < 1) throw ShapeError("input too short for ContentVec");
@@ -1148,9 +1189,9 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
             pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(knn_merge_blend_kernel, grid, dim3(256), 0, s, bp); });
         }
         add_tap(pl, "phone_ct", phone);
-        T1 sal = build_rmvpe(e, pl, B, L, frame16k, true);
-        float *d_pitchf = nullptr; int *d_pitch = nullptr;
-        build_pitch_post(e, pl, B, sal, true, frame16k, hubert_length, &d_pitchf, &d_pitch);
+        float *d_pitchf = d_pitchf0; int *d_pitch = d_pitch0;
+        (void)hubert_length;
+        pl.ops.join_at = (long)pl.ops.v.size();
         build_synth(e, pl, B, phone, d_pitchf, d_pitch);
         StreamState *st = e->d_state;
         pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(advance_chunk_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, B); });
@@ -1158,6 +1199,32 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
     HIPCHK(hipDeviceSynchronize());
     e->plans.push_back(std::move(up));
     return e->plans.back().get();
+}
+
+static void issue_ops(rvc_engine *e, Plan &pl)
+{
+    // fork the auxiliary stream off the main one, run every op on its stream, join before the first main-stream op
+    // that follows auxiliary work (the synthesizer consumes both branches)
+    bool forked = false, aux_pending = false;
+    for (size_t i = 0; i < pl.ops.v.size(); i++) {
+        const int sid = pl.ops.sid[i];
+        if (sid == 1 && !forked) {
+            HIPCHK(hipEventRecord(e->ev_fork, e->stream));
+            HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+            forked = true;
+        }
+        if ((long)i == pl.ops.join_at && aux_pending) {
+            HIPCHK(hipEventRecord(e->ev_join, e->stream2));
+            HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+            aux_pending = false;
+        }
+        pl.ops.v[i](sid == 1 ? e->stream2 : e->stream);
+        if (sid == 1) aux_pending = true;
+    }
+    if (aux_pending) {
+        HIPCHK(hipEventRecord(e->ev_join, e->stream2));
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+    }
 }
 
 static void run_plan(rvc_engine *e, Plan &pl)
@@ -1169,14 +1236,14 @@ static void run_plan(rvc_engine *e, Plan &pl)
         if (!pl.graph_exec) {
             hipGraph_t g;
             HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-            for (auto &op : pl.ops) op(e->stream);
+            issue_ops(e, pl);
             HIPCHK(hipStreamEndCapture(e->stream, &g));
             HIPCHK(hipGraphInstantiate(&pl.graph_exec, g, nullptr, nullptr, 0));
             HIPCHK(hipGraphDestroy(g));
         }
         HIPCHK(hipGraphLaunch(pl.graph_exec, e->stream));
     } else {
-        for (auto &op : pl.ops) op(e->stream);
+        issue_ops(e, pl);
     }
     HIPCHK(hipEventRecord(e->ev1, e->stream));
     HIPCHK(hipGetLastError());
@@ -1250,6 +1317,8 @@ rvc_status rvc_create(const char *data_path, int device, rvc_engine **out)
     try {
         set_device(e);
         HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
         HIPCHK(hipEventCreate(&e->ev0)); HIPCHK(hipEventCreate(&e->ev1));
         HIPCHK(hipMalloc(&e->d_cp, sizeof(CallParams)));
         HIPCHK(hipHostMalloc((void **)&e->h_cp, sizeof(CallParams)));
@@ -1281,6 +1350,9 @@ void rvc_destroy(rvc_engine *e)
     if (e->h_cp) (void)hipHostFree(e->h_cp);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->stream2) (void)hipStreamDestroy(e->stream2);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }

@@ -59,14 +59,15 @@ struct IgemmP {
     int y_rs, res_rs;        // row strides (0 for 1-D tensors)
     int nphase, ksplit, chunks_per_split;
     int act; float slope; float scale; int accumulate;
-    int pre_act; float pre_slope;
+    int pre_act; float pre_slope;   // fused input LeakyReLU: x -> max(x, x*pre_slope); pre_slope = 1 disables it
     int ntn, ntm;
 };
 
 __device__ __forceinline__ void epilogue_store(const IgemmP &p, const PhaseD &ph, int b, int m, int n, float acc)
 {
     if (m >= p.M || n >= p.N) return;
-    int nh = n / p.NW, nw = n - nh * p.NW;
+    int nh = 0, nw = n;
+    if (p.y_hm) { nh = n / p.NW; nw = n - nh * p.NW; }
     const int ow = nw * p.y_ws + ph.y_pos, oh = nh * p.y_hm + ph.y_h0;
     if (ow < 0 || ow >= p.OW) return;
     const int ch = m + ph.y_c0;
@@ -81,19 +82,33 @@ __device__ __forceinline__ void epilogue_store(const IgemmP &p, const PhaseD &ph
 }
 
 // One wave = one (16*MF) x (16*NF) tile; 4 independent waves per workgroup (consecutive tiles
-// share the weight rows through the CU's L1).  No LDS, no barriers.
-template <int MF, int NF>
+// share the weight rows through the CU's L1).  The workgroup's slice of the koff table is staged in
+// LDS once; weights and gathered activations are register-prefetched D chunks (of 16 k) ahead so
+// that HBM/L2 latency is covered even at one wave per SIMD.
+template <int MF, int NF, int D>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p)
 {
+    extern __shared__ __attribute__((aligned(16))) int s_koff[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = blockIdx.x * 4 + wave;
-    if (tile >= p.ntn * p.ntm) return;
-    const int tn = tile % p.ntn, tm = tile / p.ntn;
     int z = blockIdx.y;
     const int ks = z % p.ksplit; z /= p.ksplit;
     const int phase = z % p.nphase;
     const int b = z / p.nphase;
     const PhaseD ph = p.ph[phase];
+    const int nchunks = p.K >> 4;
+    const int c0 = ks * p.chunks_per_split;
+    int c1 = c0 + p.chunks_per_split;
+    c1 = c1 < nchunks ? c1 : nchunks;
+    const int nc = c1 - c0;
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(p.koff + ph.koff_off + c0 * 16);
+        int4 *dst = reinterpret_cast<int4 *>(s_koff);
+        for (int i = threadIdx.x; i < nc * 4; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (tile >= p.ntn * p.ntm) return;
+    const int tn = tile % p.ntn, tm = tile / p.ntn;
     const int li = lane & 15, kq = lane >> 4;
 
     const float *xb = p.x + (long long)b * p.x_bs + ph.x_off;
@@ -102,7 +117,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p)
     for (int nf = 0; nf < NF; nf++) {
         int n = tn * 16 * NF + nf * 16 + li;
         n = n < p.N ? n : p.N - 1;
-        int nh = n / p.NW, nw = n - nh * p.NW;
+        int nh = 0, nw = n;
+        if (p.x_hs) { nh = n / p.NW; nw = n - nh * p.NW; }
         xo[nf] = nh * p.x_hs + nw * p.x_ws;
     }
     const float *wrow[MF];
@@ -110,13 +126,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p)
     for (int mf = 0; mf < MF; mf++) {
         int m = tm * 16 * MF + mf * 16 + li;
         m = m < p.M ? m : p.M - 1;
-        wrow[mf] = p.w + ph.w_off + (long long)m * p.K + kq * 4;
+        wrow[mf] = p.w + ph.w_off + (long long)m * p.K + (long long)c0 * 16 + kq * 4;
     }
-    const int *kofp = p.koff + ph.koff_off + kq * 4;
-    const int nchunks = p.K >> 4;
-    const int c0 = ks * p.chunks_per_split;
-    int c1 = c0 + p.chunks_per_split;
-    c1 = c1 < nchunks ? c1 : nchunks;
+    const int4 *kol = reinterpret_cast<const int4 *>(s_koff) + kq;
 
     f32x4 acc[MF][NF];
 #pragma unroll
@@ -124,55 +136,51 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p)
 #pragma unroll
         for (int nf = 0; nf < NF; nf++) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (c0 < c1) {
-        f32x4 a_cur[MF], a_nxt[MF];
-        float b_cur[NF][4], b_nxt[NF][4];
-        int4 ko_nxt;
-        {
-            int4 ko = *reinterpret_cast<const int4 *>(kofp + c0 * 16);
+    f32x4 a_st[D][MF];
+    float b_st[D][NF][4];
+#define RVC_LOAD_STAGE(S, C)                                                                           \
+    {                                                                                                  \
+        const int cc_ = (C);                                                                           \
+        const int4 ko_ = kol[cc_ * 4];                                                                 \
+        _Pragma("unroll") for (int mf = 0; mf < MF; mf++) a_st[S][mf] = *reinterpret_cast<const f32x4 *>(wrow[mf] + cc_ * 16); \
+        _Pragma("unroll") for (int nf = 0; nf < NF; nf++) {                                            \
+            b_st[S][nf][0] = xb[xo[nf] + ko_.x]; b_st[S][nf][1] = xb[xo[nf] + ko_.y];                  \
+            b_st[S][nf][2] = xb[xo[nf] + ko_.z]; b_st[S][nf][3] = xb[xo[nf] + ko_.w];                  \
+        }                                                                                              \
+    }
+#define RVC_COMPUTE_STAGE(S)                                                                          \
+    {                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; j++)                                                  \
+            _Pragma("unroll") for (int nf = 0; nf < NF; nf++) {                                        \
+                /* fused input LeakyReLU (slope 1 = identity): branch-free so the loads stay in flight */ \
+                const float bv_ = fmaxf(b_st[S][nf][j], b_st[S][nf][j] * pre_slope);                   \
+                _Pragma("unroll") for (int mf = 0; mf < MF; mf++)                                      \
+                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[S][mf][j], bv_, acc[mf][nf], 0, 0, 0); \
+            }                                                                                          \
+    }
+    const float pre_slope = p.pre_slope;
 #pragma unroll
-            for (int mf = 0; mf < MF; mf++) a_cur[mf] = *reinterpret_cast<const f32x4 *>(wrow[mf] + c0 * 16);
+    for (int s = 0; s < D; s++)
+        if (s < nc) RVC_LOAD_STAGE(s, s)
+    int c = 0;
+    for (; c + 2 * D <= nc; c += D) {
 #pragma unroll
-            for (int nf = 0; nf < NF; nf++) {
-                b_cur[nf][0] = xb[xo[nf] + ko.x]; b_cur[nf][1] = xb[xo[nf] + ko.y];
-                b_cur[nf][2] = xb[xo[nf] + ko.z]; b_cur[nf][3] = xb[xo[nf] + ko.w];
-            }
-            int cn = c0 + 1 < c1 ? c0 + 1 : c1 - 1;
-            ko_nxt = *reinterpret_cast<const int4 *>(kofp + cn * 16);
-        }
-        for (int c = c0; c < c1; c++) {
-            const int cn = c + 1 < c1 ? c + 1 : c1 - 1;
-            const int cnn = c + 2 < c1 ? c + 2 : c1 - 1;
-            // prefetch chunk c+1 (weights + gathered activations) and the offsets of chunk c+2
-#pragma unroll
-            for (int mf = 0; mf < MF; mf++) a_nxt[mf] = *reinterpret_cast<const f32x4 *>(wrow[mf] + cn * 16);
-#pragma unroll
-            for (int nf = 0; nf < NF; nf++) {
-                b_nxt[nf][0] = xb[xo[nf] + ko_nxt.x]; b_nxt[nf][1] = xb[xo[nf] + ko_nxt.y];
-                b_nxt[nf][2] = xb[xo[nf] + ko_nxt.z]; b_nxt[nf][3] = xb[xo[nf] + ko_nxt.w];
-            }
-            ko_nxt = *reinterpret_cast<const int4 *>(kofp + cnn * 16);
-            if (p.pre_act) {
-#pragma unroll
-                for (int nf = 0; nf < NF; nf++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) b_cur[nf][j] = apply_act(b_cur[nf][j], p.pre_act, p.pre_slope);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int mf = 0; mf < MF; mf++)
-#pragma unroll
-                    for (int nf = 0; nf < NF; nf++)
-                        acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mf][j], b_cur[nf][j], acc[mf][nf], 0, 0, 0);
-#pragma unroll
-            for (int mf = 0; mf < MF; mf++) a_cur[mf] = a_nxt[mf];
-#pragma unroll
-            for (int nf = 0; nf < NF; nf++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) b_cur[nf][j] = b_nxt[nf][j];
+        for (int s = 0; s < D; s++) {
+            RVC_COMPUTE_STAGE(s)
+            RVC_LOAD_STAGE(s, c + s + D)
         }
     }
+    for (; c < nc; c += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            if (c + s < nc) {
+                RVC_COMPUTE_STAGE(s)
+                if (c + s + D < nc) RVC_LOAD_STAGE(s, c + s + D)
+            }
+        }
+    }
+#undef RVC_COMPUTE_STAGE
+#undef RVC_LOAD_STAGE
 
     // D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
     if (p.ksplit == 1) {
@@ -198,11 +206,109 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p)
     }
 }
 
+// Small-problem variant (few output tiles, long K: RMVPE's deep layers, the transformer projections at
+// T = 111, the synthesizer's encoder/flow): one 16x16 tile per workgroup, the KS waves of the workgroup
+// split the K chunks and their partial accumulators are summed through LDS in a fixed order
+// (deterministic), so no second kernel and KS times more loads in flight per tile.
+template <int KS>
+__global__ __launch_bounds__(KS * 64) void igemm_wgsplit_kernel(IgemmP p)
+{
+    constexpr int D = 4;
+    extern __shared__ __attribute__((aligned(16))) int s_koff[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = blockIdx.x;
+    int z = blockIdx.y;
+    const int phase = z % p.nphase;
+    const int b = z / p.nphase;
+    const PhaseD ph = p.ph[phase];
+    const int nchunks = p.K >> 4;
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(p.koff + ph.koff_off);
+        int4 *dst = reinterpret_cast<int4 *>(s_koff);
+        for (int i = threadIdx.x; i < nchunks * 4; i += KS * 64) dst[i] = src[i];
+    }
+    float *red = reinterpret_cast<float *>(s_koff + nchunks * 16);   // [KS][256]
+    __syncthreads();
+    const int tn = tile % p.ntn, tm = tile / p.ntn;
+    const int li = lane & 15, kq = lane >> 4;
+    const int cpw = (nchunks + KS - 1) / KS;
+    const int c0 = wave * cpw;
+    int c1 = c0 + cpw;
+    c1 = c1 < nchunks ? c1 : nchunks;
+    const int nc = c1 - c0;
+
+    const float *xb = p.x + (long long)b * p.x_bs + ph.x_off;
+    int xo;
+    {
+        int n = tn * 16 + li;
+        n = n < p.N ? n : p.N - 1;
+        int nh = 0, nw = n;
+        if (p.x_hs) { nh = n / p.NW; nw = n - nh * p.NW; }
+        xo = nh * p.x_hs + nw * p.x_ws;
+    }
+    int m = tm * 16 + li;
+    m = m < p.M ? m : p.M - 1;
+    const float *wrow = p.w + ph.w_off + (long long)m * p.K + (long long)c0 * 16 + kq * 4;
+    const int4 *kol = reinterpret_cast<const int4 *>(s_koff) + c0 * 4 + kq;
+    const float pre_slope = p.pre_slope;
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a_st[D];
+    float b_st[D][4];
+#define RVC_LOAD1(S, C)                                                                   \
+    {                                                                                     \
+        const int cc_ = (C);                                                              \
+        const int4 ko_ = kol[cc_ * 4];                                                    \
+        a_st[S] = *reinterpret_cast<const f32x4 *>(wrow + cc_ * 16);                      \
+        b_st[S][0] = xb[xo + ko_.x]; b_st[S][1] = xb[xo + ko_.y];                         \
+        b_st[S][2] = xb[xo + ko_.z]; b_st[S][3] = xb[xo + ko_.w];                         \
+    }
+#define RVC_COMPUTE1(S)                                                                   \
+    {                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) {                                   \
+            const float bv_ = fmaxf(b_st[S][j], b_st[S][j] * pre_slope);                  \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[S][j], bv_, acc, 0, 0, 0);    \
+        }                                                                                 \
+    }
+#pragma unroll
+    for (int s = 0; s < D; s++)
+        if (s < nc) RVC_LOAD1(s, s)
+    int c = 0;
+    for (; c + 2 * D <= nc; c += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            RVC_COMPUTE1(s)
+            RVC_LOAD1(s, c + s + D)
+        }
+    }
+    for (; c < nc; c += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            if (c + s < nc) {
+                RVC_COMPUTE1(s)
+                if (c + s + D < nc) RVC_LOAD1(s, c + s + D)
+            }
+        }
+    }
+#undef RVC_LOAD1
+#undef RVC_COMPUTE1
+#pragma unroll
+    for (int r = 0; r < 4; r++) red[wave * 256 + r * 64 + lane] = acc[r];
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int e = threadIdx.x, r = e >> 6, l = e & 63;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < KS; w++) v += red[w * 256 + e];
+        epilogue_store(p, ph, b, tm * 16 + (l >> 4) * 4 + r, tn * 16 + (l & 15), v);
+    }
+}
+
 // second stage of a split-K launch: fixed-order (deterministic) sum of the partials + epilogue
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(IgemmP p)
 {
-    long long total = (long long)p.M * p.N;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = p.M * p.N;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     int z = blockIdx.y;
     const int phase = z % p.nphase, b = z / p.nphase;
@@ -210,7 +316,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(IgemmP p)
     const float *pp = p.part + (long long)(b * p.nphase + phase) * p.ksplit * total + i;
     float acc = 0.f;
     for (int ks = 0; ks < p.ksplit; ks++) acc += pp[(long long)ks * total];
-    int m = (int)(i / p.N), n = (int)(i - (long long)m * p.N);
+    const int m = i / p.N, n = i - m * p.N;
     epilogue_store(p, ph, b, m, n, acc);
 }
 
@@ -315,34 +421,53 @@ __global__ __launch_bounds__(256) void mel_frontend_kernel(MelP p)
 // normalisation kernels
 // ------------------------------------------------------------------------------------
 // LayerNorm over channels of x[B][C][ld] for each time step (eps 1e-5), optional in-place.
-// block (32 t, 8 channel lanes)
+// block = 16 time steps x 16 channel lanes; each thread keeps its C/16 values in registers
+// (one global read pass, two-pass mean/variance as in the reference definition).
+template <int NV>
 __global__ __launch_bounds__(256) void layernorm_ct_kernel(const float *x, float *y, const float *g, const float *bta,
                                                            int C, int T, int x_cs, long long x_bs, int y_cs, long long y_bs)
 {
-    __shared__ float red[8][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int t = blockIdx.x * 32 + tx, b = blockIdx.y;
+    __shared__ float red[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int t = blockIdx.x * 16 + tx, b = blockIdx.y;
     const bool ok = t < T;
     const float *xp = x + (long long)b * x_bs + (ok ? t : 0);
+    float v[NV];
     float s = 0.f;
-    if (ok) for (int c = ty; c < C; c += 8) s += xp[(long long)c * x_cs];
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int c = ty + i * 16;
+        v[i] = (ok && c < C) ? xp[(long long)c * x_cs] : 0.f;
+        s += v[i];
+    }
     red[ty][tx] = s;
     __syncthreads();
     float mean = 0.f;
-    for (int i = 0; i < 8; i++) mean += red[i][tx];
+#pragma unroll
+    for (int i = 0; i < 16; i++) mean += red[i][tx];
     mean /= (float)C;
     __syncthreads();
-    float v = 0.f;
-    if (ok) for (int c = ty; c < C; c += 8) { float d = xp[(long long)c * x_cs] - mean; v += d * d; }
-    red[ty][tx] = v;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int c = ty + i * 16;
+        const float d = (c < C) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    red[ty][tx] = q;
     __syncthreads();
     float var = 0.f;
-    for (int i = 0; i < 8; i++) var += red[i][tx];
+#pragma unroll
+    for (int i = 0; i < 16; i++) var += red[i][tx];
     var /= (float)C;
     const float inv = 1.0f / sqrtf(var + 1e-5f);
     if (ok) {
         float *yp = y + (long long)b * y_bs + t;
-        for (int c = ty; c < C; c += 8) yp[(long long)c * y_cs] = (xp[(long long)c * x_cs] - mean) * inv * g[c] + bta[c];
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int c = ty + i * 16;
+            if (c < C) yp[(long long)c * y_cs] = (v[i] - mean) * inv * g[c] + bta[c];
+        }
     }
 }
 
@@ -375,59 +500,115 @@ struct AttnP {
     const float *rel_k, *rel_v; int window;
 };
 
+// One workgroup = one head x 16 query rows; each wave owns 4 query rows and keeps 4 accumulators
+// live so that every K / V LDS read feeds 4 FMAs.  grid = (heads * ceil(T/16), B)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 __global__ __launch_bounds__(256) void attention_kernel(AttnP p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int h = blockIdx.x, b = blockIdx.y;
     const int hd = p.E / p.heads, T = p.T, Tp = T | 1;
-    float *Ks = smem;                    // [hd][Tp]
-    float *Vs = Ks + hd * Tp;            // [hd][Tp]
-    float *Ps = Vs + hd * Tp;            // [4 waves][Tp]
-    float *Qs = Ps + 4 * Tp;             // [4 waves][hd]
+    const int qtiles = (T + 15) / 16;
+    const int h = blockIdx.x / qtiles, qt = blockIdx.x - h * qtiles, b = blockIdx.y;
+    float *Ks = smem;                                   // [hd][Tp]
+    float *Vs = Ks + hd * Tp;                           // [hd][Tp]
+    float *Ps = smem + ((2 * hd * Tp + 3) & ~3);        // [4 waves][Tp][4]
+    float *Qs = Ps + 16 * Tp;                           // [4 waves][hd][4]
     const float *base = p.qkv + (long long)b * p.bs;
     for (int i = threadIdx.x; i < hd * T; i += 256) {
         int d = i / T, t = i - d * T;
         Ks[d * Tp + t] = base[(long long)(p.E + h * hd + d) * p.cs + t];
         Vs[d * Tp + t] = base[(long long)(2 * p.E + h * hd + d) * p.cs + t];
     }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *P = Ps + wave * Tp, *Q = Qs + wave * hd;
+    float *P = Ps + wave * 4 * Tp, *Q = Qs + wave * 4 * hd;
+    const int t1 = qt * 16 + wave * 4;
+    for (int d = lane; d < hd; d += 64) {
+        f32x4 qv;
+#pragma unroll
+        for (int r = 0; r < 4; r++) qv[r] = (t1 + r < T) ? base[(long long)(h * hd + d) * p.cs + t1 + r] * p.scale : 0.f;
+        *reinterpret_cast<f32x4 *>(Q + d * 4) = qv;
+    }
+    __syncthreads();
+    if (t1 >= T) return;
     const int W = p.window;
-    for (int t1 = wave; t1 < T; t1 += 4) {
-        for (int d = lane; d < hd; d += 64) Q[d] = base[(long long)(h * hd + d) * p.cs + t1] * p.scale;
-        __builtin_amdgcn_wave_barrier();
-        float mx = -INFINITY;
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int t2 = lane; t2 < T; t2 += 64) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < hd; d++) {
+            const float kv = Ks[d * Tp + t2];
+            const f32x4 qv = *reinterpret_cast<const f32x4 *>(Q + d * 4);
+            a[0] += qv[0] * kv; a[1] += qv[1] * kv; a[2] += qv[2] * kv; a[3] += qv[3] * kv;
+        }
+        if (p.rel_k) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int rr = t2 - (t1 + r);
+                if (rr >= -W && rr <= W) {
+                    float ra = 0.f;
+                    const float *rk = p.rel_k + (rr + W) * hd;
+                    for (int d = 0; d < hd; d++) ra += Q[d * 4 + r] * rk[d];
+                    a[r] += ra;
+                }
+            }
+        }
+        *reinterpret_cast<f32x4 *>(P + t2 * 4) = a;
+#pragma unroll
+        for (int r = 0; r < 4; r++) mx[r] = fmaxf(mx[r], a[r]);
+    }
+    float inv[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) mx[r] = wave_max(mx[r]);
+    {
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t2 = lane; t2 < T; t2 += 64) {
-            float a = 0.f;
-            for (int d = 0; d < hd; d++) a += Q[d] * Ks[d * Tp + t2];
-            if (p.rel_k) {
-                int r = t2 - t1;
-                if (r >= -W && r <= W) { float ra = 0.f; const float *rk = p.rel_k + (r + W) * hd; for (int d = 0; d < hd; d++) ra += Q[d] * rk[d]; a += ra; }
-            }
-            P[t2] = a;
-            mx = fmaxf(mx, a);
+            f32x4 e = *reinterpret_cast<const f32x4 *>(P + t2 * 4);
+#pragma unroll
+            for (int r = 0; r < 4; r++) { e[r] = expf(e[r] - mx[r]); sum[r] += e[r]; }
+            *reinterpret_cast<f32x4 *>(P + t2 * 4) = e;
         }
-        mx = wave_max(mx);
-        float sum = 0.f;
-        for (int t2 = lane; t2 < T; t2 += 64) { float e = expf(P[t2] - mx); P[t2] = e; sum += e; }
-        sum = wave_sum(sum);
-        const float inv = 1.0f / sum;
-        __builtin_amdgcn_wave_barrier();
-        for (int d = lane; d < hd; d += 64) {
-            float a = 0.f;
-            if (p.rel_v) {
-                // oracle order: normalised probabilities, P.V first, then the relative-value term
-                for (int t2 = 0; t2 < T; t2++) a += (P[t2] * inv) * Vs[d * Tp + t2];
-                int lo = t1 - W < 0 ? 0 : t1 - W, hi = t1 + W >= T ? T - 1 : t1 + W;
-                for (int t2 = lo; t2 <= hi; t2++) a += (P[t2] * inv) * p.rel_v[(t2 - t1 + W) * hd + d];
-                p.out[(long long)b * p.o_bs + (long long)(h * hd + d) * p.o_cs + t1] = a;
-            } else {
-                for (int t2 = 0; t2 < T; t2++) a += P[t2] * Vs[d * Tp + t2];
-                p.out[(long long)b * p.o_bs + (long long)(h * hd + d) * p.o_cs + t1] = a * inv;
+#pragma unroll
+        for (int r = 0; r < 4; r++) inv[r] = 1.0f / wave_sum(sum[r]);
+        if (p.rel_v) {
+            // relative-value path uses normalised probabilities (same order as the reference definition)
+            for (int t2 = lane; t2 < T; t2 += 64) {
+                f32x4 e = *reinterpret_cast<const f32x4 *>(P + t2 * 4);
+#pragma unroll
+                for (int r = 0; r < 4; r++) e[r] *= inv[r];
+                *reinterpret_cast<f32x4 *>(P + t2 * 4) = e;
             }
         }
-        __builtin_amdgcn_wave_barrier();
+    }
+    wave_lds_sync();
+    for (int d = lane; d < hd; d += 64) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        const float *vr = Vs + d * Tp;
+        for (int t2 = 0; t2 < T; t2++) {
+            const float vv = vr[t2];
+            const f32x4 pr = *reinterpret_cast<const f32x4 *>(P + t2 * 4);
+            o[0] += pr[0] * vv; o[1] += pr[1] * vv; o[2] += pr[2] * vv; o[3] += pr[3] * vv;
+        }
+        if (p.rel_v) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int tq = t1 + r;
+                int lo = tq - W < 0 ? 0 : tq - W, hi = tq + W >= T ? T - 1 : tq + W;
+                float acc = o[r];
+                for (int t2 = lo; t2 <= hi; t2++) acc += P[t2 * 4 + r] * p.rel_v[(t2 - tq + W) * hd + d];
+                o[r] = acc;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r] *= inv[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (t1 + r < T) p.out[(long long)b * p.o_bs + (long long)(h * hd + d) * p.o_cs + t1 + r] = o[r];
     }
 }
 
