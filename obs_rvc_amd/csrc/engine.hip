@@ -129,6 +129,25 @@ static float *upload_f(const std::vector<float> &v)
 }
 static float *upload_f(const float *p, size_t n) { return upload_f(std::vector<float>(p, p + n)); }
 
+// [nphase][M][Kp] row-major panels -> MFMA-fragment-major [nphase][m_tile][chunk][lane][4] (M padded to 16 with zeros)
+static float *upload_fragments(const std::vector<float> &panel, int nphase, int M, int Kp)
+{
+    const int mt = (M + 15) / 16, nch = Kp / 16;
+    std::vector<float> out((size_t)nphase * mt * nch * 256, 0.f);
+    for (int ph = 0; ph < nphase; ph++)
+        for (int t = 0; t < mt; t++)
+            for (int c = 0; c < nch; c++)
+                for (int l = 0; l < 64; l++) {
+                    const int m = t * 16 + (l & 15);
+                    if (m >= M) continue;
+                    const float *src = &panel[((size_t)ph * M + m) * Kp + c * 16 + (l >> 4) * 4];
+                    float *dst = &out[(((size_t)ph * mt + t) * nch + c) * 256 + l * 4];
+                    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+                }
+    return upload_f(out);
+}
+static long long phase_stride(const struct ConvW &c);
+
 // Conv (any rank flattened to K = Cin/groups * KW taps): w [Cout][Cin/groups][KW]
 static ConvW prep_conv(const float *w, const float *bias, int Cout, int Cin, int KW, int groups)
 {
@@ -138,7 +157,7 @@ static ConvW prep_conv(const float *w, const float *bias, int Cout, int Cin, int
     c.M = cog; c.K = cig * KW; c.Kp = round16(c.K);
     std::vector<float> panel((size_t)Cout * c.Kp, 0.f);
     for (int co = 0; co < Cout; co++) memcpy(&panel[(size_t)co * c.Kp], w + (size_t)co * c.K, (size_t)c.K * sizeof(float));
-    c.w = upload_f(panel);
+    c.w = upload_fragments(panel, groups, cog, c.Kp);
     if (bias) c.bias = upload_f(bias, Cout);
     return c;
 }
@@ -157,7 +176,7 @@ static ConvW prep_convT1d(const float *w, const float *bias, int Cin, int Cout, 
                     int k = p + j * S;
                     if (k < K) panel[((size_t)p * Cout + co) * c.Kp + ci * c.ntaps + j] = w[((size_t)ci * Cout + co) * K + k];
                 }
-    c.w = upload_f(panel);
+    c.w = upload_fragments(panel, S, Cout, c.Kp);
     if (bias) c.bias = upload_f(bias, Cout);
     return c;
 }
@@ -181,10 +200,11 @@ static ConvW prep_convT2d(const float *w, const float *bias, int Cin, int Cout)
                             if (kh < 0 || kw < 0) continue;
                             panel[((size_t)(ph * 2 + pw) * Cout + co) * c.Kp + ci * 4 + jh * 2 + jw] = w[(((size_t)ci * Cout + co) * 3 + kh) * 3 + kw];
                         }
-    c.w = upload_f(panel);
+    c.w = upload_fragments(panel, 4, Cout, c.Kp);
     if (bias) c.bias = upload_f(bias, Cout);
     return c;
 }
+static long long phase_stride(const ConvW &c) { return (long long)((c.M + 15) / 16 * 16) * c.Kp; }
 static void free_conv(ConvW &c)
 {
     if (c.w) (void)hipFree(c.w);
@@ -250,30 +270,34 @@ struct Plan {
     }
 };
 
-template <int MF, int NF, int D> static void launch_igemm_t(const IgemmP &p, dim3 grid, hipStream_t s)
+template <int MF, int NF, int D, int KS> static void launch_igemm_t(const IgemmP &p, dim3 grid, hipStream_t s)
 {
-    const size_t lds = (size_t)p.chunks_per_split * 16 * sizeof(int);   // this workgroup's slice of the koff table
-    hipLaunchKernelGGL((igemm_kernel<MF, NF, D>), grid, dim3(256), lds, s, p);
+    // LDS: this workgroup's slice of the koff table (+ the KS partial tiles of the in-workgroup K split)
+    const size_t lds = (size_t)p.chunks_per_split * 16 * sizeof(int) + (KS > 1 ? (size_t)KS * MF * NF * 256 * sizeof(float) : 0);
+    hipLaunchKernelGGL((igemm_kernel<MF, NF, D, KS>), grid, dim3((KS > 1 ? KS : 4) * 64), lds, s, p);
 }
 
-template <int KS> static void launch_wgsplit_t(const IgemmP &p, dim3 grid, hipStream_t s)
-{
-    const size_t lds = (size_t)(p.K / 16) * 16 * sizeof(int) + (size_t)KS * 256 * sizeof(float);
-    hipLaunchKernelGGL((igemm_wgsplit_kernel<KS>), grid, dim3(KS * 64), lds, s, p);
-}
+// tile configurations: index -> (MF, NF); every tile exists with KS in {1, 4} and the small ones up to 16
+static const int kMF[5] = {1, 1, 1, 2, 2}, kNF[5] = {1, 2, 4, 2, 4};
 
-static void launch_igemm(int cfg, const IgemmP &p, dim3 grid, hipStream_t s)
+static void launch_igemm(int cfg, int ks, const IgemmP &p, dim3 grid, hipStream_t s)
 {
+#define RVC_CASE(C, MF, NF, D)                                                       \
+    case C:                                                                          \
+        switch (ks) {                                                                \
+        case 1: launch_igemm_t<MF, NF, D, 1>(p, grid, s); return;                    \
+        case 4: launch_igemm_t<MF, NF, D, 4>(p, grid, s); return;                    \
+        case 8: launch_igemm_t<MF, NF, D, 8>(p, grid, s); return;                    \
+        default: launch_igemm_t<MF, NF, (D > 8 ? 8 : D), 16>(p, grid, s); return;    \
+        }
     switch (cfg) {
-    case -4: launch_wgsplit_t<4>(p, grid, s); break;
-    case -8: launch_wgsplit_t<8>(p, grid, s); break;
-    case -16: launch_wgsplit_t<16>(p, grid, s); break;
-    case 0: launch_igemm_t<1, 1, 4>(p, grid, s); break;
-    case 1: launch_igemm_t<1, 2, 4>(p, grid, s); break;
-    case 2: launch_igemm_t<1, 4, 3>(p, grid, s); break;
-    case 3: launch_igemm_t<2, 2, 4>(p, grid, s); break;
-    default: launch_igemm_t<2, 4, 3>(p, grid, s); break;
+        RVC_CASE(0, 1, 1, 12)
+        RVC_CASE(1, 1, 2, 8)
+        RVC_CASE(2, 1, 4, 5)
+        RVC_CASE(3, 2, 2, 6)
+        RVC_CASE(4, 2, 4, 4)
     }
+#undef RVC_CASE
 }
 
 // generic: the caller fills geometry (N, NW, strides, koff, phases); this picks the tile + split-K and queues the op
@@ -282,36 +306,49 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     p.koff = pl.arena.upload(koff);
     p.ph = pl.arena.upload(phases);
     p.nphase = (int)phases.size();
-    static const int MFs[5] = {1, 1, 1, 2, 2}, NFs[5] = {1, 2, 4, 2, 4};
-    auto waves = [&](int c) {
-        long long tm = (p.M + 16 * MFs[c] - 1) / (16 * MFs[c]), tn = (p.N + 16 * NFs[c] - 1) / (16 * NFs[c]);
+    const int nchunks = p.K / 16;
+    auto tiles = [&](int c) {
+        long long tm = (p.M + 16 * kMF[c] - 1) / (16 * kMF[c]), tn = (p.N + 16 * kNF[c] - 1) / (16 * kNF[c]);
         return tm * tn * B * p.nphase;
     };
-    int cfg;
-    if (p.M > 16) cfg = waves(4) >= 1024 ? 4 : (waves(3) >= 1024 ? 3 : 0);
-    else cfg = waves(2) >= 1024 ? 2 : (waves(1) >= 1024 ? 1 : 0);
-    const int nchunks = p.K / 16;
-    int ksplit = 1, wg_ks = 0;
-    if (cfg == 0) {
-        const long long w0 = waves(0);
-        if (w0 <= 512 && nchunks >= 8 && (size_t)nchunks * 64 + 16 * 1024 <= 64 * 1024) {
-            // few tiles, long K: split K over the waves of one workgroup per tile (in-kernel LDS reduction)
-            wg_ks = 4;
-            while (wg_ks < 16 && w0 * wg_ks < 1024 && nchunks / (wg_ks * 2) >= 4) wg_ks *= 2;
-        } else if (w0 < 512 && nchunks >= 8) {
-            int want = (int)((1024 + w0 - 1) / w0);
-            ksplit = std::min(want, nchunks / 4);
-            if (ksplit < 1) ksplit = 1;
+    // Pick the largest tile that still yields >= 1024 waves (one per SIMD), using the in-workgroup K split
+    // (KS = 4/8/16 waves per tile) when the layer has too few tiles.  A wave keeps >= 4 chunks of K.
+    const int order_big[3] = {4, 3, 0}, order_small[3] = {2, 1, 0};
+    const int *order = p.M > 16 ? order_big : order_small;
+    int cfg = 0, wg_ks = 1;
+    long long best_waves = -1;
+    bool found = false;
+    for (int oi = 0; oi < 3 && !found; oi++) {
+        const int c = order[oi];
+        for (int ks = 1; ks <= 16; ks = ks == 1 ? 4 : ks * 2) {
+            if (ks > 1 && (nchunks / ks < 4 || ks * kMF[c] * kNF[c] > 32)) break;
+            if ((size_t)nchunks * 64 + (ks > 1 ? (size_t)ks * kMF[c] * kNF[c] * 1024 : 0) > 60 * 1024) break;
+            const long long w = tiles(c) * ks;
+            if (w > best_waves) { best_waves = w; cfg = c; wg_ks = ks; }
+            if (w >= 1024) { cfg = c; wg_ks = ks; found = true; break; }
         }
+    }
+    if (const char *f = getenv("RVC_FORCE_CFG")) {   // tuning aid: "cfg,ks[,mfast]"
+        int fc = 0, fk = 1; if (sscanf(f, "%d,%d", &fc, &fk) >= 1) { cfg = fc; wg_ks = fk; }
+    }
+    int ksplit = 1;
+    if ((size_t)nchunks * 64 > 60 * 1024) {     // koff slice would not fit in LDS: grid-level split (two-stage, rare)
+        ksplit = (int)(((size_t)nchunks * 64 + 60 * 1024 - 1) / (60 * 1024));
+        cfg = 0; wg_ks = 1;
     }
     int cps = (nchunks + ksplit - 1) / ksplit;
     ksplit = (nchunks + cps - 1) / cps;
     p.ksplit = ksplit; p.chunks_per_split = cps;
-    p.ntm = (p.M + 16 * MFs[cfg] - 1) / (16 * MFs[cfg]);
-    p.ntn = (p.N + 16 * NFs[cfg] - 1) / (16 * NFs[cfg]);
+    p.ntm = (p.M + 16 * kMF[cfg] - 1) / (16 * kMF[cfg]);
+    p.ntn = (p.N + 16 * kNF[cfg] - 1) / (16 * kNF[cfg]);
     if (ksplit > 1) p.part = pl.arena.floats((size_t)B * p.nphase * ksplit * p.M * p.N);
-    dim3 grid((p.ntm * p.ntn + 3) / 4, B * p.nphase * ksplit);
-    if (wg_ks) { grid = dim3(p.ntm * p.ntn, B * p.nphase); cfg = -wg_ks; }
+    // weight-heavy layers (short N: the transformer at T=111, RMVPE's deep levels, the synth encoder): keep all tiles that
+    // read the same weight rows on one XCD so each weight byte crosses the fabric once (per-XCD L2s are private)
+    bool weight_heavy = p.N <= 512 && (long long)p.M * p.K >= 64 * 1024 && p.ntm >= 8;
+    if (const char *f = getenv("RVC_FORCE_MFAST")) weight_heavy = atoi(f) != 0;
+    p.m_fast = weight_heavy ? (p.ntm + 7) / 8 * 8 : 0;
+    const int ntiles = weight_heavy ? p.m_fast * p.ntn : p.ntm * p.ntn;
+    dim3 grid(wg_ks > 1 ? ntiles : (ntiles + 3) / 4, B * p.nphase * ksplit);
     dim3 egrid((unsigned)(((long long)p.M * p.N + 255) / 256), B * p.nphase);
     const double flops = 2.0 * p.M * (double)p.N * p.K * B * p.nphase;
     pl.igemm_flops += flops;
@@ -327,7 +364,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
             pe->flops = flops;
             HIPCHK(hipEventRecord(pe->a, s));
         }
-        launch_igemm(cfg, p, grid, s);
+        launch_igemm(cfg, wg_ks, p, grid, s);
         if (ksplit > 1) hipLaunchKernelGGL(splitk_epilogue_kernel, egrid, dim3(256), 0, s, p);
         if (pe) HIPCHK(hipEventRecord(pe->b, s));
     });
@@ -352,6 +389,7 @@ static void add_conv1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int 
     if (Tout != y.T && !(Tout == y.T + 1)) throw ShapeError("conv1d output length mismatch");
     if (x.halo < pad || (y.T - 1) * stride + (KW - 1) * dil - pad > x.T - 1 + x.halo) throw ShapeError("conv1d halo too small");
     IgemmP p{};
+    if (o.m_off % 16 != 0) throw std::runtime_error("output-row sub-range must start at a multiple of 16");
     p.x = x.p; p.w = cw.w + (long long)o.m_off * cw.Kp; p.y = y.p;
     p.M = o.m_cnt >= 0 ? o.m_cnt : cw.M; p.N = y.T; p.K = cw.Kp;
     p.NW = y.T; p.x_hs = 0; p.x_ws = stride; p.y_hm = 0; p.y_ws = 1; p.OW = y.T;
@@ -363,7 +401,7 @@ static void add_conv1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int 
     std::vector<PhaseD> ph(cw.groups);
     for (int g = 0; g < cw.groups; g++) {
         ph[g] = PhaseD{};
-        ph[g].w_off = (long long)g * cw.M * cw.Kp;
+        ph[g].w_off = (long long)g * phase_stride(cw);
         ph[g].x_off = g * cig * x.ld;
         ph[g].y_c0 = g * cw.M;
         ph[g].y_pos = 0;
@@ -391,7 +429,7 @@ static void add_convT1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int
     std::vector<PhaseD> ph(S);
     for (int q = 0; q < S; q++) {
         ph[q] = PhaseD{};
-        ph[q].w_off = (long long)q * cw.M * cw.Kp;
+        ph[q].w_off = (long long)q * phase_stride(cw);
         ph[q].x_off = 0;
         ph[q].y_pos = q - pad;
         ph[q].bias_off = 0;
@@ -432,7 +470,7 @@ static void add_convT2d(Plan &pl, const ConvW &cw, const T2 &x, const T2 &y, Con
     std::vector<PhaseD> ph(4);
     for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) {
         PhaseD d{};
-        d.w_off = (long long)(a * 2 + b) * cw.M * cw.Kp;
+        d.w_off = (long long)(a * 2 + b) * phase_stride(cw);
         d.y_h0 = a;
         d.y_pos = b;
         ph[a * 2 + b] = d;
@@ -1637,6 +1675,37 @@ rvc_status rvc_profile_last(rvc_engine *e, int *launches, double *kernel_ms, dou
         if (flops) *flops = pl->prof_used ? fl : pl->igemm_flops;
         return RVC_OK;
     });
+}
+
+// tuning aid (not part of the reference surface): time one Conv1d(Cin -> M, KW taps, stride 1, "same" padding) over N positions
+double rvc_debug_conv_bench(rvc_engine *e, int M, int Cin, int KW, int dil, int N, int iters, int pre_act)
+{
+    double us = -1.0;
+    (void)guarded(e, [&]() {
+        std::vector<float> w((size_t)M * Cin * KW), bias(M, 0.1f);
+        for (size_t i = 0; i < w.size(); i++) w[i] = (float)((i * 2654435761u) % 1000) / 1000.0f - 0.5f;
+        ConvW cw = prep_conv(w.data(), bias.data(), M, Cin, KW, 1);
+        Plan pl; pl.B = 1;
+        const int pad = (KW - 1) * dil / 2;
+        T1 x = make_t1(pl.arena, 1, Cin, N, (pad + 3) / 4 * 4), y = make_t1(pl.arena, 1, M, N, 0);
+        std::vector<float> hx((size_t)Cin * x.ld, 0.25f);
+        HIPCHK(hipMemcpy(x.p - x.halo, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        ConvOpts o; if (pre_act) { o.pre_act = ACT_LRELU; o.pre_slope = 0.1f; }
+        add_conv1d(pl, cw, x, y, 1, pad, dil, o);
+        HIPCHK(hipDeviceSynchronize());
+        for (int i = 0; i < 3; i++) for (auto &op : pl.ops.v) op(e->stream);
+        hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+        HIPCHK(hipEventRecord(a, e->stream));
+        for (int i = 0; i < iters; i++) for (auto &op : pl.ops.v) op(e->stream);
+        HIPCHK(hipEventRecord(b, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        float ms; HIPCHK(hipEventElapsedTime(&ms, a, b));
+        us = ms * 1e3 / iters;
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        free_conv(cw);
+        return RVC_OK;
+    });
+    return us;
 }
 
 rvc_status rvc_get_tap(rvc_engine *e, const char *name, float *out, size_t cap, size_t *n)

@@ -61,6 +61,8 @@ struct IgemmP {
     int act; float slope; float scale; int accumulate;
     int pre_act; float pre_slope;   // fused input LeakyReLU: x -> max(x, x*pre_slope); pre_slope = 1 disables it
     int ntn, ntm;
+    int m_fast;              // XCD-aware tile order: >0 = ntm rounded up to 8, m fastest (workgroup b runs on XCD b%8, so all
+                             // n-tiles of one weight-row block share one XCD's L2); 0 = n fastest (activation-heavy layers)
 };
 
 __device__ __forceinline__ void epilogue_store(const IgemmP &p, const PhaseD &ph, int b, int m, int n, float acc)
@@ -81,35 +83,53 @@ __device__ __forceinline__ void epilogue_store(const IgemmP &p, const PhaseD &ph
     *yp = v;
 }
 
-// One wave = one (16*MF) x (16*NF) tile; 4 independent waves per workgroup (consecutive tiles
-// share the weight rows through the CU's L1).  The workgroup's slice of the koff table is staged in
-// LDS once; weights and gathered activations are register-prefetched D chunks (of 16 k) ahead so
-// that HBM/L2 latency is covered even at one wave per SIMD.
-template <int MF, int NF, int D>
-__global__ __launch_bounds__(256) void igemm_kernel(IgemmP p)
+// igemm_kernel<MF, NF, D, KS>
+//   One wave owns a (16*MF) x (16*NF) output tile of 16x16x4 fp32 MFMA fragments.
+//   KS == 1: the 4 waves of a workgroup work on 4 consecutive tiles (they share weight rows through L1).
+//   KS  > 1: the KS waves of a workgroup split the K chunks of ONE tile and sum their partial accumulators
+//            through LDS in a fixed order (deterministic) -- the shape for B=1, where a layer has few tiles
+//            but a long K (weight streaming): KS times more loads in flight, no second kernel.
+//   The workgroup's slice of the koff table is staged in LDS once; weights and gathered activations are
+//   register-prefetched D chunks (of 16 k) ahead; the koff entries of the next chunk are read from LDS
+//   one stage early so the LDS latency is off the critical path.
+template <int MF, int NF, int D, int KS>
+__global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
 {
+    constexpr int WAVES = KS > 1 ? KS : 4;
+    constexpr int NACC = (MF * NF == 1) ? 2 : 1;   // a lone fragment alternates two accumulators (MFMA dependency)
     extern __shared__ __attribute__((aligned(16))) int s_koff[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = blockIdx.x * 4 + wave;
+    const int tile = KS > 1 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
     int z = blockIdx.y;
     const int ks = z % p.ksplit; z /= p.ksplit;
     const int phase = z % p.nphase;
     const int b = z / p.nphase;
     const PhaseD ph = p.ph[phase];
     const int nchunks = p.K >> 4;
-    const int c0 = ks * p.chunks_per_split;
-    int c1 = c0 + p.chunks_per_split;
-    c1 = c1 < nchunks ? c1 : nchunks;
-    const int nc = c1 - c0;
+    const int g0 = ks * p.chunks_per_split;
+    int g1 = g0 + p.chunks_per_split;
+    g1 = g1 < nchunks ? g1 : nchunks;
+    const int gn = g1 - g0;                 // chunks of this workgroup (grid-level split)
     {
-        const int4 *src = reinterpret_cast<const int4 *>(p.koff + ph.koff_off + c0 * 16);
+        const int4 *src = reinterpret_cast<const int4 *>(p.koff + ph.koff_off + g0 * 16);
         int4 *dst = reinterpret_cast<int4 *>(s_koff);
-        for (int i = threadIdx.x; i < nc * 4; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < gn * 4; i += WAVES * 64) dst[i] = src[i];
     }
     __syncthreads();
-    if (tile >= p.ntn * p.ntm) return;
-    const int tn = tile % p.ntn, tm = tile / p.ntn;
+    int tn, tm;
+    if (p.m_fast) { tm = tile % p.m_fast; tn = tile / p.m_fast; }
+    else { tn = tile % p.ntn; tm = tile / p.ntn; }
+    if (tm >= p.ntm || tn >= p.ntn) return;   // padding of the XCD-aware order / grid tail (uniform per workgroup when KS > 1)
     const int li = lane & 15, kq = lane >> 4;
+    // this wave's chunk range inside the workgroup's slice
+    int c0 = 0, nc = gn;
+    if (KS > 1) {
+        const int cpw = (gn + KS - 1) / KS;
+        c0 = wave * cpw;
+        int c1 = c0 + cpw;
+        c1 = c1 < gn ? c1 : gn;
+        nc = c1 > c0 ? c1 - c0 : 0;
+    }
 
     const float *xb = p.x + (long long)b * p.x_bs + ph.x_off;
     int xo[NF];
@@ -121,28 +141,36 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p)
         if (p.x_hs) { nh = n / p.NW; nw = n - nh * p.NW; }
         xo[nf] = nh * p.x_hs + nw * p.x_ws;
     }
+    // weights are pre-packed in MFMA-fragment order [m_tile][chunk][lane][4]: one wave-wide dwordx4 load of a
+    // (16 rows x 16 k) fragment is 1 KiB fully contiguous (lane l holds W[mt*16 + (l&15)][c*16 + (l>>4)*4 + 0..3])
     const float *wrow[MF];
+    const int mtiles = (p.M + 15) >> 4;
 #pragma unroll
     for (int mf = 0; mf < MF; mf++) {
-        int m = tm * 16 * MF + mf * 16 + li;
-        m = m < p.M ? m : p.M - 1;
-        wrow[mf] = p.w + ph.w_off + (long long)m * p.K + (long long)c0 * 16 + kq * 4;
+        int mt = tm * MF + mf;
+        mt = mt < mtiles ? mt : mtiles - 1;
+        wrow[mf] = p.w + ph.w_off + ((long long)mt * nchunks + (g0 + c0)) * 256 + lane * 4;
     }
-    const int4 *kol = reinterpret_cast<const int4 *>(s_koff) + kq;
+    const int4 *kol = reinterpret_cast<const int4 *>(s_koff) + c0 * 4 + kq;
+    const float pre_slope = p.pre_slope;
 
-    f32x4 acc[MF][NF];
+    f32x4 acc[NACC][MF][NF];
 #pragma unroll
-    for (int mf = 0; mf < MF; mf++)
+    for (int a = 0; a < NACC; a++)
 #pragma unroll
-        for (int nf = 0; nf < NF; nf++) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+            for (int nf = 0; nf < NF; nf++) acc[a][mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     f32x4 a_st[D][MF];
     float b_st[D][NF][4];
+    int4 ko_nx = nc > 0 ? kol[0] : make_int4(0, 0, 0, 0);
 #define RVC_LOAD_STAGE(S, C)                                                                           \
     {                                                                                                  \
         const int cc_ = (C);                                                                           \
-        const int4 ko_ = kol[cc_ * 4];                                                                 \
-        _Pragma("unroll") for (int mf = 0; mf < MF; mf++) a_st[S][mf] = *reinterpret_cast<const f32x4 *>(wrow[mf] + cc_ * 16); \
+        const int4 ko_ = ko_nx;                                                                        \
+        ko_nx = kol[(cc_ + 1 < nc ? cc_ + 1 : cc_) * 4];                                               \
+        _Pragma("unroll") for (int mf = 0; mf < MF; mf++) a_st[S][mf] = *reinterpret_cast<const f32x4 *>(wrow[mf] + cc_ * 256); \
         _Pragma("unroll") for (int nf = 0; nf < NF; nf++) {                                            \
             b_st[S][nf][0] = xb[xo[nf] + ko_.x]; b_st[S][nf][1] = xb[xo[nf] + ko_.y];                  \
             b_st[S][nf][2] = xb[xo[nf] + ko_.z]; b_st[S][nf][3] = xb[xo[nf] + ko_.w];                  \
@@ -155,10 +183,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p)
                 /* fused input LeakyReLU (slope 1 = identity): branch-free so the loads stay in flight */ \
                 const float bv_ = fmaxf(b_st[S][nf][j], b_st[S][nf][j] * pre_slope);                   \
                 _Pragma("unroll") for (int mf = 0; mf < MF; mf++)                                      \
-                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[S][mf][j], bv_, acc[mf][nf], 0, 0, 0); \
+                    acc[j % NACC][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[S][mf][j], bv_, acc[j % NACC][mf][nf], 0, 0, 0); \
             }                                                                                          \
     }
-    const float pre_slope = p.pre_slope;
 #pragma unroll
     for (int s = 0; s < D; s++)
         if (s < nc) RVC_LOAD_STAGE(s, s)
@@ -167,7 +194,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p)
 #pragma unroll
         for (int s = 0; s < D; s++) {
             RVC_COMPUTE_STAGE(s)
+            __builtin_amdgcn_sched_barrier(0);
             RVC_LOAD_STAGE(s, c + s + D)
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     for (; c < nc; c += D) {
@@ -181,7 +210,36 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p)
     }
 #undef RVC_COMPUTE_STAGE
 #undef RVC_LOAD_STAGE
+    if (NACC == 2) {
+#pragma unroll
+        for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+            for (int nf = 0; nf < NF; nf++) acc[0][mf][nf] += acc[NACC - 1][mf][nf];
+    }
 
+    if (KS > 1) {
+        // fixed-order reduction of the KS partial tiles through LDS, then the first 256 threads run the epilogue
+        float *red = reinterpret_cast<float *>(s_koff + gn * 16);     // [KS][MF*NF*256]
+        constexpr int TE = MF * NF * 256;
+#pragma unroll
+        for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+            for (int nf = 0; nf < NF; nf++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) red[wave * TE + ((mf * NF + nf) * 4 + r) * 64 + lane] = acc[0][mf][nf][r];
+        __syncthreads();
+        for (int e = threadIdx.x; e < TE; e += WAVES * 64) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < KS; w++) v += red[w * TE + e];
+            const int l = e & 63, r = (e >> 6) & 3, f = e >> 8, mf = f / NF, nf = f - mf * NF;
+            const int m = tm * 16 * MF + mf * 16 + (l >> 4) * 4 + r, n = tn * 16 * NF + nf * 16 + (l & 15);
+            if (p.ksplit == 1) epilogue_store(p, ph, b, m, n, v);
+            else if (m < p.M && n < p.N)
+                p.part[(((long long)(b * p.nphase + phase) * p.ksplit + ks) * p.M + m) * (long long)p.N + n] = v;
+        }
+        return;
+    }
     // D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
     if (p.ksplit == 1) {
 #pragma unroll
@@ -190,7 +248,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p)
             for (int nf = 0; nf < NF; nf++)
 #pragma unroll
                 for (int r = 0; r < 4; r++)
-                    epilogue_store(p, ph, b, tm * 16 * MF + mf * 16 + kq * 4 + r, tn * 16 * NF + nf * 16 + li, acc[mf][nf][r]);
+                    epilogue_store(p, ph, b, tm * 16 * MF + mf * 16 + kq * 4 + r, tn * 16 * NF + nf * 16 + li, acc[0][mf][nf][r]);
     } else {
         // partial sums: part[((b*nphase + phase)*ksplit + ks)][M][N]
         float *pp = p.part + ((long long)(b * p.nphase + phase) * p.ksplit + ks) * (long long)p.M * p.N;
@@ -201,106 +259,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmP p)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     int m = tm * 16 * MF + mf * 16 + kq * 4 + r, n = tn * 16 * NF + nf * 16 + li;
-                    if (m < p.M && n < p.N) pp[(long long)m * p.N + n] = acc[mf][nf][r];
+                    if (m < p.M && n < p.N) pp[(long long)m * p.N + n] = acc[0][mf][nf][r];
                 }
-    }
-}
-
-// Small-problem variant (few output tiles, long K: RMVPE's deep layers, the transformer projections at
-// T = 111, the synthesizer's encoder/flow): one 16x16 tile per workgroup, the KS waves of the workgroup
-// split the K chunks and their partial accumulators are summed through LDS in a fixed order
-// (deterministic), so no second kernel and KS times more loads in flight per tile.
-template <int KS>
-__global__ __launch_bounds__(KS * 64) void igemm_wgsplit_kernel(IgemmP p)
-{
-    constexpr int D = 4;
-    extern __shared__ __attribute__((aligned(16))) int s_koff[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = blockIdx.x;
-    int z = blockIdx.y;
-    const int phase = z % p.nphase;
-    const int b = z / p.nphase;
-    const PhaseD ph = p.ph[phase];
-    const int nchunks = p.K >> 4;
-    {
-        const int4 *src = reinterpret_cast<const int4 *>(p.koff + ph.koff_off);
-        int4 *dst = reinterpret_cast<int4 *>(s_koff);
-        for (int i = threadIdx.x; i < nchunks * 4; i += KS * 64) dst[i] = src[i];
-    }
-    float *red = reinterpret_cast<float *>(s_koff + nchunks * 16);   // [KS][256]
-    __syncthreads();
-    const int tn = tile % p.ntn, tm = tile / p.ntn;
-    const int li = lane & 15, kq = lane >> 4;
-    const int cpw = (nchunks + KS - 1) / KS;
-    const int c0 = wave * cpw;
-    int c1 = c0 + cpw;
-    c1 = c1 < nchunks ? c1 : nchunks;
-    const int nc = c1 - c0;
-
-    const float *xb = p.x + (long long)b * p.x_bs + ph.x_off;
-    int xo;
-    {
-        int n = tn * 16 + li;
-        n = n < p.N ? n : p.N - 1;
-        int nh = 0, nw = n;
-        if (p.x_hs) { nh = n / p.NW; nw = n - nh * p.NW; }
-        xo = nh * p.x_hs + nw * p.x_ws;
-    }
-    int m = tm * 16 + li;
-    m = m < p.M ? m : p.M - 1;
-    const float *wrow = p.w + ph.w_off + (long long)m * p.K + (long long)c0 * 16 + kq * 4;
-    const int4 *kol = reinterpret_cast<const int4 *>(s_koff) + c0 * 4 + kq;
-    const float pre_slope = p.pre_slope;
-
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    f32x4 a_st[D];
-    float b_st[D][4];
-#define RVC_LOAD1(S, C)                                                                   \
-    {                                                                                     \
-        const int cc_ = (C);                                                              \
-        const int4 ko_ = kol[cc_ * 4];                                                    \
-        a_st[S] = *reinterpret_cast<const f32x4 *>(wrow + cc_ * 16);                      \
-        b_st[S][0] = xb[xo + ko_.x]; b_st[S][1] = xb[xo + ko_.y];                         \
-        b_st[S][2] = xb[xo + ko_.z]; b_st[S][3] = xb[xo + ko_.w];                         \
-    }
-#define RVC_COMPUTE1(S)                                                                   \
-    {                                                                                     \
-        _Pragma("unroll") for (int j = 0; j < 4; j++) {                                   \
-            const float bv_ = fmaxf(b_st[S][j], b_st[S][j] * pre_slope);                  \
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[S][j], bv_, acc, 0, 0, 0);    \
-        }                                                                                 \
-    }
-#pragma unroll
-    for (int s = 0; s < D; s++)
-        if (s < nc) RVC_LOAD1(s, s)
-    int c = 0;
-    for (; c + 2 * D <= nc; c += D) {
-#pragma unroll
-        for (int s = 0; s < D; s++) {
-            RVC_COMPUTE1(s)
-            RVC_LOAD1(s, c + s + D)
-        }
-    }
-    for (; c < nc; c += D) {
-#pragma unroll
-        for (int s = 0; s < D; s++) {
-            if (c + s < nc) {
-                RVC_COMPUTE1(s)
-                if (c + s + D < nc) RVC_LOAD1(s, c + s + D)
-            }
-        }
-    }
-#undef RVC_LOAD1
-#undef RVC_COMPUTE1
-#pragma unroll
-    for (int r = 0; r < 4; r++) red[wave * 256 + r * 64 + lane] = acc[r];
-    __syncthreads();
-    if (threadIdx.x < 256) {
-        const int e = threadIdx.x, r = e >> 6, l = e & 63;
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < KS; w++) v += red[w * 256 + e];
-        epilogue_store(p, ph, b, tm * 16 + (l >> 4) * 4 + r, tn * 16 + (l & 15), v);
     }
 }
 

@@ -1,0 +1,38 @@
+"""Tuning aid (not a test): isolated timings of the implicit-GEMM kernel on representative layer shapes."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+SHAPES = {  # name: (M, Cin, KW, dil, N)
+    "cv_qkv": (2304, 768, 1, 1, 111), "cv_o": (768, 768, 1, 1, 111), "cv_ff1": (3072, 768, 1, 1, 111), "cv_ff2": (768, 3072, 1, 1, 111),
+    "hg3_k11": (32, 32, 11, 1, 10080), "hg3_k3": (32, 32, 3, 5, 10080), "hg2_k11": (64, 64, 11, 1, 5040), "hg1_k7": (128, 128, 7, 3, 2520),
+    "hg0_k11": (256, 256, 11, 1, 252), "cv_conv2": (512, 512, 3, 1, 1791), "enc_ff1": (768, 192, 3, 1, 21),
+}
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from obs_rvc_amd import _native
+    L = _native.lib()
+    L.rvc_debug_conv_bench.restype = C.c_double
+    L.rvc_debug_conv_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    h = C.c_void_p()
+    assert L.rvc_create(b"/tmp", 0, C.byref(h)) == 0
+    out = []
+    for name in sys.argv[2].split(","):
+        M, Cin, KW, dil, N = SHAPES[name]
+        us = L.rvc_debug_conv_bench(h, M, Cin, KW, dil, N, 200, 0)
+        fl = 2.0 * M * Cin * KW * N
+        out.append("%s %.1fus %.1fTF" % (name, us, fl / us / 1e6))
+    print(os.environ.get("RVC_FORCE_CFG", "auto"), os.environ.get("RVC_FORCE_MFAST", "-"), " | ".join(out))
+else:
+    names = ",".join(SHAPES)
+    cfgs = [None] + ["%d,%d" % (c, k) for c in (0, 3, 4) for k in (1, 4, 8)] + ["0,16", "1,4", "2,4"]
+    if len(sys.argv) > 1 and sys.argv[1] == "quick":
+        cfgs = [None, "0,1", "0,4", "3,1", "3,4", "4,4"]
+    for cfg in cfgs:
+        for mf in ("0",) if len(sys.argv) > 1 else ("0", "1"):
+            env = dict(os.environ)
+            if cfg:
+                env["RVC_FORCE_CFG"] = cfg
+            env["RVC_FORCE_MFAST"] = mf
+            subprocess.run([sys.executable, __file__, "child", names], env=env)
