@@ -270,26 +270,28 @@ struct Plan {
     }
 };
 
-template <int MF, int NF, int D, int KS> static void launch_igemm_t(const IgemmP &p, dim3 grid, hipStream_t s)
+template <int MF, int NF, int D, int KS, bool PRE> static void launch_igemm_t(const IgemmP &p, dim3 grid, hipStream_t s)
 {
-    // LDS: this workgroup's slice of the koff table (+ the KS partial tiles of the in-workgroup K split)
+    // LDS: this workgroup's slice of the koff table + the KS partial tiles of the in-workgroup K split
     const size_t lds = (size_t)p.chunks_per_split * 16 * sizeof(int) + (KS > 1 ? (size_t)KS * MF * NF * 256 * sizeof(float) : 0);
-    hipLaunchKernelGGL((igemm_kernel<MF, NF, D, KS>), grid, dim3((KS > 1 ? KS : 4) * 64), lds, s, p);
+    hipLaunchKernelGGL((igemm_kernel<MF, NF, D, KS, PRE>), grid, dim3((KS > 1 ? KS : 4) * 64), lds, s, p);
 }
 
-// tile configurations: index -> (MF, NF); every tile exists with KS in {1, 4} and the small ones up to 16
+// tile configurations: index -> (MF, NF); every tile exists with KS in {1, 4, 8, 16}
 static const int kMF[5] = {1, 1, 1, 2, 2}, kNF[5] = {1, 2, 4, 2, 4};
 
-static void launch_igemm(int cfg, int ks, const IgemmP &p, dim3 grid, hipStream_t s)
+static void launch_igemm(int cfg, int ks, bool pre, const IgemmP &p, dim3 grid, hipStream_t s)
 {
+#define RVC_KS(MF, NF, D, PRE)                                                       \
+        switch (ks) {                                                                \
+        case 1: launch_igemm_t<MF, NF, D, 1, PRE>(p, grid, s); return;               \
+        case 4: launch_igemm_t<MF, NF, D, 4, PRE>(p, grid, s); return;               \
+        case 8: launch_igemm_t<MF, NF, D, 8, PRE>(p, grid, s); return;               \
+        default: launch_igemm_t<MF, NF, (D > 8 ? 8 : D), 16, PRE>(p, grid, s); return; \
+        }
 #define RVC_CASE(C, MF, NF, D)                                                       \
     case C:                                                                          \
-        switch (ks) {                                                                \
-        case 1: launch_igemm_t<MF, NF, D, 1>(p, grid, s); return;                    \
-        case 4: launch_igemm_t<MF, NF, D, 4>(p, grid, s); return;                    \
-        case 8: launch_igemm_t<MF, NF, D, 8>(p, grid, s); return;                    \
-        default: launch_igemm_t<MF, NF, (D > 8 ? 8 : D), 16>(p, grid, s); return;    \
-        }
+        if (pre) { RVC_KS(MF, NF, D, true) } else { RVC_KS(MF, NF, D, false) }
     switch (cfg) {
         RVC_CASE(0, 1, 1, 12)
         RVC_CASE(1, 1, 2, 8)
@@ -298,14 +300,23 @@ static void launch_igemm(int cfg, int ks, const IgemmP &p, dim3 grid, hipStream_
         RVC_CASE(4, 2, 4, 4)
     }
 #undef RVC_CASE
+#undef RVC_KS
 }
 
 // generic: the caller fills geometry (N, NW, strides, koff, phases); this picks the tile + split-K and queues the op
 static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases)
 {
-    p.koff = pl.arena.upload(koff);
+    // table entries become non-negative byte offsets; the kernel moves the base pointer back by koff_bias bytes
+    std::vector<int> kb(koff);
+    int kmin = 0;
+    for (int v : kb) kmin = std::min(kmin, v);
+    for (int &v : kb) v = (v - kmin) * 4;
+    p.koff_bias = -kmin * 4;
+    const bool pre = p.pre_act != ACT_NONE;
+    p.koff = pl.arena.upload(kb);
     p.ph = pl.arena.upload(phases);
     p.nphase = (int)phases.size();
+    p.ph0 = phases[0];
     const int nchunks = p.K / 16;
     auto tiles = [&](int c) {
         long long tm = (p.M + 16 * kMF[c] - 1) / (16 * kMF[c]), tn = (p.N + 16 * kNF[c] - 1) / (16 * kNF[c]);
@@ -364,7 +375,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
             pe->flops = flops;
             HIPCHK(hipEventRecord(pe->a, s));
         }
-        launch_igemm(cfg, wg_ks, p, grid, s);
+        launch_igemm(cfg, wg_ks, pre, p, grid, s);
         if (ksplit > 1) hipLaunchKernelGGL(splitk_epilogue_kernel, egrid, dim3(256), 0, s, p);
         if (pe) HIPCHK(hipEventRecord(pe->b, s));
     });
@@ -395,6 +406,44 @@ static void add_conv1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int 
     p.NW = y.T; p.x_hs = 0; p.x_ws = stride; p.y_hm = 0; p.y_ws = 1; p.OW = y.T;
     p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.ld; p.y_rs = 0;
     fill_epilogue(p, cw, o);
+    // HiFiGAN-style stride-1 convs with several taps: LDS-resident input tile (each input element fetched once per workgroup)
+    if (stride == 1 && cw.groups == 1 && KW >= 3 && o.m_off == 0 && o.m_cnt < 0 && y.T >= 256 && getenv("RVC_LDS_CONV")) {   // opt-in: measured slower than the register-direct kernel so far
+        const int span = (KW - 1) * dil;
+        const int mt = (cw.M + 15) / 16;
+        for (int nf : {4, 1}) {
+            const int BN = 64 * nf, RL = BN + span;
+            const size_t lds = ((size_t)cw.Cin * RL + cw.Kp) * sizeof(float);
+            if (lds > 128 * 1024) continue;
+            const long long ntn = (y.T + BN - 1) / BN;
+            int mf = mt >= 4 ? 4 : (mt >= 2 ? 2 : 1);
+            if (nf == 4 && ntn * ((mt + mf - 1) / mf) * x.B < 512) continue;          // too few workgroups: use the 64-column tile
+            while (mf > 1 && ntn * ((mt + mf - 1) / mf) * x.B < 256) mf /= 2;
+            p.ksplit = 1; p.nphase = 1;
+            std::vector<int> loff(cw.Kp, 0);
+            for (int ci = 0; ci < cw.Cin; ci++) for (int k = 0; k < KW; k++) loff[ci * KW + k] = ci * RL + k * dil;
+            p.loff = pl.arena.upload(loff);
+            p.c_in = cw.Cin; p.c_rl = RL; p.c_pad = pad; p.c_t = x.T; p.c_halo = x.halo; p.x_cs = x.ld;
+            dim3 grid((unsigned)ntn, (mt + mf - 1) / mf, x.B);
+            const double flops = 2.0 * cw.M * (double)y.T * cw.Kp * x.B;
+            pl.igemm_flops += flops; pl.n_igemm++;
+            Plan *plp = &pl;
+            const int nf_ = nf, mf_ = mf;
+            pl.ops.push_back([=](hipStream_t s) {
+                ProfEvent *pe = nullptr;
+                if (plp->profile) {
+                    if (plp->prof_used == plp->prof.size()) { ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; plp->prof.push_back(e); }
+                    pe = &plp->prof[plp->prof_used++]; pe->flops = flops;
+                    HIPCHK(hipEventRecord(pe->a, s));
+                }
+#define RVC_LC(MF, NF) hipLaunchKernelGGL((conv1d_lds_kernel<MF, NF>), grid, dim3(256), lds, s, p)
+                if (nf_ == 4) { if (mf_ == 4) RVC_LC(4, 4); else if (mf_ == 2) RVC_LC(2, 4); else RVC_LC(1, 4); }
+                else { if (mf_ == 4) RVC_LC(4, 1); else if (mf_ == 2) RVC_LC(2, 1); else RVC_LC(1, 1); }
+#undef RVC_LC
+                if (pe) HIPCHK(hipEventRecord(pe->b, s));
+            });
+            return;
+        }
+    }
     if (cw.groups > 1 && (o.m_off != 0 || o.m_cnt >= 0)) throw std::runtime_error("row sub-range on grouped conv");
     std::vector<int> koff(cw.Kp, 0);
     for (int ci = 0; ci < cig; ci++) for (int k = 0; k < KW; k++) koff[ci * KW + k] = ci * x.ld + k * dil - pad;
@@ -480,12 +529,12 @@ static void add_convT2d(Plan &pl, const ConvW &cw, const T2 &x, const T2 &y, Con
 
 static void add_layernorm(Plan &pl, const T1 &x, const float *g, const float *b)
 {
-    dim3 grid((x.T + 15) / 16, x.B);
+    dim3 grid((x.T + 3) / 4, x.B);
     if (x.C > 1024) throw ShapeError("layernorm: more than 1024 channels");
     const bool small = x.C <= 256;
     pl.ops.push_back([=](hipStream_t s) {
-        if (small) hipLaunchKernelGGL((layernorm_ct_kernel<16>), grid, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
-        else hipLaunchKernelGGL((layernorm_ct_kernel<64>), grid, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
+        if (small) hipLaunchKernelGGL((layernorm_ct_kernel<4>), grid, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
+        else hipLaunchKernelGGL((layernorm_ct_kernel<16>), grid, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
     });
 }
 
@@ -790,8 +839,23 @@ namespace rvc {
 
 static void set_device(rvc_engine *e) { HIPCHK(hipSetDevice(e->device)); }
 
+static void init_kernel_attrs()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+}
+
 static void init_constants(rvc_engine *e)
 {
+    init_kernel_attrs();
     // periodic Hann, f64 cosine cast to f32 then 0.5*(1-c) in f32 (rmvpe.rs:33-37, Q9)
     std::vector<float> win(1024), tw(1024), basis((size_t)128 * 513);
     for (int i = 0; i < 1024; i++) { float c = (float)cos(2.0 * M_PI * (double)i / 1024.0); win[i] = 0.5f * (1.0f - c); }

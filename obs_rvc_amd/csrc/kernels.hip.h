@@ -49,6 +49,7 @@ struct IgemmP {
     float *y, *part;
     const int *koff;
     const PhaseD *ph;
+    PhaseD ph0;              // copy of ph[0]: single-phase layers skip the dependent table load
     int M, N, K;             // K already padded to a multiple of 16
     int NW;                  // n -> (nh, nw) = (n / NW, n % NW)
     int x_hs, x_ws;          // input offset of position n  = nh*x_hs + nw*x_ws
@@ -61,6 +62,9 @@ struct IgemmP {
     int act; float slope; float scale; int accumulate;
     int pre_act; float pre_slope;   // fused input LeakyReLU: x -> max(x, x*pre_slope); pre_slope = 1 disables it
     int ntn, ntm;
+    // LDS-tiled stride-1 conv (conv1d_lds_kernel): tap-offset table, input channels, LDS row length, padding, input length/halo
+    const int *loff; int c_in, c_rl, c_pad, c_t, c_halo, x_cs;
+    int koff_bias;           // bytes: the koff table holds (offset - min offset) * 4, the base pointer is moved back by this
     int m_fast;              // XCD-aware tile order: >0 = ntm rounded up to 8, m fastest (workgroup b runs on XCD b%8, so all
                              // n-tiles of one weight-row block share one XCD's L2); 0 = n fastest (activation-heavy layers)
 };
@@ -83,6 +87,40 @@ __device__ __forceinline__ void epilogue_store(const IgemmP &p, const PhaseD &ph
     *yp = v;
 }
 
+// Latency-chain reduction for short kernels (B = 1): the epilogue's operands (bias, residual, previous output for
+// accumulate) depend only on the kernel arguments, so they are loaded at kernel start and consumed at the end.
+struct EpiPre { float bias, res, yold; };
+__device__ __forceinline__ bool epi_locate(const IgemmP &p, const PhaseD &ph, int m, int n, int &ch, int &oh, int &ow)
+{
+    if (m >= p.M || n >= p.N) return false;
+    int nh = 0, nw = n;
+    if (p.y_hm) { nh = n / p.NW; nw = n - nh * p.NW; }
+    ow = nw * p.y_ws + ph.y_pos; oh = nh * p.y_hm + ph.y_h0;
+    if (ow < 0 || ow >= p.OW) return false;
+    ch = m + ph.y_c0;
+    return true;
+}
+__device__ __forceinline__ EpiPre epi_prefetch(const IgemmP &p, const PhaseD &ph, int b, int m, int n)
+{
+    EpiPre e = {0.f, 0.f, 0.f};
+    int ch, oh, ow;
+    if (!epi_locate(p, ph, m, n, ch, oh, ow)) return e;
+    if (p.bias) e.bias = p.bias[ph.bias_off + m];
+    if (p.res) e.res = p.res[(long long)b * p.res_bs + (long long)ch * p.res_cs + (long long)oh * p.res_rs + ow];
+    if (p.accumulate) e.yold = p.y[(long long)b * p.y_bs + (long long)ch * p.y_cs + (long long)oh * p.y_rs + ow];
+    return e;
+}
+__device__ __forceinline__ void epi_finish(const IgemmP &p, const PhaseD &ph, int b, int m, int n, float acc, const EpiPre &e)
+{
+    int ch, oh, ow;
+    if (!epi_locate(p, ph, m, n, ch, oh, ow)) return;
+    float v = apply_act(acc + e.bias, p.act, p.slope);
+    v += e.res;
+    v *= p.scale;
+    v += e.yold;
+    p.y[(long long)b * p.y_bs + (long long)ch * p.y_cs + (long long)oh * p.y_rs + ow] = v;
+}
+
 // igemm_kernel<MF, NF, D, KS>
 //   One wave owns a (16*MF) x (16*NF) output tile of 16x16x4 fp32 MFMA fragments.
 //   KS == 1: the 4 waves of a workgroup work on 4 consecutive tiles (they share weight rows through L1).
@@ -92,11 +130,14 @@ __device__ __forceinline__ void epilogue_store(const IgemmP &p, const PhaseD &ph
 //   The workgroup's slice of the koff table is staged in LDS once; weights and gathered activations are
 //   register-prefetched D chunks (of 16 k) ahead; the koff entries of the next chunk are read from LDS
 //   one stage early so the LDS latency is off the critical path.
-template <int MF, int NF, int D, int KS>
+template <int MF, int NF, int D, int KS, bool PRE>
 __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
 {
     constexpr int WAVES = KS > 1 ? KS : 4;
     constexpr int NACC = (MF * NF == 1) ? 2 : 1;   // a lone fragment alternates two accumulators (MFMA dependency)
+    constexpr int TE = MF * NF * 256;              // elements of one tile
+    constexpr int PE = (KS > 1) ? ((TE + WAVES * 64 - 1) / (WAVES * 64)) : 1;
+    constexpr bool PF = (KS > 1) || (MF * NF <= 4);   // prefetch the epilogue operands (register budget permitting)
     extern __shared__ __attribute__((aligned(16))) int s_koff[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = KS > 1 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
@@ -104,7 +145,7 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
     const int ks = z % p.ksplit; z /= p.ksplit;
     const int phase = z % p.nphase;
     const int b = z / p.nphase;
-    const PhaseD ph = p.ph[phase];
+    const PhaseD ph = p.nphase == 1 ? p.ph0 : p.ph[phase];
     const int nchunks = p.K >> 4;
     const int g0 = ks * p.chunks_per_split;
     int g1 = g0 + p.chunks_per_split;
@@ -115,12 +156,35 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
         int4 *dst = reinterpret_cast<int4 *>(s_koff);
         for (int i = threadIdx.x; i < gn * 4; i += WAVES * 64) dst[i] = src[i];
     }
-    __syncthreads();
     int tn, tm;
     if (p.m_fast) { tm = tile % p.m_fast; tn = tile / p.m_fast; }
     else { tn = tile % p.ntn; tm = tile / p.ntn; }
-    if (tm >= p.ntm || tn >= p.ntn) return;   // padding of the XCD-aware order / grid tail (uniform per workgroup when KS > 1)
+    const bool live = tm < p.ntm && tn < p.ntn;   // padding of the XCD-aware order / grid tail (uniform per workgroup when KS > 1)
     const int li = lane & 15, kq = lane >> 4;
+
+    // epilogue operands, loaded up front
+    EpiPre pre_w[(KS > 1 || !PF) ? 1 : MF][(KS > 1 || !PF) ? 1 : NF][4];
+    EpiPre pre_r[PE];
+    if (PF && live && p.ksplit == 1) {
+        if (KS > 1) {
+#pragma unroll
+            for (int q = 0; q < PE; q++) {
+                const int e = threadIdx.x + q * WAVES * 64;
+                const int l = e & 63, r = (e >> 6) & 3, f = e >> 8, mf = f / NF, nf = f - mf * NF;
+                pre_r[q] = (e < TE) ? epi_prefetch(p, ph, b, tm * 16 * MF + mf * 16 + (l >> 4) * 4 + r, tn * 16 * NF + nf * 16 + (l & 15)) : EpiPre{0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int mf = 0; mf < ((KS > 1 || !PF) ? 1 : MF); mf++)
+#pragma unroll
+                for (int nf = 0; nf < ((KS > 1 || !PF) ? 1 : NF); nf++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        pre_w[mf][nf][r] = epi_prefetch(p, ph, b, tm * 16 * MF + mf * 16 + kq * 4 + r, tn * 16 * NF + nf * 16 + li);
+        }
+    }
+    __syncthreads();
+    if (!live) return;
     // this wave's chunk range inside the workgroup's slice
     int c0 = 0, nc = gn;
     if (KS > 1) {
@@ -131,15 +195,17 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
         nc = c1 > c0 ? c1 - c0 : 0;
     }
 
-    const float *xb = p.x + (long long)b * p.x_bs + ph.x_off;
-    int xo[NF];
+    // gathered-activation addressing: wave-uniform base (SGPR pair) + unsigned 32-bit BYTE offset per lane, so each load
+    // costs one v_add_u32 (table entries are byte offsets biased by koff_bias to be non-negative)
+    const char *xb = reinterpret_cast<const char *>(p.x + (long long)b * p.x_bs + ph.x_off) - p.koff_bias;
+    unsigned xo[NF];
 #pragma unroll
     for (int nf = 0; nf < NF; nf++) {
         int n = tn * 16 * NF + nf * 16 + li;
         n = n < p.N ? n : p.N - 1;
         int nh = 0, nw = n;
         if (p.x_hs) { nh = n / p.NW; nw = n - nh * p.NW; }
-        xo[nf] = nh * p.x_hs + nw * p.x_ws;
+        xo[nf] = (unsigned)(nh * p.x_hs + nw * p.x_ws) * 4u;
     }
     // weights are pre-packed in MFMA-fragment order [m_tile][chunk][lane][4]: one wave-wide dwordx4 load of a
     // (16 rows x 16 k) fragment is 1 KiB fully contiguous (lane l holds W[mt*16 + (l&15)][c*16 + (l>>4)*4 + 0..3])
@@ -172,16 +238,18 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
         ko_nx = kol[(cc_ + 1 < nc ? cc_ + 1 : cc_) * 4];                                               \
         _Pragma("unroll") for (int mf = 0; mf < MF; mf++) a_st[S][mf] = *reinterpret_cast<const f32x4 *>(wrow[mf] + cc_ * 256); \
         _Pragma("unroll") for (int nf = 0; nf < NF; nf++) {                                            \
-            b_st[S][nf][0] = xb[xo[nf] + ko_.x]; b_st[S][nf][1] = xb[xo[nf] + ko_.y];                  \
-            b_st[S][nf][2] = xb[xo[nf] + ko_.z]; b_st[S][nf][3] = xb[xo[nf] + ko_.w];                  \
+            b_st[S][nf][0] = *reinterpret_cast<const float *>(xb + (xo[nf] + (unsigned)ko_.x));        \
+            b_st[S][nf][1] = *reinterpret_cast<const float *>(xb + (xo[nf] + (unsigned)ko_.y));        \
+            b_st[S][nf][2] = *reinterpret_cast<const float *>(xb + (xo[nf] + (unsigned)ko_.z));        \
+            b_st[S][nf][3] = *reinterpret_cast<const float *>(xb + (xo[nf] + (unsigned)ko_.w));        \
         }                                                                                              \
     }
 #define RVC_COMPUTE_STAGE(S)                                                                          \
     {                                                                                                  \
         _Pragma("unroll") for (int j = 0; j < 4; j++)                                                  \
             _Pragma("unroll") for (int nf = 0; nf < NF; nf++) {                                        \
-                /* fused input LeakyReLU (slope 1 = identity): branch-free so the loads stay in flight */ \
-                const float bv_ = fmaxf(b_st[S][nf][j], b_st[S][nf][j] * pre_slope);                   \
+                /* fused input LeakyReLU, branch-free so the loads stay in flight (PRE layers only) */ \
+                const float bv_ = PRE ? fmaxf(b_st[S][nf][j], b_st[S][nf][j] * pre_slope) : b_st[S][nf][j]; \
                 _Pragma("unroll") for (int mf = 0; mf < MF; mf++)                                      \
                     acc[j % NACC][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[S][mf][j], bv_, acc[j % NACC][mf][nf], 0, 0, 0); \
             }                                                                                          \
@@ -218,9 +286,8 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
     }
 
     if (KS > 1) {
-        // fixed-order reduction of the KS partial tiles through LDS, then the first 256 threads run the epilogue
-        float *red = reinterpret_cast<float *>(s_koff + gn * 16);     // [KS][MF*NF*256]
-        constexpr int TE = MF * NF * 256;
+        // fixed-order reduction of the KS partial tiles through LDS, then every thread finishes its share of the tile
+        float *red = reinterpret_cast<float *>(s_koff + gn * 16);     // [KS][TE]
 #pragma unroll
         for (int mf = 0; mf < MF; mf++)
 #pragma unroll
@@ -228,13 +295,16 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
 #pragma unroll
                 for (int r = 0; r < 4; r++) red[wave * TE + ((mf * NF + nf) * 4 + r) * 64 + lane] = acc[0][mf][nf][r];
         __syncthreads();
-        for (int e = threadIdx.x; e < TE; e += WAVES * 64) {
+#pragma unroll
+        for (int q = 0; q < PE; q++) {
+            const int e = threadIdx.x + q * WAVES * 64;
+            if (e >= TE) break;
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < KS; w++) v += red[w * TE + e];
             const int l = e & 63, r = (e >> 6) & 3, f = e >> 8, mf = f / NF, nf = f - mf * NF;
             const int m = tm * 16 * MF + mf * 16 + (l >> 4) * 4 + r, n = tn * 16 * NF + nf * 16 + (l & 15);
-            if (p.ksplit == 1) epilogue_store(p, ph, b, m, n, v);
+            if (p.ksplit == 1) epi_finish(p, ph, b, m, n, v, pre_r[q]);
             else if (m < p.M && n < p.N)
                 p.part[(((long long)(b * p.nphase + phase) * p.ksplit + ks) * p.M + m) * (long long)p.N + n] = v;
         }
@@ -247,8 +317,11 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
 #pragma unroll
             for (int nf = 0; nf < NF; nf++)
 #pragma unroll
-                for (int r = 0; r < 4; r++)
-                    epilogue_store(p, ph, b, tm * 16 * MF + mf * 16 + kq * 4 + r, tn * 16 * NF + nf * 16 + li, acc[0][mf][nf][r]);
+                for (int r = 0; r < 4; r++) {
+                    const int m = tm * 16 * MF + mf * 16 + kq * 4 + r, n = tn * 16 * NF + nf * 16 + li;
+                    if (PF) epi_finish(p, ph, b, m, n, acc[0][mf][nf][r], pre_w[PF ? mf : 0][PF ? nf : 0][r]);
+                    else epilogue_store(p, ph, b, m, n, acc[0][mf][nf][r]);
+                }
     } else {
         // partial sums: part[((b*nphase + phase)*ksplit + ks)][M][N]
         float *pp = p.part + ((long long)(b * p.nphase + phase) * p.ksplit + ks) * (long long)p.M * p.N;
@@ -262,6 +335,85 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
                     if (m < p.M && n < p.N) pp[(long long)m * p.N + n] = acc[0][mf][nf][r];
                 }
     }
+}
+
+// Stride-1 (dilated) Conv1d with the input tile resident in LDS -- the HiFiGAN ResBlock shape (C = 32..128,
+// k = 3/7/11, dilation 1/3/5, long N).  One workgroup stages x[all Cin][BN + (k-1)*d] once (coalesced rows, the
+// fused input LeakyReLU applied once per element), then every tap of every channel is a shifted LDS read:
+// global/L2 traffic drops by ~k versus re-gathering per tap.  4 waves x (16*NF) columns, MF row fragments;
+// weights stream from L2 in MFMA-fragment order, double-buffered in registers.
+template <int MF, int NF>
+__global__ __launch_bounds__(256) void conv1d_lds_kernel(IgemmP p)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_x[];
+    constexpr int BN = 64 * NF;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * BN, tm = blockIdx.y, b = blockIdx.z;
+    const int RL = p.c_rl, nchunks = p.K >> 4;
+    int *lo = reinterpret_cast<int *>(s_x + p.c_in * RL);
+    for (int i = threadIdx.x; i < p.K; i += 256) lo[i] = p.loff[i];
+    {
+        const float *xb = p.x + (long long)b * p.x_bs;
+        const float ps = p.pre_slope;
+        const int lo_pos = -p.c_halo, hi_pos = p.c_t + p.c_halo - 1;
+        for (int ci = wave; ci < p.c_in; ci += 4) {
+            const float *xr = xb + (long long)ci * p.x_cs;
+            for (int r = lane; r < RL; r += 64) {
+                int pos = n0 - p.c_pad + r;
+                pos = pos < lo_pos ? lo_pos : (pos > hi_pos ? hi_pos : pos);
+                const float v = xr[pos];
+                s_x[ci * RL + r] = fmaxf(v, v * ps);
+            }
+        }
+    }
+    __syncthreads();
+    const int li = lane & 15, kq = lane >> 4;
+    const int mtiles = (p.M + 15) >> 4;
+    const float *wrow[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; mf++) {
+        int mt = tm * MF + mf;
+        mt = mt < mtiles ? mt : mtiles - 1;
+        wrow[mf] = p.w + (long long)mt * nchunks * 256 + lane * 4;
+    }
+    const float *xl = s_x + wave * 16 * NF + li;
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+        for (int nf = 0; nf < NF; nf++) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 a_cur[MF], a_nxt[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; mf++) a_cur[mf] = *reinterpret_cast<const f32x4 *>(wrow[mf]);
+    for (int c = 0; c < nchunks; c++) {
+        const int cn = c + 1 < nchunks ? c + 1 : c;
+#pragma unroll
+        for (int mf = 0; mf < MF; mf++) a_nxt[mf] = *reinterpret_cast<const f32x4 *>(wrow[mf] + cn * 256);
+        const int4 l4 = *reinterpret_cast<const int4 *>(lo + c * 16 + kq * 4);
+        float bv[NF][4];
+#pragma unroll
+        for (int nf = 0; nf < NF; nf++) {
+            bv[nf][0] = xl[l4.x + nf * 16]; bv[nf][1] = xl[l4.y + nf * 16];
+            bv[nf][2] = xl[l4.z + nf * 16]; bv[nf][3] = xl[l4.w + nf * 16];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+                for (int nf = 0; nf < NF; nf++)
+                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mf][j], bv[nf][j], acc[mf][nf], 0, 0, 0);
+#pragma unroll
+        for (int mf = 0; mf < MF; mf++) a_cur[mf] = a_nxt[mf];
+    }
+    PhaseD ph{};
+#pragma unroll
+    for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+        for (int nf = 0; nf < NF; nf++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                epilogue_store(p, ph, b, (tm * MF + mf) * 16 + kq * 4 + r, n0 + wave * 16 * NF + nf * 16 + li, acc[mf][nf][r]);
 }
 
 // second stage of a split-K launch: fixed-order (deterministic) sum of the partials + epilogue
@@ -381,51 +533,51 @@ __global__ __launch_bounds__(256) void mel_frontend_kernel(MelP p)
 // normalisation kernels
 // ------------------------------------------------------------------------------------
 // LayerNorm over channels of x[B][C][ld] for each time step (eps 1e-5), optional in-place.
-// block = 16 time steps x 16 channel lanes; each thread keeps its C/16 values in registers
-// (one global read pass, two-pass mean/variance as in the reference definition).
+// block = 4 time steps x 64 channel lanes (so T = 111 already spreads over 28 workgroups); each thread keeps
+// its C/64 values in registers: one global read pass, two-pass mean/variance as in the reference definition.
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_ct_kernel(const float *x, float *y, const float *g, const float *bta,
                                                            int C, int T, int x_cs, long long x_bs, int y_cs, long long y_bs)
 {
-    __shared__ float red[16][17];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int t = blockIdx.x * 16 + tx, b = blockIdx.y;
+    __shared__ float red[4][4];
+    const int tx = threadIdx.x & 3, ty = threadIdx.x >> 2;      // ty = 0..63
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * 4 + tx, b = blockIdx.y;
     const bool ok = t < T;
     const float *xp = x + (long long)b * x_bs + (ok ? t : 0);
     float v[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; i++) {
-        const int c = ty + i * 16;
+        const int c = ty + i * 64;
         v[i] = (ok && c < C) ? xp[(long long)c * x_cs] : 0.f;
         s += v[i];
     }
-    red[ty][tx] = s;
-    __syncthreads();
-    float mean = 0.f;
+    // reduce over the 16 lanes of this wave that share tx (lane bits 2..5), then over the 4 waves through LDS
 #pragma unroll
-    for (int i = 0; i < 16; i++) mean += red[i][tx];
-    mean /= (float)C;
+    for (int o = 4; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+    if (lane < 4) red[wave][lane] = s;
+    __syncthreads();
+    const float mean = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)C;
     __syncthreads();
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; i++) {
-        const int c = ty + i * 16;
+        const int c = ty + i * 64;
         const float d = (c < C) ? v[i] - mean : 0.f;
         q += d * d;
     }
-    red[ty][tx] = q;
-    __syncthreads();
-    float var = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; i++) var += red[i][tx];
-    var /= (float)C;
+    for (int o = 4; o < 64; o <<= 1) q += __shfl_xor(q, o, 64);
+    if (lane < 4) red[wave][lane] = q;
+    __syncthreads();
+    const float var = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)C;
     const float inv = 1.0f / sqrtf(var + 1e-5f);
     if (ok) {
         float *yp = y + (long long)b * y_bs + t;
 #pragma unroll
         for (int i = 0; i < NV; i++) {
-            const int c = ty + i * 16;
+            const int c = ty + i * 64;
             if (c < C) yp[(long long)c * y_cs] = (v[i] - mean) * inv * g[c] + bta[c];
         }
     }
