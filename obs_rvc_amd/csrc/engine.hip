@@ -116,6 +116,7 @@ struct ConvW {
     int Cin = 0, Cout = 0, KW = 1, groups = 1;
     int S = 1, ntaps = 1;      // transposed convs
     bool transposed = false;
+    std::vector<float> host_w; // row-major [Cout][K] copy kept for big 3x3 convs (plan-time tap pruning)
 };
 
 static int round16(int k) { return (k + 15) / 16 * 16; }
@@ -159,6 +160,7 @@ static ConvW prep_conv(const float *w, const float *bias, int Cout, int Cin, int
     for (int co = 0; co < Cout; co++) memcpy(&panel[(size_t)co * c.Kp], w + (size_t)co * c.K, (size_t)c.K * sizeof(float));
     c.w = upload_fragments(panel, groups, cog, c.Kp);
     if (bias) c.bias = upload_f(bias, Cout);
+    if (KW == 9 && groups == 1 && c.K >= 1024) c.host_w.assign(w, w + (size_t)Cout * c.K);
     return c;
 }
 // ConvTranspose1d: w [Cin][Cout][K], stride S -> S polyphase sub-convolutions with ntaps = ceil(K/S) taps:
@@ -234,10 +236,12 @@ struct TapRec { std::string name; int rank; T1 t1; T2 t2; };
 // concurrently with ContentVec; fork/join through events, captured as parallel branches of the hipGraph)
 struct OpList {
     std::vector<Op> v;
-    std::vector<int> sid;
+    std::vector<int> sid;    // stream of the op (0 = main, 1..3 auxiliary)
+    std::vector<int> kind;   // 0 = op, 1 = fork(sid): stream sid waits for main, 2 = join(sid): main waits for stream sid
     int cur = 0;
-    long join_at = -1;   // index of the first op that consumes both branches
-    void push_back(Op o) { v.push_back(std::move(o)); sid.push_back(cur); }
+    void push_back(Op o) { v.push_back(std::move(o)); sid.push_back(cur); kind.push_back(0); }
+    void fork(int s) { v.push_back(Op()); sid.push_back(s); kind.push_back(1); }
+    void join(int s) { v.push_back(Op()); sid.push_back(s); kind.push_back(2); }
 };
 
 struct Plan {
@@ -261,10 +265,12 @@ struct Plan {
     size_t prof_used = 0;
     double igemm_flops = 0;
     int n_igemm = 0;
+    std::vector<float *> owned_dev;   // plan-time repacked weights
     // graph
     hipGraphExec_t graph_exec = nullptr;
     ~Plan()
     {
+        for (float *p : owned_dev) (void)hipFree(p);
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         for (auto &e : prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     }
@@ -497,9 +503,25 @@ static void add_conv2d(Plan &pl, const ConvW &cw, const T2 &x, const T2 &y, Conv
     p.NW = x.W; p.x_hs = x.ld; p.x_ws = 1; p.y_hm = 1; p.y_ws = 1; p.OW = y.W;
     p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.cs; p.y_rs = y.ld;
     fill_epilogue(p, cw, o);
-    std::vector<int> koff(cw.Kp, 0);
-    if (cw.KW == 9) { for (int ci = 0; ci < cw.Cin; ci++) for (int k = 0; k < 9; k++) koff[ci * 9 + k] = ci * x.cs + (k / 3 - 1) * x.ld + (k % 3 - 1); }
-    else { for (int ci = 0; ci < cw.Cin; ci++) koff[ci] = ci * x.cs; }
+    std::vector<int> koff;
+    if (cw.KW == 9 && x.H == 1 && !cw.host_w.empty() && !getenv("RVC_NO_TAP_PRUNE")) {
+        // one-row image (RMVPE's bottleneck at Tm = 32): the kh = 0 and kh = 2 taps only ever read the zero halo rows, so two
+        // thirds of the weight stream is dead.  Repack the middle row of every 3x3 filter once per plan (K = Cin*3).
+        const int K3 = cw.Cin * 3, Kp3 = round16(K3);
+        std::vector<float> panel((size_t)cw.M * Kp3, 0.f);
+        for (int mo = 0; mo < cw.M; mo++)
+            for (int ci = 0; ci < cw.Cin; ci++)
+                for (int kw = 0; kw < 3; kw++) panel[(size_t)mo * Kp3 + ci * 3 + kw] = cw.host_w[(size_t)mo * cw.K + ci * 9 + 3 + kw];
+        float *dw = upload_fragments(panel, 1, cw.M, Kp3);
+        pl.owned_dev.push_back(dw);
+        p.w = dw; p.K = Kp3;
+        koff.assign(Kp3, 0);
+        for (int ci = 0; ci < cw.Cin; ci++) for (int kw = 0; kw < 3; kw++) koff[ci * 3 + kw] = ci * x.cs + (kw - 1);
+    } else {
+        koff.assign(cw.Kp, 0);
+        if (cw.KW == 9) { for (int ci = 0; ci < cw.Cin; ci++) for (int k = 0; k < 9; k++) koff[ci * 9 + k] = ci * x.cs + (k / 3 - 1) * x.ld + (k % 3 - 1); }
+        else { for (int ci = 0; ci < cw.Cin; ci++) koff[ci] = ci * x.cs; }
+    }
     std::vector<PhaseD> ph(1);
     ph[0] = PhaseD{};
     queue_igemm(pl, p, x.B, koff, ph);
@@ -810,8 +832,8 @@ using namespace rvc;
 struct rvc_engine {
     std::string data_path, err;
     int device = 0;
-    hipStream_t stream = nullptr, stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream = nullptr, aux[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
     std::unique_ptr<ModelCV> cv;
     std::unique_ptr<ModelRM> rm;
     std::unique_ptr<ModelSY> sy;
@@ -1170,20 +1192,36 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, float *
         int sf = 1; for (int q = i + 1; q < m.n_ups; q++) sf *= m.up_rate[q];
         { ConvOpts o; o.accumulate = true; if (i + 1 < m.n_ups) add_conv1d(pl, m.ncs[i], src, u, sf, sf / 2, 1, o); else add_conv1d(pl, m.ncs[i], src, u, 1, 0, 1, o); }
         if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "sy.up%d", i); add_tap(pl, nm, u); }
-        T1 xs = make_t1(A, B, co, Tn, DH), ra = make_t1(A, B, co, Tn, DH), rb = make_t1(A, B, co, Tn, DH), tt = make_t1(A, B, co, Tn, DH);
+        // the n_rb ResBlock chains of a stage are independent until their average: run them as parallel graph branches
+        T1 xs = make_t1(A, B, co, Tn, DH);
+        std::vector<T1> finals;
+        const bool par = m.n_rb <= 3 && getenv("RVC_PARALLEL_RESBLOCKS");   // measured slower than serial at B = 1 (each conv already fills the chip)
         for (int j = 0; j < m.n_rb; j++) {
             const int k = m.rb_k[j];
+            T1 ra = make_t1(A, B, co, Tn, DH), rb = make_t1(A, B, co, Tn, DH), tt = make_t1(A, B, co, Tn, DH), fin = make_t1(A, B, co, Tn, 0);
+            if (par && j > 0) { pl.ops.fork(j); pl.ops.cur = j; }
             T1 cur = u;
             for (int q = 0; q < m.n_rbd; q++) {
                 const int d = m.rb_d[q];
                 { ConvOpts o; o.pre_act = ACT_LRELU; o.pre_slope = 0.1f; o.act = ACT_LRELU; o.slope = 0.1f; add_conv1d(pl, m.rbs[i][j][q].first, cur, tt, 1, (k * d - d) / 2, d, o); }
                 const bool last = q == m.n_rbd - 1;
-                T1 dst = last ? xs : (cur.p == ra.p ? rb : ra);
+                T1 dst = last ? fin : (cur.p == ra.p ? rb : ra);
                 ConvOpts o; o.res = cur.p; o.res_cs = cur.ld; o.res_bs = cur.bs;
-                if (last) { o.scale = 1.0f / (float)m.n_rb; o.accumulate = j > 0; }
                 add_conv1d(pl, m.rbs[i][j][q].second, tt, dst, 1, (k - 1) / 2, 1, o);
                 cur = dst;
             }
+            pl.ops.cur = 0;
+            finals.push_back(fin);
+        }
+        if (par) for (int j = 1; j < m.n_rb; j++) pl.ops.join(j);
+        {
+            // xs = (r0 + r1 + ...) / n_rb, summed in chain order as in the reference definition
+            const int nrb = m.n_rb; const float inv = 1.0f / (float)m.n_rb;
+            const float *f0 = finals[0].p, *f1 = nrb > 1 ? finals[1].p : nullptr, *f2 = nrb > 2 ? finals[2].p : nullptr;
+            if (nrb > 3) throw ShapeError("more than 3 ResBlock kernels per stage");
+            T1 fi = finals[0];
+            dim3 grid((co * Tn + 255) / 256, B);
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(mean3_kernel, grid, dim3(256), 0, s, f0, f1, f2, fi.ld, fi.bs, xs.p, xs.ld, xs.bs, co, Tn, inv); });
         }
         if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "sy.rb%d", i); add_tap(pl, nm, xs); }
         xd = xs; c = co; Tc = Tn;
@@ -1219,6 +1257,7 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         const int Tcv = e->cv->out_frames(L);
         if (Tcv < 1) throw ShapeError("input too short for ContentVec");
         const size_t hubert_length0 = std::min(L / 160, 2 * (size_t)Tcv + 1);   // rvc.rs:153
+        pl.ops.fork(1);
         pl.ops.cur = 1;
         sal0 = build_rmvpe(e, pl, B, L, frame16k, true);
         build_pitch_post(e, pl, B, sal0, true, frame16k, hubert_length0, &d_pitchf0, &d_pitch0);
@@ -1293,7 +1332,7 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         add_tap(pl, "phone_ct", phone);
         float *d_pitchf = d_pitchf0; int *d_pitch = d_pitch0;
         (void)hubert_length;
-        pl.ops.join_at = (long)pl.ops.v.size();
+        pl.ops.join(1);
         build_synth(e, pl, B, phone, d_pitchf, d_pitch);
         StreamState *st = e->d_state;
         pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(advance_chunk_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, B); });
@@ -1305,27 +1344,19 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
 
 static void issue_ops(rvc_engine *e, Plan &pl)
 {
-    // fork the auxiliary stream off the main one, run every op on its stream, join before the first main-stream op
-    // that follows auxiliary work (the synthesizer consumes both branches)
-    bool forked = false, aux_pending = false;
+    // fork/join through events; under stream capture the auxiliary streams become parallel branches of the hipGraph
     for (size_t i = 0; i < pl.ops.v.size(); i++) {
         const int sid = pl.ops.sid[i];
-        if (sid == 1 && !forked) {
-            HIPCHK(hipEventRecord(e->ev_fork, e->stream));
-            HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
-            forked = true;
+        hipStream_t st = sid == 0 ? e->stream : e->aux[sid - 1];
+        if (pl.ops.kind[i] == 1) {
+            HIPCHK(hipEventRecord(e->ev_fork[sid - 1], e->stream));
+            HIPCHK(hipStreamWaitEvent(st, e->ev_fork[sid - 1], 0));
+        } else if (pl.ops.kind[i] == 2) {
+            HIPCHK(hipEventRecord(e->ev_join[sid - 1], st));
+            HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join[sid - 1], 0));
+        } else {
+            pl.ops.v[i](st);
         }
-        if ((long)i == pl.ops.join_at && aux_pending) {
-            HIPCHK(hipEventRecord(e->ev_join, e->stream2));
-            HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
-            aux_pending = false;
-        }
-        pl.ops.v[i](sid == 1 ? e->stream2 : e->stream);
-        if (sid == 1) aux_pending = true;
-    }
-    if (aux_pending) {
-        HIPCHK(hipEventRecord(e->ev_join, e->stream2));
-        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
     }
 }
 
@@ -1419,8 +1450,10 @@ rvc_status rvc_create(const char *data_path, int device, rvc_engine **out)
     try {
         set_device(e);
         HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+        for (int i = 0; i < 3; i++) {
+            HIPCHK(hipStreamCreateWithFlags(&e->aux[i], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&e->ev_fork[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
+        }
         HIPCHK(hipEventCreate(&e->ev0)); HIPCHK(hipEventCreate(&e->ev1));
         HIPCHK(hipMalloc(&e->d_cp, sizeof(CallParams)));
         HIPCHK(hipHostMalloc((void **)&e->h_cp, sizeof(CallParams)));
@@ -1452,9 +1485,11 @@ void rvc_destroy(rvc_engine *e)
     if (e->h_cp) (void)hipHostFree(e->h_cp);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
-    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-    if (e->stream2) (void)hipStreamDestroy(e->stream2);
+    for (int i = 0; i < 3; i++) {
+        if (e->ev_fork[i]) (void)hipEventDestroy(e->ev_fork[i]);
+        if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
+        if (e->aux[i]) (void)hipStreamDestroy(e->aux[i]);
+    }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }

@@ -938,6 +938,19 @@ __global__ void gate_kernel(const float *a, int a_cs, long long a_bs, float *y, 
     y[(long long)b * y_bs + (long long)c * y_cs + t] = tanhf(ta) * (1.0f / (1.0f + expf(-sa)));
 }
 
+// average of up to three ResBlock outputs: y = ((a + b) + c) * inv
+__global__ void mean3_kernel(const float *a, const float *b2, const float *c, int i_cs, long long i_bs, float *y, int y_cs, long long y_bs, int C, int T, float inv)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= C * T) return;
+    int ch = i / T, t = i - ch * T;
+    const long long o = (long long)b * i_bs + (long long)ch * i_cs + t;
+    float v = a[o];
+    if (b2) v += b2[o];
+    if (c) v += c[o];
+    y[(long long)b * y_bs + (long long)ch * y_cs + t] = v * inv;
+}
+
 // AvgPool2d(2,2): x [B][C][H(+2)][ld] -> y [B][C][H/2(+2)][ld2]
 __global__ void avgpool2_kernel(const float *x, int x_ld, int x_cs, long long x_bs, float *y, int y_ld, int y_cs, long long y_bs, int C, int H2, int W2)
 {
