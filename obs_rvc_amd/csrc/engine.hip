@@ -873,6 +873,7 @@ static void init_kernel_attrs()
     HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)relpos_attention_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
 
 static void init_constants(rvc_engine *e)
@@ -1098,7 +1099,27 @@ static void build_pitch_post(rvc_engine *e, Plan &pl, int B, const T1 &sal, bool
 }
 
 // ------------------------------- synthesizer ------------------------------------------
-static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, float *d_pitchf, int *d_pitch)
+// NSF harmonic source: depends only on the f0 branch, so it is queued on that branch's stream
+static T1 build_nsf_source(rvc_engine *e, Plan &pl, int B, float *d_pitchf)
+{
+    ModelSY &m = *e->sy;
+    Arena &A = pl.arena;
+    const int R = (int)pl.R;
+    const int upp = m.upp();
+    const size_t N = (size_t)R * upp;
+    if (R > 512) throw ShapeError("return_length too long for the NSF source kernel");
+    int max_sf = 1; { int sf = 1; for (int i = m.n_ups - 1; i >= 1; i--) { sf *= m.up_rate[i]; max_sf = std::max(max_sf, sf); } }
+    T1 src = make_t1(A, B, 1, (int)N, max_sf + 2);
+    {
+        SrcP sp{}; sp.pitchf = d_pitchf; sp.src = src.p; sp.src_bs = src.bs; sp.T = R; sp.upp = upp; sp.sr = (float)m.sr;
+        sp.lin_w = m.src_w; sp.lin_b = m.src_b; sp.st = e->d_state; sp.cp = e->d_cp;
+        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(nsf_source_kernel, dim3(B), dim3(1024), 0, s, sp); });
+    }
+    add_tap(pl, "sy.src", src);
+    return src;
+}
+
+static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T1 &src, float *d_pitchf, int *d_pitch)
 {
     ModelSY &m = *e->sy;
     Arena &A = pl.arena;
@@ -1121,8 +1142,14 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, float *
         add_conv1d(pl, Ly.qkv, x, qkv, 1, 0, 1);
         AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = H; ap.T = R; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;
         ap.scale = 1.0f / sqrtf((float)kc); ap.rel_k = Ly.rel_k; ap.rel_v = Ly.rel_v; ap.window = m.window;
-        dim3 ag(m.heads * ((R + 15) / 16), B);
-        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(attention_kernel, ag, dim3(256), attn_lds, s, ap); });
+        const size_t small_lds = ((size_t)3 * kc * Tp + 2 * (2 * m.window + 1) * kc + (size_t)R * Tp) * sizeof(float);
+        if (R <= 64 && small_lds <= 160 * 1024 && !getenv("RVC_NO_SMALL_ATTN")) {
+            dim3 ag(m.heads, B);
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(relpos_attention_small_kernel, ag, dim3(256), small_lds, s, ap); });
+        } else {
+            dim3 ag(m.heads * ((R + 15) / 16), B);
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(attention_kernel, ag, dim3(256), attn_lds, s, ap); });
+        }
         { ConvOpts o; o.res = x.p; o.res_cs = x.ld; o.res_bs = x.bs; add_conv1d(pl, Ly.o, att, x, 1, 0, 1, o); }
         add_layernorm(pl, x, Ly.ln1_g, Ly.ln1_b);
         { ConvOpts o; o.act = ACT_RELU; add_conv1d(pl, Ly.ff1, x, ff, 1, m.enc_k / 2, 1, o); }
@@ -1164,18 +1191,9 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, float *
         { ConvOpts o; o.scale = -1.f; o.accumulate = true; add_conv1d(pl, Fw.post, skip, z.rows(half, half), 1, 0, 1, o); }
     }
     add_tap(pl, "sy.z", z);
-    // NSF source
     const int upp = m.upp();
     const size_t N = (size_t)R * upp;
-    if (R > 512) throw ShapeError("return_length too long for the NSF source kernel");
-    int max_sf = 1; { int sf = 1; for (int i = m.n_ups - 1; i >= 1; i--) { sf *= m.up_rate[i]; max_sf = std::max(max_sf, sf); } }
-    T1 src = make_t1(A, B, 1, (int)N, max_sf + 2);
-    {
-        SrcP sp{}; sp.pitchf = d_pitchf; sp.src = src.p; sp.src_bs = src.bs; sp.T = R; sp.upp = upp; sp.sr = (float)m.sr;
-        sp.lin_w = m.src_w; sp.lin_b = m.src_b; sp.st = e->d_state; sp.cp = e->d_cp;
-        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(nsf_source_kernel, dim3(B), dim3(1024), 0, s, sp); });
-    }
-    add_tap(pl, "sy.src", src);
+    (void)N;
     // decoder
     int max_pad = 3;
     for (int j = 0; j < m.n_rb; j++) for (int q = 0; q < m.n_rbd; q++) max_pad = std::max(max_pad, (m.rb_k[j] * m.rb_d[q] - m.rb_d[q]) / 2);
@@ -1251,7 +1269,7 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
     Plan &pl = *up;
     pl.mode = mode; pl.L = L; pl.frame16k = frame16k; pl.skip_head = skip_head; pl.R = R; pl.B = B; pl.with_index = with_index; pl.with_taps = e->taps_on;
     pl.d_in = pl.arena.floats((size_t)B * L + 64);
-    T1 sal0; float *d_pitchf0 = nullptr; int *d_pitch0 = nullptr;
+    T1 sal0, src0; float *d_pitchf0 = nullptr; int *d_pitch0 = nullptr;
     if (mode == 0) {
         // f0 branch first (auxiliary stream): independent of ContentVec until the synthesizer
         const int Tcv = e->cv->out_frames(L);
@@ -1261,6 +1279,7 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         pl.ops.cur = 1;
         sal0 = build_rmvpe(e, pl, B, L, frame16k, true);
         build_pitch_post(e, pl, B, sal0, true, frame16k, hubert_length0, &d_pitchf0, &d_pitch0);
+        if (!getenv("RVC_NSF_MAIN")) src0 = build_nsf_source(e, pl, B, d_pitchf0);
         pl.ops.cur = 0;
     }
     if (mode == 0 || mode == 1) {
@@ -1333,7 +1352,8 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         float *d_pitchf = d_pitchf0; int *d_pitch = d_pitch0;
         (void)hubert_length;
         pl.ops.join(1);
-        build_synth(e, pl, B, phone, d_pitchf, d_pitch);
+        if (getenv("RVC_NSF_MAIN")) src0 = build_nsf_source(e, pl, B, d_pitchf0);
+        build_synth(e, pl, B, phone, src0, d_pitchf, d_pitch);
         StreamState *st = e->d_state;
         pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(advance_chunk_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, B); });
     }

@@ -724,6 +724,59 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnP p)
     }
 }
 
+// Small-T attention with relative-position terms (synthesizer TextEncoder: T = return_length <= 64, 2 heads x 96).
+// One workgroup per (head, stream); Q/K/V, both relative tables and the T x T score matrix live in LDS.
+__global__ __launch_bounds__(256) void relpos_attention_small_kernel(AttnP p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int hd = p.E / p.heads, T = p.T, Tp = T | 1, W = p.window, NR = 2 * W + 1;
+    const int h = blockIdx.x, b = blockIdx.y;
+    float *Qs = smem, *Ks = Qs + hd * Tp, *Vs = Ks + hd * Tp;     // [hd][Tp]
+    float *Rk = Vs + hd * Tp, *Rv = Rk + NR * hd;                  // [NR][hd]
+    float *S = Rv + NR * hd;                                       // [T][Tp]
+    const float *base = p.qkv + (long long)b * p.bs;
+    for (int i = threadIdx.x; i < hd * T; i += 256) {
+        int d = i / T, t = i - d * T;
+        Qs[d * Tp + t] = base[(long long)(h * hd + d) * p.cs + t] * p.scale;
+        Ks[d * Tp + t] = base[(long long)(p.E + h * hd + d) * p.cs + t];
+        Vs[d * Tp + t] = base[(long long)(2 * p.E + h * hd + d) * p.cs + t];
+    }
+    for (int i = threadIdx.x; i < NR * hd; i += 256) { Rk[i] = p.rel_k[i]; Rv[i] = p.rel_v[i]; }
+    __syncthreads();
+    for (int e = threadIdx.x; e < T * T; e += 256) {
+        const int i = e / T, j = e - i * T;
+        float a = 0.f;
+        for (int d = 0; d < hd; d++) a += Qs[d * Tp + i] * Ks[d * Tp + j];
+        const int r = j - i;
+        if (r >= -W && r <= W) {
+            float ra = 0.f;
+            const float *rk = Rk + (r + W) * hd;
+            for (int d = 0; d < hd; d++) ra += Qs[d * Tp + i] * rk[d];
+            a += ra;
+        }
+        S[i * Tp + j] = a;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < T; i += 4) {
+        float v = lane < T ? S[i * Tp + lane] : -INFINITY;
+        const float mx = wave_max(v);
+        const float ex = lane < T ? expf(v - mx) : 0.f;
+        const float inv = 1.0f / wave_sum(ex);
+        if (lane < T) S[i * Tp + lane] = ex * inv;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < hd * T; e += 256) {
+        const int d = e / T, i = e - d * T;
+        const float *pr = S + i * Tp;
+        float a = 0.f;
+        for (int j = 0; j < T; j++) a += pr[j] * Vs[d * Tp + j];
+        const int lo = i - W < 0 ? 0 : i - W, hi = i + W >= T ? T - 1 : i + W;
+        for (int j = lo; j <= hi; j++) a += pr[j] * Rv[(j - i + W) * hd + d];
+        p.out[(long long)b * p.o_bs + (long long)(h * hd + d) * p.o_cs + i] = a;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // RMVPE head: bidirectional GRU recurrence (input projections come from the implicit GEMM)
 // gi: [B][2*3H][ld] (forward gates rows 0..3H, backward rows 3H..6H; biases b_ih included)
