@@ -345,6 +345,41 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
             if (w >= 1024) { cfg = c; wg_ks = ks; found = true; break; }
         }
     }
+    // throughput mode (many streams): workgroup-tiled kernel with the activation tile shared through LDS
+    int lds_cfg = -1;
+    if (!getenv("RVC_NO_LDS_GEMM") && nchunks >= 2 && (size_t)nchunks * 64 + 2 * 16 * 260 * 4 <= 60 * 1024) {
+        const int bm = p.M >= 96 ? 128 : (p.M >= 48 ? 64 : (p.M > 16 ? 32 : 0));
+        const int bn = bm == 128 ? 128 : 256;
+        if (bm) {
+            const long long wgs = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * B * p.nphase;
+            if (wgs >= 384) lds_cfg = bm == 128 ? 0 : (bm == 64 ? 1 : 2);
+        }
+    }
+    if (lds_cfg >= 0) {
+        const int bm = lds_cfg == 0 ? 128 : (lds_cfg == 1 ? 64 : 32), bn = lds_cfg == 0 ? 128 : 256;
+        p.ksplit = 1; p.chunks_per_split = nchunks; p.m_fast = 0;
+        p.ntm = (p.M + bm - 1) / bm; p.ntn = (p.N + bn - 1) / bn;
+        dim3 grid(p.ntm * p.ntn, B * p.nphase);
+        const size_t lds = (size_t)nchunks * 64 + (size_t)2 * 16 * (bn + 4) * 4;
+        const double flops = 2.0 * p.M * (double)p.N * p.K * B * p.nphase;
+        pl.igemm_flops += flops; pl.n_igemm++;
+        Plan *plp = &pl;
+        const int lc = lds_cfg;
+        pl.ops.push_back([=](hipStream_t s) {
+            ProfEvent *pe = nullptr;
+            if (plp->profile) {
+                if (plp->prof_used == plp->prof.size()) { ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; plp->prof.push_back(e); }
+                pe = &plp->prof[plp->prof_used++]; pe->flops = flops;
+                HIPCHK(hipEventRecord(pe->a, s));
+            }
+#define RVC_LG(WM, WN, MF, NF) { if (pre) hipLaunchKernelGGL((igemm_lds_kernel<WM, WN, MF, NF, true>), grid, dim3(256), lds, s, p); \
+                                 else hipLaunchKernelGGL((igemm_lds_kernel<WM, WN, MF, NF, false>), grid, dim3(256), lds, s, p); }
+            if (lc == 0) RVC_LG(2, 2, 4, 4) else if (lc == 1) RVC_LG(1, 4, 4, 4) else RVC_LG(1, 4, 2, 4)
+#undef RVC_LG
+            if (pe) HIPCHK(hipEventRecord(pe->b, s));
+        });
+        return;
+    }
     if (const char *f = getenv("RVC_FORCE_CFG")) {   // tuning aid: "cfg,ks[,mfast]"
         int fc = 0, fk = 1; if (sscanf(f, "%d,%d", &fc, &fk) >= 1) { cfg = fc; wg_ks = fk; }
     }

@@ -337,6 +337,114 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
     }
 }
 
+// Throughput-mode implicit GEMM (many streams batched: N = B*T is large).  Classic CDNA anatomy: a 256-thread
+// workgroup owns a (WM*MF*16) x (WN*NF*16) tile; per K step of 16 the gathered activation tile [16][BN] is staged
+// global -> registers -> LDS (double-buffered, one barrier per step, fused input LeakyReLU applied once per element)
+// and read back as MFMA B fragments by all waves; weight fragments stream global -> registers in fragment order.
+// Each activation element is fetched once per workgroup instead of once per wave.
+template <int WM, int WN, int MF, int NF, bool PRE>
+__global__ __launch_bounds__(256) void igemm_lds_kernel(IgemmP p)
+{
+    constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
+    constexpr int RS = BN + 4;                 // LDS row stride: the 4 k-rows read by one MFMA operand fall on disjoint bank groups
+    constexpr int KR = 256 / BN > 0 ? 256 / BN : 1;   // k rows staged per pass
+    constexpr int EPT = 16 / KR;               // staged elements per thread per K step
+    static_assert(BN <= 256 && 256 % BN == 0, "BN must divide 256");
+    extern __shared__ __attribute__((aligned(16))) int s_mem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tn = blockIdx.x % p.ntn, tm = blockIdx.x / p.ntn;
+    int z = blockIdx.y;
+    const int phase = z % p.nphase;
+    const int b = z / p.nphase;
+    const PhaseD ph = p.nphase == 1 ? p.ph0 : p.ph[phase];
+    const int nchunks = p.K >> 4;
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(p.koff + ph.koff_off);
+        int4 *dst = reinterpret_cast<int4 *>(s_mem);
+        for (int i = threadIdx.x; i < nchunks * 4; i += 256) dst[i] = src[i];
+    }
+    float *bt = reinterpret_cast<float *>(s_mem + nchunks * 16);     // [2][16][RS]
+    const int li = lane & 15, kq = lane >> 4;
+    const char *xb = reinterpret_cast<const char *>(p.x + (long long)b * p.x_bs + ph.x_off) - p.koff_bias;
+    // staging role: column n_s of the tile, k rows kr0, kr0 + KR, ...
+    const int n_s = threadIdx.x % BN, kr0 = threadIdx.x / BN;
+    unsigned xo_s;
+    {
+        int n = tn * BN + n_s;
+        n = n < p.N ? n : p.N - 1;
+        int nh = 0, nw = n;
+        if (p.x_hs) { nh = n / p.NW; nw = n - nh * p.NW; }
+        xo_s = (unsigned)(nh * p.x_hs + nw * p.x_ws) * 4u;
+    }
+    const float *wrow[MF];
+    const int mtiles = (p.M + 15) >> 4;
+#pragma unroll
+    for (int mf = 0; mf < MF; mf++) {
+        int mt = (tm * WM + wm) * MF + mf;
+        mt = mt < mtiles ? mt : mtiles - 1;
+        wrow[mf] = p.w + ph.w_off + (long long)mt * nchunks * 256 + lane * 4;
+    }
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+        for (int nf = 0; nf < NF; nf++) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float pre_slope = p.pre_slope;
+    __syncthreads();
+    const int *kof = s_mem;
+    float sb[EPT];
+    f32x4 a_cur[MF], a_nxt[MF];
+#pragma unroll
+    for (int i = 0; i < EPT; i++) sb[i] = *reinterpret_cast<const float *>(xb + (xo_s + (unsigned)kof[kr0 + i * KR]));
+#pragma unroll
+    for (int mf = 0; mf < MF; mf++) a_cur[mf] = *reinterpret_cast<const f32x4 *>(wrow[mf]);
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const float v = sb[i];
+        bt[(kr0 + i * KR) * RS + n_s] = PRE ? fmaxf(v, v * pre_slope) : v;
+    }
+    __syncthreads();
+    const float *br = bt + wn * NF * 16 + li + kq * 4 * RS;
+    for (int c = 0; c < nchunks; c++) {
+        const int cn = c + 1 < nchunks ? c + 1 : c;
+        const float *bcur = br + (c & 1) * 16 * RS;
+        float *bnxt = bt + ((c + 1) & 1) * 16 * RS;
+        // prefetch the next K step (global -> registers)
+#pragma unroll
+        for (int i = 0; i < EPT; i++) sb[i] = *reinterpret_cast<const float *>(xb + (xo_s + (unsigned)kof[cn * 16 + kr0 + i * KR]));
+#pragma unroll
+        for (int mf = 0; mf < MF; mf++) a_nxt[mf] = *reinterpret_cast<const f32x4 *>(wrow[mf] + cn * 256);
+        float bv[NF][4];
+#pragma unroll
+        for (int nf = 0; nf < NF; nf++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) bv[nf][j] = bcur[j * RS + nf * 16];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+                for (int nf = 0; nf < NF; nf++)
+                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mf][j], bv[nf][j], acc[mf][nf], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            const float v = sb[i];
+            bnxt[(kr0 + i * KR) * RS + n_s] = PRE ? fmaxf(v, v * pre_slope) : v;
+        }
+#pragma unroll
+        for (int mf = 0; mf < MF; mf++) a_cur[mf] = a_nxt[mf];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+        for (int nf = 0; nf < NF; nf++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                epilogue_store(p, ph, b, ((tm * WM + wm) * MF + mf) * 16 + kq * 4 + r, tn * BN + (wn * NF + nf) * 16 + li, acc[mf][nf][r]);
+}
+
 // Stride-1 (dilated) Conv1d with the input tile resident in LDS -- the HiFiGAN ResBlock shape (C = 32..128,
 // k = 3/7/11, dilation 1/3/5, long N).  One workgroup stages x[all Cin][BN + (k-1)*d] once (coalesced rows, the
 // fused input LeakyReLU applied once per element), then every tap of every channel is a shifted LDS read:

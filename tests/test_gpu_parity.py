@@ -217,6 +217,27 @@ def test_batched_streams_match_single_stream_oracles():
         assert np.allclose(eng.pitch_cache(s), oras[s].pitch_cache(), rtol=1e-5, atol=1e-3)
 
 
+def test_batched_streams_full_size_throughput_kernels():
+    # full-size models, several streams: exercises the workgroup-tiled (LDS) implicit-GEMM path used in throughput mode
+    from oracle import oracle as O
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("full")
+    S = 6
+    eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"])
+    eng.set_streams(S); eng.set_noise_seed(5, 100)
+    xin = np.stack([voice_signal(g.input_buffer_16k_size, seed=50 + s) for s in range(S)])
+    for c in range(2):
+        ye = eng.infer_batch(xin, g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+        if c == 0:
+            oras = []
+            for s in range(S):
+                o = O.OracleRvcInfer(z["data"]); o.load_contentvec(2); o.load_f0(1); o.load_model(z["model"]); o.set_noise_seed(5, 100 + s)
+                oras.append(o)
+        for s in (0, 3, 5):
+            yo = oras[s].infer(xin[s], g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+            assert rms(ye[s] - yo) < PCM_TOL, (c, s, rms(ye[s] - yo))
+
+
 def test_graph_replay_equals_eager_and_device_api():
     import torch
     z, ora, eng = _pair("tiny")
