@@ -92,6 +92,14 @@ rvc_status rvc_infer_device(rvc_engine *e, const void *d_input, size_t n, size_t
 rvc_status rvc_synchronize(rvc_engine *e);
 void rvc_set_use_graph(rvc_engine *e, int on);    /* replay the per-chunk launch sequence from a hipGraph */
 
+/* ---- caller-side post-processing of the plugin, same host-buffer convention ---- */
+/* envelop_mixing (obs-rvc/src/rt_utils.rs:119-132): output[i] *= (rms(input)/max(rms(output),1e-3))^(1-mix_rate) */
+rvc_status rvc_envelop_mixing(rvc_engine *e, const float *input, float *output, size_t output_len, size_t sample_rate, double mix_rate);
+/* get_sola_offset (rt_utils.rs:60-90) + crossfade / tail save / frame extraction (obs-rvc/src/lib.rs:768-794).
+ * output needs sola_len + search + frame valid samples; sola_buffer (sola_len) is updated in place. */
+rvc_status rvc_sola_step(rvc_engine *e, float *output, size_t output_len, float *sola_buffer, size_t sola_len, size_t search,
+                         size_t frame, float *frame_out, size_t *sola_offset);
+
 /* ---- measurement / debugging ---- */
 /* total milliseconds of the last infer measured with HIP events on the engine's stream */
 float rvc_last_gpu_ms(rvc_engine *e);

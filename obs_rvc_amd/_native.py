@@ -19,7 +19,7 @@ SYMBOLS = [
     "rvc_load_index", "rvc_load_index_device", "rvc_set_index_rate", "rvc_get_knn", "rvc_set_noise_seed", "rvc_reset_state",
     "rvc_set_streams", "rvc_infer_batch", "rvc_infer_device", "rvc_synchronize", "rvc_set_use_graph",
     "rvc_last_gpu_ms", "rvc_profile_last", "rvc_set_profile", "rvc_enable_taps", "rvc_get_tap", "rvc_get_pitch_cache",
-    "rvc_index_device_ptr", "rvc_device", "rvc_version",
+    "rvc_index_device_ptr", "rvc_device", "rvc_version", "rvc_envelop_mixing", "rvc_sola_step",
 ]
 
 
@@ -94,5 +94,7 @@ def lib():
     L.rvc_index_device_ptr.restype = vp
     L.rvc_device.argtypes = [vp]
     L.rvc_version.restype = C.c_char_p
+    L.rvc_envelop_mixing.argtypes = [vp, fp, fp, sz, sz, C.c_double]
+    L.rvc_sola_step.argtypes = [vp, fp, sz, fp, sz, sz, sz, fp, C.POINTER(sz)]
     _LIB = L
     return L

@@ -1831,6 +1831,50 @@ rvc_status rvc_profile_last(rvc_engine *e, int *launches, double *kernel_ms, dou
     });
 }
 
+rvc_status rvc_envelop_mixing(rvc_engine *e, const float *input, float *output, size_t output_len, size_t sample_rate, double mix_rate)
+{
+    return guarded(e, [&]() {
+        const size_t zc = sample_rate / 100;
+        if (zc == 0 || output_len < zc) throw ShapeError("envelop_mixing: output shorter than one 10 ms hop");
+        const int n = (int)output_len, frame = (int)(4 * zc), hop = (int)zc;
+        const int nf = (n + 2 * (frame / 2) - frame) / hop + 1;
+        float *d_in, *d_out, *d_r;
+        HIPCHK(hipMalloc(&d_in, output_len * 4)); HIPCHK(hipMalloc(&d_out, output_len * 4)); HIPCHK(hipMalloc(&d_r, (size_t)2 * nf * 4));
+        HIPCHK(hipMemcpyAsync(d_in, input, output_len * 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(d_out, output, output_len * 4, hipMemcpyHostToDevice, e->stream));
+        hipLaunchKernelGGL(post_rms_kernel, dim3(nf), dim3(256), 0, e->stream, d_in, n, frame, hop, d_r);
+        hipLaunchKernelGGL(post_rms_kernel, dim3(nf), dim3(256), 0, e->stream, d_out, n, frame, hop, d_r + nf);
+        hipLaunchKernelGGL(post_mix_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, d_out, n, d_r, nf, d_r + nf, nf, (float)(1.0 - mix_rate));
+        HIPCHK(hipMemcpyAsync(output, d_out, output_len * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_r);
+        return RVC_OK;
+    });
+}
+
+rvc_status rvc_sola_step(rvc_engine *e, float *output, size_t output_len, float *sola_buffer, size_t sola_len, size_t search,
+                         size_t frame, float *frame_out, size_t *sola_offset)
+{
+    return guarded(e, [&]() {
+        if (search + 1 > 1024) throw ShapeError("sola search range too long");
+        if (output_len < sola_len + search || output_len < search + frame + sola_len) throw PanicError("sola: output shorter than offset + frame + tail (the reference slices out of range)");
+        float *d_out, *d_sola, *d_frame; int *d_off;
+        HIPCHK(hipMalloc(&d_out, output_len * 4)); HIPCHK(hipMalloc(&d_sola, sola_len * 4)); HIPCHK(hipMalloc(&d_frame, frame * 4)); HIPCHK(hipMalloc(&d_off, 4));
+        HIPCHK(hipMemcpyAsync(d_out, output, output_len * 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(d_sola, sola_buffer, sola_len * 4, hipMemcpyHostToDevice, e->stream));
+        hipLaunchKernelGGL(post_sola_kernel, dim3(1), dim3(1024), 0, e->stream, d_out, d_sola, (int)sola_len, (int)search, (int)frame, d_frame, d_off);
+        int off = 0;
+        HIPCHK(hipMemcpyAsync(output, d_out, output_len * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(sola_buffer, d_sola, sola_len * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(frame_out, d_frame, frame * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(&off, d_off, 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (sola_offset) *sola_offset = (size_t)off;
+        (void)hipFree(d_out); (void)hipFree(d_sola); (void)hipFree(d_frame); (void)hipFree(d_off);
+        return RVC_OK;
+    });
+}
+
 // tuning aid (not part of the reference surface): time one Conv1d(Cin -> M, KW taps, stride 1, "same" padding) over N positions
 double rvc_debug_conv_bench(rvc_engine *e, int M, int Cin, int KW, int dil, int N, int iters, int pre_act)
 {

@@ -1371,4 +1371,72 @@ __global__ void knn_queries_kernel(const float *cv, int cv_cs, long long cv_bs, 
     q[(long long)b * nq * C + i] = cv[(long long)b * cv_bs + (long long)c * cv_cs + first_raw + j];
 }
 
+// ------------------------------------------------------------------------------------
+// caller-side post-processing (reference: obs-rvc/src/rt_utils.rs:60-132, lib.rs:758-794)
+// ------------------------------------------------------------------------------------
+// rt_utils.rs:94-103: zero-pad frame/2, square, windowed mean (window frame, step hop), sqrt.  One workgroup per frame.
+__global__ __launch_bounds__(256) void post_rms_kernel(const float *y, int n, int frame, int hop, float *out)
+{
+    __shared__ float red[16];
+    const int f = blockIdx.x, pad = frame / 2;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < frame; j += 256) {
+        int q = f * hop + j - pad;
+        float v = (q >= 0 && q < n) ? y[q] : 0.f;
+        s += v * v;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[f] = sqrtf(s / (float)frame);
+}
+// rt_utils.rs:105-117 evaluated at one index of the (size)-point output
+__device__ __forceinline__ float lerp_align_corners_at(const float *in, int n_in, int size, int i)
+{
+    const float step = (float)(n_in - 1) / (float)(size - 1);
+    const float idx = (float)i * step;
+    int fl = (int)floorf(idx), ce = (int)ceilf(idx);
+    fl = fl < 0 ? 0 : (fl > n_in - 1 ? n_in - 1 : fl);
+    ce = ce < 0 ? 0 : (ce > n_in - 1 ? n_in - 1 : ce);
+    const float fr = idx - (float)fl;
+    return in[fl] * (1.0f - fr) + in[ce] * fr;
+}
+// rt_utils.rs:119-132
+__global__ void post_mix_kernel(float *out, int n, const float *r1, int n1, const float *r2, int n2, float mix_power)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a = lerp_align_corners_at(r1, n1, n + 1, i);
+    const float b = fmaxf(lerp_align_corners_at(r2, n2, n + 1, i), 1e-3f);
+    out[i] = out[i] * powf(a / b, mix_power);
+}
+// rt_utils.rs:60-90 + lib.rs:768-794 in one workgroup: normalised cross-correlation over search+1 lags (last maximum wins),
+// sin^2 crossfade with the previous tail, new tail saved, first `frame` samples returned.
+__global__ __launch_bounds__(1024) void post_sola_kernel(float *output, float *sola, int sola_len, int search, int frame, float *frame_out, int *offset_out)
+{
+    __shared__ float cor[1024];
+    __shared__ int s_off;
+    const int t = threadIdx.x;
+    for (int l = t; l <= search; l += 1024) {
+        double nom = 0.0, den = 0.0;
+        for (int j = 0; j < sola_len; j++) { const double v = (double)output[l + j]; nom += v * (double)sola[j]; den += v * v; }
+        cor[l] = (float)nom / sqrtf((float)den + 1e-8f);
+    }
+    __syncthreads();
+    if (t == 0) {
+        int best = 0; float bv = cor[0];
+        for (int l = 1; l <= search; l++) if (!(bv > cor[l])) { best = l; bv = cor[l]; }
+        s_off = best; *offset_out = best;
+    }
+    __syncthreads();
+    float *o = output + s_off;
+    for (int i = t; i < sola_len; i += 1024) {
+        const float x = sola_len > 1 ? (float)i / (float)(sola_len - 1) : 0.f;
+        const float sn = sinf(x * 0.5f * 3.14159265358979323846f);
+        const float fi = sn * sn, fo = 1.0f - fi;
+        o[i] = o[i] * fi + sola[i] * fo;
+    }
+    __syncthreads();
+    for (int i = t; i < sola_len; i += 1024) sola[i] = o[frame + i];
+    for (int i = t; i < frame; i += 1024) frame_out[i] = o[i];
+}
+
 }  // namespace rvc

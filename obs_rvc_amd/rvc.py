@@ -171,6 +171,24 @@ class RvcInfer:
         self._L.rvc_get_pitch_cache(self._h, int(stream), out.ctypes.data_as(_FP))
         return out
 
+    # -- caller-side post-processing (obs-rvc/src/rt_utils.rs) ---------------------------------
+    def envelop_mixing(self, input, output, sample_rate: int, mix_rate: float):
+        """rt_utils.rs:119-132; returns the mixed copy of `output`."""
+        x, xp = _f32(input)
+        o = np.array(output, dtype=np.float32, copy=True)
+        self._chk(self._L.rvc_envelop_mixing(self._h, xp, o.ctypes.data_as(_FP), len(o), int(sample_rate), float(mix_rate)))
+        return o
+
+    def sola_step(self, output, sola_buffer, search: int, frame: int):
+        """rt_utils.rs:60-90 + lib.rs:768-794; returns (offset, frame samples, new sola buffer)."""
+        o = np.array(output, dtype=np.float32, copy=True)
+        sb = np.array(sola_buffer, dtype=np.float32, copy=True)
+        fr = np.empty(frame, np.float32)
+        off = C.c_size_t()
+        self._chk(self._L.rvc_sola_step(self._h, o.ctypes.data_as(_FP), len(o), sb.ctypes.data_as(_FP), len(sb), int(search), int(frame),
+                                        fr.ctypes.data_as(_FP), C.byref(off)))
+        return off.value, fr, sb
+
     def index_device_ptr(self):
         b = C.c_size_t()
         p = self._L.rvc_index_device_ptr(self._h, C.byref(b))

@@ -75,6 +75,14 @@ def lib():
         L.ora_f0_extractor_frame.argtypes = [sz]
         L.ora_knn_search.argtypes = [fp, sz, sz, fp, sz, C.c_int, i32p, fp]
         L.ora_philox_normal.argtypes = [u32, u32, u32, u32, sz, fp]
+        L.ora_rms.restype = sz
+        L.ora_rms.argtypes = [fp, sz, sz, sz, fp]
+        L.ora_lerp_align_corners.argtypes = [fp, sz, sz, fp]
+        L.ora_envelop_mixing.argtypes = [fp, fp, sz, sz, C.c_double]
+        L.ora_sola_offset.restype = sz
+        L.ora_sola_offset.argtypes = [fp, fp, sz, sz]
+        L.ora_sola_step.restype = sz
+        L.ora_sola_step.argtypes = [fp, sz, fp, sz, sz, sz, fp]
         L.ora_set_threads(max(1, min(int(os.environ.get('RVC_ORACLE_THREADS', '16')), os.cpu_count() or 1)))
         _LIB = L
     return _LIB
@@ -162,6 +170,42 @@ def philox_normal(seed, stream, chunk, purpose, n):
     return out
 
 
+def rms(y, frame_length, hop_length):
+    y, yp = _f(y)
+    out = np.empty(len(y) // hop_length + 8, np.float32)
+    n = lib().ora_rms(yp, len(y), frame_length, hop_length, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out[:n].copy()
+
+
+def lerp_align_corners(x, size):
+    x, xp = _f(x)
+    out = np.empty(size, np.float32)
+    lib().ora_lerp_align_corners(xp, len(x), size, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def envelop_mixing(inp, out, sample_rate, mix_rate):
+    inp, ip = _f(inp)
+    o = np.array(out, dtype=np.float32, copy=True)
+    lib().ora_envelop_mixing(ip, o.ctypes.data_as(C.POINTER(C.c_float)), len(o), sample_rate, float(mix_rate))
+    return o
+
+
+def sola_offset(input_buffer, sola_buffer, buffer_frame_size, search_frame_size):
+    a, ap = _f(input_buffer)
+    b, bp = _f(sola_buffer)
+    return int(lib().ora_sola_offset(ap, bp, buffer_frame_size, search_frame_size))
+
+
+def sola_step(output, sola_buffer, search, frame):
+    o = np.array(output, dtype=np.float32, copy=True)
+    sb = np.array(sola_buffer, dtype=np.float32, copy=True)
+    fr = np.empty(frame, np.float32)
+    fp_ = C.POINTER(C.c_float)
+    off = lib().ora_sola_step(o.ctypes.data_as(fp_), len(o), sb.ctypes.data_as(fp_), len(sb), search, frame, fr.ctypes.data_as(fp_))
+    return int(off), fr, sb
+
+
 def set_threads(n):
     lib().ora_set_threads(int(n))
 
@@ -236,6 +280,13 @@ class OracleRvcInfer:
         self._chk(lib().ora_get_knn(self._h, idx.ctypes.data_as(C.POINTER(C.c_int32)), dist.ctypes.data_as(C.POINTER(C.c_float)),
                                     rows_cap, C.byref(rows)))
         return idx[:rows.value].copy(), dist[:rows.value].copy()
+
+    # caller-side post-processing with the engine's method names (lets tests drive obs_rvc_amd.streaming with the oracle)
+    def envelop_mixing(self, inp, out, sample_rate, mix_rate):
+        return envelop_mixing(np.asarray(inp)[:len(out)], out, sample_rate, mix_rate)
+
+    def sola_step(self, output, sola_buffer, search, frame):
+        return sola_step(output, sola_buffer, search, frame)
 
     def hubert(self, x):
         x, xp = _f(x)

@@ -1012,3 +1012,76 @@ int ora_infer(ora_engine *e, const float *in, size_t n, size_t sample_frame_16k,
     free(au);
     return ORA_OK;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* caller-side post-processing                               */
+/* ------------------------------------------------------------------------------------ */
+/* obs-rvc/src/rt_utils.rs:94-103: zero-pad frame/2 both sides, square, sliding mean (window frame, step hop), sqrt */
+size_t ora_rms(const float *y, size_t n, size_t frame_length, size_t hop_length, float *out)
+{
+    size_t pad = frame_length / 2, plen = n + 2 * pad;
+    float *sq = falloc(plen);
+    for (size_t i = 0; i < n; i++) sq[pad + i] = y[i] * y[i];
+    size_t nwin = plen >= frame_length ? plen - frame_length + 1 : 0, nf = 0;
+    for (size_t w = 0; w < nwin; w += hop_length) {
+        float s = 0.f; for (size_t j = 0; j < frame_length; j++) s += sq[w + j];
+        out[nf++] = sqrtf(s / (float)frame_length);
+    }
+    free(sq);
+    return nf;
+}
+/* rt_utils.rs:105-117 */
+void ora_lerp_align_corners(const float *in, size_t n_in, size_t size, float *out)
+{
+    float step = (float)(n_in - 1) / (float)(size - 1);
+    for (size_t i = 0; i < size; i++) {
+        float idx = (float)i * step;
+        long fl = (long)floorf(idx), ce = (long)ceilf(idx);
+        if (fl < 0) fl = 0; if (fl > (long)n_in - 1) fl = (long)n_in - 1;
+        if (ce < 0) ce = 0; if (ce > (long)n_in - 1) ce = (long)n_in - 1;
+        float fr = idx - (float)fl;
+        out[i] = in[fl] * (1.0f - fr) + in[ce] * fr;
+    }
+}
+/* rt_utils.rs:119-132 */
+void ora_envelop_mixing(const float *input, float *output, size_t output_len, size_t sample_rate, double mix_rate)
+{
+    size_t zc = sample_rate / 100;
+    float *r1 = falloc(output_len / zc + 8), *r2 = falloc(output_len / zc + 8);
+    size_t n1 = ora_rms(input, output_len, 4 * zc, zc, r1), n2 = ora_rms(output, output_len, 4 * zc, zc, r2);
+    float *i1 = falloc(output_len + 1), *i2 = falloc(output_len + 1);
+    ora_lerp_align_corners(r1, n1, output_len + 1, i1);
+    ora_lerp_align_corners(r2, n2, output_len + 1, i2);
+    float mix_power = (float)(1.0 - mix_rate);
+    for (size_t i = 0; i < output_len; i++) { float b = i2[i] > 1e-3f ? i2[i] : 1e-3f; output[i] = output[i] * powf(i1[i] / b, mix_power); }
+    free(r1); free(r2); free(i1); free(i2);
+}
+/* rt_utils.rs:60-90.  ndarray-conv 0.3.3 `conv_fft(.., Valid, Zeros)` is cross-correlation here (the reference's own golden
+ * vector, obs-rvc/src/tests/sola.rs:15 == 321, is reproduced with correlation; true convolution gives 118).  Ties: the fold
+ * keeps the LAST maximum (`if val_max > val keep else replace`). */
+size_t ora_sola_offset(const float *in, const float *sola, size_t bfs, size_t sfs)
+{
+    size_t nlag = sfs + 1, best = 0; float bestv = 0.f;
+    for (size_t l = 0; l < nlag; l++) {
+        double nom = 0.0, den = 0.0;
+        for (size_t j = 0; j < bfs; j++) { nom += (double)in[l + j] * (double)sola[j]; den += (double)in[l + j] * (double)in[l + j]; }
+        float cor = (float)nom / sqrtf((float)den + 1e-8f);
+        if (l == 0 || !(bestv > cor)) { best = l; bestv = cor; }
+    }
+    return best;
+}
+/* obs-rvc/src/lib.rs:768-794 with fade windows of lib.rs:231-233 */
+size_t ora_sola_step(float *output, size_t output_len, float *sola_buffer, size_t sola_len, size_t search, size_t frame, float *frame_out)
+{
+    (void)output_len;
+    size_t off = ora_sola_offset(output, sola_buffer, sola_len, search);
+    float *o = output + off;
+    for (size_t i = 0; i < sola_len; i++) {
+        float x = sola_len > 1 ? (float)i / (float)(sola_len - 1) : 0.f;
+        float s = sinf(x * 0.5f * 3.14159265358979323846f); float fi = s * s, fo = 1.0f - fi;
+        o[i] = o[i] * fi + sola_buffer[i] * fo;
+    }
+    memcpy(sola_buffer, o + frame, sola_len * sizeof(float));
+    memcpy(frame_out, o, frame * sizeof(float));
+    return off;
+}

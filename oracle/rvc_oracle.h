@@ -73,6 +73,14 @@ void ora_knn_search(const float *index, size_t n, size_t dim, const float *q, si
 /* Philox4x32-10 + Box-Muller normal stream shared with the GPU path */
 void ora_philox_normal(uint32_t seed, uint32_t stream, uint32_t chunk, uint32_t purpose, size_t n, float *out);
 
+/* --- caller-side post-processing (obs-rvc/src/rt_utils.rs, obs-rvc/src/lib.rs:758-794) --- */
+size_t ora_rms(const float *y, size_t n, size_t frame_length, size_t hop_length, float *out);         /* rt_utils.rs:94-103; returns #frames */
+void ora_lerp_align_corners(const float *in, size_t n_in, size_t size, float *out);                    /* rt_utils.rs:105-117 */
+void ora_envelop_mixing(const float *input, float *output, size_t output_len, size_t sample_rate, double mix_rate);  /* rt_utils.rs:119-132 */
+size_t ora_sola_offset(const float *input_buffer, const float *sola_buffer, size_t buffer_frame_size, size_t search_frame_size); /* rt_utils.rs:60-90 */
+/* lib.rs:768-794: offset search, sin^2 crossfade with the previous tail, save the new tail, return the frame */
+size_t ora_sola_step(float *output, size_t output_len, float *sola_buffer, size_t sola_len, size_t search, size_t frame, float *frame_out);
+
 #ifdef __cplusplus
 }
 #endif

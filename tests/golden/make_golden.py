@@ -1,6 +1,7 @@
 """Regenerates tests/golden/*.  Run in the build container (needs /root/reference):
     python tests/golden/make_golden.py
 * ref_*.npy        -- data files held by the reference's own tests (rvc/src/tests/*.npy), copied verbatim
+* ref_post_*.npy   -- data files of the reference's post-processing tests (obs-rvc/src/tests/*.npy), copied verbatim
 * ref_stft_kat.npy -- the 9x4 torch.stft table quoted in rvc/src/f0/rmvpe.rs:278-288
 * tiny_chain.npz   -- oracle outputs (C restatement, tiny synthetic zoo) for a 4-chunk stream; the GPU tests
                       compare the HIP path against these committed vectors as well as against the live oracle
@@ -19,6 +20,9 @@ REF = "/root/reference"
 
 for name in ("input_wav.npy", "input_wav2.npy", "feats.npy"):
     shutil.copyfile(os.path.join(REF, "rvc/src/tests", name), os.path.join(HERE, "ref_" + name))
+
+for name in ("infer_wav", "sola_buffer", "envelop_input_wav", "envelop_infer_wav", "envelop_rms1", "envelop_rms2", "envelop_infer_wav2"):
+    shutil.copyfile(os.path.join(REF, "obs-rvc/src/tests", name + ".npy"), os.path.join(HERE, "ref_post_" + name + ".npy"))
 
 np.save(os.path.join(HERE, "ref_stft_kat.npy"), np.array([
     [3.7801e-02, 2.5651e+00, 5.1303e+00, 7.6954e+00], [5.7373e-03, 1.2829e+00, 2.5653e+00, 3.8478e+00],
