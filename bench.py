@@ -138,7 +138,7 @@ def main():
                 "avg_launch_us": round(tot_ms * 1e3 / max(n_l, 1), 3), "flops_per_step": tot_fl / reps}
 
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:
         # CPU baseline: the C oracle (a port of the reference's path; the reference itself -- Rust + ONNX Runtime -- cannot
         # run here) on this node's host cores, bounded sample of the same workload
         from oracle import oracle as O
