@@ -137,6 +137,17 @@ def main():
                 "kernel": "rvc::igemm_kernel<MF,NF> (all instantiations)", "launches_per_step": n_l // reps,
                 "avg_launch_us": round(tot_ms * 1e3 / max(n_l, 1), 3), "flops_per_step": tot_fl / reps}
 
+    # the reference's boundary hands over host buffers: the same chunk through the host-pointer C ABI (H2D 143 KB + D2H 40 KB
+    # + sync inside the call); reported separately, never as `value`
+    host_ms = None
+    if rank == 0 and S == 1:
+        ts = []
+        for i in range(30):
+            h0 = time.perf_counter()
+            eng.infer(rings[i % n_rings, 0], chunk, 12, g.skip_head, g.model_return_length)
+            ts.append(time.perf_counter() - h0)
+        host_ms = round(float(np.median(ts[5:])) * 1e3, 4)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         # CPU baseline: the C oracle (a port of the reference's path; the reference itself -- Rust + ONNX Runtime -- cannot
@@ -170,7 +181,7 @@ def main():
                        "streams_per_gpu": S, "chunk_ms": 160, "input_samples_16k": L, "output_samples": N, "hip_graph": not args.no_graph},
             "latency_ms": {"p50": round(float(np.percentile(lat, 50)) * 1e3, 4), "p99": round(float(np.percentile(lat, 99)) * 1e3, 4),
                            "max": round(float(lat.max()) * 1e3, 4)},
-            "rtf": round(float(np.percentile(lat, 99)) / 0.160, 5),
+            "rtf": round(float(np.percentile(lat, 99)) / 0.160, 5), "host_buffer_api_ms_per_chunk": host_ms,
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

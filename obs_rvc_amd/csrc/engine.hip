@@ -1393,6 +1393,8 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(advance_chunk_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, B); });
     }
     HIPCHK(hipDeviceSynchronize());
+    // bounded plan cache (each geometry owns its activation arena and graph): evict the oldest
+    while (e->plans.size() >= 6) { if (e->last_plan == e->plans.front().get()) e->last_plan = nullptr; e->plans.erase(e->plans.begin()); }
     e->plans.push_back(std::move(up));
     return e->plans.back().get();
 }

@@ -123,7 +123,15 @@ def test_error_behaviour_matches_reference():
     assert e.value.kind == "Panic"
     with pytest.raises(RvcInferError):                               # ragged / too-short input
         eng.infer(x[:300], 2560, 12, 0, 1)
+    with pytest.raises(RvcInferError):                               # empty input
+        eng.infer(x[:0], 2560, 12, 0, 1)
+    with pytest.raises(RvcInferError):
+        eng.hubert(x[:5])
+    with pytest.raises(RvcInferError):                               # shorter than f0_extractor_frame: the reference's slice panics
+        eng.pitch(x[:3000], 0, 2560)
     assert eng.infer(x, 2560, 12, 200, 21).shape == (1008,)          # the engine survives errors
+    for n_geo in range(8):                                            # plan cache is bounded: many geometries in a row
+        assert eng.infer(x, 2560, 12, 200 - n_geo, 21).shape == (1008,)
 
 
 def test_other_geometries():

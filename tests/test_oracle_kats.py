@@ -198,6 +198,10 @@ def test_error_paths():
     assert e.value.code == 3
     ora.load_contentvec(2); ora.load_f0(1)
     assert ora.infer(x, 2560, None, 200, 21).shape == (1008,)
+    with pytest.raises(O.OracleError):            # empty / too-short inputs
+        ora.infer(x[:0], 2560, 12, 0, 1)
+    with pytest.raises(O.OracleError):
+        ora.pitch(x[:3000], 0, 2560)
     ora.unload_model()
     with pytest.raises(O.OracleError):
         ora.infer(x, 2560, 12, 200, 21)
