@@ -19,7 +19,7 @@ SYMBOLS = [
     "rvc_load_index", "rvc_load_index_device", "rvc_set_index_rate", "rvc_get_knn", "rvc_set_noise_seed", "rvc_reset_state",
     "rvc_set_streams", "rvc_infer_batch", "rvc_infer_device", "rvc_synchronize", "rvc_set_use_graph",
     "rvc_last_gpu_ms", "rvc_profile_last", "rvc_set_profile", "rvc_enable_taps", "rvc_get_tap", "rvc_get_pitch_cache",
-    "rvc_index_device_ptr", "rvc_device", "rvc_version", "rvc_envelop_mixing", "rvc_sola_step",
+    "rvc_index_device_ptr", "rvc_device", "rvc_version", "rvc_envelop_mixing", "rvc_sola_step", "rvc_profile_last_knn",
 ]
 
 
@@ -83,6 +83,7 @@ def lib():
     L.rvc_last_gpu_ms.argtypes = [vp]
     L.rvc_last_gpu_ms.restype = C.c_float
     L.rvc_profile_last.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.rvc_profile_last_knn.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.rvc_set_profile.argtypes = [vp, C.c_int]
     L.rvc_set_profile.restype = None
     L.rvc_enable_taps.argtypes = [vp, C.c_int]

@@ -225,7 +225,7 @@ struct ConvOpts {
     bool no_bias = false;
 };
 
-struct ProfEvent { hipEvent_t a, b; double flops; };
+struct ProfEvent { hipEvent_t a, b; double flops; double bytes; };   // bytes > 0: HBM-bound retrieval scan (flops = 0)
 
 struct Plan;
 typedef std::function<void(hipStream_t)> Op;
@@ -368,8 +368,8 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
         pl.ops.push_back([=](hipStream_t s) {
             ProfEvent *pe = nullptr;
             if (plp->profile) {
-                if (plp->prof_used == plp->prof.size()) { ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; plp->prof.push_back(e); }
-                pe = &plp->prof[plp->prof_used++]; pe->flops = flops;
+                if (plp->prof_used == plp->prof.size()) { ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; e.bytes = 0; plp->prof.push_back(e); }
+                pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0;
                 HIPCHK(hipEventRecord(pe->a, s));
             }
 #define RVC_LG(WM, WN, MF, NF) { if (pre) hipLaunchKernelGGL((igemm_lds_kernel<WM, WN, MF, NF, true>), grid, dim3(256), lds, s, p); \
@@ -410,10 +410,10 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
         ProfEvent *pe = nullptr;
         if (plp->profile) {
             if (plp->prof_used == plp->prof.size()) {
-                ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; plp->prof.push_back(e);
+                ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; e.bytes = 0; plp->prof.push_back(e);
             }
             pe = &plp->prof[plp->prof_used++];
-            pe->flops = flops;
+            pe->flops = flops; pe->bytes = 0;
             HIPCHK(hipEventRecord(pe->a, s));
         }
         launch_igemm(cfg, wg_ks, pre, p, grid, s);
@@ -472,8 +472,8 @@ static void add_conv1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int 
             pl.ops.push_back([=](hipStream_t s) {
                 ProfEvent *pe = nullptr;
                 if (plp->profile) {
-                    if (plp->prof_used == plp->prof.size()) { ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; plp->prof.push_back(e); }
-                    pe = &plp->prof[plp->prof_used++]; pe->flops = flops;
+                    if (plp->prof_used == plp->prof.size()) { ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; e.bytes = 0; plp->prof.push_back(e); }
+                    pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0;
                     HIPCHK(hipEventRecord(pe->a, s));
                 }
 #define RVC_LC(MF, NF) hipLaunchKernelGGL((conv1d_lds_kernel<MF, NF>), grid, dim3(256), lds, s, p)
@@ -875,7 +875,7 @@ struct rvc_engine {
     // constants for the mel front end
     float *d_window = nullptr, *d_twiddle = nullptr, *d_basis = nullptr;
     // retrieval index
-    float *d_index = nullptr, *d_indexT = nullptr; size_t index_n = 0, index_dim = 0; bool index_owned = true;
+    float *d_index = nullptr, *d_indexT = nullptr, *d_indexF = nullptr, *d_ynorm = nullptr; size_t index_n = 0, index_dim = 0; bool index_owned = true;
     float index_rate = 0.f;
     // streams
     int n_streams = 1;
@@ -908,6 +908,8 @@ static void init_kernel_attrs()
     HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)knn_select_blend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));   // + ~5 KB static
+    HIPCHK(hipFuncSetAttribute((const void *)knn_dot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)relpos_attention_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
 
@@ -1364,22 +1366,58 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
                 dim3 grid((nq * C + 255) / 256, B);
                 pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(knn_queries_kernel, grid, dim3(256), 0, s, cvo.p, cvo.ld, cvo.bs, C, first_raw, nq, d_q); });
             }
-            if ((size_t)KNN_MAXQ * C * sizeof(float) > 64 * 1024) throw ShapeError("feature dimension too large for the kNN scan kernel");
+            // Stage A + B: approximate distances on the matrix cores in one pass over the index (HBM-bound), exact re-rank of a
+            // provably sufficient candidate set; the exhaustive exact scan below only runs for streams whose candidate set overflowed.
+            const bool fast = C % 16 == 0 && !getenv("RVC_KNN_EXHAUSTIVE");
+            int *d_overflow = (int *)pl.arena.alloc((size_t)B * sizeof(int));
+            if (fast) {
+                float *d_approx = pl.arena.floats((size_t)B * nq * e->index_n);
+                for (int q0 = 0; q0 < nq; q0 += 16) {
+                    KnnDotP dp{}; dp.indexF = e->d_indexF; dp.ynorm = e->d_ynorm; dp.n = (int)e->index_n; dp.dim = C;
+                    dp.q = d_q; dp.q_bs = (long long)nq * C; dp.nq = nq; dp.q0 = q0; dp.approx = d_approx; dp.approx_bs = (long long)nq * e->index_n;
+                    dp.overflow = d_overflow;
+                    dim3 grid((unsigned)((e->index_n + 63) / 64), B);
+                    const size_t qlds = (size_t)16 * (C + 4) * sizeof(float);
+                    if (qlds > 160 * 1024) throw ShapeError("feature dimension too large for the retrieval kernel");
+                    Plan *plp = &pl;
+                    const double scan_bytes = (double)e->index_n * C * sizeof(float) * B;     // algorithmic bytes: the index, read once per query group
+                    pl.ops.push_back([=](hipStream_t s) {
+                        ProfEvent *pe = nullptr;
+                        if (plp->profile) {
+                            if (plp->prof_used == plp->prof.size()) { ProfEvent ev; HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b)); ev.flops = 0; ev.bytes = 0; plp->prof.push_back(ev); }
+                            pe = &plp->prof[plp->prof_used++]; pe->flops = 0; pe->bytes = scan_bytes;
+                            HIPCHK(hipEventRecord(pe->a, s));
+                        }
+                        hipLaunchKernelGGL(knn_dot_kernel, grid, dim3(256), qlds, s, dp);
+                        if (pe) HIPCHK(hipEventRecord(pe->b, s));
+                    });
+                }
+                KnnSelP sp{}; sp.approx = d_approx; sp.approx_bs = (long long)nq * e->index_n; sp.n = (int)e->index_n; sp.dim = C; sp.nq = nq;
+                sp.index = e->d_index; sp.q = d_q; sp.q_bs = (long long)nq * C; sp.skip_head = (int)skip_head; sp.T = T; sp.R = (int)R; sp.first_raw = first_raw;
+                sp.rate = e->index_rate; sp.phone = phone.p; sp.ph_cs = phone.ld; sp.ph_bs = phone.bs; sp.out_idx = pl.d_knn_idx; sp.out_dist = pl.d_knn_dist;
+                sp.overflow = d_overflow;
+                dim3 sgrid(nq, B);
+                const size_t slds = (size_t)33 * (C + 4) * sizeof(float);
+                if (slds > 128 * 1024) throw ShapeError("feature dimension too large for the retrieval kernel");
+                pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(knn_select_blend_kernel, sgrid, dim3(1024), slds, s, sp); });
+            }
             for (int q0 = 0; q0 < nq; q0 += KNN_MAXQ) {
                 const int qn = std::min(KNN_MAXQ, nq - q0);
                 KnnP kp{}; kp.indexT = e->d_indexT; kp.index = e->d_index; kp.n = (int)e->index_n; kp.dim = C; kp.nblk = nblk;
                 // query sub-range: pointers offset so that [B][nq] strides stay those of the full arrays
                 kp.q = d_q + (size_t)q0 * C; kp.nq = qn; kp.cand_d = cand_d + (size_t)q0 * nblk * KNN_K; kp.cand_i = cand_i + (size_t)q0 * nblk * KNN_K;
+                kp.overflow = fast ? d_overflow : nullptr;
                 const int nq_total = nq;
-                dim3 grid(nblk, B); size_t lds = (size_t)qn * C * sizeof(float);
+                dim3 grid(nblk, B);
                 pl.ops.push_back([=](hipStream_t s) {
                     KnnP k2 = kp; k2.q_bs = (long long)nq_total * C; k2.cand_bs = (long long)nq_total * nblk * KNN_K;
-                    hipLaunchKernelGGL(knn_scan_kernel, grid, dim3(256), lds, s, k2);
+                    hipLaunchKernelGGL(knn_scan_kernel, grid, dim3(256), 0, s, k2);
                 });
             }
             KnnBlendP bp{}; bp.cand_d = cand_d; bp.cand_i = cand_i; bp.nblk = nblk; bp.nq = nq; bp.index = e->d_index; bp.dim = C; bp.q = d_q;
             bp.skip_head = (int)skip_head; bp.T = T; bp.R = (int)R; bp.first_raw = first_raw; bp.rate = e->index_rate;
             bp.phone = phone.p; bp.ph_cs = phone.ld; bp.ph_bs = phone.bs; bp.out_idx = pl.d_knn_idx; bp.out_dist = pl.d_knn_dist;
+            bp.overflow = fast ? d_overflow : nullptr;
             dim3 grid(nq, B);
             pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(knn_merge_blend_kernel, grid, dim3(256), 0, s, bp); });
         }
@@ -1537,6 +1575,8 @@ void rvc_destroy(rvc_engine *e)
     if (e->d_basis) (void)hipFree(e->d_basis);
     if (e->d_index && e->index_owned) (void)hipFree(e->d_index);
     if (e->d_indexT) (void)hipFree(e->d_indexT);
+    if (e->d_ynorm) (void)hipFree(e->d_ynorm);
+    if (e->d_indexF) (void)hipFree(e->d_indexF);
     if (e->d_state) (void)hipFree(e->d_state);
     if (e->d_cp) (void)hipFree(e->d_cp);
     if (e->h_cp) (void)hipHostFree(e->h_cp);
@@ -1762,6 +1802,25 @@ static void build_index_transpose(rvc_engine *e)
     if (e->d_indexT) (void)hipFree(e->d_indexT);
     HIPCHK(hipMalloc(&e->d_indexT, t.size() * sizeof(float)));
     HIPCHK(hipMemcpy(e->d_indexT, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    // MFMA-fragment-major copy for the one-pass approximate-distance kernel: [tile of 16 vectors][chunk of 16 dims][lane][4]
+    if (e->d_indexF) { (void)hipFree(e->d_indexF); e->d_indexF = nullptr; }
+    if (e->index_dim % 16 == 0) {
+        const size_t nt = (e->index_n + 15) / 16, nc = e->index_dim / 16;
+        std::vector<float> f(nt * nc * 256, 0.f);
+        for (size_t tl = 0; tl < nt; tl++)
+            for (size_t c = 0; c < nc; c++)
+                for (size_t l = 0; l < 64; l++) {
+                    const size_t v = tl * 16 + (l & 15);
+                    if (v >= e->index_n) continue;
+                    memcpy(&f[((tl * nc + c) * 64 + l) * 4], &h[v * e->index_dim + c * 16 + (l >> 4) * 4], 16);
+                }
+        HIPCHK(hipMalloc(&e->d_indexF, f.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(e->d_indexF, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (e->d_ynorm) (void)hipFree(e->d_ynorm);
+    HIPCHK(hipMalloc(&e->d_ynorm, e->index_n * sizeof(float)));
+    hipLaunchKernelGGL(knn_norms_kernel, dim3((unsigned)((e->index_n + 255) / 256)), dim3(256), 0, 0, e->d_index, (int)e->index_n, (int)e->index_dim, e->d_ynorm);
+    HIPCHK(hipDeviceSynchronize());
 }
 
 rvc_status rvc_load_index(rvc_engine *e, const float *vectors, size_t n, size_t dim)
@@ -1825,8 +1884,9 @@ rvc_status rvc_profile_last(rvc_engine *e, int *launches, double *kernel_ms, dou
         if (!pl) return RVC_SHAPE;
         HIPCHK(hipDeviceSynchronize());
         double ms = 0, fl = 0;
-        for (size_t i = 0; i < pl->prof_used; i++) { float t; HIPCHK(hipEventElapsedTime(&t, pl->prof[i].a, pl->prof[i].b)); ms += t; fl += pl->prof[i].flops; }
-        if (launches) *launches = (int)pl->prof_used;
+        int nl = 0;
+        for (size_t i = 0; i < pl->prof_used; i++) { if (pl->prof[i].bytes > 0) continue; float t; HIPCHK(hipEventElapsedTime(&t, pl->prof[i].a, pl->prof[i].b)); ms += t; fl += pl->prof[i].flops; nl++; }
+        if (launches) *launches = nl;
         if (kernel_ms) *kernel_ms = ms;
         if (flops) *flops = pl->prof_used ? fl : pl->igemm_flops;
         return RVC_OK;
@@ -1906,6 +1966,21 @@ double rvc_debug_conv_bench(rvc_engine *e, int M, int Cin, int KW, int dil, int 
         return RVC_OK;
     });
     return us;
+}
+
+rvc_status rvc_profile_last_knn(rvc_engine *e, int *launches, double *kernel_ms, double *bytes)
+{
+    return guarded(e, [&]() {
+        Plan *pl = e->last_plan;
+        if (!pl) return RVC_SHAPE;
+        HIPCHK(hipDeviceSynchronize());
+        double ms = 0, by = 0; int nl = 0;
+        for (size_t i = 0; i < pl->prof_used; i++) { if (!(pl->prof[i].bytes > 0)) continue; float t; HIPCHK(hipEventElapsedTime(&t, pl->prof[i].a, pl->prof[i].b)); ms += t; by += pl->prof[i].bytes; nl++; }
+        if (launches) *launches = nl;
+        if (kernel_ms) *kernel_ms = ms;
+        if (bytes) *bytes = by;
+        return RVC_OK;
+    });
 }
 
 rvc_status rvc_get_tap(rvc_engine *e, const char *name, float *out, size_t cap, size_t *n)

@@ -1233,24 +1233,38 @@ struct KnnP {
     int nq;
     float *cand_d; int *cand_i;   // [B][nq][nblk][K]
     int nblk;
+    const int *overflow;     // when set: run only for streams whose candidate set overflowed (exhaustive fallback)
 };
 
 __global__ __launch_bounds__(256) void knn_scan_kernel(KnnP p)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // queries [nq][dim]
+    if (p.overflow && p.overflow[blockIdx.y] == 0) return;
     __shared__ float bd[KNN_MAXQ][4][KNN_K];
     __shared__ int bi[KNN_MAXQ][4][KNN_K];
     const int b = blockIdx.y;
-    const float *q = p.q + (long long)b * p.q_bs;
-    for (int i = threadIdx.x; i < p.nq * p.dim; i += 256) smem[i] = q[i];
-    __syncthreads();
+    // the queries are wave-uniform: read through the scalar cache (s_load) so they cost no LDS/VALU bandwidth
+    const float *__restrict__ smem = p.q + (long long)b * p.q_bs;
     const int i = blockIdx.x * 256 + threadIdx.x;
     float acc[KNN_MAXQ];
 #pragma unroll
     for (int j = 0; j < KNN_MAXQ; j++) acc[j] = 0.f;
     if (i < p.n) {
-        for (int d = 0; d < p.dim; d++) {
-            float v = p.indexT[(long long)d * p.n + i];
+        // HBM-streaming loop: 8 independent coalesced loads in flight per thread, then the FMAs in ascending-d order
+        // (the distance stays a sequential fmaf chain over d, bit-identical to the reference definition)
+        const float *col = p.indexT + i;
+        int d = 0;
+        for (; d + 8 <= p.dim; d += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(col + (long long)(d + u) * p.n);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+#pragma unroll
+                for (int j = 0; j < KNN_MAXQ; j++) if (j < p.nq) { float df = smem[j * p.dim + d + u] - v[u]; acc[j] = fmaf(df, df, acc[j]); }
+            }
+        }
+        for (; d < p.dim; d++) {
+            float v = col[(long long)d * p.n];
 #pragma unroll
             for (int j = 0; j < KNN_MAXQ; j++) if (j < p.nq) { float df = smem[j * p.dim + d] - v; acc[j] = fmaf(df, df, acc[j]); }
         }
@@ -1296,6 +1310,7 @@ struct KnnBlendP {
     float rate;
     float *phone; int ph_cs; long long ph_bs;
     int *out_idx; float *out_dist;   // [B][R][K]
+    const int *overflow;
 };
 
 // one workgroup per (unique query, stream): merge candidates, then blend every sliced frame that maps to it
@@ -1304,6 +1319,7 @@ __global__ __launch_bounds__(256) void knn_merge_blend_kernel(KnnBlendP p)
     __shared__ float sd[KNN_K]; __shared__ int si[KNN_K];
     __shared__ float wd[4][KNN_K]; __shared__ int wi[4][KNN_K];
     const int j = blockIdx.x, b = blockIdx.y;
+    if (p.overflow && p.overflow[b] == 0) return;
     const long long base = ((long long)b * p.nq + j) * p.nblk * KNN_K;
     const int total = p.nblk * KNN_K;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1356,6 +1372,225 @@ __global__ __launch_bounds__(256) void knn_merge_blend_kernel(KnnBlendP p)
         }
         for (int c = threadIdx.x; c < p.dim; c += 256) {
             float acc = 0.f;
+            for (int k = 0; k < KNN_K; k++) acc += (w[k] / ws) * p.index[(long long)si[k] * p.dim + c];
+            p.phone[(long long)b * p.ph_bs + (long long)c * p.ph_cs + r] = p.rate * acc + (1.0f - p.rate) * qv[c];
+        }
+    }
+}
+
+// ---- HBM-roofline retrieval: approximate distances on the matrix cores, exact re-rank of a provably sufficient candidate set ----
+// Stage A (knn_dot_kernel): one pass over the row-major index.  A wave owns 16 consecutive index vectors (a contiguous
+// 16*dim*4-byte block of HBM, read exactly once) against up to 16 queries: dot products on v_mfma_f32_16x16x4_f32, then
+// approx[q][i] = |y_i|^2 - 2 x_q.y_i  (|x_q|^2 is constant per query).  Algorithmic traffic: n*dim*4 bytes per query group.
+struct KnnDotP {
+    const float *indexF;     // index repacked at load in MFMA-fragment order [tile of 16 vectors][chunk of 16 dims][lane][4]
+    const float *ynorm; int n, dim;
+    const float *q; long long q_bs; int nq, q0;
+    float *approx; long long approx_bs;        // approx[b][q][n]
+    int *overflow;                              // [B], cleared here, raised by the select stage
+};
+__global__ __launch_bounds__(256) void knn_dot_kernel(KnnDotP p)
+{
+    constexpr int D = 8;
+    extern __shared__ __attribute__((aligned(16))) float s_q[];      // [16][dim + 4] queries of this group (row pad: conflict-free b128 reads)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.q0 == 0) p.overflow[b] = 0;
+    const int QS = p.dim + 4;
+    {
+        const float *qb = p.q + (long long)b * p.q_bs;
+        const int nv = p.dim >> 2;
+        for (int i = threadIdx.x; i < 16 * nv; i += 256) {
+            const int r = i / nv, c4 = i - r * nv;
+            int qq = p.q0 + r; qq = qq < p.nq ? qq : p.nq - 1;
+            *reinterpret_cast<f32x4 *>(s_q + r * QS + c4 * 4) = *reinterpret_cast<const f32x4 *>(qb + (long long)qq * p.dim + c4 * 4);
+        }
+    }
+    __syncthreads();
+    const int i0 = (blockIdx.x * 4 + wave) * 16;
+    if (i0 >= p.n) return;
+    const int li = lane & 15, kq = lane >> 4;
+    const int nc = p.dim >> 4;
+    // one wave-wide dwordx4 load = one 1 KiB fragment, fully contiguous: the wave streams its 16 vectors as nc consecutive KiB
+    const float *ar = p.indexF + (long long)(i0 >> 4) * nc * 256 + lane * 4;
+    const float *br = s_q + li * QS + kq * 4;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a_st[D];
+#pragma unroll
+    for (int s = 0; s < D; s++)
+        if (s < nc) a_st[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(ar + s * 256));
+    for (int c = 0; c < nc; c += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            if (c + s < nc) {
+                const f32x4 bq = *reinterpret_cast<const f32x4 *>(br + (c + s) * 16);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[s][0], bq[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[s][1], bq[1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[s][2], bq[2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[s][3], bq[3], acc1, 0, 0, 0);
+                if (c + s + D < nc) a_st[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(ar + (c + s + D) * 256));
+            }
+        }
+    }
+    // D layout: row (index vector) = (lane >> 4) * 4 + r, column (query) = lane & 15
+    const int qcol = p.q0 + li;
+    if (qcol < p.nq) {
+        float *out = p.approx + (long long)b * p.approx_bs + (long long)qcol * p.n;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int v = i0 + kq * 4 + r;
+            if (v < p.n) out[v] = p.ynorm[v] - 2.0f * (acc0[r] + acc1[r]);
+        }
+    }
+}
+
+// |y_i|^2 for every index vector (load time)
+__global__ void knn_norms_kernel(const float *index, int n, int dim, float *ynorm)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *r = index + (long long)i * dim;
+    float s = 0.f;
+    for (int d = 0; d < dim; d++) s = fmaf(r[d], r[d], s);
+    ynorm[i] = s;
+}
+
+// Stage B (knn_select_blend_kernel): one workgroup per (unique query, stream).
+//  1. exact top-4 of the APPROXIMATE distances -> 4th smallest a4;
+//  2. candidate set = { i : approx_i <= a4 + margin }: since |approx - true| <= err < margin/2, every vector of the true top-4
+//     (true distance <= true 4th distance <= a4 + err) is in the set;
+//  3. exact sequential-fmaf distances (the reference definition) for the candidates, final order by (distance, index);
+//  4. w = (1/d)^2 blend of the duplicated frames (as before).
+// More than KNN_CAND candidates (degenerate data, e.g. thousands of duplicate vectors): overflow[b] is raised and the
+// exhaustive exact scan (knn_scan_kernel + knn_merge_blend_kernel) recomputes this stream.
+#define KNN_CAND 512
+struct KnnSelP {
+    const float *approx; long long approx_bs; int n, dim, nq;
+    const float *index; const float *q; long long q_bs;
+    int skip_head, T, R, first_raw; float rate;
+    float *phone; int ph_cs; long long ph_bs;
+    int *out_idx; float *out_dist; int *overflow;
+};
+__global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p)
+{
+    __shared__ float wd[16][KNN_K]; __shared__ int wi[16][KNN_K];
+    __shared__ float sd[KNN_K]; __shared__ int si[KNN_K];
+    __shared__ int cand_i[KNN_CAND]; __shared__ float cand_d[KNN_CAND];
+    __shared__ int cnt; __shared__ float s_xn;
+    extern __shared__ __attribute__((aligned(16))) float s_rows[];     // [32][dim + 4] candidate rows + the query
+    const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *a = p.approx + (long long)b * p.approx_bs + (long long)j * p.n;
+    const float *qv = p.q + (long long)b * p.q_bs + (long long)j * p.dim;
+    if (tid == 0) cnt = 0;
+    // |x|^2 (only to scale the error margin)
+    float xn = 0.f;
+    for (int d = tid; d < p.dim; d += 1024) xn += qv[d] * qv[d];
+    xn = wave_sum(xn);
+    if (lane == 0) wd[wave][0] = xn;
+    __syncthreads();
+    if (tid == 0) { float t = 0.f; for (int w = 0; w < 16; w++) t += wd[w][0]; s_xn = t; }
+    __syncthreads();
+    // 1. per-thread sorted top-4 of the approximate distances
+    float ld[KNN_K]; int li_[KNN_K];
+#pragma unroll
+    for (int k = 0; k < KNN_K; k++) { ld[k] = INFINITY; li_[k] = 0x7fffffff; }
+    for (int i = tid; i < p.n; i += 1024) {
+        const float d = a[i];
+        if (d < ld[KNN_K - 1]) {
+            int q = KNN_K - 1;
+            while (q > 0 && d < ld[q - 1]) { ld[q] = ld[q - 1]; li_[q] = li_[q - 1]; q--; }
+            ld[q] = d; li_[q] = i;
+        }
+    }
+    int pos = 0;
+    for (int k = 0; k < KNN_K; k++) {
+        float md = pos < KNN_K ? ld[pos] : INFINITY; int mi = pos < KNN_K ? li_[pos] : 0x7fffffff;
+        const float d0 = md; const int i0 = mi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float od = __shfl_xor(md, o, 64); int oi = __shfl_xor(mi, o, 64);
+            if (od < md || (od == md && oi < mi)) { md = od; mi = oi; }
+        }
+        if (d0 == md && i0 == mi && mi != 0x7fffffff) pos++;
+        if (lane == 0) { wd[wave][k] = md; wi[wave][k] = mi; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int ps[16];
+        for (int w = 0; w < 16; w++) ps[w] = 0;
+        float last = INFINITY;
+        for (int k = 0; k < KNN_K; k++) {
+            float md = INFINITY; int mi = 0x7fffffff, mw = 0;
+            for (int w = 0; w < 16; w++) if (ps[w] < KNN_K) {
+                float od = wd[w][ps[w]]; int oi = wi[w][ps[w]];
+                if (od < md || (od == md && oi < mi)) { md = od; mi = oi; mw = w; }
+            }
+            ps[mw]++;
+            last = md;
+        }
+        sd[0] = last;      // approximate 4th-smallest
+    }
+    __syncthreads();
+    // 2. candidates within the error margin of the approximate 4th distance.  fp32 error of approx is bounded by
+    //    ~dim*2^-24*(|y|^2 + 2|x||y|) <= 1e-4*(|x|^2 + |y|^2) for dim <= 1024; the margin is 20x that.
+    const float a4 = sd[0];
+    const float margin = 2e-3f * (fabsf(a4 + s_xn) + s_xn + 1e-3f);
+    const float thr = a4 + margin;
+    __syncthreads();
+    for (int i = tid; i < p.n; i += 1024) {
+        if (a[i] <= thr) { int c = atomicAdd(&cnt, 1); if (c < KNN_CAND) cand_i[c] = i; }
+    }
+    __syncthreads();
+    const int ncand = cnt;
+    if (ncand > KNN_CAND) { if (tid == 0) p.overflow[b] = 1; return; }
+    // 3. exact distances in the reference's order (ascending-d sequential fmaf), one candidate per thread; the rows are first
+    //    staged in LDS with coalesced 16-byte loads (32 candidates per round) so the dependent chain never waits on HBM
+    {
+        const int RS = p.dim + 4, nv = p.dim >> 2;
+        float *s_qv = s_rows + 32 * RS;
+        for (int i = tid; i < nv; i += 1024) *reinterpret_cast<f32x4 *>(s_qv + i * 4) = *reinterpret_cast<const f32x4 *>(qv + i * 4);
+        for (int base = 0; base < ncand; base += 32) {
+            __syncthreads();
+            for (int i = tid; i < 32 * nv; i += 1024) {
+                const int r = i / nv, c4 = i - r * nv;
+                if (base + r < ncand)
+                    *reinterpret_cast<f32x4 *>(s_rows + r * RS + c4 * 4) = *reinterpret_cast<const f32x4 *>(p.index + (long long)cand_i[base + r] * p.dim + c4 * 4);
+            }
+            __syncthreads();
+            if (tid < 32 && base + tid < ncand) {
+                const float *v = s_rows + tid * RS;
+                float acc = 0.f;
+                for (int d = 0; d < p.dim; d++) { const float df = s_qv[d] - v[d]; acc = fmaf(df, df, acc); }
+                cand_d[base + tid] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 0; k < KNN_K; k++) {
+            float md = INFINITY; int mi = 0x7fffffff, mc = -1;
+            for (int c = 0; c < ncand; c++) {
+                const float od = cand_d[c]; const int oi = cand_i[c];
+                if (oi >= 0 && (od < md || (od == md && oi < mi))) { md = od; mi = oi; mc = c; }
+            }
+            sd[k] = md; si[k] = mi;
+            if (mc >= 0) cand_i[mc] = -1;
+        }
+    }
+    __syncthreads();
+    // 4. blend: w = (1/d)^2 normalised, feat = rate * sum w_i y_i + (1 - rate) * feat
+    float w[KNN_K], ws = 0.f;
+#pragma unroll
+    for (int k = 0; k < KNN_K; k++) { float inv = 1.0f / sd[k]; w[k] = inv * inv; ws += w[k]; }
+    for (int r = 0; r < p.R; r++) {
+        int s = (p.skip_head + r) / 2; s = s < p.T - 1 ? s : p.T - 1;
+        if (s - p.first_raw != j) continue;
+        if (tid < KNN_K) {
+            p.out_idx[((long long)b * p.R + r) * KNN_K + tid] = si[tid];
+            p.out_dist[((long long)b * p.R + r) * KNN_K + tid] = sd[tid];
+        }
+        for (int c = tid; c < p.dim; c += 1024) {
+            float acc = 0.f;
+#pragma unroll
             for (int k = 0; k < KNN_K; k++) acc += (w[k] / ws) * p.index[(long long)si[k] * p.dim + c];
             p.phone[(long long)b * p.ph_bs + (long long)c * p.ph_cs + r] = p.rate * acc + (1.0f - p.rate) * qv[c];
         }

@@ -156,6 +156,11 @@ class RvcInfer:
         self._chk(self._L.rvc_profile_last(self._h, C.byref(n), C.byref(ms), C.byref(fl)))
         return n.value, ms.value, fl.value
 
+    def profile_last_knn(self):
+        n, ms, by = C.c_int(), C.c_double(), C.c_double()
+        self._chk(self._L.rvc_profile_last_knn(self._h, C.byref(n), C.byref(ms), C.byref(by)))
+        return n.value, ms.value, by.value
+
     def enable_taps(self, on: bool = True):
         self._L.rvc_enable_taps(self._h, 1 if on else 0)
 

@@ -202,6 +202,24 @@ def test_retrieval_scan_exact_on_identical_queries():
     assert io2[0, :3].tolist() == [50, 100, 2000]
 
 
+def test_retrieval_degenerate_index_takes_exhaustive_fallback():
+    # thousands of exact duplicates: every one is within the error margin of the 4th-nearest, the candidate set overflows
+    # and the exhaustive exact scan must produce the same hits (ties broken by ascending index)
+    from oracle import oracle as O
+    z, ora, eng = _pair("tiny", taps=True)
+    base = W.make_index(40, 48, seed=3)
+    index = np.tile(base, (60, 1))                         # 2400 vectors, each repeated 60 times
+    ora.load_index(index); ora.set_index_rate(0.5)
+    eng.load_index(index); eng.set_index_rate(0.5)
+    x = voice_signal(g.input_buffer_16k_size, seed=3)
+    yo = ora.infer(x, 2560, 12, 200, 21)
+    ye = eng.infer(x, 2560, 12, 200, 21)
+    io, do = ora.knn(); ie, de = eng.knn()
+    assert np.array_equal(ie, io) and np.allclose(de, do, rtol=1e-4)
+    assert (np.diff(ie, axis=1) == 40).all()               # the four smallest indices of one duplicated vector
+    assert rms(ye - yo) < PCM_TOL
+
+
 def test_batched_streams_match_single_stream_oracles():
     # BASELINE config 4 in miniature: S concurrent streams batched per stage, each with its own state
     from oracle import oracle as O
