@@ -136,14 +136,23 @@ def main():
             k_n += kn; k_ms += kms; k_by += kby
         eng.set_profile(False)
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        # HBM traffic per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, gfx950 x2 correction; see the file's
+        # "source" note) -- PMC counters cannot be collected inside this process
+        traffic = {}
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        except Exception:
+            pass
         roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": None,
+                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 5),
+                "traffic": (traffic.get("igemm_all_instantiations", {}).get("hbm_read_bytes_per_launch") if S == 1 else None),
                 "kernel": "rvc::igemm_kernel<MF,NF> (all instantiations)", "launches_per_step": n_l // reps,
                 "avg_launch_us": round(tot_ms * 1e3 / max(n_l, 1), 3), "flops_per_step": tot_fl / reps}
         if k_n:
             ach = k_by / (k_ms * 1e-3) / 1e9
             roof["retrieval_scan"] = {"bound": "hbm", "kernel": "rvc::knn_dot_kernel", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                                      "frac": round(ach / 8000.0, 4), "bytes_per_launch": k_by / k_n, "avg_launch_us": round(k_ms * 1e3 / k_n, 2), "traffic": None}
+                                      "frac": round(ach / 8000.0, 4), "bytes_per_launch": k_by / k_n, "avg_launch_us": round(k_ms * 1e3 / k_n, 2),
+                                      "traffic": (traffic.get("knn_dot_kernel", {}).get("hbm_read_bytes_per_launch") if S == 1 else None)}
 
     # the reference's boundary hands over host buffers: the same chunk through the host-pointer C ABI (H2D 143 KB + D2H 40 KB
     # + sync inside the call); reported separately, never as `value`
