@@ -908,6 +908,7 @@ static void init_kernel_attrs()
     HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)gru256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)knn_select_blend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));   // + ~5 KB static
     HIPCHK(hipFuncSetAttribute((const void *)knn_dot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)relpos_attention_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1100,7 +1101,12 @@ static T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k,
         size_t lds = (size_t)4 * Hg * sizeof(float);
         float *wt = m.whhT, *bh = m.bhh;
         dim3 grid(2, B);
-        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(gru_kernel, grid, dim3(threads), lds, s, gi.p, gi.ld, gi.bs, wt, bh, gout.p, gout.ld, gout.bs, Hg, Tm); });
+        if (Hg == 256 && getenv("RVC_GRU256")) {   // opt-in: the register-resident variant currently spills and measures slower
+            const size_t lds2 = (size_t)(256 + 768 + 48 * 768) * sizeof(float);
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(gru256_kernel, grid, dim3(768), lds2, s, gi.p, gi.ld, gi.bs, wt, bh, gout.p, gout.ld, gout.bs, Tm); });
+        } else {
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(gru_kernel, grid, dim3(threads), lds, s, gi.p, gi.ld, gi.bs, wt, bh, gout.p, gout.ld, gout.bs, Hg, Tm); });
+        }
     }
     { ConvOpts o; o.act = ACT_SIGMOID; add_conv1d(pl, m.fc, gout, sal, 1, 0, 1, o); }
     if (pl.with_taps) { add_tap(pl, "rm.sal_ct", sal); add_tap(pl, "rm.gru_ct", gout); add_tap(pl, "rm.cnn_ct", feat); }
