@@ -683,7 +683,7 @@ struct ModelRM {
     std::vector<std::vector<ResBlockW>> enc, inter, dec;
     std::vector<ConvW> up;
     ConvW cnn, gru_ih, fc;
-    float *whhT = nullptr, *bhh = nullptr;
+    float *whhT = nullptr, *bhh = nullptr, *whh = nullptr;
     size_t weight_bytes = 0;
     static ResBlockW block(const Blob &b, const std::string &pre, int ci, int co)
     {
@@ -732,6 +732,11 @@ struct ModelRM {
         }
         gru_ih = prep_conv(wih.data(), bih.data(), 6 * H, I, 1, 1);
         whhT = upload_f(wt); bhh = upload_f(bh);
+        {
+            std::vector<float> wr((size_t)2 * 3 * H * H);
+            for (int d = 0; d < 2; d++) memcpy(&wr[(size_t)d * 3 * H * H], b.w(std::string("rm.gru.w_hh_") + sfx[d]), (size_t)3 * H * H * 4);
+            whh = upload_f(wr);
+        }
         fc = prep_conv(b.w("rm.fc.w"), b.w("rm.fc.b"), n_out, 2 * H, 1, 1);
         weight_bytes = b.bytes();
     }
@@ -743,6 +748,7 @@ struct ModelRM {
         free_conv(cnn); free_conv(gru_ih); free_conv(fc);
         if (whhT) (void)hipFree(whhT);
         if (bhh) (void)hipFree(bhh);
+        if (whh) (void)hipFree(whh);
     }
 };
 
@@ -873,7 +879,7 @@ struct rvc_engine {
     std::unique_ptr<ModelRM> rm;
     std::unique_ptr<ModelSY> sy;
     // constants for the mel front end
-    float *d_window = nullptr, *d_twiddle = nullptr, *d_basis = nullptr;
+    float *d_window = nullptr, *d_twiddle = nullptr, *d_basis = nullptr; int *d_band = nullptr;
     // retrieval index
     float *d_index = nullptr, *d_indexT = nullptr, *d_indexF = nullptr, *d_ynorm = nullptr; size_t index_n = 0, index_dim = 0; bool index_owned = true;
     float index_rate = 0.f;
@@ -908,6 +914,8 @@ static void init_kernel_attrs()
     HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)gru_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)gru256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)knn_select_blend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));   // + ~5 KB static
     HIPCHK(hipFuncSetAttribute((const void *)knn_dot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -938,6 +946,15 @@ static void init_constants(rvc_engine *e)
         }
     }
     e->d_window = upload_f(win); e->d_twiddle = upload_f(tw); e->d_basis = upload_f(basis);
+    std::vector<int> band(256);
+    for (int i = 0; i < nm; i++) {
+        int lo = nb, hi = 0;
+        for (int j = 0; j < nb; j++) if (basis[(size_t)i * nb + j] != 0.f) { lo = std::min(lo, j); hi = std::max(hi, j + 1); }
+        if (hi <= lo) { lo = 0; hi = 0; }
+        band[2 * i] = lo; band[2 * i + 1] = hi;
+    }
+    HIPCHK(hipMalloc(&e->d_band, band.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(e->d_band, band.data(), band.size() * sizeof(int), hipMemcpyHostToDevice));
 }
 
 static void reset_state(rvc_engine *e)
@@ -997,7 +1014,12 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
         AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = E; ap.T = T; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;
         ap.scale = 1.0f / sqrtf((float)hd); ap.rel_k = nullptr; ap.rel_v = nullptr; ap.window = 0;
         dim3 ag(m.heads * ((T + 15) / 16), B);
-        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(attention_kernel, ag, dim3(256), attn_lds, s, ap); });
+        const size_t mfma_lds = ((size_t)hd * Tp + 16 * (((T + 15) / 16) * 16 + 1) + 128) * sizeof(float);
+        if (hd % 16 == 0 && T <= 256 && mfma_lds <= 160 * 1024 && !getenv("RVC_ATTN_VALU")) {
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(attention_mfma_kernel, ag, dim3(256), mfma_lds, s, ap); });
+        } else {
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(attention_kernel, ag, dim3(256), attn_lds, s, ap); });
+        }
         { ConvOpts o; o.res = h2.p; o.res_cs = h2.ld; o.res_bs = h2.bs; add_conv1d(pl, Ly.o, att, h2, 1, 0, 1, o); }
         add_layernorm(pl, h2, Ly.ln1_g, Ly.ln1_b);
         { ConvOpts o; o.act = ACT_GELU; add_conv1d(pl, Ly.ff1, h2, ff, 1, 0, 1, o); }
@@ -1044,7 +1066,7 @@ static T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k,
     {
         MelP mp{};
         mp.audio = pl.d_in; mp.audio_bs = (long long)L; mp.n = (int)L; mp.frame = (int)fr; mp.Tm = Tm;
-        mp.window = e->d_window; mp.twiddle = e->d_twiddle; mp.basis = e->d_basis;
+        mp.window = e->d_window; mp.twiddle = e->d_twiddle; mp.basis = e->d_basis; mp.band = e->d_band;
         mp.mel = d_mel; mp.img = img.p; mp.img_bs = img.bs; mp.img_ld = img.ld; mp.bn_scale = m.bn_scale; mp.bn_shift = m.bn_shift;
         dim3 grid(Tm, B);
         pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(mel_frontend_kernel, grid, dim3(256), 0, s, mp); });
@@ -1101,7 +1123,19 @@ static T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k,
         size_t lds = (size_t)4 * Hg * sizeof(float);
         float *wt = m.whhT, *bh = m.bhh;
         dim3 grid(2, B);
-        if (Hg == 256 && getenv("RVC_GRU256")) {   // opt-in: the register-resident variant currently spills and measures slower
+        if (Hg == 256 && B <= 8 && !getenv("RVC_GRU_GENERIC")) {
+            // few streams: spread each direction over 8 CUs with W_hh resident in LDS (granule hand-off per step)
+            GruMultiP gp{}; gp.gi = gi.p; gp.gi_cs = gi.ld; gp.gi_bs = gi.bs; gp.whh = m.whh; gp.bhh = m.bhh; gp.out = gout.p; gp.o_cs = gout.ld; gp.o_bs = gout.bs;
+            gp.Tm = Tm; gp.status = &e->d_state[0].status; gp.status_stride = (int)(sizeof(StreamState) / sizeof(int));
+            const size_t gbytes = (size_t)B * 2 * 2 * 256 * sizeof(unsigned long long);
+            gp.gran = (unsigned long long *)pl.arena.alloc(gbytes);
+            const size_t lds3 = (size_t)(96 * 260 + 256 + 96) * sizeof(float);
+            dim3 g3(8, 2, B);
+            pl.ops.push_back([=](hipStream_t s) {
+                HIPCHK(hipMemsetAsync(gp.gran, 0, gbytes, s));
+                hipLaunchKernelGGL(gru_multi_kernel, g3, dim3(256), lds3, s, gp);
+            });
+        } else if (Hg == 256 && getenv("RVC_GRU256")) {   // opt-in: the register-resident variant currently spills and measures slower
             const size_t lds2 = (size_t)(256 + 768 + 48 * 768) * sizeof(float);
             pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(gru256_kernel, grid, dim3(768), lds2, s, gi.p, gi.ld, gi.bs, wt, bh, gout.p, gout.ld, gout.bs, Tm); });
         } else {
@@ -1313,17 +1347,20 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
     pl.mode = mode; pl.L = L; pl.frame16k = frame16k; pl.skip_head = skip_head; pl.R = R; pl.B = B; pl.with_index = with_index; pl.with_taps = e->taps_on;
     pl.d_in = pl.arena.floats((size_t)B * L + 64);
     T1 sal0, src0; float *d_pitchf0 = nullptr; int *d_pitch0 = nullptr;
+    size_t rm_begin = 0, rm_end = 0;
     if (mode == 0) {
         // f0 branch first (auxiliary stream): independent of ContentVec until the synthesizer
         const int Tcv = e->cv->out_frames(L);
         if (Tcv < 1) throw ShapeError("input too short for ContentVec");
         const size_t hubert_length0 = std::min(L / 160, 2 * (size_t)Tcv + 1);   // rvc.rs:153
         pl.ops.fork(1);
+        rm_begin = pl.ops.v.size();
         pl.ops.cur = 1;
         sal0 = build_rmvpe(e, pl, B, L, frame16k, true);
         build_pitch_post(e, pl, B, sal0, true, frame16k, hubert_length0, &d_pitchf0, &d_pitch0);
         if (!getenv("RVC_NSF_MAIN")) src0 = build_nsf_source(e, pl, B, d_pitchf0);
         pl.ops.cur = 0;
+        rm_end = pl.ops.v.size();
     }
     if (mode == 0 || mode == 1) {
         if (!e->cv) throw std::logic_error("contentvec");
@@ -1430,6 +1467,14 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         add_tap(pl, "phone_ct", phone);
         float *d_pitchf = d_pitchf0; int *d_pitch = d_pitch0;
         (void)hubert_length;
+        if (!getenv("RVC_RM_FIRST") && rm_end > rm_begin) {
+            // submission order matters under graph replay (nodes are pushed to the hardware queues in creation order): the
+            // ContentVec branch is the longer one, so its kernels are created first and the f0 branch's after them
+            const size_t cv_end = pl.ops.v.size();
+            std::rotate(pl.ops.v.begin() + rm_begin, pl.ops.v.begin() + rm_end, pl.ops.v.begin() + cv_end);
+            std::rotate(pl.ops.sid.begin() + rm_begin, pl.ops.sid.begin() + rm_end, pl.ops.sid.begin() + cv_end);
+            std::rotate(pl.ops.kind.begin() + rm_begin, pl.ops.kind.begin() + rm_end, pl.ops.kind.begin() + cv_end);
+        }
         pl.ops.join(1);
         if (getenv("RVC_NSF_MAIN")) src0 = build_nsf_source(e, pl, B, d_pitchf0);
         build_synth(e, pl, B, phone, src0, d_pitchf, d_pitch);
@@ -1506,6 +1551,7 @@ static rvc_status check_status(rvc_engine *e)
         if (e->h_status[b] != 0) {
             int zero = 0;
             HIPCHK(hipMemcpy((char *)(e->d_state + b) + offsetof(StreamState, status), &zero, sizeof(int), hipMemcpyHostToDevice));
+            if (e->h_status[b] == 7) { e->err = "GRU hand-off timed out (multi-CU recurrence)"; return RVC_BACKEND; }
             e->err = "to_local_average_cents: index out of bounds (argmax bin >= 348), the reference panics here";
             return RVC_PANIC;
         }
@@ -1579,6 +1625,7 @@ void rvc_destroy(rvc_engine *e)
     if (e->d_window) (void)hipFree(e->d_window);
     if (e->d_twiddle) (void)hipFree(e->d_twiddle);
     if (e->d_basis) (void)hipFree(e->d_basis);
+    if (e->d_band) (void)hipFree(e->d_band);
     if (e->d_index && e->index_owned) (void)hipFree(e->d_index);
     if (e->d_indexT) (void)hipFree(e->d_indexT);
     if (e->d_ynorm) (void)hipFree(e->d_ynorm);

@@ -584,6 +584,7 @@ struct MelP {
     const float *window;    // [1024]
     const float *twiddle;   // [512][2] cos,sin of -2*pi*j/1024
     const float *basis;     // [128][513]
+    const int *band;        // [128][2] first / one-past-last non-zero bin of each mel filter
     float *mel;             // [B][128][Tm] raw log-mel (tap / parity)
     float *img;             // RMVPE input image interior pointer
     long long img_bs; int img_ld;
@@ -622,18 +623,16 @@ __global__ __launch_bounds__(256) void mel_frontend_kernel(MelP p)
     }
     for (int k = tid; k < 513; k += 256) mag[k] = sqrtf(re[k] * re[k] + im[k] * im[k]);
     __syncthreads();
-    // 128 mel bins: each wave reduces 32 of them, lanes stride over the 513 magnitudes
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int m = wave * 32; m < wave * 32 + 32; m++) {
+    // 128 mel bins: the triangular filters are sparse (a few to ~45 non-zero bins each), so one thread per filter walks only
+    // its non-zero range [lo, hi) -- ascending k, i.e. the dense k-ordered sum without the exact zeros
+    if (tid < 128) {
+        const int m = tid, lo = p.band[2 * m], hi = p.band[2 * m + 1];
         const float *br = p.basis + m * 513;
         float s = 0.f;
-        for (int k = lane; k < 513; k += 64) s += br[k] * mag[k];
-        s = wave_sum(s);
-        if (lane == 0) {
-            float lm = logf(fmaxf(s, 1e-5f));
-            p.mel[((long long)b * 128 + m) * p.Tm + t] = lm;
-            p.img[(long long)b * p.img_bs + (long long)t * p.img_ld + m] = lm * p.bn_scale + p.bn_shift;
-        }
+        for (int k = lo; k < hi; k++) s += br[k] * mag[k];
+        const float lm = logf(fmaxf(s, 1e-5f));
+        p.mel[((long long)b * 128 + m) * p.Tm + t] = lm;
+        p.img[(long long)b * p.img_bs + (long long)t * p.img_ld + m] = lm * p.bn_scale + p.bn_shift;
     }
 }
 
@@ -832,6 +831,109 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnP p)
     }
 }
 
+// Matrix-core attention for ContentVec (no relative terms, head_dim % 16 == 0, T <= 256).  One workgroup = one head x 16
+// query rows.  S = (Q*scale) K^T: A = the 16-row Q tile (registers), B = K read straight from global (lanes along t, coalesced),
+// the 4 waves split the key fragments.  Softmax over the D fragments (16-lane shuffles + a 4-wave LDS exchange).  O = P V: P goes
+// through LDS into the A layout, V is staged once in LDS ([hd][T|1], so lanes-along-d reads are conflict-free), waves split head_dim.
+__global__ __launch_bounds__(256) void attention_mfma_kernel(AttnP p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int hd = p.E / p.heads, T = p.T, Tp = T | 1;
+    const int qtiles = (T + 15) / 16, kfr = (T + 15) / 16, T4 = (T + 3) & ~3;
+    const int h = blockIdx.x / qtiles, qt = blockIdx.x - h * qtiles, b = blockIdx.y;
+    float *Vs = smem;                         // [hd][Tp]
+    float *Ps = Vs + hd * Tp;                 // [16][Tq], Tq = kfr*16 + 1
+    const int Tq = kfr * 16 + 1;
+    float *red = Ps + 16 * Tq;                // [4 waves][16 rows] x 2
+    const float *base = p.qkv + (long long)b * p.bs;
+    const float *qb = base + (long long)(h * hd) * p.cs, *kb = base + (long long)(p.E + h * hd) * p.cs, *vb = base + (long long)(2 * p.E + h * hd) * p.cs;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
+    for (int d = wave; d < hd; d += 4)
+        for (int t = lane; t < T; t += 64) Vs[d * Tp + t] = vb[(long long)d * p.cs + t];
+    const int t1 = qt * 16;
+    // S fragments of this wave: key fragments wave, wave+4, ... (at most 4 for T <= 256)
+    f32x4 sacc[4];
+#pragma unroll
+    for (int f = 0; f < 4; f++) sacc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        const int tq = t1 + li < T ? t1 + li : T - 1;
+        for (int c = 0; c < hd / 4; c++) {
+            const int d = c * 4 + kq;
+            const float a = qb[(long long)d * p.cs + tq] * p.scale;
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+                const int kf = wave + f * 4;
+                if (kf < kfr) {
+                    int t2 = kf * 16 + li; t2 = t2 < T ? t2 : T - 1;
+                    const float bv = kb[(long long)d * p.cs + t2];
+                    sacc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, sacc[f], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // row statistics: this lane holds rows kq*4 + r, column li of each of its key fragments
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        const int kf = wave + f * 4;
+        const bool ok = kf < kfr && kf * 16 + li < T;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { if (!ok) sacc[f][r] = -INFINITY; mx[r] = fmaxf(mx[r], sacc[f][r]); }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
+        if (li == 0) red[wave * 16 + kq * 4 + r] = mx[r];
+    }
+    __syncthreads();
+    float sum[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = kq * 4 + r;
+        mx[r] = fmaxf(fmaxf(red[row], red[16 + row]), fmaxf(red[32 + row], red[48 + row]));
+        sum[r] = 0.f;
+    }
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        const int kf = wave + f * 4;
+        if (kf < kfr) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float e = expf(sacc[f][r] - mx[r]);      // exp(-inf) = 0 for the masked columns
+                sum[r] += e;
+                Ps[(kq * 4 + r) * Tq + kf * 16 + li] = e;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) sum[r] += __shfl_xor(sum[r], o, 64);
+        if (li == 0) red[64 + wave * 16 + kq * 4 + r] = sum[r];
+    }
+    __syncthreads();
+    // O = P V, this wave's head_dim fragments dt = wave, wave + 4, ...
+    for (int dt = wave; dt * 16 < hd; dt += 4) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        const float *pr = Ps + li * Tq + kq;
+        const float *vr = Vs + (dt * 16 + li) * Tp + kq;
+        for (int c = 0; c < T4; c += 4) {
+            const float a = pr[c];                                   // columns >= T hold exp(-inf) = 0 or were never used: guard below
+            const float bv = (c + kq < T) ? vr[c] : 0.f;
+            const float aa = (c + kq < T) ? a : 0.f;
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, bv, o, 0, 0, 0);
+        }
+        // D: row = kq*4 + r (query), col = li (d)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = kq * 4 + r, tq = t1 + row;
+            const float inv = 1.0f / (red[64 + row] + red[64 + 16 + row] + red[64 + 32 + row] + red[64 + 48 + row]);
+            if (tq < T) p.out[(long long)b * p.o_bs + (long long)(h * hd + dt * 16 + li) * p.o_cs + tq] = o[r] * inv;
+        }
+    }
+}
+
 // Small-T attention with relative-position terms (synthesizer TextEncoder: T = return_length <= 64, 2 heads x 96).
 // One workgroup per (head, stream); Q/K/V, both relative tables and the T x T score matrix live in LDS.
 __global__ __launch_bounds__(256) void relpos_attention_small_kernel(AttnP p)
@@ -988,6 +1090,89 @@ __global__ __launch_bounds__(768) void gru256_kernel(const float *gi, int gi_cs,
             float hn = (1.f - zg) * ng + zg * hs[r];
             hs[r] = hn;
             ob[(long long)r * o_cs + t] = hn;
+        }
+        __syncthreads();
+    }
+}
+
+// Multi-CU recurrence for few streams (B <= 8): 8 workgroups per direction, each owning 32 hidden units = 96 gate rows
+// whose 96 KB slice of W_hh stays in LDS for all steps.  After every step the 8 slices exchange their 32 new h values through
+// 8-byte {epoch, value} granules (cdna_hip_programming.md guideline 16, form R2: the data is the flag; relaxed agent-scope
+// stores / loads, no fences, placement independent).  Two granule slots alternate by step parity; the granule buffer is zeroed
+// by a memset node before every launch.  Every spin is bounded: on timeout the stream's status word is raised instead of hanging.
+struct GruMultiP {
+    const float *gi; int gi_cs; long long gi_bs;
+    const float *whh;          // [2][3H][H] row-major
+    const float *bhh;          // [2][3H]
+    float *out; int o_cs; long long o_bs;
+    unsigned long long *gran;  // [B][2 dirs][2 slots][H]
+    int *status;               // per stream, stride status_stride ints
+    int status_stride;
+    int Tm;
+};
+__global__ __launch_bounds__(256) void gru_multi_kernel(GruMultiP p)
+{
+    constexpr int H = 256, G = 8, U = H / G, ROWS = 3 * U, RS = H + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *w = smem;                    // [ROWS][RS]
+    float *hs = w + ROWS * RS;          // [H]
+    float *gh = hs + H;                 // [ROWS]
+    const int g = blockIdx.x, dir = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const float *wsrc = p.whh + (long long)dir * 3 * H * H;
+    for (int i = tid; i < ROWS * (H / 4); i += 256) {
+        const int row = i / (H / 4), c4 = i - row * (H / 4);
+        const int gate = row / U, u = row - gate * U;
+        *reinterpret_cast<f32x4 *>(w + row * RS + c4 * 4) = *reinterpret_cast<const f32x4 *>(wsrc + (long long)(gate * H + g * U + u) * H + c4 * 4);
+    }
+    hs[tid] = 0.f;
+    const float *gib = p.gi + (long long)b * p.gi_bs + (long long)dir * 3 * H * p.gi_cs;
+    const float *bh = p.bhh + dir * 3 * H;
+    float *ob = p.out + (long long)b * p.o_bs + (long long)dir * H * p.o_cs;
+    unsigned long long *gr = p.gran + ((long long)(b * 2 + dir) * 2) * H;
+    __syncthreads();
+    bool dead = false;
+    for (int step = 0; step < p.Tm; step++) {
+        const int t = dir == 0 ? step : p.Tm - 1 - step;
+        if (step > 0) {
+            // gather h_{step-1}: granule `tid` of slot (step-1)&1 must carry tag == step
+            const unsigned long long *src = gr + ((step - 1) & 1) * H + tid;
+            unsigned long long x = 0;
+            unsigned spins = 0;
+            while (!dead) {
+                x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(x >> 32) == (unsigned)step) break;
+                if (++spins > (1u << 22)) { dead = true; p.status[b * p.status_stride] = 7; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            hs[tid] = __uint_as_float((unsigned)x);
+            __syncthreads();
+        }
+        // 96 rows x 256: two threads per row, 128 k each
+        if (tid < 2 * ROWS) {
+            const int row = tid >> 1, half = tid & 1;
+            const float *wr = w + row * RS + half * (H / 2);
+            const float *hr = hs + half * (H / 2);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < H / 2; k += 4) {
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(wr + k), hv = *reinterpret_cast<const f32x4 *>(hr + k);
+                a0 += wv[0] * hv[0]; a1 += wv[1] * hv[1]; a2 += wv[2] * hv[2]; a3 += wv[3] * hv[3];
+            }
+            float a = (a0 + a1) + (a2 + a3);
+            a += __shfl_xor(a, 1, 64);
+            if (half == 0) { const int gate = row / U, u = row - gate * U; gh[row] = a + bh[gate * H + g * U + u]; }
+        }
+        __syncthreads();
+        if (tid < U) {
+            const int unit = g * U + tid;
+            const float ir = gib[(long long)unit * p.gi_cs + t], iz = gib[(long long)(H + unit) * p.gi_cs + t], in_ = gib[(long long)(2 * H + unit) * p.gi_cs + t];
+            const float rg = 1.0f / (1.0f + expf(-(ir + gh[tid])));
+            const float zg = 1.0f / (1.0f + expf(-(iz + gh[U + tid])));
+            const float ng = tanhf(in_ + rg * gh[2 * U + tid]);
+            const float hn = (1.f - zg) * ng + zg * hs[unit];
+            ob[(long long)unit * p.o_cs + t] = hn;
+            __hip_atomic_store(gr + (step & 1) * H + unit, ((unsigned long long)(unsigned)(step + 1) << 32) | (unsigned long long)__float_as_uint(hn),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
     }
