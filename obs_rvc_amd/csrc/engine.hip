@@ -116,6 +116,7 @@ struct ConvW {
     int Cin = 0, Cout = 0, KW = 1, groups = 1;
     int S = 1, ntaps = 1;      // transposed convs
     bool transposed = false;
+    bool owns = true;          // false: w / bias point into a buffer owned by another ConvW (merge_convs)
     std::vector<float> host_w; // row-major [Cout][K] copy kept for big 3x3 convs (plan-time tap pruning)
 };
 
@@ -209,9 +210,30 @@ static ConvW prep_convT2d(const float *w, const float *bias, int Cin, int Cout)
 static long long phase_stride(const ConvW &c) { return (long long)((c.M + 15) / 16 * 16) * c.Kp; }
 static void free_conv(ConvW &c)
 {
-    if (c.w) (void)hipFree(c.w);
-    if (c.bias) (void)hipFree(c.bias);
+    if (c.owns) {
+        if (c.w) (void)hipFree(c.w);
+        if (c.bias) (void)hipFree(c.bias);
+    }
     c.w = c.bias = nullptr;
+}
+// Re-home the weights of several convolutions in ONE device allocation (the first one owns it), so that a fused launch can
+// address them as phases of one weight buffer (PhaseD::w_off / bias_off are offsets from the first conv's pointers).
+static void merge_convs(const std::vector<ConvW *> &cs)
+{
+    size_t tw = 0, tb = 0;
+    for (ConvW *c : cs) { if (!c->owns || !c->bias) throw std::runtime_error("merge_convs: unexpected conv"); tw += (size_t)c->nphase * phase_stride(*c); tb += (size_t)c->Cout; }
+    float *W, *Bv;
+    HIPCHK(hipMalloc(&W, tw * sizeof(float))); HIPCHK(hipMalloc(&Bv, std::max<size_t>(tb, 4) * sizeof(float)));
+    size_t ow = 0, ob = 0;
+    for (size_t i = 0; i < cs.size(); i++) {
+        ConvW *c = cs[i];
+        const size_t nw = (size_t)c->nphase * phase_stride(*c);
+        HIPCHK(hipMemcpy(W + ow, c->w, nw * sizeof(float), hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(Bv + ob, c->bias, (size_t)c->Cout * sizeof(float), hipMemcpyDeviceToDevice));
+        (void)hipFree(c->w); (void)hipFree(c->bias);
+        c->w = W + ow; c->bias = Bv + ob; c->owns = i == 0;
+        ow += nw; ob += c->Cout;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -320,9 +342,12 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     p.koff_bias = -kmin * 4;
     const bool pre = p.pre_act != ACT_NONE;
     p.koff = pl.arena.upload(kb);
-    p.ph = pl.arena.upload(phases);
-    p.nphase = (int)phases.size();
-    p.ph0 = phases[0];
+    std::vector<PhaseD> phv(phases);
+    double ksum = 0;   // sum of the phases' K (phases of a fused launch may differ; p.K is the maximum)
+    for (PhaseD &q : phv) { if (q.nchunks == 0) q.nchunks = p.K / 16; ksum += q.nchunks * 16.0; }
+    p.ph = pl.arena.upload(phv);
+    p.nphase = (int)phv.size();
+    p.ph0 = phv[0];
     const int nchunks = p.K / 16;
     auto tiles = [&](int c) {
         long long tm = (p.M + 16 * kMF[c] - 1) / (16 * kMF[c]), tn = (p.N + 16 * kNF[c] - 1) / (16 * kNF[c]);
@@ -361,7 +386,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
         p.ntm = (p.M + bm - 1) / bm; p.ntn = (p.N + bn - 1) / bn;
         dim3 grid(p.ntm * p.ntn, B * p.nphase);
         const size_t lds = (size_t)nchunks * 64 + (size_t)2 * 16 * (bn + 4) * 4;
-        const double flops = 2.0 * p.M * (double)p.N * p.K * B * p.nphase;
+        const double flops = 2.0 * p.M * (double)p.N * ksum * B;
         pl.igemm_flops += flops; pl.n_igemm++;
         Plan *plp = &pl;
         const int lc = lds_cfg;
@@ -402,7 +427,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     const int ntiles = weight_heavy ? p.m_fast * p.ntn : p.ntm * p.ntn;
     dim3 grid(wg_ks > 1 ? ntiles : (ntiles + 3) / 4, B * p.nphase * ksplit);
     dim3 egrid((unsigned)(((long long)p.M * p.N + 255) / 256), B * p.nphase);
-    const double flops = 2.0 * p.M * (double)p.N * p.K * B * p.nphase;
+    const double flops = 2.0 * p.M * (double)p.N * ksum * B;
     pl.igemm_flops += flops;
     pl.n_igemm++;
     Plan *plp = &pl;
@@ -497,6 +522,45 @@ static void add_conv1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int 
         ph[g].y_pos = 0;
         ph[g].bias_off = g * cw.M;
         ph[g].koff_off = 0;
+    }
+    queue_igemm(pl, p, x.B, koff, ph);
+}
+
+// Several stride-1 convs of the same Cin/Cout but different kernel size / dilation as ONE launch (phase j = conv j): the
+// HiFiGAN stage's parallel ResBlock chains.  x is either shared by all convs or a [n*Cin] tensor holding conv j's input in rows
+// j*Cin..; y is a [n*Cout] tensor (conv j writes rows j*Cout..); the residual is shared or grouped likewise.
+static void add_conv1d_multi(Plan &pl, const std::vector<const ConvW *> &cws, const T1 &x, bool x_grouped, const T1 &y,
+                             const std::vector<int> &pads, const std::vector<int> &dils, ConvOpts o = ConvOpts(), bool res_grouped = true)
+{
+    const int n = (int)cws.size();
+    const ConvW &c0 = *cws[0];
+    IgemmP p{};
+    p.x = x.p; p.w = c0.w; p.y = y.p;
+    p.M = c0.M; p.N = y.T; p.K = 0;
+    p.NW = y.T; p.x_hs = 0; p.x_ws = 1; p.y_hm = 0; p.y_ws = 1; p.OW = y.T;
+    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.ld; p.y_rs = 0;
+    fill_epilogue(p, c0, o);
+    p.res_nogroup = res_grouped ? 0 : 1;
+    std::vector<int> koff;
+    std::vector<PhaseD> ph(n);
+    for (int j = 0; j < n; j++) {
+        const ConvW &cw = *cws[j];
+        if (cw.transposed || cw.groups != 1 || cw.Cin != c0.Cin || cw.Cout != c0.Cout || (x_grouped ? x.C != n * cw.Cin : x.C != cw.Cin) || y.C != n * cw.Cout)
+            throw std::runtime_error("add_conv1d_multi: incompatible convs");
+        const int KW = cw.KW, pad = pads[j], dil = dils[j];
+        if (x.T + 2 * pad - dil * (KW - 1) != y.T) throw ShapeError("conv1d_multi output length mismatch");
+        if (x.halo < pad || (KW - 1) * dil - pad > x.halo) throw ShapeError("conv1d_multi halo too small");
+        ph[j] = PhaseD{};
+        ph[j].w_off = cw.w - c0.w;                       // same allocation (merge_convs)
+        ph[j].bias_off = (int)(cw.bias - c0.bias);
+        ph[j].x_off = x_grouped ? j * cw.Cin * x.ld : 0;
+        ph[j].y_c0 = j * cw.Cout;
+        ph[j].koff_off = (int)koff.size();
+        ph[j].nchunks = cw.Kp / 16;
+        p.K = std::max(p.K, cw.Kp);
+        const size_t base = koff.size();
+        koff.resize(base + cw.Kp, 0);
+        for (int ci = 0; ci < cw.Cin; ci++) for (int k = 0; k < KW; k++) koff[base + ci * KW + k] = ci * x.ld + k * dil - pad;
     }
     queue_igemm(pl, p, x.B, koff, ph);
 }
@@ -844,6 +908,12 @@ struct ModelSY {
                 stage.push_back(chain);
             }
             rbs.push_back(stage);
+            // the n_rb chains' q-th convs run as phases of one launch: their weights share an allocation
+            for (int m = 0; m < n_rbd && n_rb > 1; m++) {
+                std::vector<ConvW *> a, bb;
+                for (int j = 0; j < n_rb; j++) { a.push_back(&rbs.back()[j][m].first); bb.push_back(&rbs.back()[j][m].second); }
+                merge_convs(a); merge_convs(bb);
+            }
             c = co;
         }
         dec_post = prep_conv(b.w("sy.dec.post.w"), nullptr, 1, c, 7, 1);
@@ -914,7 +984,6 @@ static void init_kernel_attrs()
     HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)gru_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)gru256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)knn_select_blend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));   // + ~5 KB static
@@ -1014,9 +1083,12 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
         AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = E; ap.T = T; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;
         ap.scale = 1.0f / sqrtf((float)hd); ap.rel_k = nullptr; ap.rel_v = nullptr; ap.window = 0;
         dim3 ag(m.heads * ((T + 15) / 16), B);
-        const size_t mfma_lds = ((size_t)hd * Tp + 16 * (((T + 15) / 16) * 16 + 1) + 128) * sizeof(float);
-        if (hd % 16 == 0 && T <= 256 && mfma_lds <= 160 * 1024 && !getenv("RVC_ATTN_VALU")) {
-            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(attention_mfma_kernel, ag, dim3(256), mfma_lds, s, ap); });
+        if (hd == 64 && T <= 128 && !getenv("RVC_ATTN_VALU")) {
+            const size_t mfma_lds = ((size_t)16 * (2 * 64 + 1) + 128) * sizeof(float);
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL((attention_mfma_kernel<64, 2>), ag, dim3(256), mfma_lds, s, ap); });
+        } else if (hd == 64 && T <= 256 && !getenv("RVC_ATTN_VALU")) {
+            const size_t mfma_lds = ((size_t)16 * (4 * 64 + 1) + 128) * sizeof(float);
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL((attention_mfma_kernel<64, 4>), ag, dim3(256), mfma_lds, s, ap); });
         } else {
             pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(attention_kernel, ag, dim3(256), attn_lds, s, ap); });
         }
@@ -1222,7 +1294,7 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         const size_t small_lds = ((size_t)3 * kc * Tp + 2 * (2 * m.window + 1) * kc + (size_t)R * Tp) * sizeof(float);
         if (R <= 64 && small_lds <= 160 * 1024 && !getenv("RVC_NO_SMALL_ATTN")) {
             dim3 ag(m.heads, B);
-            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(relpos_attention_small_kernel, ag, dim3(256), small_lds, s, ap); });
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(relpos_attention_small_kernel, ag, dim3(1024), small_lds, s, ap); });
         } else {
             dim3 ag(m.heads * ((R + 15) / 16), B);
             pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(attention_kernel, ag, dim3(256), attn_lds, s, ap); });
@@ -1287,11 +1359,33 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         int sf = 1; for (int q = i + 1; q < m.n_ups; q++) sf *= m.up_rate[q];
         { ConvOpts o; o.accumulate = true; if (i + 1 < m.n_ups) add_conv1d(pl, m.ncs[i], src, u, sf, sf / 2, 1, o); else add_conv1d(pl, m.ncs[i], src, u, 1, 0, 1, o); }
         if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "sy.up%d", i); add_tap(pl, nm, u); }
-        // the n_rb ResBlock chains of a stage are independent until their average: run them as parallel graph branches
+        // the n_rb ResBlock chains of a stage are independent until their average
         T1 xs = make_t1(A, B, co, Tn, DH);
         std::vector<T1> finals;
-        const bool par = m.n_rb <= 3 && getenv("RVC_PARALLEL_RESBLOCKS");   // measured slower than serial at B = 1 (each conv already fills the chip)
-        for (int j = 0; j < m.n_rb; j++) {
+        const bool fused = m.n_rb > 1 && m.n_rb <= 3 && B < 16 && !getenv("RVC_SERIAL_RESBLOCKS");   // many streams: every conv fills the chip by itself
+        const bool par = !fused && m.n_rb <= 3 && getenv("RVC_PARALLEL_RESBLOCKS");   // stream-parallel chains: measured slower than serial at B = 1
+        if (fused) {
+            // one launch per (dilation, conv): phase j = chain j (kernel size rb_k[j]); 6 launches per stage instead of 6*n_rb
+            const int nr = m.n_rb;
+            T1 ra = make_t1(A, B, nr * co, Tn, DH), rb = make_t1(A, B, nr * co, Tn, DH), tt = make_t1(A, B, nr * co, Tn, DH), fin = make_t1(A, B, nr * co, Tn, 0);
+            T1 cur = u; bool grouped = false;
+            for (int q = 0; q < m.n_rbd; q++) {
+                const int d = m.rb_d[q];
+                std::vector<const ConvW *> c1, c2; std::vector<int> p1, d1, p2, d2;
+                for (int j = 0; j < nr; j++) {
+                    c1.push_back(&m.rbs[i][j][q].first); c2.push_back(&m.rbs[i][j][q].second);
+                    p1.push_back((m.rb_k[j] * d - d) / 2); d1.push_back(d); p2.push_back((m.rb_k[j] - 1) / 2); d2.push_back(1);
+                }
+                { ConvOpts o; o.pre_act = ACT_LRELU; o.pre_slope = 0.1f; o.act = ACT_LRELU; o.slope = 0.1f; add_conv1d_multi(pl, c1, cur, grouped, tt, p1, d1, o); }
+                const bool last = q == m.n_rbd - 1;
+                T1 dst = last ? fin : (cur.p == ra.p ? rb : ra);
+                ConvOpts o; o.res = cur.p; o.res_cs = cur.ld; o.res_bs = cur.bs;
+                add_conv1d_multi(pl, c2, tt, true, dst, p2, d2, o, grouped);
+                cur = dst; grouped = true;
+            }
+            for (int j = 0; j < nr; j++) finals.push_back(fin.rows(j * co, co));
+        }
+        for (int j = 0; j < m.n_rb && !fused; j++) {
             const int k = m.rb_k[j];
             T1 ra = make_t1(A, B, co, Tn, DH), rb = make_t1(A, B, co, Tn, DH), tt = make_t1(A, B, co, Tn, DH), fin = make_t1(A, B, co, Tn, 0);
             if (par && j > 0) { pl.ops.fork(j); pl.ops.cur = j; }

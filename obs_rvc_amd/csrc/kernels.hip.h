@@ -42,6 +42,7 @@ struct PhaseD {
     int y_pos;         // output column of nw = 0 (polyphase transposed convs); checked against [0, OW)
     int bias_off;      // offset into bias
     int koff_off;      // offset into the koff table
+    int nchunks;       // K/16 of this phase (fused launches of convs with different kernel sizes; filled by queue_igemm)
 };
 
 struct IgemmP {
@@ -65,6 +66,7 @@ struct IgemmP {
     // LDS-tiled stride-1 conv (conv1d_lds_kernel): tap-offset table, input channels, LDS row length, padding, input length/halo
     const int *loff; int c_in, c_rl, c_pad, c_t, c_halo, x_cs;
     int koff_bias;           // bytes: the koff table holds (offset - min offset) * 4, the base pointer is moved back by this
+    int res_nogroup;         // residual channel = m (a tensor shared by all phases) instead of m + y_c0
     int m_fast;              // XCD-aware tile order: >0 = ntm rounded up to 8, m fastest (workgroup b runs on XCD b%8, so all
                              // n-tiles of one weight-row block share one XCD's L2); 0 = n fastest (activation-heavy layers)
 };
@@ -80,7 +82,7 @@ __device__ __forceinline__ void epilogue_store(const IgemmP &p, const PhaseD &ph
     float v = acc;
     if (p.bias) v += p.bias[ph.bias_off + m];
     v = apply_act(v, p.act, p.slope);
-    if (p.res) v += p.res[(long long)b * p.res_bs + (long long)ch * p.res_cs + (long long)oh * p.res_rs + ow];
+    if (p.res) v += p.res[(long long)b * p.res_bs + (long long)(p.res_nogroup ? m : ch) * p.res_cs + (long long)oh * p.res_rs + ow];
     v *= p.scale;
     float *yp = p.y + (long long)b * p.y_bs + (long long)ch * p.y_cs + (long long)oh * p.y_rs + ow;
     if (p.accumulate) v += *yp;
@@ -106,7 +108,7 @@ __device__ __forceinline__ EpiPre epi_prefetch(const IgemmP &p, const PhaseD &ph
     int ch, oh, ow;
     if (!epi_locate(p, ph, m, n, ch, oh, ow)) return e;
     if (p.bias) e.bias = p.bias[ph.bias_off + m];
-    if (p.res) e.res = p.res[(long long)b * p.res_bs + (long long)ch * p.res_cs + (long long)oh * p.res_rs + ow];
+    if (p.res) e.res = p.res[(long long)b * p.res_bs + (long long)(p.res_nogroup ? m : ch) * p.res_cs + (long long)oh * p.res_rs + ow];
     if (p.accumulate) e.yold = p.y[(long long)b * p.y_bs + (long long)ch * p.y_cs + (long long)oh * p.y_rs + ow];
     return e;
 }
@@ -146,7 +148,7 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
     const int phase = z % p.nphase;
     const int b = z / p.nphase;
     const PhaseD ph = p.nphase == 1 ? p.ph0 : p.ph[phase];
-    const int nchunks = p.K >> 4;
+    const int nchunks = ph.nchunks;
     const int g0 = ks * p.chunks_per_split;
     int g1 = g0 + p.chunks_per_split;
     g1 = g1 < nchunks ? g1 : nchunks;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256) void igemm_lds_kernel(IgemmP p)
     const int phase = z % p.nphase;
     const int b = z / p.nphase;
     const PhaseD ph = p.nphase == 1 ? p.ph0 : p.ph[phase];
-    const int nchunks = p.K >> 4;
+    const int nchunks = ph.nchunks;
     {
         const int4 *src = reinterpret_cast<const int4 *>(p.koff + ph.koff_off);
         int4 *dst = reinterpret_cast<int4 *>(s_mem);
@@ -660,6 +662,12 @@ __global__ __launch_bounds__(256) void layernorm_ct_kernel(const float *x, float
         v[i] = (ok && c < C) ? xp[(long long)c * x_cs] : 0.f;
         s += v[i];
     }
+    float gv[NV], bv[NV];       // loaded now, consumed after the two reductions
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int c = ty + i * 64;
+        gv[i] = c < C ? g[c] : 0.f; bv[i] = c < C ? bta[c] : 0.f;
+    }
     // reduce over the 16 lanes of this wave that share tx (lane bits 2..5), then over the 4 waves through LDS
 #pragma unroll
     for (int o = 4; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
@@ -685,7 +693,7 @@ __global__ __launch_bounds__(256) void layernorm_ct_kernel(const float *x, float
 #pragma unroll
         for (int i = 0; i < NV; i++) {
             const int c = ty + i * 64;
-            if (c < C) yp[(long long)c * y_cs] = (v[i] - mean) * inv * g[c] + bta[c];
+            if (c < C) yp[(long long)c * y_cs] = (v[i] - mean) * inv * gv[i] + bv[i];
         }
     }
 }
@@ -831,50 +839,56 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnP p)
     }
 }
 
-// Matrix-core attention for ContentVec (no relative terms, head_dim % 16 == 0, T <= 256).  One workgroup = one head x 16
-// query rows.  S = (Q*scale) K^T: A = the 16-row Q tile (registers), B = K read straight from global (lanes along t, coalesced),
-// the 4 waves split the key fragments.  Softmax over the D fragments (16-lane shuffles + a 4-wave LDS exchange).  O = P V: P goes
-// through LDS into the A layout, V is staged once in LDS ([hd][T|1], so lanes-along-d reads are conflict-free), waves split head_dim.
+// Matrix-core attention for ContentVec (no relative terms, T <= 64*KF).  One workgroup = one head x 16 query rows.
+// Latency-shaped for B = 1: every global operand (the Q tile, this wave's K fragments, this wave's V fragments) is loaded into
+// registers up front in fully unrolled code, so the kernel pays ~one memory round trip instead of one per loop iteration.
+// S = (Q*scale) K^T: A = Q tile, B = K (lanes along t, coalesced), the 4 waves split the key fragments.  Softmax over the
+// D fragments (16-lane shuffles + a 4-wave LDS exchange).  O = P V: P goes through LDS into the A layout, V stays in registers
+// in the B layout (lane (kq, li) holds V[d = dt*16 + li][t = 4c + kq]); the 4 waves split head_dim (HD/16 <= 4 fragments... one per wave
+// for HD = 64; HD = 128 would need two passes and is handled by the VALU kernel).
+template <int HD, int KF>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnP p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int hd = p.E / p.heads, T = p.T, Tp = T | 1;
-    const int qtiles = (T + 15) / 16, kfr = (T + 15) / 16, T4 = (T + 3) & ~3;
+    constexpr int NC = KF * 16;                // t-chunks of 4 covered by the V registers
+    const int T = p.T;
+    const int qtiles = (T + 15) / 16, kfr = (T + 15) / 16;
     const int h = blockIdx.x / qtiles, qt = blockIdx.x - h * qtiles, b = blockIdx.y;
-    float *Vs = smem;                         // [hd][Tp]
-    float *Ps = Vs + hd * Tp;                 // [16][Tq], Tq = kfr*16 + 1
-    const int Tq = kfr * 16 + 1;
+    const int Tq = KF * 64 + 1;
+    float *Ps = smem;                         // [16][Tq]
     float *red = Ps + 16 * Tq;                // [4 waves][16 rows] x 2
     const float *base = p.qkv + (long long)b * p.bs;
-    const float *qb = base + (long long)(h * hd) * p.cs, *kb = base + (long long)(p.E + h * hd) * p.cs, *vb = base + (long long)(2 * p.E + h * hd) * p.cs;
+    const float *qb = base + (long long)(h * HD) * p.cs, *kb = base + (long long)(p.E + h * HD) * p.cs, *vb = base + (long long)(2 * p.E + h * HD) * p.cs;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
-    for (int d = wave; d < hd; d += 4)
-        for (int t = lane; t < T; t += 64) Vs[d * Tp + t] = vb[(long long)d * p.cs + t];
     const int t1 = qt * 16;
-    // S fragments of this wave: key fragments wave, wave+4, ... (at most 4 for T <= 256)
-    f32x4 sacc[4];
-#pragma unroll
-    for (int f = 0; f < 4; f++) sacc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float qa[HD / 4], kv[HD / 4][KF], vv[NC];
     {
         const int tq = t1 + li < T ? t1 + li : T - 1;
-        for (int c = 0; c < hd / 4; c++) {
-            const int d = c * 4 + kq;
-            const float a = qb[(long long)d * p.cs + tq] * p.scale;
 #pragma unroll
-            for (int f = 0; f < 4; f++) {
-                const int kf = wave + f * 4;
-                if (kf < kfr) {
-                    int t2 = kf * 16 + li; t2 = t2 < T ? t2 : T - 1;
-                    const float bv = kb[(long long)d * p.cs + t2];
-                    sacc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, sacc[f], 0, 0, 0);
-                }
-            }
+        for (int c = 0; c < HD / 4; c++) qa[c] = qb[(long long)(c * 4 + kq) * p.cs + tq];
+#pragma unroll
+        for (int f = 0; f < KF; f++) {
+            int t2 = (wave + f * 4) * 16 + li; t2 = t2 < T ? t2 : T - 1;
+#pragma unroll
+            for (int c = 0; c < HD / 4; c++) kv[c][f] = kb[(long long)(c * 4 + kq) * p.cs + t2];
         }
+        const float *vr = vb + (long long)(wave * 16 + li) * p.cs + kq;
+#pragma unroll
+        for (int c = 0; c < NC; c++) vv[c] = (wave * 16 < HD && c * 4 + kq < T) ? vr[c * 4] : 0.f;
+    }
+    f32x4 sacc[KF];
+#pragma unroll
+    for (int f = 0; f < KF; f++) sacc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < HD / 4; c++) {
+        const float a = qa[c] * p.scale;
+#pragma unroll
+        for (int f = 0; f < KF; f++) sacc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, kv[c][f], sacc[f], 0, 0, 0);
     }
     // row statistics: this lane holds rows kq*4 + r, column li of each of its key fragments
     float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-    for (int f = 0; f < 4; f++) {
+    for (int f = 0; f < KF; f++) {
         const int kf = wave + f * 4;
         const bool ok = kf < kfr && kf * 16 + li < T;
 #pragma unroll
@@ -895,15 +909,13 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnP p)
         sum[r] = 0.f;
     }
 #pragma unroll
-    for (int f = 0; f < 4; f++) {
+    for (int f = 0; f < KF; f++) {
         const int kf = wave + f * 4;
-        if (kf < kfr) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float e = expf(sacc[f][r] - mx[r]);      // exp(-inf) = 0 for the masked columns
-                sum[r] += e;
-                Ps[(kq * 4 + r) * Tq + kf * 16 + li] = e;
-            }
+        for (int r = 0; r < 4; r++) {
+            const float e = expf(sacc[f][r] - mx[r]);      // exp(-inf) = 0 for the masked columns
+            sum[r] += e;
+            Ps[(kq * 4 + r) * Tq + kf * 16 + li] = e;       // every column of [0, 64*KF) is written (zeros beyond T)
         }
     }
 #pragma unroll
@@ -913,47 +925,61 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnP p)
         if (li == 0) red[64 + wave * 16 + kq * 4 + r] = sum[r];
     }
     __syncthreads();
-    // O = P V, this wave's head_dim fragments dt = wave, wave + 4, ...
-    for (int dt = wave; dt * 16 < hd; dt += 4) {
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    // O = P V, this wave's head_dim fragment dt = wave
+    if (wave * 16 < HD) {
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
         const float *pr = Ps + li * Tq + kq;
-        const float *vr = Vs + (dt * 16 + li) * Tp + kq;
-        for (int c = 0; c < T4; c += 4) {
-            const float a = pr[c];                                   // columns >= T hold exp(-inf) = 0 or were never used: guard below
-            const float bv = (c + kq < T) ? vr[c] : 0.f;
-            const float aa = (c + kq < T) ? a : 0.f;
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, bv, o, 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NC; c += 2) {
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[c * 4], vv[c], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[c * 4 + 4], vv[c + 1], o1, 0, 0, 0);
         }
         // D: row = kq*4 + r (query), col = li (d)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = kq * 4 + r, tq = t1 + row;
             const float inv = 1.0f / (red[64 + row] + red[64 + 16 + row] + red[64 + 32 + row] + red[64 + 48 + row]);
-            if (tq < T) p.out[(long long)b * p.o_bs + (long long)(h * hd + dt * 16 + li) * p.o_cs + tq] = o[r] * inv;
+            if (tq < T) p.out[(long long)b * p.o_bs + (long long)(h * HD + wave * 16 + li) * p.o_cs + tq] = (o0[r] + o1[r]) * inv;
         }
     }
 }
 
 // Small-T attention with relative-position terms (synthesizer TextEncoder: T = return_length <= 64, 2 heads x 96).
-// One workgroup per (head, stream); Q/K/V, both relative tables and the T x T score matrix live in LDS.
-__global__ __launch_bounds__(256) void relpos_attention_small_kernel(AttnP p)
+// One workgroup of 1024 threads per (head, stream); Q/K/V, both relative tables and the T x T score matrix live in LDS.
+// Staging is "all loads into registers, then all LDS stores" in unrolled batches: the kernel is a latency chain at B = 1.
+__global__ __launch_bounds__(1024) void relpos_attention_small_kernel(AttnP p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = 1024, U = 8;
     const int hd = p.E / p.heads, T = p.T, Tp = T | 1, W = p.window, NR = 2 * W + 1;
     const int h = blockIdx.x, b = blockIdx.y;
-    float *Qs = smem, *Ks = Qs + hd * Tp, *Vs = Ks + hd * Tp;     // [hd][Tp]
-    float *Rk = Vs + hd * Tp, *Rv = Rk + NR * hd;                  // [NR][hd]
+    float *Qs = smem, *Ks = Qs + hd * Tp, *Vs = Ks + hd * Tp;     // [hd][Tp] each, contiguous: Q, K, V
+    float *Rk = Vs + hd * Tp, *Rv = Rk + NR * hd;                  // [NR][hd] each, contiguous
     float *S = Rv + NR * hd;                                       // [T][Tp]
     const float *base = p.qkv + (long long)b * p.bs;
-    for (int i = threadIdx.x; i < hd * T; i += 256) {
-        int d = i / T, t = i - d * T;
-        Qs[d * Tp + t] = base[(long long)(h * hd + d) * p.cs + t] * p.scale;
-        Ks[d * Tp + t] = base[(long long)(p.E + h * hd + d) * p.cs + t];
-        Vs[d * Tp + t] = base[(long long)(2 * p.E + h * hd + d) * p.cs + t];
+    const int hT = hd * T, tot = 3 * hT, rtot = 2 * NR * hd;
+    for (int i0 = 0; i0 < tot + rtot; i0 += NT * U) {
+        float v[U]; int dst[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u * NT + (int)threadIdx.x;
+            dst[u] = -1; v[u] = 0.f;
+            if (i < tot) {
+                const int which = i / hT, rem = i - which * hT, d = rem / T, t = rem - d * T;
+                v[u] = base[(long long)(which * p.E + h * hd + d) * p.cs + t];
+                if (which == 0) v[u] *= p.scale;
+                dst[u] = which * hd * Tp + d * Tp + t;
+            } else if (i < tot + rtot) {
+                const int j = i - tot;
+                v[u] = j < NR * hd ? p.rel_k[j] : p.rel_v[j - NR * hd];
+                dst[u] = 3 * hd * Tp + j;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) if (dst[u] >= 0) smem[dst[u]] = v[u];
     }
-    for (int i = threadIdx.x; i < NR * hd; i += 256) { Rk[i] = p.rel_k[i]; Rv[i] = p.rel_v[i]; }
     __syncthreads();
-    for (int e = threadIdx.x; e < T * T; e += 256) {
+    for (int e = threadIdx.x; e < T * T; e += NT) {
         const int i = e / T, j = e - i * T;
         float a = 0.f;
         for (int d = 0; d < hd; d++) a += Qs[d * Tp + i] * Ks[d * Tp + j];
@@ -968,7 +994,7 @@ __global__ __launch_bounds__(256) void relpos_attention_small_kernel(AttnP p)
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = wave; i < T; i += 4) {
+    for (int i = wave; i < T; i += NT / 64) {
         float v = lane < T ? S[i * Tp + lane] : -INFINITY;
         const float mx = wave_max(v);
         const float ex = lane < T ? expf(v - mx) : 0.f;
@@ -976,7 +1002,7 @@ __global__ __launch_bounds__(256) void relpos_attention_small_kernel(AttnP p)
         if (lane < T) S[i * Tp + lane] = ex * inv;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < hd * T; e += 256) {
+    for (int e = threadIdx.x; e < hd * T; e += NT) {
         const int d = e / T, i = e - d * T;
         const float *pr = S + i * Tp;
         float a = 0.f;

@@ -148,6 +148,19 @@ def test_other_geometries():
     assert rms(eng.infer(x, 2560, 0, 222, 1) - ora.infer(x, 2560, 0, 222, 1)) < PCM_TOL   # last frame of the 2T+1 (Q2 clamp)
 
 
+def test_hubert_window_lengths_full_preset():
+    # ContentVec attention has three code paths by window length: T <= 128 and T <= 256 (matrix-core kernel with 2 / 4 key
+    # fragments per wave) and the LDS-resident VALU kernel beyond; hubert() on 0.8 s .. 5.5 s windows crosses all of them
+    z, ora, eng = _pair("full")
+    for L in (12800, 38080, 60000, 88000):
+        x = voice_signal(L, seed=11)
+        ho, he = ora.hubert(x), eng.hubert(x)
+        assert he.shape == ho.shape and he.shape[1] == 768
+        assert rel_rms(he, ho) < 1e-4, (L, rel_rms(he, ho))
+    fo, fe = ora.extract_feature(voice_signal(60000, seed=12)), eng.extract_feature(voice_signal(60000, seed=12))
+    assert fe.shape == fo.shape and rel_rms(fe, fo) < 1e-4
+
+
 def test_silence_and_loud_inputs():
     z, ora, eng = _pair("tiny")
     for x in (np.zeros(g.input_buffer_16k_size, np.float32), np.load(os.path.join(GOLDEN, "ref_input_wav.npy"))[:g.input_buffer_16k_size],
