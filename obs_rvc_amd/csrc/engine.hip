@@ -245,6 +245,7 @@ struct ConvOpts {
     const float *res = nullptr; int res_cs = 0; long long res_bs = 0; int res_rs = 0;
     int m_off = 0, m_cnt = -1;   // output-row sub-range of the weight panel
     bool no_bias = false;
+    bool glu = false;            // GLU-packed weight rows, gate fused into the epilogue (ModelSY flows)
 };
 
 struct ProfEvent { hipEvent_t a, b; double flops; double bytes; };   // bytes > 0: HBM-bound retrieval scan (flops = 0)
@@ -260,6 +261,9 @@ struct OpList {
     std::vector<Op> v;
     std::vector<int> sid;    // stream of the op (0 = main, 1..3 auxiliary)
     std::vector<int> kind;   // 0 = op, 1 = fork(sid): stream sid waits for main, 2 = join(sid): main waits for stream sid
+    // issue order (indices into v): host launch order decides which concurrent branch is fed first.  Eager launches follow it
+    // exactly; a captured hipGraph is submitted branch by branch, the branch of the first created node first.
+    std::vector<int> order_eager, order_graph;
     int cur = 0;
     void push_back(Op o) { v.push_back(std::move(o)); sid.push_back(cur); kind.push_back(0); }
     void fork(int s) { v.push_back(Op()); sid.push_back(s); kind.push_back(1); }
@@ -288,6 +292,8 @@ struct Plan {
     double igemm_flops = 0;
     int n_igemm = 0;
     std::vector<float *> owned_dev;   // plan-time repacked weights
+    // timeline probe (RVC_STAMPS=1): one device timestamp per section boundary
+    unsigned long long *d_stamps = nullptr; std::vector<std::string> stamp_names;
     // graph
     hipGraphExec_t graph_exec = nullptr;
     ~Plan()
@@ -331,6 +337,7 @@ static void launch_igemm(int cfg, int ks, bool pre, const IgemmP &p, dim3 grid, 
 #undef RVC_KS
 }
 
+static bool g_in_multi = false;   // set while add_conv1d_multi queues its launch (plan construction is single-threaded per engine)
 // generic: the caller fills geometry (N, NW, strides, koff, phases); this picks the tile + split-K and queues the op
 static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases)
 {
@@ -362,7 +369,9 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     bool found = false;
     for (int oi = 0; oi < 3 && !found; oi++) {
         const int c = order[oi];
-        for (int ks = 1; ks <= 16; ks = ks == 1 ? 4 : ks * 2) {
+        static const int aux_maxks = getenv("RVC_AUX_MAXKS") ? atoi(getenv("RVC_AUX_MAXKS")) : 16;
+        const int max_ks = pl.ops.cur == 1 ? aux_maxks : 16;
+        for (int ks = 1; ks <= max_ks; ks = ks == 1 ? 4 : ks * 2) {
             if (ks > 1 && (nchunks / ks < 4 || ks * kMF[c] * kNF[c] > 32)) break;
             if ((size_t)nchunks * 64 + (ks > 1 ? (size_t)ks * kMF[c] * kNF[c] * 1024 : 0) > 60 * 1024) break;
             const long long w = tiles(c) * ks;
@@ -405,10 +414,14 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
         });
         return;
     }
+    if (g_in_multi) if (const char *f = getenv("RVC_MULTI_CFG")) {   // tuning aid for the fused ResBlock launches: "cfg,ks"
+        int fc = 0, fk = 1; if (sscanf(f, "%d,%d", &fc, &fk) >= 1) { cfg = fc; wg_ks = fk; lds_cfg = -1; }
+    }
     if (const char *f = getenv("RVC_FORCE_CFG")) {   // tuning aid: "cfg,ks[,mfast]"
         int fc = 0, fk = 1; if (sscanf(f, "%d,%d", &fc, &fk) >= 1) { cfg = fc; wg_ks = fk; }
     }
     int ksplit = 1;
+    if ((size_t)nchunks * 64 > 60 * 1024 && p.glu) throw ShapeError("gated conv too long for the fused epilogue");
     if ((size_t)nchunks * 64 > 60 * 1024) {     // koff slice would not fit in LDS: grid-level split (two-stage, rare)
         ksplit = (int)(((size_t)nchunks * 64 + 60 * 1024 - 1) / (60 * 1024));
         cfg = 0; wg_ks = 1;
@@ -455,6 +468,8 @@ static void fill_epilogue(IgemmP &p, const ConvW &cw, const ConvOpts &o)
     if (o.pre_act != ACT_NONE && o.pre_act != ACT_LRELU) throw std::runtime_error("only LeakyReLU can be fused on the input side");
     p.pre_act = o.pre_act; p.pre_slope = o.pre_act == ACT_LRELU ? o.pre_slope : 1.0f;
     p.part = nullptr;
+    p.glu = o.glu ? 1 : 0;
+    if (o.glu && (p.bias == nullptr || o.res || o.accumulate || o.act != ACT_NONE)) throw std::runtime_error("glu epilogue takes bias only");
 }
 
 // Conv1d (stride s, dilation d, symmetric zero padding pad, groups) on halo'd rows
@@ -473,7 +488,7 @@ static void add_conv1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int 
     p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.ld; p.y_rs = 0;
     fill_epilogue(p, cw, o);
     // HiFiGAN-style stride-1 convs with several taps: LDS-resident input tile (each input element fetched once per workgroup)
-    if (stride == 1 && cw.groups == 1 && KW >= 3 && o.m_off == 0 && o.m_cnt < 0 && y.T >= 256 && getenv("RVC_LDS_CONV")) {   // opt-in: measured slower than the register-direct kernel so far
+    if (stride == 1 && cw.groups == 1 && KW >= 3 && o.m_off == 0 && o.m_cnt < 0 && !o.glu && y.T >= 256 && getenv("RVC_LDS_CONV")) {   // opt-in: measured slower than the register-direct kernel so far
         const int span = (KW - 1) * dil;
         const int mt = (cw.M + 15) / 16;
         for (int nf : {4, 1}) {
@@ -562,7 +577,9 @@ static void add_conv1d_multi(Plan &pl, const std::vector<const ConvW *> &cws, co
         koff.resize(base + cw.Kp, 0);
         for (int ci = 0; ci < cw.Cin; ci++) for (int k = 0; k < KW; k++) koff[base + ci * KW + k] = ci * x.ld + k * dil - pad;
     }
+    g_in_multi = true;
     queue_igemm(pl, p, x.B, koff, ph);
+    g_in_multi = false;
 }
 
 // ConvTranspose1d (polyphase), pad = (K - S) / 2 as in HiFiGAN
@@ -659,8 +676,19 @@ static void add_layernorm(Plan &pl, const T1 &x, const float *g, const float *b)
     });
 }
 
+static void add_stamp(Plan &pl, const char *name)
+{
+    static const bool on = getenv("RVC_STAMPS") != nullptr;
+    if (!on) return;
+    if (!pl.d_stamps) pl.d_stamps = reinterpret_cast<unsigned long long *>(pl.arena.floats(2 * 256));
+    if (pl.stamp_names.size() >= 256) return;
+    unsigned long long *slot = pl.d_stamps + pl.stamp_names.size();
+    pl.stamp_names.push_back(name);
+    pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, s, slot); });
+}
 static void add_tap(Plan &pl, const char *name, const T1 &t)
 {
+    add_stamp(pl, name);
     if (!pl.with_taps) return;
     // snapshot into a private contiguous-row tensor so later in-place ops do not clobber it
     T1 snap = make_t1(pl.arena, 1, t.C, t.T, 0);
@@ -671,6 +699,7 @@ static void add_tap(Plan &pl, const char *name, const T1 &t)
 }
 static void add_tap2(Plan &pl, const char *name, const T2 &t)
 {
+    add_stamp(pl, name);
     if (!pl.with_taps) return;
     TapRec r; r.name = name; r.rank = 2; r.t2 = t; pl.taps.push_back(r);   // RMVPE images are never overwritten
 }
@@ -823,7 +852,7 @@ struct ModelSY {
     float *pitch_emb = nullptr;
     struct Layer { ConvW qkv, o, ff1, ff2; float *rel_k, *rel_v, *ln1_g, *ln1_b, *ln2_g, *ln2_b; };
     std::vector<Layer> layers;
-    struct Flow { ConvW pre, post; std::vector<ConvW> in, rs; };
+    struct Flow { ConvW pre, post; std::vector<ConvW> in, rs; bool flipped = false; };
     std::vector<Flow> flows;
     ConvW dec_pre, dec_post;
     std::vector<ConvW> ups, ncs;
@@ -866,7 +895,20 @@ struct ModelSY {
         const int half = inter / 2;
         for (int i = 0; i < flow_n; i++) {
             Flow F;
-            F.pre = prep_conv(b.w(fmt("sy.flow%d.pre.w", i)), b.w(fmt("sy.flow%d.pre.b", i)), H, half, 1, 1);
+            // Flip layers are folded into the weights: the latent stays in its physical channel order and a flow that sees it
+            // flipped (inference runs flip -> coupling from the last flow to the first: flow i after flow_n - i flips) reads its
+            // x0 from the upper half with reversed input columns and writes x1 to the lower half with reversed output rows
+            F.flipped = ((flow_n - i) & 1) != 0;
+            {
+                // rows H..2H are zero: the launch also clears the skip accumulator that sits behind hh in one tensor
+                std::vector<float> w((size_t)2 * H * half, 0.f), bb((size_t)2 * H, 0.f);
+                const float *pw = b.w(fmt("sy.flow%d.pre.w", i)), *pb = b.w(fmt("sy.flow%d.pre.b", i));
+                for (int r = 0; r < H; r++) {
+                    bb[r] = pb[r];
+                    for (int q = 0; q < half; q++) w[(size_t)r * half + q] = pw[(size_t)r * half + (F.flipped ? half - 1 - q : q)];
+                }
+                F.pre = prep_conv(w.data(), bb.data(), 2 * H, half, 1, 1);
+            }
             // speaker conditioning is a load-time constant (sid baked, rvc.rs:186-187): fold cond(g) into the in-layer biases
             const float *cw = b.w(fmt("sy.flow%d.cond.w", i)), *cb = b.w(fmt("sy.flow%d.cond.b", i));
             for (int j = 0; j < wn_layers; j++) {
@@ -877,11 +919,33 @@ struct ModelSY {
                     for (int q = 0; q < G; q++) a += cw[(size_t)(j * 2 * H + r) * G + q] * g[q];
                     bias[r] = ib[r] + a;
                 }
-                F.in.push_back(prep_conv(b.w(fmt("sy.flow%d.in%d.w", i, j)), bias.data(), 2 * H, H, wn_k, 1));
+                {
+                    // GLU row packing (kernels.hip.h glu_store): packed row f*16 + kq*4 + r <- channel f*8 + kq*2 + (r&1), sigmoid half for r >= 2
+                    if (H % 8 != 0) throw std::runtime_error("synth hidden size must be a multiple of 8");
+                    const float *iw = b.w(fmt("sy.flow%d.in%d.w", i, j));
+                    const size_t Kin = (size_t)H * wn_k;
+                    std::vector<float> w((size_t)2 * H * Kin), pb((size_t)2 * H);
+                    for (int r = 0; r < 2 * H; r++) {
+                        const int f = r >> 4, kq = (r & 15) >> 2, rr = r & 3;
+                        const int src = f * 8 + kq * 2 + (rr & 1) + (rr >= 2 ? H : 0);
+                        memcpy(&w[(size_t)r * Kin], iw + (size_t)src * Kin, Kin * sizeof(float));
+                        pb[r] = bias[src];
+                    }
+                    F.in.push_back(prep_conv(w.data(), pb.data(), 2 * H, H, wn_k, 1));
+                }
                 int rs_c = j < wn_layers - 1 ? 2 * H : H;
                 F.rs.push_back(prep_conv(b.w(fmt("sy.flow%d.rs%d.w", i, j)), b.w(fmt("sy.flow%d.rs%d.b", i, j)), rs_c, H, 1, 1));
             }
-            F.post = prep_conv(b.w(fmt("sy.flow%d.post.w", i)), b.w(fmt("sy.flow%d.post.b", i)), half, H, 1, 1);
+            {
+                const float *pw = b.w(fmt("sy.flow%d.post.w", i)), *pb = b.w(fmt("sy.flow%d.post.b", i));
+                std::vector<float> w((size_t)half * H), bb(half);
+                for (int r = 0; r < half; r++) {
+                    const int src = F.flipped ? half - 1 - r : r;
+                    memcpy(&w[(size_t)r * H], pw + (size_t)src * H, (size_t)H * sizeof(float));
+                    bb[r] = pb[src];
+                }
+                F.post = prep_conv(w.data(), bb.data(), half, H, 1, 1);
+            }
             flows.push_back(F);
         }
         {
@@ -1097,7 +1161,7 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
         { ConvOpts o; o.act = ACT_GELU; add_conv1d(pl, Ly.ff1, h2, ff, 1, 0, 1, o); }
         { ConvOpts o; o.res = h2.p; o.res_cs = h2.ld; o.res_bs = h2.bs; add_conv1d(pl, Ly.ff2, ff, h2, 1, 0, 1, o); }
         add_layernorm(pl, h2, Ly.ln2_g, Ly.ln2_b);
-        if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "cv.l%d", l); add_tap(pl, nm, h2); }
+        if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "cv.l%d", l); add_tap(pl, nm, h2); } else if (l % 4 == 3) add_stamp(pl, "cv.l4");
     }
     T1 out = h2;
     if (m.out_dim != E) { out = make_t1(A, B, m.out_dim, T, 0); add_conv1d(pl, m.final_proj, h2, out, 1, 0, 1); }
@@ -1142,6 +1206,7 @@ static T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k,
         mp.mel = d_mel; mp.img = img.p; mp.img_bs = img.bs; mp.img_ld = img.ld; mp.bn_scale = m.bn_scale; mp.bn_shift = m.bn_shift;
         dim3 grid(Tm, B);
         pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(mel_frontend_kernel, grid, dim3(256), 0, s, mp); });
+        add_stamp(pl, "rm.mel0");
         if (pl.with_taps) { T1 t; t.p = d_mel; t.B = B; t.C = 128; t.T = Tm; t.ld = Tm; t.halo = 0; t.bs = 128LL * Tm; add_tap(pl, "rm.mel", t); }
     }
     // encoder; every level's pre-pool output is written straight into the second half of the decoder's concat buffer
@@ -1202,7 +1267,8 @@ static T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k,
             const size_t gbytes = (size_t)B * 2 * 2 * 256 * sizeof(unsigned long long);
             gp.gran = (unsigned long long *)pl.arena.alloc(gbytes);
             const size_t lds3 = (size_t)(96 * 260 + 256 + 96) * sizeof(float);
-            dim3 g3(8, 2, B);
+            gp.B = B; gp.xcd_local = getenv("RVC_GRU_XCD_LOCAL") ? 1 : 0;   // measured: no gain (the agent-scope exchange goes through memory either way)
+            const dim3 g3 = gp.xcd_local ? dim3(64 * ((2 * B + 7) / 8)) : dim3(8, 2, B);
             pl.ops.push_back([=](hipStream_t s) {
                 HIPCHK(hipMemsetAsync(gp.gran, 0, gbytes, s));
                 hipLaunchKernelGGL(gru_multi_kernel, g3, dim3(256), lds3, s, gp);
@@ -1215,7 +1281,7 @@ static T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k,
         }
     }
     { ConvOpts o; o.act = ACT_SIGMOID; add_conv1d(pl, m.fc, gout, sal, 1, 0, 1, o); }
-    if (pl.with_taps) { add_tap(pl, "rm.sal_ct", sal); add_tap(pl, "rm.gru_ct", gout); add_tap(pl, "rm.cnn_ct", feat); }
+    if (pl.with_taps) { add_tap(pl, "rm.sal_ct", sal); add_tap(pl, "rm.gru_ct", gout); add_tap(pl, "rm.cnn_ct", feat); } else add_stamp(pl, "rm.sal");
     return sal;
 }
 
@@ -1268,7 +1334,7 @@ static T1 build_nsf_source(rvc_engine *e, Plan &pl, int B, float *d_pitchf)
     return src;
 }
 
-static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T1 &src, float *d_pitchf, int *d_pitch)
+static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T1 &src, float *d_pitchf, int *d_pitch, int src_join_sid)
 {
     ModelSY &m = *e->sy;
     Arena &A = pl.arena;
@@ -1291,10 +1357,10 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         add_conv1d(pl, Ly.qkv, x, qkv, 1, 0, 1);
         AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = H; ap.T = R; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;
         ap.scale = 1.0f / sqrtf((float)kc); ap.rel_k = Ly.rel_k; ap.rel_v = Ly.rel_v; ap.window = m.window;
-        const size_t small_lds = ((size_t)3 * kc * Tp + 2 * (2 * m.window + 1) * kc + (size_t)R * Tp) * sizeof(float);
+        const size_t small_lds = ((size_t)2 * kc * Tp + 2 * (2 * m.window + 1) * kc + 4 * kc + 4 * 64) * sizeof(float);
         if (R <= 64 && small_lds <= 160 * 1024 && !getenv("RVC_NO_SMALL_ATTN")) {
-            dim3 ag(m.heads, B);
-            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(relpos_attention_small_kernel, ag, dim3(1024), small_lds, s, ap); });
+            dim3 ag(m.heads * ((R + 3) / 4), B);
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(relpos_attention_small_kernel, ag, dim3(256), small_lds, s, ap); });
         } else {
             dim3 ag(m.heads * ((R + 15) / 16), B);
             pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(attention_kernel, ag, dim3(256), attn_lds, s, ap); });
@@ -1315,29 +1381,27 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(prior_sample_kernel, grid, dim3(256), 0, s, stats.p, stats.ld, stats.bs, z.p, z.ld, z.bs, I, R, st, cp); });
     }
     add_tap(pl, "sy.zp", z);
-    T1 hh = make_t1(A, B, H, R, HALO), gate_in = make_t1(A, B, 2 * H, R, 0), acts = make_t1(A, B, H, R, 0), skip = make_t1(A, B, H, R, 0);
+    // hh (WaveNet state, rows 0..H) and skip (rows H..2H) share one tensor: the res_skip conv updates both in one launch
+    T1 hs = make_t1(A, B, 2 * H, R, HALO), acts = make_t1(A, B, H, R, 0);
+    T1 hh = hs.rows(0, H), skip = hs.rows(H, H);
     for (int fi = m.flow_n - 1; fi >= 0; fi--) {
         ModelSY::Flow &Fw = m.flows[fi];
-        {
-            T1 zi = z, zo = zf; dim3 grid((I * R + 255) / 256, B);
-            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(flip_channels_kernel, grid, dim3(256), 0, s, zi.p, zo.p, I, R, zi.ld, zi.bs); });
-        }
-        std::swap(z, zf);   // z now holds the flipped tensor
-        add_conv1d(pl, Fw.pre, z.rows(0, half), hh, 1, 0, 1);
+        const T1 x0 = Fw.flipped ? z.rows(half, half) : z.rows(0, half), x1 = Fw.flipped ? z.rows(0, half) : z.rows(half, half);
+        add_conv1d(pl, Fw.pre, x0, hs, 1, 0, 1);                       // hh = pre(x0), skip = 0
         for (int j = 0; j < m.wn_layers; j++) {
-            add_conv1d(pl, Fw.in[j], hh, gate_in, 1, (m.wn_k - 1) / 2, 1);
-            {
-                dim3 grid((H * R + 255) / 256, B);
-                pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(gate_kernel, grid, dim3(256), 0, s, gate_in.p, gate_in.ld, gate_in.bs, acts.p, acts.ld, acts.bs, H, R); });
-            }
-            if (j < m.wn_layers - 1) {
-                { ConvOpts o; o.m_off = 0; o.m_cnt = H; o.accumulate = true; add_conv1d(pl, Fw.rs[j], acts, hh, 1, 0, 1, o); }
-                { ConvOpts o; o.m_off = H; o.m_cnt = H; o.accumulate = j > 0; add_conv1d(pl, Fw.rs[j], acts, skip, 1, 0, 1, o); }
-            } else {
-                ConvOpts o; o.accumulate = j > 0; add_conv1d(pl, Fw.rs[j], acts, skip, 1, 0, 1, o);
-            }
+            { ConvOpts o; o.glu = true; add_conv1d(pl, Fw.in[j], hh, acts, 1, (m.wn_k - 1) / 2, 1, o); }   // acts = tanh(.) * sigmoid(.)
+            ConvOpts o; o.accumulate = true;
+            if (j < m.wn_layers - 1) add_conv1d(pl, Fw.rs[j], acts, hs, 1, 0, 1, o);     // hh += res, skip += skip part
+            else add_conv1d(pl, Fw.rs[j], acts, skip, 1, 0, 1, o);
         }
-        { ConvOpts o; o.scale = -1.f; o.accumulate = true; add_conv1d(pl, Fw.post, skip, z.rows(half, half), 1, 0, 1, o); }
+        { ConvOpts o; o.scale = -1.f; o.accumulate = true; add_conv1d(pl, Fw.post, skip, x1, 1, 0, 1, o); }
+        add_stamp(pl, "sy.flow");
+    }
+    if (m.flow_n & 1) {
+        // odd number of flips: materialise the last one
+        T1 zi = z, zo = zf; dim3 grid((I * R + 255) / 256, B);
+        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(flip_channels_kernel, grid, dim3(256), 0, s, zi.p, zo.p, I, R, zi.ld, zi.bs); });
+        std::swap(z, zf);
     }
     add_tap(pl, "sy.z", z);
     const int upp = m.upp();
@@ -1348,6 +1412,7 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
     for (int j = 0; j < m.n_rb; j++) for (int q = 0; q < m.n_rbd; q++) max_pad = std::max(max_pad, (m.rb_k[j] * m.rb_d[q] - m.rb_d[q]) / 2);
     const int DH = (max_pad + 3) / 4 * 4;
     int c = m.up_init, Tc = R;
+    if (src_join_sid > 0) pl.ops.join(src_join_sid);     // the harmonic source was produced on a side stream
     T1 xd = make_t1(A, B, c, Tc, DH);
     add_conv1d(pl, m.dec_pre, z, xd, 1, 3, 1);
     add_tap(pl, "sy.pre", xd);
@@ -1358,7 +1423,7 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         { ConvOpts o; o.pre_act = ACT_LRELU; o.pre_slope = 0.1f; add_convT1d(pl, m.ups[i], xd, u, (K - S) / 2, o); }
         int sf = 1; for (int q = i + 1; q < m.n_ups; q++) sf *= m.up_rate[q];
         { ConvOpts o; o.accumulate = true; if (i + 1 < m.n_ups) add_conv1d(pl, m.ncs[i], src, u, sf, sf / 2, 1, o); else add_conv1d(pl, m.ncs[i], src, u, 1, 0, 1, o); }
-        if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "sy.up%d", i); add_tap(pl, nm, u); }
+        if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "sy.up%d", i); add_tap(pl, nm, u); } else add_stamp(pl, "sy.up");
         // the n_rb ResBlock chains of a stage are independent until their average
         T1 xs = make_t1(A, B, co, Tn, DH);
         std::vector<T1> finals;
@@ -1412,7 +1477,7 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
             dim3 grid((co * Tn + 255) / 256, B);
             pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(mean3_kernel, grid, dim3(256), 0, s, f0, f1, f2, fi.ld, fi.bs, xs.p, xs.ld, xs.bs, co, Tn, inv); });
         }
-        if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "sy.rb%d", i); add_tap(pl, nm, xs); }
+        if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "sy.rb%d", i); add_tap(pl, nm, xs); } else add_stamp(pl, "sy.rb");
         xd = xs; c = co; Tc = Tn;
     }
     pl.audio = make_t1(A, B, 1, Tc, 0);
@@ -1425,6 +1490,7 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         pl.ops.push_back([=](hipStream_t s) { HIPCHK(hipMemcpy2DAsync(a2.p, (size_t)Tc * 4, a1.p, (size_t)a1.bs * 4, (size_t)Tc * 4, B, hipMemcpyDeviceToDevice, s)); });
         pl.audio = a2;
     }
+    add_stamp(pl, "sy.audio");
 }
 
 // ------------------------------- plan -------------------------------------------------
@@ -1452,7 +1518,6 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         pl.ops.cur = 1;
         sal0 = build_rmvpe(e, pl, B, L, frame16k, true);
         build_pitch_post(e, pl, B, sal0, true, frame16k, hubert_length0, &d_pitchf0, &d_pitch0);
-        if (!getenv("RVC_NSF_MAIN")) src0 = build_nsf_source(e, pl, B, d_pitchf0);
         pl.ops.cur = 0;
         rm_end = pl.ops.v.size();
     }
@@ -1561,17 +1626,28 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         add_tap(pl, "phone_ct", phone);
         float *d_pitchf = d_pitchf0; int *d_pitch = d_pitch0;
         (void)hubert_length;
-        if (!getenv("RVC_RM_FIRST") && rm_end > rm_begin) {
-            // submission order matters under graph replay (nodes are pushed to the hardware queues in creation order): the
-            // ContentVec branch is the longer one, so its kernels are created first and the f0 branch's after them
-            const size_t cv_end = pl.ops.v.size();
-            std::rotate(pl.ops.v.begin() + rm_begin, pl.ops.v.begin() + rm_end, pl.ops.v.begin() + cv_end);
-            std::rotate(pl.ops.sid.begin() + rm_begin, pl.ops.sid.begin() + rm_end, pl.ops.sid.begin() + cv_end);
-            std::rotate(pl.ops.kind.begin() + rm_begin, pl.ops.kind.begin() + rm_end, pl.ops.kind.begin() + cv_end);
+        if (rm_end > rm_begin && !getenv("RVC_RM_FIRST")) {
+            // Two concurrent branches: f0 (ops [rm_begin, rm_end), aux stream 1) and ContentVec (ops [rm_end, here), main stream).
+            // Launches reach the hardware queues in host order (~3 us each).  Eager: interleave the branches in proportion to
+            // their lengths so both queues are fed from the start (the f0 branch is the longer one once they share the chip).
+            // Graph replay submits a whole branch at a time: put ContentVec first, the f0 branch then starts ~0.2 ms late.
+            OpList &ol = pl.ops;
+            const size_t cv_end = ol.v.size(), na = rm_end - rm_begin, nb = cv_end - rm_end;
+            for (size_t i = 0; i < rm_begin; i++) { ol.order_eager.push_back((int)i); ol.order_graph.push_back((int)i); }
+            size_t ia = 0, ib = 0;
+            while (ia < na || ib < nb) {
+                const bool take_a = ib >= nb || (ia < na && (2 * ia + 1) * nb <= (2 * ib + 1) * na);
+                ol.order_eager.push_back((int)(take_a ? rm_begin + ia++ : rm_end + ib++));
+            }
+            for (size_t i = rm_end; i < cv_end; i++) ol.order_graph.push_back((int)i);
+            for (size_t i = rm_begin; i < rm_end; i++) ol.order_graph.push_back((int)i);
         }
         pl.ops.join(1);
-        if (getenv("RVC_NSF_MAIN")) src0 = build_nsf_source(e, pl, B, d_pitchf0);
-        build_synth(e, pl, B, phone, src0, d_pitchf, d_pitch);
+        // the NSF harmonic source is first needed by the decoder: it runs on a side stream next to the text encoder and the flow
+        pl.ops.fork(2); pl.ops.cur = 2;
+        src0 = build_nsf_source(e, pl, B, d_pitchf0);
+        pl.ops.cur = 0;
+        build_synth(e, pl, B, phone, src0, d_pitchf, d_pitch, 2);
         StreamState *st = e->d_state;
         pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(advance_chunk_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, B); });
     }
@@ -1582,10 +1658,13 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
     return e->plans.back().get();
 }
 
-static void issue_ops(rvc_engine *e, Plan &pl)
+static void issue_ops(rvc_engine *e, Plan &pl, bool capturing)
 {
     // fork/join through events; under stream capture the auxiliary streams become parallel branches of the hipGraph
-    for (size_t i = 0; i < pl.ops.v.size(); i++) {
+    const std::vector<int> &ord = capturing ? pl.ops.order_graph : pl.ops.order_eager;
+    const size_t n = pl.ops.v.size();
+    for (size_t k = 0; k < n; k++) {
+        const size_t i = k < ord.size() ? (size_t)ord[k] : k;      // ops queued after the reordered prefix keep their position
         const int sid = pl.ops.sid[i];
         hipStream_t st = sid == 0 ? e->stream : e->aux[sid - 1];
         if (pl.ops.kind[i] == 1) {
@@ -1609,14 +1688,14 @@ static void run_plan(rvc_engine *e, Plan &pl)
         if (!pl.graph_exec) {
             hipGraph_t g;
             HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-            issue_ops(e, pl);
+            issue_ops(e, pl, true);
             HIPCHK(hipStreamEndCapture(e->stream, &g));
             HIPCHK(hipGraphInstantiate(&pl.graph_exec, g, nullptr, nullptr, 0));
             HIPCHK(hipGraphDestroy(g));
         }
         HIPCHK(hipGraphLaunch(pl.graph_exec, e->stream));
     } else {
-        issue_ops(e, pl);
+        issue_ops(e, pl, false);
     }
     HIPCHK(hipEventRecord(e->ev1, e->stream));
     HIPCHK(hipGetLastError());
@@ -2085,6 +2164,21 @@ rvc_status rvc_sola_step(rvc_engine *e, float *output, size_t output_len, float 
 }
 
 // tuning aid (not part of the reference surface): time one Conv1d(Cin -> M, KW taps, stride 1, "same" padding) over N positions
+// timeline of the last call (RVC_STAMPS=1): "name us-since-first-stamp" lines
+extern "C" int rvc_debug_stamps(rvc_engine *e, char *buf, size_t cap)
+{
+    if (!e || !e->last_plan || !e->last_plan->d_stamps) return 0;
+    Plan &pl = *e->last_plan;
+    std::vector<unsigned long long> h(pl.stamp_names.size());
+    if (hipMemcpy(h.data(), pl.d_stamps, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    unsigned long long t0 = ~0ull; for (auto v : h) t0 = std::min(t0, v);
+    std::string out;
+    for (size_t i = 0; i < h.size(); i++) { char ln[96]; snprintf(ln, sizeof ln, "%s %.2f\n", pl.stamp_names[i].c_str(), (double)(h[i] - t0) / 100.0); out += ln; }
+    if (out.size() + 1 > cap) return -1;
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return (int)h.size();
+}
+
 double rvc_debug_conv_bench(rvc_engine *e, int M, int Cin, int KW, int dil, int N, int iters, int pre_act)
 {
     double us = -1.0;

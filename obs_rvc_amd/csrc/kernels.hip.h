@@ -66,6 +66,7 @@ struct IgemmP {
     // LDS-tiled stride-1 conv (conv1d_lds_kernel): tap-offset table, input channels, LDS row length, padding, input length/halo
     const int *loff; int c_in, c_rl, c_pad, c_t, c_halo, x_cs;
     int koff_bias;           // bytes: the koff table holds (offset - min offset) * 4, the base pointer is moved back by this
+    int glu;                 // WaveNet gate fused into the epilogue: rows are GLU-packed (see glu_store), output has M/2 channels
     int res_nogroup;         // residual channel = m (a tensor shared by all phases) instead of m + y_c0
     int m_fast;              // XCD-aware tile order: >0 = ntm rounded up to 8, m fastest (workgroup b runs on XCD b%8, so all
                              // n-tiles of one weight-row block share one XCD's L2); 0 = n fastest (activation-heavy layers)
@@ -87,6 +88,17 @@ __device__ __forceinline__ void epilogue_store(const IgemmP &p, const PhaseD &ph
     float *yp = p.y + (long long)b * p.y_bs + (long long)ch * p.y_cs + (long long)oh * p.y_rs + ow;
     if (p.accumulate) v += *yp;
     *yp = v;
+}
+
+// Fused WaveNet gate: the weight rows of the in-layer are packed so that every 16-row MFMA fragment holds 8 output channels --
+// fragment row kq*4 + r is the tanh row of channel f*8 + kq*2 + (r&1) for r < 2 and the sigmoid row of the same channel for
+// r >= 2 -- so one lane owns both halves of a channel in its accumulator registers (r, r + 2).
+__device__ __forceinline__ void glu_store(const IgemmP &p, const PhaseD &ph, int b, int m1, int n, float a1, float a2)
+{
+    if (m1 >= p.M || n >= p.N) return;
+    const float ta = a1 + p.bias[ph.bias_off + m1], sa = a2 + p.bias[ph.bias_off + m1 + 2];
+    const int ch = (m1 >> 4) * 8 + ((m1 & 15) >> 2) * 2 + (m1 & 1) + ph.y_c0;
+    p.y[(long long)b * p.y_bs + (long long)ch * p.y_cs + n] = tanhf(ta) * (1.0f / (1.0f + expf(-sa)));
 }
 
 // Latency-chain reduction for short kernels (B = 1): the epilogue's operands (bias, residual, previous output for
@@ -306,6 +318,15 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
             for (int w = 0; w < KS; w++) v += red[w * TE + e];
             const int l = e & 63, r = (e >> 6) & 3, f = e >> 8, mf = f / NF, nf = f - mf * NF;
             const int m = tm * 16 * MF + mf * 16 + (l >> 4) * 4 + r, n = tn * 16 * NF + nf * 16 + (l & 15);
+            if (p.glu) {
+                if (r < 2) {
+                    float v2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < KS; w++) v2 += red[w * TE + e + 128];
+                    glu_store(p, ph, b, m, n, v, v2);
+                }
+                continue;
+            }
             if (p.ksplit == 1) epi_finish(p, ph, b, m, n, v, pre_r[q]);
             else if (m < p.M && n < p.N)
                 p.part[(((long long)(b * p.nphase + phase) * p.ksplit + ks) * p.M + m) * (long long)p.N + n] = v;
@@ -313,6 +334,16 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
         return;
     }
     // D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
+    if (p.glu) {
+#pragma unroll
+        for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+            for (int nf = 0; nf < NF; nf++)
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+                    glu_store(p, ph, b, tm * 16 * MF + mf * 16 + kq * 4 + r, tn * 16 * NF + nf * 16 + li, acc[0][mf][nf][r], acc[0][mf][nf][r + 2]);
+        return;
+    }
     if (p.ksplit == 1) {
 #pragma unroll
         for (int mf = 0; mf < MF; mf++)
@@ -437,6 +468,16 @@ __global__ __launch_bounds__(256) void igemm_lds_kernel(IgemmP p)
 #pragma unroll
         for (int mf = 0; mf < MF; mf++) a_cur[mf] = a_nxt[mf];
         __syncthreads();
+    }
+    if (p.glu) {
+#pragma unroll
+        for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+            for (int nf = 0; nf < NF; nf++)
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+                    glu_store(p, ph, b, ((tm * WM + wm) * MF + mf) * 16 + kq * 4 + r, tn * BN + (wn * NF + nf) * 16 + li, acc[mf][nf][r], acc[mf][nf][r + 2]);
+        return;
     }
 #pragma unroll
     for (int mf = 0; mf < MF; mf++)
@@ -945,20 +986,23 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnP p)
 }
 
 // Small-T attention with relative-position terms (synthesizer TextEncoder: T = return_length <= 64, 2 heads x 96).
-// One workgroup of 1024 threads per (head, stream); Q/K/V, both relative tables and the T x T score matrix live in LDS.
-// Staging is "all loads into registers, then all LDS stores" in unrolled batches: the kernel is a latency chain at B = 1.
-__global__ __launch_bounds__(1024) void relpos_attention_small_kernel(AttnP p)
+// grid = (heads * ceil(T/4), streams); a workgroup owns 4 query rows of one head (one per wave), lanes run along the key axis.
+// K, V, both relative tables and the 4 Q rows are staged "all loads into registers, then all LDS stores" in unrolled batches
+// (the kernel is a latency chain at B = 1); the dot products keep the sequential d / j order of the definition.
+__global__ __launch_bounds__(256) void relpos_attention_small_kernel(AttnP p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NT = 1024, U = 8;
+    constexpr int NT = 256, U = 12;
     const int hd = p.E / p.heads, T = p.T, Tp = T | 1, W = p.window, NR = 2 * W + 1;
-    const int h = blockIdx.x, b = blockIdx.y;
-    float *Qs = smem, *Ks = Qs + hd * Tp, *Vs = Ks + hd * Tp;     // [hd][Tp] each, contiguous: Q, K, V
+    const int qtiles = (T + 3) / 4;
+    const int h = blockIdx.x / qtiles, qt = blockIdx.x - h * qtiles, b = blockIdx.y;
+    float *Ks = smem, *Vs = Ks + hd * Tp;                          // [hd][Tp] each, contiguous: K, V
     float *Rk = Vs + hd * Tp, *Rv = Rk + NR * hd;                  // [NR][hd] each, contiguous
-    float *S = Rv + NR * hd;                                       // [T][Tp]
+    float *Qs = Rv + NR * hd;                                      // [4][hd]
+    float *S = Qs + 4 * hd;                                        // [4][64]
     const float *base = p.qkv + (long long)b * p.bs;
-    const int hT = hd * T, tot = 3 * hT, rtot = 2 * NR * hd;
-    for (int i0 = 0; i0 < tot + rtot; i0 += NT * U) {
+    const int hT = hd * T, tot = 2 * hT, rtot = 2 * NR * hd, qtot = 4 * hd;
+    for (int i0 = 0; i0 < tot + rtot + qtot; i0 += NT * U) {
         float v[U]; int dst[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -966,49 +1010,55 @@ __global__ __launch_bounds__(1024) void relpos_attention_small_kernel(AttnP p)
             dst[u] = -1; v[u] = 0.f;
             if (i < tot) {
                 const int which = i / hT, rem = i - which * hT, d = rem / T, t = rem - d * T;
-                v[u] = base[(long long)(which * p.E + h * hd + d) * p.cs + t];
-                if (which == 0) v[u] *= p.scale;
+                v[u] = base[(long long)((which + 1) * p.E + h * hd + d) * p.cs + t];
                 dst[u] = which * hd * Tp + d * Tp + t;
             } else if (i < tot + rtot) {
                 const int j = i - tot;
                 v[u] = j < NR * hd ? p.rel_k[j] : p.rel_v[j - NR * hd];
-                dst[u] = 3 * hd * Tp + j;
+                dst[u] = 2 * hd * Tp + j;
+            } else if (i < tot + rtot + qtot) {
+                const int j = i - tot - rtot, r = j / hd, d = j - r * hd, tq = qt * 4 + r;
+                v[u] = tq < T ? base[(long long)(h * hd + d) * p.cs + tq] * p.scale : 0.f;
+                dst[u] = 2 * hd * Tp + rtot + j;
             }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) if (dst[u] >= 0) smem[dst[u]] = v[u];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < T * T; e += NT) {
-        const int i = e / T, j = e - i * T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = qt * 4 + wave;
+    if (i >= T) return;
+    const float *q = Qs + wave * hd;
+    float *Sr = S + wave * 64;
+    float sc = -INFINITY;
+    if (lane < T) {
+        const int j = lane;
         float a = 0.f;
-        for (int d = 0; d < hd; d++) a += Qs[d * Tp + i] * Ks[d * Tp + j];
+#pragma unroll 8
+        for (int d = 0; d < hd; d++) a += q[d] * Ks[d * Tp + j];
         const int r = j - i;
         if (r >= -W && r <= W) {
             float ra = 0.f;
             const float *rk = Rk + (r + W) * hd;
-            for (int d = 0; d < hd; d++) ra += Qs[d * Tp + i] * rk[d];
+#pragma unroll 8
+            for (int d = 0; d < hd; d++) ra += q[d] * rk[d];
             a += ra;
         }
-        S[i * Tp + j] = a;
+        sc = a;
     }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = wave; i < T; i += NT / 64) {
-        float v = lane < T ? S[i * Tp + lane] : -INFINITY;
-        const float mx = wave_max(v);
-        const float ex = lane < T ? expf(v - mx) : 0.f;
-        const float inv = 1.0f / wave_sum(ex);
-        if (lane < T) S[i * Tp + lane] = ex * inv;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < hd * T; e += NT) {
-        const int d = e / T, i = e - d * T;
-        const float *pr = S + i * Tp;
+    const float mx = wave_max(sc);
+    const float ex = lane < T ? expf(sc - mx) : 0.f;
+    const float inv = 1.0f / wave_sum(ex);
+    if (lane < T) Sr[lane] = ex * inv;
+    wave_lds_sync();
+    const int lo = i - W < 0 ? 0 : i - W, hi = i + W >= T ? T - 1 : i + W;
+    for (int d = lane; d < hd; d += 64) {
         float a = 0.f;
-        for (int j = 0; j < T; j++) a += pr[j] * Vs[d * Tp + j];
-        const int lo = i - W < 0 ? 0 : i - W, hi = i + W >= T ? T - 1 : i + W;
-        for (int j = lo; j <= hi; j++) a += pr[j] * Rv[(j - i + W) * hd + d];
+#pragma unroll 8
+        for (int j = 0; j < T; j++) a += Sr[j] * Vs[d * Tp + j];
+#pragma unroll 8
+        for (int j = lo; j <= hi; j++) a += Sr[j] * Rv[(j - i + W) * hd + d];
         p.out[(long long)b * p.o_bs + (long long)(h * hd + d) * p.o_cs + i] = a;
     }
 }
@@ -1135,6 +1185,7 @@ struct GruMultiP {
     int *status;               // per stream, stride status_stride ints
     int status_stride;
     int Tm;
+    int B, xcd_local;
 };
 __global__ __launch_bounds__(256) void gru_multi_kernel(GruMultiP p)
 {
@@ -1143,7 +1194,15 @@ __global__ __launch_bounds__(256) void gru_multi_kernel(GruMultiP p)
     float *w = smem;                    // [ROWS][RS]
     float *hs = w + ROWS * RS;          // [H]
     float *gh = hs + H;                 // [ROWS]
-    const int g = blockIdx.x, dir = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    // Workgroups are dealt to the 8 XCDs round-robin by linear id.  The 8 members of one (stream, direction) group exchange
+    // h every step, so a group takes linear ids slot + 8*member (+ 64*round): all on XCD `slot`.  Ids whose slot has no group exit.
+    int g, dir, b;
+    const int tid = threadIdx.x;
+    if (p.xcd_local) {
+        const int L = blockIdx.x, slot = L & 7, member = (L >> 3) & 7, round = L >> 6, q = round * 8 + slot;
+        if (q >= 2 * p.B) return;
+        g = member; dir = q & 1; b = q >> 1;
+    } else { g = blockIdx.x; dir = blockIdx.y; b = blockIdx.z; }
     const float *wsrc = p.whh + (long long)dir * 3 * H * H;
     for (int i = tid; i < ROWS * (H / 4); i += 256) {
         const int row = i / (H / 4), c4 = i - row * (H / 4);
@@ -1239,29 +1298,58 @@ __global__ __launch_bounds__(1024) void pitch_post_kernel(PitchP p)
 {
     __shared__ float f0s[1024];
     __shared__ float cache[1024];
+    __shared__ int idxs[1024];
     const int b = blockIdx.x, t = threadIdx.x;
     StreamState *st = p.st + b;
     const float up = p.cp->uppower;
-    if (t < p.Tm) {
-        const float *col = p.sal + (long long)b * p.sal_bs + t;
-        // argmax over the zero-padded row (368): first strictly greater wins; padded[0] = 0
+    // Row scan split over bin groups: thread (tt = t % TT, grp = t / TT) scans bins [grp*BPG, ...) of time step tt (loads
+    // coalesced along time), then group 0 combines.  Same result as the sequential scan of the zero-padded row (368 wide,
+    // "first strictly greater wins", padded[0] = 0): start = first index of the maximum if it is > 0, else 0.
+    int TT = 1; while (TT < p.Tm) TT <<= 1;
+    TT = TT < 1024 ? TT : 1024;
+    const int NG = 1024 / TT, BPG = (360 + NG - 1) / NG, tt = t & (TT - 1), grp = t / TT;
+    {
+        float best = 0.f, mx = -INFINITY; int start = 0;
+        if (tt < p.Tm) {
+            const float *col = p.sal + (long long)b * p.sal_bs + tt;
+            const int i0 = grp * BPG, i1 = (i0 + BPG < 360) ? i0 + BPG : 360;
+#pragma unroll 4
+            for (int i = i0; i < i1; i++) { const float v = col[(long long)i * p.sal_cs]; if (v > best) { best = v; start = i + 4; } mx = fmaxf(mx, v); }
+        }
+        f0s[t] = best; cache[t] = mx; idxs[t] = start;
+    }
+    __syncthreads();
+    float hz_out = 0.f;
+    if (grp == 0 && tt < p.Tm) {
+        const float *col = p.sal + (long long)b * p.sal_bs + tt;
         int start = 0; float best = 0.f, mx = -INFINITY;
-        for (int i = 0; i < 360; i++) { float v = col[(long long)i * p.sal_cs]; if (v > best) { best = v; start = i + 4; } mx = fmaxf(mx, v); }
+        for (int g = 0; g < NG; g++) {
+            const float v = f0s[g * TT + tt];
+            if (v > best) { best = v; start = idxs[g * TT + tt]; }
+            mx = fmaxf(mx, cache[g * TT + tt]);
+        }
         float hz = 0.f;
         if (start + 8 >= 360) { st->status = 6; }
         else {
+            float sv[9];
+#pragma unroll
+            for (int y = 0; y < 9; y++) sv[y] = col[(long long)(start + y) * p.sal_cs];
             float ps = 0.f, ws = 0.f;
-            for (int y = 0; y < 9; y++) { float s = col[(long long)(start + y) * p.sal_cs]; float cm = ((float)(start + y) - 4.f) * 20.f + 1997.3794084376191f; ps += s * cm; ws += s; }
+#pragma unroll
+            for (int y = 0; y < 9; y++) { const float cm = ((float)(start + y) - 4.f) * 20.f + 1997.3794084376191f; ps += sv[y] * cm; ws += sv[y]; }
             float cents = ps / ws;
             if (!(mx > p.threshold)) cents = 0.f;
             hz = 10.0f * powf(2.0f, cents / 1200.0f);
             if (hz == 10.0f) hz = 0.f;
         }
         hz *= up;
-        f0s[t] = hz;
-        p.f0[(long long)b * p.Tm + t] = hz;
+        hz_out = hz;
+        p.f0[(long long)b * p.Tm + tt] = hz;
     }
+    __syncthreads();
+    if (grp == 0 && tt < p.Tm) f0s[tt] = hz_out;
     if (!p.update) return;
+    __syncthreads();
     cache[t] = st->cache_pitchf[t];
     __syncthreads();
     // copy_within(shift.., 0): cache[i] = cache[i+shift] for i < 1024-shift (tail keeps old values)
@@ -1377,6 +1465,9 @@ __global__ void gate_kernel(const float *a, int a_cs, long long a_bs, float *y, 
     float ta = a[(long long)b * a_bs + (long long)c * a_cs + t], sa = a[(long long)b * a_bs + (long long)(H + c) * a_cs + t];
     y[(long long)b * y_bs + (long long)c * y_cs + t] = tanhf(ta) * (1.0f / (1.0f + expf(-sa)));
 }
+
+// timeline probe (RVC_STAMPS=1): device wall clock (constant 100 MHz) at a point of a stream's kernel chain
+__global__ void stamp_kernel(unsigned long long *slot) { *slot = wall_clock64(); }
 
 // average of up to three ResBlock outputs: y = ((a + b) + c) * inv
 __global__ void mean3_kernel(const float *a, const float *b2, const float *c, int i_cs, long long i_bs, float *y, int y_cs, long long y_bs, int C, int T, float inv)

@@ -33,3 +33,15 @@ for graph in (True, False):
         for _ in range(30):
             t0 = time.perf_counter(); fn(); ms.append((time.perf_counter() - t0) * 1e3)
         print("graph=%d %-7s wall ms median %.3f min %.3f" % (graph, name, np.median(ms[5:]), min(ms[5:])))
+
+if os.environ.get("RVC_STAMPS"):
+    import ctypes
+    lib = eng._L
+    lib.rvc_debug_stamps.restype = ctypes.c_int
+    lib.rvc_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    eng.set_use_graph(bool(int(os.environ.get('PROBE_GRAPH', '0'))))
+    for _ in range(4):
+        eng.infer_device(x.data_ptr(), L, chunk, 12, g.skip_head, g.model_return_length, out.data_ptr(), N, sync=True)
+    buf = ctypes.create_string_buffer(1 << 16)
+    n = lib.rvc_debug_stamps(eng._h, buf, len(buf))
+    print("stamps", n); print(buf.value.decode())
