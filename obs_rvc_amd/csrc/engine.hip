@@ -1007,7 +1007,10 @@ using namespace rvc;
 struct rvc_engine {
     std::string data_path, err;
     int device = 0;
+    // aux streams: 1 = f0 branch, 2 = side work (NSF source), 3 = ContentVec branch when the CUs are partitioned.  Four streams
+    // in total: the runtime multiplexes streams onto 4 hardware queues, a fifth stream would share (and serialise with) another.
     hipStream_t stream = nullptr, aux[3] = {nullptr, nullptr, nullptr};
+    bool partition_ok = false, partitioned = false;   // CU-masked streams available / currently in use (n_streams <= 4)
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
     std::unique_ptr<ModelCV> cv;
     std::unique_ptr<ModelRM> rm;
@@ -1095,6 +1098,29 @@ static void reset_state(rvc_engine *e)
     std::vector<StreamState> st(e->n_streams);
     for (int b = 0; b < e->n_streams; b++) { memset(&st[b], 0, sizeof(StreamState)); st[b].stream_id = e->stream_id0 + (uint32_t)b; }
     HIPCHK(hipMemcpy(e->d_state, st.data(), sizeof(StreamState) * e->n_streams, hipMemcpyHostToDevice));
+}
+
+// CU partition for the two concurrent branches of a chunk at low stream counts: the f0 branch (RMVPE: ~140 short weight-streaming
+// kernels) gets 1/8 of the CUs, ContentVec the rest.  Sharing CUs slows the f0 branch by ~35 % (measured).  With
+// many streams every kernel fills the chip and the streams are plain.
+static void configure_aux_streams(rvc_engine *e)
+{
+    hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, e->device));
+    const int ncu = prop.multiProcessorCount, nf0 = ncu / 8;
+    bool want = e->partition_ok && ncu >= 64 && ncu <= 1024 && e->n_streams <= 4;
+    if (e->aux[0] && want == e->partitioned) return;
+    for (int i = 0; i < 3; i++) if (e->aux[i]) { HIPCHK(hipStreamDestroy(e->aux[i])); e->aux[i] = nullptr; }
+    for (int i = 0; i < 3; i++) {
+        if (want && i != 1) {
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+            for (int c = 0; c < ncu; c++) if ((c < nf0) == (i == 0)) mask[c / 32] |= 1u << (c % 32);
+            if (hipExtStreamCreateWithCUMask(&e->aux[i], (uint32_t)mask.size(), mask.data()) == hipSuccess) continue;
+            (void)hipGetLastError(); want = false; e->partition_ok = false;
+            if (i == 2) { HIPCHK(hipStreamDestroy(e->aux[0])); HIPCHK(hipStreamCreateWithFlags(&e->aux[0], hipStreamNonBlocking)); }
+        }
+        HIPCHK(hipStreamCreateWithFlags(&e->aux[i], hipStreamNonBlocking));
+    }
+    e->partitioned = want;
 }
 
 static void alloc_state(rvc_engine *e)
@@ -1428,7 +1454,6 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         T1 xs = make_t1(A, B, co, Tn, DH);
         std::vector<T1> finals;
         const bool fused = m.n_rb > 1 && m.n_rb <= 3 && B < 16 && !getenv("RVC_SERIAL_RESBLOCKS");   // many streams: every conv fills the chip by itself
-        const bool par = !fused && m.n_rb <= 3 && getenv("RVC_PARALLEL_RESBLOCKS");   // stream-parallel chains: measured slower than serial at B = 1
         if (fused) {
             // one launch per (dilation, conv): phase j = chain j (kernel size rb_k[j]); 6 launches per stage instead of 6*n_rb
             const int nr = m.n_rb;
@@ -1453,7 +1478,6 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         for (int j = 0; j < m.n_rb && !fused; j++) {
             const int k = m.rb_k[j];
             T1 ra = make_t1(A, B, co, Tn, DH), rb = make_t1(A, B, co, Tn, DH), tt = make_t1(A, B, co, Tn, DH), fin = make_t1(A, B, co, Tn, 0);
-            if (par && j > 0) { pl.ops.fork(j); pl.ops.cur = j; }
             T1 cur = u;
             for (int q = 0; q < m.n_rbd; q++) {
                 const int d = m.rb_d[q];
@@ -1464,10 +1488,8 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
                 add_conv1d(pl, m.rbs[i][j][q].second, tt, dst, 1, (k - 1) / 2, 1, o);
                 cur = dst;
             }
-            pl.ops.cur = 0;
             finals.push_back(fin);
         }
-        if (par) for (int j = 1; j < m.n_rb; j++) pl.ops.join(j);
         {
             // xs = (r0 + r1 + ...) / n_rb, summed in chain order as in the reference definition
             const int nrb = m.n_rb; const float inv = 1.0f / (float)m.n_rb;
@@ -1508,14 +1530,16 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
     pl.d_in = pl.arena.floats((size_t)B * L + 64);
     T1 sal0, src0; float *d_pitchf0 = nullptr; int *d_pitch0 = nullptr;
     size_t rm_begin = 0, rm_end = 0;
+    const bool part = mode == 0 && e->partitioned;
+    const int f0_sid = 1, cv_sid = part ? 3 : 0;
     if (mode == 0) {
         // f0 branch first (auxiliary stream): independent of ContentVec until the synthesizer
         const int Tcv = e->cv->out_frames(L);
         if (Tcv < 1) throw ShapeError("input too short for ContentVec");
         const size_t hubert_length0 = std::min(L / 160, 2 * (size_t)Tcv + 1);   // rvc.rs:153
-        pl.ops.fork(1);
+        pl.ops.fork(f0_sid);
         rm_begin = pl.ops.v.size();
-        pl.ops.cur = 1;
+        pl.ops.cur = f0_sid;
         sal0 = build_rmvpe(e, pl, B, L, frame16k, true);
         build_pitch_post(e, pl, B, sal0, true, frame16k, hubert_length0, &d_pitchf0, &d_pitch0);
         pl.ops.cur = 0;
@@ -1524,6 +1548,7 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
     if (mode == 0 || mode == 1) {
         if (!e->cv) throw std::logic_error("contentvec");
         if (e->cv->out_frames(L) < 1) throw ShapeError("input too short for ContentVec");
+        if (cv_sid) { pl.ops.fork(cv_sid); pl.ops.cur = cv_sid; }
         pl.cv_out = build_contentvec(e, pl, B, L);
         if (mode == 1) {
             const int T = pl.T, C = pl.C;
@@ -1626,6 +1651,7 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         add_tap(pl, "phone_ct", phone);
         float *d_pitchf = d_pitchf0; int *d_pitch = d_pitch0;
         (void)hubert_length;
+        pl.ops.cur = 0;
         if (rm_end > rm_begin && !getenv("RVC_RM_FIRST")) {
             // Two concurrent branches: f0 (ops [rm_begin, rm_end), aux stream 1) and ContentVec (ops [rm_end, here), main stream).
             // Launches reach the hardware queues in host order (~3 us each).  Eager: interleave the branches in proportion to
@@ -1642,7 +1668,8 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
             for (size_t i = rm_end; i < cv_end; i++) ol.order_graph.push_back((int)i);
             for (size_t i = rm_begin; i < rm_end; i++) ol.order_graph.push_back((int)i);
         }
-        pl.ops.join(1);
+        if (cv_sid) pl.ops.join(cv_sid);
+        pl.ops.join(f0_sid);
         // the NSF harmonic source is first needed by the decoder: it runs on a side stream next to the text encoder and the flow
         pl.ops.fork(2); pl.ops.cur = 2;
         src0 = build_nsf_source(e, pl, B, d_pitchf0);
@@ -1770,10 +1797,9 @@ rvc_status rvc_create(const char *data_path, int device, rvc_engine **out)
     try {
         set_device(e);
         HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-        for (int i = 0; i < 3; i++) {
-            HIPCHK(hipStreamCreateWithFlags(&e->aux[i], hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&e->ev_fork[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
-        }
+        for (int i = 0; i < 3; i++) { HIPCHK(hipEventCreateWithFlags(&e->ev_fork[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming)); }
+        e->partition_ok = !getenv("RVC_NO_CUMASK");
+        configure_aux_streams(e);
         HIPCHK(hipEventCreate(&e->ev0)); HIPCHK(hipEventCreate(&e->ev1));
         HIPCHK(hipMalloc(&e->d_cp, sizeof(CallParams)));
         HIPCHK(hipHostMalloc((void **)&e->h_cp, sizeof(CallParams)));
@@ -1978,6 +2004,7 @@ rvc_status rvc_set_streams(rvc_engine *e, int n_streams)
         HIPCHK(hipDeviceSynchronize());
         e->n_streams = n_streams;
         alloc_state(e);
+        configure_aux_streams(e);
         return RVC_OK;
     });
 }
