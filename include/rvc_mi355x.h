@@ -100,6 +100,22 @@ rvc_status rvc_envelop_mixing(rvc_engine *e, const float *input, float *output, 
 rvc_status rvc_sola_step(rvc_engine *e, float *output, size_t output_len, float *sola_buffer, size_t sola_len, size_t search,
                          size_t frame, float *frame_out, size_t *sola_offset);
 
+/* ---- the plugin's two sample-rate converters ---- */
+/* rubato::FftFixedInOut::<f32>::new(rate_in, rate_out, chunk_size_in, 1) at obs-rvc/src/lib.rs:236-242 (host rate -> 16 kHz in front
+ * of infer, model rate -> host rate behind it); one channel.  The converter runs on the engine's device and stream and must be
+ * destroyed before the engine. */
+typedef struct rvc_resampler rvc_resampler;
+rvc_status rvc_resampler_create(rvc_engine *e, size_t rate_in, size_t rate_out, size_t chunk_size_in, rvc_resampler **out);
+void rvc_resampler_destroy(rvc_resampler *r);
+size_t rvc_resampler_input_frames_next(rvc_resampler *r);    /* Resampler::input_frames_next: frames one process call consumes */
+size_t rvc_resampler_output_frames_max(rvc_resampler *r);    /* Resampler::output_frames_max (lib.rs:244): frames it produces */
+void rvc_resampler_reset(rvc_resampler *r);                  /* Resampler::reset */
+/* Resampler::process (lib.rs:675) / process_into_buffer (lib.rs:747-749).  n_in must equal input_frames_next(), otherwise
+ * RVC_SHAPE (rubato: ResampleError::WrongNumberOfInputFrames, on which the plugin panics); *n_out = output_frames_max(). */
+rvc_status rvc_resampler_process(rvc_resampler *r, const float *in, size_t n_in, float *out, size_t cap, size_t *n_out);
+/* device-resident variant (HIP device pointers, engine's stream; no sync unless sync != 0) */
+rvc_status rvc_resampler_process_device(rvc_resampler *r, const void *d_in, void *d_out, int sync);
+
 /* ---- measurement / debugging ---- */
 /* total milliseconds of the last infer measured with HIP events on the engine's stream */
 float rvc_last_gpu_ms(rvc_engine *e);

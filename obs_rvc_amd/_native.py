@@ -20,12 +20,14 @@ SYMBOLS = [
     "rvc_set_streams", "rvc_infer_batch", "rvc_infer_device", "rvc_synchronize", "rvc_set_use_graph",
     "rvc_last_gpu_ms", "rvc_profile_last", "rvc_set_profile", "rvc_enable_taps", "rvc_get_tap", "rvc_get_pitch_cache",
     "rvc_index_device_ptr", "rvc_device", "rvc_version", "rvc_envelop_mixing", "rvc_sola_step", "rvc_profile_last_knn",
+    "rvc_resampler_create", "rvc_resampler_destroy", "rvc_resampler_input_frames_next", "rvc_resampler_output_frames_max",
+    "rvc_resampler_reset", "rvc_resampler_process", "rvc_resampler_process_device",
 ]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950: the engine library and the rvc-rpc protocol-compatible executable."""
-    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "kernels.hip.h", "blob.h")] + \
+    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "kernels.hip.h", "resample.hip.h", "blob.h")] + \
            [os.path.join(os.path.dirname(_HERE), "include", "rvc_mi355x.h")]
     newest = max(os.path.getmtime(s) for s in srcs)
     if force or not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < newest:
@@ -97,5 +99,16 @@ def lib():
     L.rvc_version.restype = C.c_char_p
     L.rvc_envelop_mixing.argtypes = [vp, fp, fp, sz, sz, C.c_double]
     L.rvc_sola_step.argtypes = [vp, fp, sz, fp, sz, sz, sz, fp, C.POINTER(sz)]
+    L.rvc_resampler_create.argtypes = [vp, sz, sz, sz, C.POINTER(vp)]
+    L.rvc_resampler_destroy.argtypes = [vp]
+    L.rvc_resampler_destroy.restype = None
+    L.rvc_resampler_input_frames_next.argtypes = [vp]
+    L.rvc_resampler_input_frames_next.restype = sz
+    L.rvc_resampler_output_frames_max.argtypes = [vp]
+    L.rvc_resampler_output_frames_max.restype = sz
+    L.rvc_resampler_reset.argtypes = [vp]
+    L.rvc_resampler_reset.restype = None
+    L.rvc_resampler_process.argtypes = [vp, fp, sz, fp, sz, C.POINTER(sz)]
+    L.rvc_resampler_process_device.argtypes = [vp, vp, vp, C.c_int]
     _LIB = L
     return L

@@ -2283,3 +2283,5 @@ rvc_status rvc_get_tap(rvc_engine *e, const char *name, float *out, size_t cap, 
 }
 
 }  // extern "C"
+
+#include "resample.hip.h"

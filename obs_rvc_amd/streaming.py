@@ -1,8 +1,11 @@
-"""Caller-side streaming state machine: the plugin's `process_one_frame`
-(/root/reference/obs-rvc/src/lib.rs:659-795) around `RvcInfer::infer`, minus the two rubato resamplers (row f3,
-not built yet): the caller supplies each chunk at BOTH the host rate (for the RMS envelope) and 16 kHz (for the
-engine), and the model rate must equal the host rate.  Backend-agnostic: `engine` only needs
-infer / envelop_mixing / sola_step with the signatures of obs_rvc_amd.rvc.RvcInfer."""
+"""Caller-side streaming state machine (SURVEY.md section 8 rows f1 + f3): the plugin's `process_one_frame`
+(/root/reference/obs-rvc/src/lib.rs:659-795) around `RvcInfer::infer`, including its two rubato resamplers
+(lib.rs:236-242): host rate -> 16 kHz in front of the engine and model rate -> host rate behind it.
+
+Backend-agnostic: `engine` needs infer / envelop_mixing / sola_step with the signatures of obs_rvc_amd.rvc.RvcInfer and
+`resampler` is a factory `(rate_in, rate_out, chunk_size_in) -> object with process()` -- for the HIP engine
+`lambda ri, ro, n: obs_rvc_amd.resample.FftFixedInOut(engine, ri, ro, n)`.  With `resampler=None` both converters are
+bypassed: the caller then supplies every chunk at the host rate AND at 16 kHz and the model rate must equal the host rate."""
 from __future__ import annotations
 
 import numpy as np
@@ -11,27 +14,53 @@ from .geometry import Geometry
 
 
 class StreamingSession:
-    def __init__(self, engine, geom: Geometry, pitch_shift: int = 12, rms_mix_rate: float = 1.0):
+    def __init__(self, engine, geom: Geometry, pitch_shift: int = 12, rms_mix_rate: float = 1.0,
+                 model_output_sample_rate: int | None = None, resampler=None, skip_inference: bool = False):
         self.e, self.g = engine, geom
-        self.pitch_shift, self.rms_mix_rate = pitch_shift, rms_mix_rate
-        if geom.model_return_size != geom.model_return_length * (geom.sample_rate // 100):
-            raise ValueError("model rate must equal the host rate until the resamplers (row f3) exist")
-        self.input_buffer = np.zeros(geom.input_buffer_size, np.float32)            # lib.rs:215
-        self.input_buffer_16k = np.zeros(geom.input_buffer_16k_size, np.float32)    # lib.rs:218
-        self.sola_buffer = np.zeros(geom.sola_buffer_frame_size, np.float32)        # lib.rs:229
+        self.pitch_shift, self.rms_mix_rate, self.skip_inference = pitch_shift, rms_mix_rate, skip_inference
+        g = geom
+        host_hop = g.sample_rate // 100
+        self.model_return_size = g.model_return_size
+        if model_output_sample_rate is None:
+            model_output_sample_rate = g.model_return_size // g.model_return_length * 100
+        if skip_inference:                                                          # lib.rs:224-227
+            model_output_sample_rate, self.model_return_size = 16000, g.model_return_length * 160
+        self.downsampler = self.upsampler = None
+        if resampler is not None:
+            self.downsampler = resampler(g.sample_rate, 16000, g.sample_frame_size + 2 * g.zc)       # lib.rs:236-237
+            self.upsampler = resampler(model_output_sample_rate, g.sample_rate, self.model_return_size)   # lib.rs:240-242
+        elif self.model_return_size != g.model_return_length * host_hop:
+            raise ValueError("without resamplers the model rate must equal the host rate")
+        self.input_buffer = np.zeros(g.input_buffer_size, np.float32)            # lib.rs:215
+        self.input_buffer_16k = np.zeros(g.input_buffer_16k_size, np.float32)    # lib.rs:218
+        self.sola_buffer = np.zeros(g.sola_buffer_frame_size, np.float32)        # lib.rs:229
         self.last_sola_offset = 0
 
-    def process_one_frame(self, chunk_host_rate: np.ndarray, chunk_16k: np.ndarray) -> np.ndarray:
+    def process_one_frame(self, input_sample: np.ndarray, chunk_16k: np.ndarray | None = None) -> np.ndarray:
         g = self.g
-        assert len(chunk_host_rate) == g.sample_frame_size and len(chunk_16k) == g.sample_frame_16k
+        assert len(input_sample) == g.sample_frame_size
         # lib.rs:661-665: move and append the last n samples
         self.input_buffer[:-g.sample_frame_size] = self.input_buffer[g.sample_frame_size:]
-        self.input_buffer[-g.sample_frame_size:] = chunk_host_rate
-        # lib.rs:669-683 (resampler output replaced by the caller's 16 kHz chunk)
+        self.input_buffer[-g.sample_frame_size:] = input_sample
+        # lib.rs:669-683: resample and set to 16k.  The converter is fed the new chunk plus the 2*zc samples before it and its
+        # first 160 output samples are dropped: the write covers the new 16 kHz chunk and re-writes the 160 samples before it.
         self.input_buffer_16k[:-g.sample_frame_16k] = self.input_buffer_16k[g.sample_frame_16k:]
-        self.input_buffer_16k[-g.sample_frame_16k:] = chunk_16k
+        if self.downsampler is not None:
+            start = len(self.input_buffer) - g.sample_frame_size - 2 * g.sample_rate // 100
+            result = self.downsampler.process(self.input_buffer[start:])
+            copy_begin = len(self.input_buffer_16k) - (g.sample_frame_size // (g.sample_rate // 100) + 1) * 160
+            self.input_buffer_16k[copy_begin:] = result[160:]
+        else:
+            assert chunk_16k is not None and len(chunk_16k) == g.sample_frame_16k
+            self.input_buffer_16k[-g.sample_frame_16k:] = chunk_16k
         # lib.rs:694-707
-        out = self.e.infer(self.input_buffer_16k, g.sample_frame_16k, self.pitch_shift, g.skip_head, g.model_return_length)
+        if self.skip_inference:
+            out = self.input_buffer_16k[len(self.input_buffer_16k) - self.model_return_size:].copy()
+        else:
+            out = self.e.infer(self.input_buffer_16k, g.sample_frame_16k, self.pitch_shift, g.skip_head, g.model_return_length)
+        # lib.rs:742-756: model rate -> host rate
+        if self.upsampler is not None:
+            out = self.upsampler.process(out)
         # lib.rs:758-765
         if self.rms_mix_rate < 1.0:
             out = self.e.envelop_mixing(self.input_buffer[g.extra_frame_size:], out, g.sample_rate, self.rms_mix_rate)

@@ -94,3 +94,51 @@ def test_streaming_state_machine_matches_oracle():
         assert fe.shape == fo.shape == (768,)
         assert se.last_sola_offset == so.last_sola_offset, c
         assert rms(fe - fo) < 1e-3, (c, rms(fe - fo))
+
+
+@pytest.mark.gpu
+def test_streaming_with_both_resamplers_matches_oracle():
+    # the whole plugin-side chain at a 48 kHz host: rubato-style 48k -> 16k converter (with the 2*zc overlap trick of
+    # lib.rs:673-679), infer, model rate (tiny synth: 4.8 kHz) -> 48 kHz converter, envelope mixing, SOLA
+    from oracle import resample_oracle as RO
+    from obs_rvc_amd.resample import FftFixedInOut
+    from obs_rvc_amd.rvc import RvcInfer
+    from obs_rvc_amd.streaming import StreamingSession
+    g = derive(48000, 0.16, 0.07, 2.0, 4800)
+    z = zoo("tiny")
+    eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"]); eng.set_noise_seed(3, 0)
+    ora = O.OracleRvcInfer(z["data"]); ora.load_contentvec(2); ora.load_f0(1); ora.load_model(z["model"]); ora.set_noise_seed(3, 0)
+    assert (g.sample_frame_size, g.input_buffer_size, g.model_return_size) == (7680, 107520, 1008)
+    se = StreamingSession(eng, g, 12, 0.6, 4800, lambda ri, ro, n: FftFixedInOut(eng, ri, ro, n))
+    so = StreamingSession(ora, g, 12, 0.6, 4800, lambda ri, ro, n: RO.FftFixedInOut(ri, ro, n))
+    assert se.downsampler.input_frames_next() == 8640 and se.upsampler.output_frames_max() == 10080
+    a = np.interp(np.arange(7680 * 18) / 48000.0, np.arange(2560 * 18) / 16000.0, voice_signal(2560 * 18, seed=9)).astype(np.float32)
+    for c in range(18):
+        fe, fo = se.process_one_frame(a[c * 7680:(c + 1) * 7680]), so.process_one_frame(a[c * 7680:(c + 1) * 7680])
+        assert fe.shape == fo.shape == (7680,)
+        assert np.abs(se.input_buffer_16k - so.input_buffer_16k).max() < 5e-5
+        assert rms(fe - fo) < 1e-3, (c, rms(fe - fo))
+    # skip-inference mode (lib.rs:224-227, 697-699): the 16 kHz ring is passed through the 16k -> host converter
+    ss = StreamingSession(eng, g, 12, 1.0, None, lambda ri, ro, n: FftFixedInOut(eng, ri, ro, n), skip_inference=True)
+    sr = StreamingSession(ora, g, 12, 1.0, None, lambda ri, ro, n: RO.FftFixedInOut(ri, ro, n), skip_inference=True)
+    for c in range(6):
+        fe, fo = ss.process_one_frame(a[c * 7680:(c + 1) * 7680]), sr.process_one_frame(a[c * 7680:(c + 1) * 7680])
+        assert rms(fe - fo) < 1e-4
+    assert rms(fe) > 1e-3
+
+
+def test_streaming_host_logic_with_oracle_backends():
+    # CPU-only coverage of the state machine + resampler plumbing (the engine and both converters are the oracle's)
+    from oracle import resample_oracle as RO
+    from obs_rvc_amd.streaming import StreamingSession
+    g = derive(48000, 0.16, 0.07, 2.0, 4800)
+    ora = O.OracleRvcInfer(zoo("tiny")["data"])
+    s = StreamingSession(ora, g, 12, 1.0, None, lambda ri, ro, n: RO.FftFixedInOut(ri, ro, n), skip_inference=True)
+    assert s.model_return_size == 21 * 160 and s.upsampler.input_frames_next() == 3360 and s.upsampler.output_frames_max() == 10080
+    tone = np.sin(2 * np.pi * 300.0 * np.arange(7680 * 8) / 48000.0).astype(np.float32) * 0.3
+    frames = [s.process_one_frame(tone[c * 7680:(c + 1) * 7680]) for c in range(8)]
+    assert all(f.shape == (7680,) for f in frames)
+    # after the pipeline fills, the pass-through chain reproduces the tone's level (two converters + SOLA crossfades)
+    assert abs(rms(frames[-1]) - 0.3 / np.sqrt(2)) < 0.01
+    with pytest.raises(ValueError):
+        StreamingSession(ora, g, 12, 1.0, 4800, None)          # no converters but model rate != host rate
