@@ -98,6 +98,15 @@ class RvcInfer:
 
     # -- extensions ---------------------------------------------------------------------
     def load_index(self, vectors):
+        """`vectors`: an (n, dim) float32 array, or the path of a Faiss `.index` file (IndexFlat / IndexIVFFlat: the stored
+        vectors are reconstructed in id order, obs_rvc_amd.faiss_index) or of a `.npy` matrix (upstream's total_fea.npy)."""
+        if isinstance(vectors, (str, os.PathLike)):
+            path = os.fspath(vectors)
+            if path.endswith(".npy"):
+                vectors = np.load(path)
+            else:
+                from .faiss_index import read_index
+                vectors = read_index(path)
         v, vp = _f32(vectors)
         self._chk(self._L.rvc_load_index(self._h, vp, v.shape[0], v.shape[1]))
 
