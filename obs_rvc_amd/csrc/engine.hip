@@ -7,6 +7,7 @@
 #include "../../include/rvc_mi355x.h"
 #include "blob.h"
 #include "kernels.hip.h"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -304,24 +305,27 @@ struct Plan {
     }
 };
 
-template <int MF, int NF, int D, int KS, bool PRE> static void launch_igemm_t(const IgemmP &p, dim3 grid, hipStream_t s)
+// Profile mode times a kernel with the start / stop events of hipExtLaunchKernelGGL: they carry the dispatch's own begin / end
+// timestamps (what rocprofv3 --kernel-trace reports), not the time between two event-record packets around it.
+template <int MF, int NF, int D, int KS, bool PRE> static void launch_igemm_t(const IgemmP &p, dim3 grid, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
 {
     // LDS: this workgroup's slice of the koff table + the KS partial tiles of the in-workgroup K split
     const size_t lds = (size_t)p.chunks_per_split * 16 * sizeof(int) + (KS > 1 ? (size_t)KS * MF * NF * 256 * sizeof(float) : 0);
-    hipLaunchKernelGGL((igemm_kernel<MF, NF, D, KS, PRE>), grid, dim3((KS > 1 ? KS : 4) * 64), lds, s, p);
+    if (ea) hipExtLaunchKernelGGL((igemm_kernel<MF, NF, D, KS, PRE>), grid, dim3((KS > 1 ? KS : 4) * 64), (uint32_t)lds, s, ea, eb, 0, p);
+    else hipLaunchKernelGGL((igemm_kernel<MF, NF, D, KS, PRE>), grid, dim3((KS > 1 ? KS : 4) * 64), lds, s, p);
 }
 
 // tile configurations: index -> (MF, NF); every tile exists with KS in {1, 4, 8, 16}
 static const int kMF[5] = {1, 1, 1, 2, 2}, kNF[5] = {1, 2, 4, 2, 4};
 
-static void launch_igemm(int cfg, int ks, bool pre, const IgemmP &p, dim3 grid, hipStream_t s)
+static void launch_igemm(int cfg, int ks, bool pre, const IgemmP &p, dim3 grid, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr)
 {
 #define RVC_KS(MF, NF, D, PRE)                                                       \
         switch (ks) {                                                                \
-        case 1: launch_igemm_t<MF, NF, D, 1, PRE>(p, grid, s); return;               \
-        case 4: launch_igemm_t<MF, NF, D, 4, PRE>(p, grid, s); return;               \
-        case 8: launch_igemm_t<MF, NF, D, 8, PRE>(p, grid, s); return;               \
-        default: launch_igemm_t<MF, NF, (D > 8 ? 8 : D), 16, PRE>(p, grid, s); return; \
+        case 1: launch_igemm_t<MF, NF, D, 1, PRE>(p, grid, s, ea, eb); return;               \
+        case 4: launch_igemm_t<MF, NF, D, 4, PRE>(p, grid, s, ea, eb); return;               \
+        case 8: launch_igemm_t<MF, NF, D, 8, PRE>(p, grid, s, ea, eb); return;               \
+        default: launch_igemm_t<MF, NF, (D > 8 ? 8 : D), 16, PRE>(p, grid, s, ea, eb); return; \
         }
 #define RVC_CASE(C, MF, NF, D)                                                       \
     case C:                                                                          \
@@ -404,13 +408,13 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
             if (plp->profile) {
                 if (plp->prof_used == plp->prof.size()) { ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; e.bytes = 0; plp->prof.push_back(e); }
                 pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0;
-                HIPCHK(hipEventRecord(pe->a, s));
             }
-#define RVC_LG(WM, WN, MF, NF) { if (pre) hipLaunchKernelGGL((igemm_lds_kernel<WM, WN, MF, NF, true>), grid, dim3(256), lds, s, p); \
-                                 else hipLaunchKernelGGL((igemm_lds_kernel<WM, WN, MF, NF, false>), grid, dim3(256), lds, s, p); }
+            hipEvent_t ea = pe ? pe->a : nullptr, eb = pe ? pe->b : nullptr;
+#define RVC_LG1(K) { if (ea) hipExtLaunchKernelGGL((K), grid, dim3(256), (uint32_t)lds, s, ea, eb, 0, p); else hipLaunchKernelGGL((K), grid, dim3(256), lds, s, p); }
+#define RVC_LG(WM, WN, MF, NF) { if (pre) RVC_LG1((igemm_lds_kernel<WM, WN, MF, NF, true>)) else RVC_LG1((igemm_lds_kernel<WM, WN, MF, NF, false>)) }
             if (lc == 0) RVC_LG(2, 2, 4, 4) else if (lc == 1) RVC_LG(1, 4, 4, 4) else RVC_LG(1, 4, 2, 4)
 #undef RVC_LG
-            if (pe) HIPCHK(hipEventRecord(pe->b, s));
+#undef RVC_LG1
         });
         return;
     }
@@ -452,11 +456,12 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
             }
             pe = &plp->prof[plp->prof_used++];
             pe->flops = flops; pe->bytes = 0;
-            HIPCHK(hipEventRecord(pe->a, s));
+            if (ksplit > 1) HIPCHK(hipEventRecord(pe->a, s));
         }
-        launch_igemm(cfg, wg_ks, pre, p, grid, s);
+        if (pe && ksplit == 1) launch_igemm(cfg, wg_ks, pre, p, grid, s, pe->a, pe->b);
+        else launch_igemm(cfg, wg_ks, pre, p, grid, s);
         if (ksplit > 1) hipLaunchKernelGGL(splitk_epilogue_kernel, egrid, dim3(256), 0, s, p);
-        if (pe) HIPCHK(hipEventRecord(pe->b, s));
+        if (pe && ksplit > 1) HIPCHK(hipEventRecord(pe->b, s));
     });
 }
 
@@ -1613,10 +1618,9 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
                         if (plp->profile) {
                             if (plp->prof_used == plp->prof.size()) { ProfEvent ev; HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b)); ev.flops = 0; ev.bytes = 0; plp->prof.push_back(ev); }
                             pe = &plp->prof[plp->prof_used++]; pe->flops = 0; pe->bytes = scan_bytes;
-                            HIPCHK(hipEventRecord(pe->a, s));
                         }
-                        hipLaunchKernelGGL(knn_dot_kernel, grid, dim3(256), qlds, s, dp);
-                        if (pe) HIPCHK(hipEventRecord(pe->b, s));
+                        if (pe) hipExtLaunchKernelGGL(knn_dot_kernel, grid, dim3(256), (uint32_t)qlds, s, pe->a, pe->b, 0, dp);
+                        else hipLaunchKernelGGL(knn_dot_kernel, grid, dim3(256), qlds, s, dp);
                     });
                 }
                 KnnSelP sp{}; sp.approx = d_approx; sp.approx_bs = (long long)nq * e->index_n; sp.n = (int)e->index_n; sp.dim = C; sp.nq = nq;
