@@ -390,7 +390,10 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
         const int bn = bm == 128 ? 128 : 256;
         if (bm) {
             const long long wgs = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * B * p.nphase;
-            if (wgs >= 384) lds_cfg = bm == 128 ? 0 : (bm == 64 ? 1 : 2);
+            // isolated B = 64 timings (tests/gemm_microbench.py): the LDS-tiled kernel wins for very tall (M >= 2048) and very short
+            // (M <= 64) weight panels, the register-direct kernel in between (cv_ff2 91 vs 73 TF/s, cv_o 77 vs 62, enc_ff1 24 vs 13)
+            const bool lds_wins = p.M >= 2048 || p.M <= 64 || getenv("RVC_LDS_ALWAYS");
+            if (wgs >= 384 && lds_wins) lds_cfg = bm == 128 ? 0 : (bm == 64 ? 1 : 2);
         }
     }
     if (lds_cfg >= 0) {
@@ -2217,11 +2220,12 @@ double rvc_debug_conv_bench(rvc_engine *e, int M, int Cin, int KW, int dil, int 
         std::vector<float> w((size_t)M * Cin * KW), bias(M, 0.1f);
         for (size_t i = 0; i < w.size(); i++) w[i] = (float)((i * 2654435761u) % 1000) / 1000.0f - 0.5f;
         ConvW cw = prep_conv(w.data(), bias.data(), M, Cin, KW, 1);
-        Plan pl; pl.B = 1;
+        const int Bb = getenv("RVC_BENCH_B") ? atoi(getenv("RVC_BENCH_B")) : 1;     // streams batched (throughput-mode kernels)
+        Plan pl; pl.B = Bb;
         const int pad = (KW - 1) * dil / 2;
-        T1 x = make_t1(pl.arena, 1, Cin, N, (pad + 3) / 4 * 4), y = make_t1(pl.arena, 1, M, N, 0);
+        T1 x = make_t1(pl.arena, Bb, Cin, N, (pad + 3) / 4 * 4), y = make_t1(pl.arena, Bb, M, N, 0);
         std::vector<float> hx((size_t)Cin * x.ld, 0.25f);
-        HIPCHK(hipMemcpy(x.p - x.halo, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        for (int b = 0; b < Bb; b++) HIPCHK(hipMemcpy(x.p + (long long)b * x.bs - x.halo, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
         ConvOpts o; if (pre_act) { o.pre_act = ACT_LRELU; o.pre_slope = 0.1f; }
         add_conv1d(pl, cw, x, y, 1, pad, dil, o);
         HIPCHK(hipDeviceSynchronize());

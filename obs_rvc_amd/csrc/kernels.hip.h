@@ -135,6 +135,14 @@ __device__ __forceinline__ void epi_finish(const IgemmP &p, const PhaseD &ph, in
     p.y[(long long)b * p.y_bs + (long long)ch * p.y_cs + (long long)oh * p.y_rs + ow] = v;
 }
 
+// Workgroup barrier that only orders LDS traffic: waits for this wave's LDS operations (lgkmcnt(0)) and joins the barrier, leaving
+// global loads in flight (gfx9 s_waitcnt encoding: vmcnt = 63, expcnt = 7, lgkmcnt = 0).
+__device__ __forceinline__ void lds_only_barrier()
+{
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+}
+
 // igemm_kernel<MF, NF, D, KS>
 //   One wave owns a (16*MF) x (16*NF) output tile of 16x16x4 fp32 MFMA fragments.
 //   KS == 1: the 4 waves of a workgroup work on 4 consecutive tiles (they share weight rows through L1).
@@ -197,8 +205,8 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
                         pre_w[mf][nf][r] = epi_prefetch(p, ph, b, tm * 16 * MF + mf * 16 + kq * 4 + r, tn * 16 * NF + nf * 16 + li);
         }
     }
-    __syncthreads();
-    if (!live) return;
+    // (the barrier that publishes the koff slice comes after the weight loads of the first D stages have been issued:
+    //  they do not depend on it, so their latency overlaps the table's round trip)
     // this wave's chunk range inside the workgroup's slice
     int c0 = 0, nc = gn;
     if (KS > 1) {
@@ -244,13 +252,15 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
 
     f32x4 a_st[D][MF];
     float b_st[D][NF][4];
-    int4 ko_nx = nc > 0 ? kol[0] : make_int4(0, 0, 0, 0);
-#define RVC_LOAD_STAGE(S, C)                                                                           \
+#define RVC_LOAD_A(S, C)                                                                               \
+    {                                                                                                  \
+        _Pragma("unroll") for (int mf = 0; mf < MF; mf++) a_st[S][mf] = *reinterpret_cast<const f32x4 *>(wrow[mf] + (C) * 256); \
+    }
+#define RVC_LOAD_B(S, C)                                                                               \
     {                                                                                                  \
         const int cc_ = (C);                                                                           \
         const int4 ko_ = ko_nx;                                                                        \
         ko_nx = kol[(cc_ + 1 < nc ? cc_ + 1 : cc_) * 4];                                               \
-        _Pragma("unroll") for (int mf = 0; mf < MF; mf++) a_st[S][mf] = *reinterpret_cast<const f32x4 *>(wrow[mf] + cc_ * 256); \
         _Pragma("unroll") for (int nf = 0; nf < NF; nf++) {                                            \
             b_st[S][nf][0] = *reinterpret_cast<const float *>(xb + (xo[nf] + (unsigned)ko_.x));        \
             b_st[S][nf][1] = *reinterpret_cast<const float *>(xb + (xo[nf] + (unsigned)ko_.y));        \
@@ -268,9 +278,18 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
                     acc[j % NACC][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[S][mf][j], bv_, acc[j % NACC][mf][nf], 0, 0, 0); \
             }                                                                                          \
     }
+#define RVC_LOAD_STAGE(S, C) { RVC_LOAD_A(S, C) RVC_LOAD_B(S, C) }
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < D; s++)
+            if (s < nc) RVC_LOAD_A(s, s)
+    }
+    lds_only_barrier();        // not __syncthreads(): its vmcnt(0) would drain the weight loads just issued
+    if (!live) return;
+    int4 ko_nx = nc > 0 ? kol[0] : make_int4(0, 0, 0, 0);
 #pragma unroll
     for (int s = 0; s < D; s++)
-        if (s < nc) RVC_LOAD_STAGE(s, s)
+        if (s < nc) RVC_LOAD_B(s, s)
     int c = 0;
     for (; c + 2 * D <= nc; c += D) {
 #pragma unroll
@@ -292,6 +311,8 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
     }
 #undef RVC_COMPUTE_STAGE
 #undef RVC_LOAD_STAGE
+#undef RVC_LOAD_A
+#undef RVC_LOAD_B
     if (NACC == 2) {
 #pragma unroll
         for (int mf = 0; mf < MF; mf++)

@@ -20,8 +20,8 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "child":
     out = []
     for name in sys.argv[2].split(","):
         M, Cin, KW, dil, N = SHAPES[name]
-        us = L.rvc_debug_conv_bench(h, M, Cin, KW, dil, N, 200, 0)
-        fl = 2.0 * M * Cin * KW * N
+        us = L.rvc_debug_conv_bench(h, M, Cin, KW, dil, N, 200 if int(os.environ.get("RVC_BENCH_B", "1")) == 1 else 20, 0)
+        fl = 2.0 * M * Cin * KW * N * int(os.environ.get("RVC_BENCH_B", "1"))
         out.append("%s %.1fus %.1fTF" % (name, us, fl / us / 1e6))
     print(os.environ.get("RVC_FORCE_CFG", "auto"), os.environ.get("RVC_FORCE_MFAST", "-"), " | ".join(out))
 elif __name__ == "__main__":

@@ -161,6 +161,27 @@ def test_hubert_window_lengths_full_preset():
     assert fe.shape == fo.shape and rel_rms(fe, fo) < 1e-4
 
 
+def test_plugin_default_configuration_full_size():
+    # the plugin's own defaults (obs-rvc/src/lib.rs:200-227): 0.30 s chunks, 40 kHz v2 synthesizer (rates 10*10*2*2), 48 kHz host
+    # -> L = 38080, R = 35, Tm = 64, N = 14000; and the v1 family (256-d ContentVec layer 9 + final_proj) at full size
+    from oracle import oracle as O
+    from obs_rvc_amd.rvc import RvcInfer
+    gg = derive(48000, 0.30, 0.07, 2.0, 40000)
+    assert (gg.sample_frame_16k, gg.input_buffer_16k_size, gg.model_return_length, gg.model_return_size) == (4800, 38080, 35, 14000)
+    for version in (2, 1):
+        z = zoo("full", version, "full40k")
+        ora = O.OracleRvcInfer(z["data"]); ora.load_contentvec(version); ora.load_f0(1); ora.load_model(z["model"]); ora.set_noise_seed(9, 2)
+        eng = RvcInfer(z["data"]); eng.load_contentvec(RvcModelVersion.from_value(version)); eng.load_f0(); eng.load_model(z["model"]); eng.set_noise_seed(9, 2)
+        audio = voice_signal(gg.sample_frame_16k * 12, seed=21)
+        rings = list(chunk_stream(audio, gg.input_buffer_16k_size, gg.sample_frame_16k))[-2:]
+        for r in rings:
+            yo = ora.infer(r, gg.sample_frame_16k, 5, gg.skip_head, gg.model_return_length)
+            ye = eng.infer(r, gg.sample_frame_16k, 5, gg.skip_head, gg.model_return_length)
+            assert ye.shape == yo.shape == (gg.model_return_size,)
+            assert rms(ye - yo) < PCM_TOL, (version, rms(ye - yo))
+        assert np.allclose(eng.pitch_cache(), ora.pitch_cache(), rtol=1e-5, atol=1e-3)
+
+
 def test_silence_and_loud_inputs():
     z, ora, eng = _pair("tiny")
     for x in (np.zeros(g.input_buffer_16k_size, np.float32), np.load(os.path.join(GOLDEN, "ref_input_wav.npy"))[:g.input_buffer_16k_size],
