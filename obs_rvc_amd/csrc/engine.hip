@@ -341,7 +341,6 @@ static void launch_igemm(int cfg, int ks, bool pre, const IgemmP &p, dim3 grid, 
 #undef RVC_KS
 }
 
-static bool g_in_multi = false;   // set while add_conv1d_multi queues its launch (plan construction is single-threaded per engine)
 // generic: the caller fills geometry (N, NW, strides, koff, phases); this picks the tile + split-K and queues the op
 static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases)
 {
@@ -373,9 +372,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     bool found = false;
     for (int oi = 0; oi < 3 && !found; oi++) {
         const int c = order[oi];
-        static const int aux_maxks = getenv("RVC_AUX_MAXKS") ? atoi(getenv("RVC_AUX_MAXKS")) : 16;
-        const int max_ks = pl.ops.cur == 1 ? aux_maxks : 16;
-        for (int ks = 1; ks <= max_ks; ks = ks == 1 ? 4 : ks * 2) {
+        for (int ks = 1; ks <= 16; ks = ks == 1 ? 4 : ks * 2) {
             if (ks > 1 && (nchunks / ks < 4 || ks * kMF[c] * kNF[c] > 32)) break;
             if ((size_t)nchunks * 64 + (ks > 1 ? (size_t)ks * kMF[c] * kNF[c] * 1024 : 0) > 60 * 1024) break;
             const long long w = tiles(c) * ks;
@@ -392,7 +389,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
             const long long wgs = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * B * p.nphase;
             // isolated B = 64 timings (tests/gemm_microbench.py): the LDS-tiled kernel wins for very tall (M >= 2048) and very short
             // (M <= 64) weight panels, the register-direct kernel in between (cv_ff2 91 vs 73 TF/s, cv_o 77 vs 62, enc_ff1 24 vs 13)
-            const bool lds_wins = p.M >= 2048 || p.M <= 64 || getenv("RVC_LDS_ALWAYS");
+            const bool lds_wins = p.M >= 2048 || p.M <= 64;
             if (wgs >= 384 && lds_wins) lds_cfg = bm == 128 ? 0 : (bm == 64 ? 1 : 2);
         }
     }
@@ -420,9 +417,6 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
 #undef RVC_LG1
         });
         return;
-    }
-    if (g_in_multi) if (const char *f = getenv("RVC_MULTI_CFG")) {   // tuning aid for the fused ResBlock launches: "cfg,ks"
-        int fc = 0, fk = 1; if (sscanf(f, "%d,%d", &fc, &fk) >= 1) { cfg = fc; wg_ks = fk; lds_cfg = -1; }
     }
     if (const char *f = getenv("RVC_FORCE_CFG")) {   // tuning aid: "cfg,ks[,mfast]"
         int fc = 0, fk = 1; if (sscanf(f, "%d,%d", &fc, &fk) >= 1) { cfg = fc; wg_ks = fk; }
@@ -495,44 +489,6 @@ static void add_conv1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int 
     p.NW = y.T; p.x_hs = 0; p.x_ws = stride; p.y_hm = 0; p.y_ws = 1; p.OW = y.T;
     p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.ld; p.y_rs = 0;
     fill_epilogue(p, cw, o);
-    // HiFiGAN-style stride-1 convs with several taps: LDS-resident input tile (each input element fetched once per workgroup)
-    if (stride == 1 && cw.groups == 1 && KW >= 3 && o.m_off == 0 && o.m_cnt < 0 && !o.glu && y.T >= 256 && getenv("RVC_LDS_CONV")) {   // opt-in: measured slower than the register-direct kernel so far
-        const int span = (KW - 1) * dil;
-        const int mt = (cw.M + 15) / 16;
-        for (int nf : {4, 1}) {
-            const int BN = 64 * nf, RL = BN + span;
-            const size_t lds = ((size_t)cw.Cin * RL + cw.Kp) * sizeof(float);
-            if (lds > 128 * 1024) continue;
-            const long long ntn = (y.T + BN - 1) / BN;
-            int mf = mt >= 4 ? 4 : (mt >= 2 ? 2 : 1);
-            if (nf == 4 && ntn * ((mt + mf - 1) / mf) * x.B < 512) continue;          // too few workgroups: use the 64-column tile
-            while (mf > 1 && ntn * ((mt + mf - 1) / mf) * x.B < 256) mf /= 2;
-            p.ksplit = 1; p.nphase = 1;
-            std::vector<int> loff(cw.Kp, 0);
-            for (int ci = 0; ci < cw.Cin; ci++) for (int k = 0; k < KW; k++) loff[ci * KW + k] = ci * RL + k * dil;
-            p.loff = pl.arena.upload(loff);
-            p.c_in = cw.Cin; p.c_rl = RL; p.c_pad = pad; p.c_t = x.T; p.c_halo = x.halo; p.x_cs = x.ld;
-            dim3 grid((unsigned)ntn, (mt + mf - 1) / mf, x.B);
-            const double flops = 2.0 * cw.M * (double)y.T * cw.Kp * x.B;
-            pl.igemm_flops += flops; pl.n_igemm++;
-            Plan *plp = &pl;
-            const int nf_ = nf, mf_ = mf;
-            pl.ops.push_back([=](hipStream_t s) {
-                ProfEvent *pe = nullptr;
-                if (plp->profile) {
-                    if (plp->prof_used == plp->prof.size()) { ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; e.bytes = 0; plp->prof.push_back(e); }
-                    pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0;
-                    HIPCHK(hipEventRecord(pe->a, s));
-                }
-#define RVC_LC(MF, NF) hipLaunchKernelGGL((conv1d_lds_kernel<MF, NF>), grid, dim3(256), lds, s, p)
-                if (nf_ == 4) { if (mf_ == 4) RVC_LC(4, 4); else if (mf_ == 2) RVC_LC(2, 4); else RVC_LC(1, 4); }
-                else { if (mf_ == 4) RVC_LC(4, 1); else if (mf_ == 2) RVC_LC(2, 1); else RVC_LC(1, 1); }
-#undef RVC_LC
-                if (pe) HIPCHK(hipEventRecord(pe->b, s));
-            });
-            return;
-        }
-    }
     if (cw.groups > 1 && (o.m_off != 0 || o.m_cnt >= 0)) throw std::runtime_error("row sub-range on grouped conv");
     std::vector<int> koff(cw.Kp, 0);
     for (int ci = 0; ci < cig; ci++) for (int k = 0; k < KW; k++) koff[ci * KW + k] = ci * x.ld + k * dil - pad;
@@ -585,9 +541,7 @@ static void add_conv1d_multi(Plan &pl, const std::vector<const ConvW *> &cws, co
         koff.resize(base + cw.Kp, 0);
         for (int ci = 0; ci < cw.Cin; ci++) for (int k = 0; k < KW; k++) koff[base + ci * KW + k] = ci * x.ld + k * dil - pad;
     }
-    g_in_multi = true;
     queue_igemm(pl, p, x.B, koff, ph);
-    g_in_multi = false;
 }
 
 // ConvTranspose1d (polyphase), pad = (K - S) / 2 as in HiFiGAN
@@ -1052,15 +1006,8 @@ static void init_kernel_attrs()
     static bool done = false;
     if (done) return;
     done = true;
-    HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)conv1d_lds_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)gru_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)gru256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)knn_select_blend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));   // + ~5 KB static
     HIPCHK(hipFuncSetAttribute((const void *)knn_dot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)relpos_attention_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1301,15 +1248,11 @@ static T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k,
             const size_t gbytes = (size_t)B * 2 * 2 * 256 * sizeof(unsigned long long);
             gp.gran = (unsigned long long *)pl.arena.alloc(gbytes);
             const size_t lds3 = (size_t)(96 * 260 + 256 + 96) * sizeof(float);
-            gp.B = B; gp.xcd_local = getenv("RVC_GRU_XCD_LOCAL") ? 1 : 0;   // measured: no gain (the agent-scope exchange goes through memory either way)
-            const dim3 g3 = gp.xcd_local ? dim3(64 * ((2 * B + 7) / 8)) : dim3(8, 2, B);
+            const dim3 g3(8, 2, B);
             pl.ops.push_back([=](hipStream_t s) {
                 HIPCHK(hipMemsetAsync(gp.gran, 0, gbytes, s));
                 hipLaunchKernelGGL(gru_multi_kernel, g3, dim3(256), lds3, s, gp);
             });
-        } else if (Hg == 256 && getenv("RVC_GRU256")) {   // opt-in: the register-resident variant currently spills and measures slower
-            const size_t lds2 = (size_t)(256 + 768 + 48 * 768) * sizeof(float);
-            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(gru256_kernel, grid, dim3(768), lds2, s, gi.p, gi.ld, gi.bs, wt, bh, gout.p, gout.ld, gout.bs, Tm); });
         } else {
             pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(gru_kernel, grid, dim3(threads), lds, s, gi.p, gi.ld, gi.bs, wt, bh, gout.p, gout.ld, gout.bs, Hg, Tm); });
         }
@@ -1659,7 +1602,7 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         float *d_pitchf = d_pitchf0; int *d_pitch = d_pitch0;
         (void)hubert_length;
         pl.ops.cur = 0;
-        if (rm_end > rm_begin && !getenv("RVC_RM_FIRST")) {
+        if (rm_end > rm_begin) {
             // Two concurrent branches: f0 (ops [rm_begin, rm_end), aux stream 1) and ContentVec (ops [rm_end, here), main stream).
             // Launches reach the hardware queues in host order (~3 us each).  Eager: interleave the branches in proportion to
             // their lengths so both queues are fed from the start (the f0 branch is the longer one once they share the chip).

@@ -63,8 +63,6 @@ struct IgemmP {
     int act; float slope; float scale; int accumulate;
     int pre_act; float pre_slope;   // fused input LeakyReLU: x -> max(x, x*pre_slope); pre_slope = 1 disables it
     int ntn, ntm;
-    // LDS-tiled stride-1 conv (conv1d_lds_kernel): tap-offset table, input channels, LDS row length, padding, input length/halo
-    const int *loff; int c_in, c_rl, c_pad, c_t, c_halo, x_cs;
     int koff_bias;           // bytes: the koff table holds (offset - min offset) * 4, the base pointer is moved back by this
     int glu;                 // WaveNet gate fused into the epilogue: rows are GLU-packed (see glu_store), output has M/2 channels
     int res_nogroup;         // residual channel = m (a tensor shared by all phases) instead of m + y_c0
@@ -507,85 +505,6 @@ __global__ __launch_bounds__(256) void igemm_lds_kernel(IgemmP p)
 #pragma unroll
             for (int r = 0; r < 4; r++)
                 epilogue_store(p, ph, b, ((tm * WM + wm) * MF + mf) * 16 + kq * 4 + r, tn * BN + (wn * NF + nf) * 16 + li, acc[mf][nf][r]);
-}
-
-// Stride-1 (dilated) Conv1d with the input tile resident in LDS -- the HiFiGAN ResBlock shape (C = 32..128,
-// k = 3/7/11, dilation 1/3/5, long N).  One workgroup stages x[all Cin][BN + (k-1)*d] once (coalesced rows, the
-// fused input LeakyReLU applied once per element), then every tap of every channel is a shifted LDS read:
-// global/L2 traffic drops by ~k versus re-gathering per tap.  4 waves x (16*NF) columns, MF row fragments;
-// weights stream from L2 in MFMA-fragment order, double-buffered in registers.
-template <int MF, int NF>
-__global__ __launch_bounds__(256) void conv1d_lds_kernel(IgemmP p)
-{
-    extern __shared__ __attribute__((aligned(16))) float s_x[];
-    constexpr int BN = 64 * NF;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n0 = blockIdx.x * BN, tm = blockIdx.y, b = blockIdx.z;
-    const int RL = p.c_rl, nchunks = p.K >> 4;
-    int *lo = reinterpret_cast<int *>(s_x + p.c_in * RL);
-    for (int i = threadIdx.x; i < p.K; i += 256) lo[i] = p.loff[i];
-    {
-        const float *xb = p.x + (long long)b * p.x_bs;
-        const float ps = p.pre_slope;
-        const int lo_pos = -p.c_halo, hi_pos = p.c_t + p.c_halo - 1;
-        for (int ci = wave; ci < p.c_in; ci += 4) {
-            const float *xr = xb + (long long)ci * p.x_cs;
-            for (int r = lane; r < RL; r += 64) {
-                int pos = n0 - p.c_pad + r;
-                pos = pos < lo_pos ? lo_pos : (pos > hi_pos ? hi_pos : pos);
-                const float v = xr[pos];
-                s_x[ci * RL + r] = fmaxf(v, v * ps);
-            }
-        }
-    }
-    __syncthreads();
-    const int li = lane & 15, kq = lane >> 4;
-    const int mtiles = (p.M + 15) >> 4;
-    const float *wrow[MF];
-#pragma unroll
-    for (int mf = 0; mf < MF; mf++) {
-        int mt = tm * MF + mf;
-        mt = mt < mtiles ? mt : mtiles - 1;
-        wrow[mf] = p.w + (long long)mt * nchunks * 256 + lane * 4;
-    }
-    const float *xl = s_x + wave * 16 * NF + li;
-    f32x4 acc[MF][NF];
-#pragma unroll
-    for (int mf = 0; mf < MF; mf++)
-#pragma unroll
-        for (int nf = 0; nf < NF; nf++) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 a_cur[MF], a_nxt[MF];
-#pragma unroll
-    for (int mf = 0; mf < MF; mf++) a_cur[mf] = *reinterpret_cast<const f32x4 *>(wrow[mf]);
-    for (int c = 0; c < nchunks; c++) {
-        const int cn = c + 1 < nchunks ? c + 1 : c;
-#pragma unroll
-        for (int mf = 0; mf < MF; mf++) a_nxt[mf] = *reinterpret_cast<const f32x4 *>(wrow[mf] + cn * 256);
-        const int4 l4 = *reinterpret_cast<const int4 *>(lo + c * 16 + kq * 4);
-        float bv[NF][4];
-#pragma unroll
-        for (int nf = 0; nf < NF; nf++) {
-            bv[nf][0] = xl[l4.x + nf * 16]; bv[nf][1] = xl[l4.y + nf * 16];
-            bv[nf][2] = xl[l4.z + nf * 16]; bv[nf][3] = xl[l4.w + nf * 16];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int mf = 0; mf < MF; mf++)
-#pragma unroll
-                for (int nf = 0; nf < NF; nf++)
-                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mf][j], bv[nf][j], acc[mf][nf], 0, 0, 0);
-#pragma unroll
-        for (int mf = 0; mf < MF; mf++) a_cur[mf] = a_nxt[mf];
-    }
-    PhaseD ph{};
-#pragma unroll
-    for (int mf = 0; mf < MF; mf++)
-#pragma unroll
-        for (int nf = 0; nf < NF; nf++)
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                epilogue_store(p, ph, b, (tm * MF + mf) * 16 + kq * 4 + r, n0 + wave * 16 * NF + nf * 16 + li, acc[mf][nf][r]);
 }
 
 // second stage of a split-K launch: fixed-order (deterministic) sum of the partials + epilogue
@@ -1124,74 +1043,6 @@ __global__ __launch_bounds__(1024) void gru_kernel(const float *gi, int gi_cs, l
     }
 }
 
-// H = 256 variant of the recurrence (the real RMVPE): one workgroup of 768 threads per direction keeps
-// 37 % of W_hh^T in registers (96 weights per gate row), 19 % in LDS, and streams only the remaining 44 % from L2 each step.
-__global__ __launch_bounds__(768) void gru256_kernel(const float *gi, int gi_cs, long long gi_bs, const float *whhT, const float *bhh,
-                                                     float *out, int o_cs, long long o_bs, int Tm)
-{
-    constexpr int H = 256, R3 = 768, NR = 96, NL = 48, NS = H - NR - NL, SB = 16;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *hs = smem;                 // [H]
-    float *gh = smem + H;             // [3H]
-    float *wl = smem + H + R3;        // [NL][3H]
-    const int dir = blockIdx.x, b = blockIdx.y, r = threadIdx.x;
-    const float *gib = gi + (long long)b * gi_bs + (long long)dir * R3 * gi_cs;
-    const float *wt = whhT + (long long)dir * H * R3;
-    float *ob = out + (long long)b * o_bs + (long long)dir * H * o_cs;
-    float wreg[NR];
-#pragma unroll
-    for (int j = 0; j < NR; j++) wreg[j] = wt[(long long)j * R3 + r];
-    for (int j = 0; j < NL; j++) wl[j * R3 + r] = wt[(long long)(NR + j) * R3 + r];
-    const float *ws = wt + (long long)(NR + NL) * R3 + r;
-    const float bias = bhh[dir * R3 + r];
-    if (r < H) hs[r] = 0.f;
-    __syncthreads();
-    for (int step = 0; step < Tm; step++) {
-        const int t = dir == 0 ? step : Tm - 1 - step;
-        float a0 = bias, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        // first streamed batch issued before the register/LDS part so its L2 latency is covered
-        float sv[SB], sn[SB];
-#pragma unroll
-        for (int j = 0; j < SB; j++) sv[j] = ws[(long long)j * R3];
-#pragma unroll
-        for (int j = 0; j < NR; j += 4) {
-            const f32x4 h4 = *reinterpret_cast<const f32x4 *>(hs + j);
-            a0 += wreg[j] * h4[0]; a1 += wreg[j + 1] * h4[1]; a2 += wreg[j + 2] * h4[2]; a3 += wreg[j + 3] * h4[3];
-        }
-#pragma unroll
-        for (int j = 0; j < NL; j += 4) {
-            const f32x4 h4 = *reinterpret_cast<const f32x4 *>(hs + NR + j);
-            a0 += wl[j * R3 + r] * h4[0]; a1 += wl[(j + 1) * R3 + r] * h4[1]; a2 += wl[(j + 2) * R3 + r] * h4[2]; a3 += wl[(j + 3) * R3 + r] * h4[3];
-        }
-#pragma unroll
-        for (int jb = 0; jb < NS; jb += SB) {
-            if (jb + SB < NS) {
-#pragma unroll
-                for (int j = 0; j < SB; j++) sn[j] = ws[(long long)(jb + SB + j) * R3];
-            }
-#pragma unroll
-            for (int j = 0; j < SB; j += 4) {
-                const f32x4 h4 = *reinterpret_cast<const f32x4 *>(hs + NR + NL + jb + j);
-                a0 += sv[j] * h4[0]; a1 += sv[j + 1] * h4[1]; a2 += sv[j + 2] * h4[2]; a3 += sv[j + 3] * h4[3];
-            }
-#pragma unroll
-            for (int j = 0; j < SB; j++) sv[j] = sn[j];
-        }
-        gh[r] = (a0 + a1) + (a2 + a3);
-        __syncthreads();
-        if (r < H) {
-            float ir = gib[(long long)r * gi_cs + t], iz = gib[(long long)(H + r) * gi_cs + t], in_ = gib[(long long)(2 * H + r) * gi_cs + t];
-            float rg = 1.0f / (1.0f + expf(-(ir + gh[r])));
-            float zg = 1.0f / (1.0f + expf(-(iz + gh[H + r])));
-            float ng = tanhf(in_ + rg * gh[2 * H + r]);
-            float hn = (1.f - zg) * ng + zg * hs[r];
-            hs[r] = hn;
-            ob[(long long)r * o_cs + t] = hn;
-        }
-        __syncthreads();
-    }
-}
-
 // Multi-CU recurrence for few streams (B <= 8): 8 workgroups per direction, each owning 32 hidden units = 96 gate rows
 // whose 96 KB slice of W_hh stays in LDS for all steps.  After every step the 8 slices exchange their 32 new h values through
 // 8-byte {epoch, value} granules (cdna_hip_programming.md guideline 16, form R2: the data is the flag; relaxed agent-scope
@@ -1206,7 +1057,6 @@ struct GruMultiP {
     int *status;               // per stream, stride status_stride ints
     int status_stride;
     int Tm;
-    int B, xcd_local;
 };
 __global__ __launch_bounds__(256) void gru_multi_kernel(GruMultiP p)
 {
@@ -1215,15 +1065,8 @@ __global__ __launch_bounds__(256) void gru_multi_kernel(GruMultiP p)
     float *w = smem;                    // [ROWS][RS]
     float *hs = w + ROWS * RS;          // [H]
     float *gh = hs + H;                 // [ROWS]
-    // Workgroups are dealt to the 8 XCDs round-robin by linear id.  The 8 members of one (stream, direction) group exchange
-    // h every step, so a group takes linear ids slot + 8*member (+ 64*round): all on XCD `slot`.  Ids whose slot has no group exit.
-    int g, dir, b;
-    const int tid = threadIdx.x;
-    if (p.xcd_local) {
-        const int L = blockIdx.x, slot = L & 7, member = (L >> 3) & 7, round = L >> 6, q = round * 8 + slot;
-        if (q >= 2 * p.B) return;
-        g = member; dir = q & 1; b = q >> 1;
-    } else { g = blockIdx.x; dir = blockIdx.y; b = blockIdx.z; }
+    // (placing a group's 8 workgroups on one XCD was measured: no gain, the agent-scope hand-off goes through memory either way)
+    const int g = blockIdx.x, dir = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
     const float *wsrc = p.whh + (long long)dir * 3 * H * H;
     for (int i = tid; i < ROWS * (H / 4); i += 256) {
         const int row = i / (H / 4), c4 = i - row * (H / 4);
