@@ -370,6 +370,12 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     int cfg = 0, wg_ks = 1;
     long long best_waves = -1;
     bool found = false;
+    // phases of unequal length (fused ResBlock chains, kernel sizes 3/7/11) are all co-resident: finer tiles even out the
+    // per-SIMD load (measured on the decoder: 32x32 tiles 185 vs 200 us at C = 128, 127 vs 133 us at C = 64; folding the
+    // chains' average into one K-concatenated GEMM was also measured: no gain)
+    bool uneven = false;
+    for (const PhaseD &q : phv) uneven = uneven || q.nchunks != phv[0].nchunks;
+    const long long want_waves = (uneven && p.M >= 64) ? 2048 : 1024;
     for (int oi = 0; oi < 3 && !found; oi++) {
         const int c = order[oi];
         for (int ks = 1; ks <= 16; ks = ks == 1 ? 4 : ks * 2) {
@@ -377,7 +383,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
             if ((size_t)nchunks * 64 + (ks > 1 ? (size_t)ks * kMF[c] * kNF[c] * 1024 : 0) > 60 * 1024) break;
             const long long w = tiles(c) * ks;
             if (w > best_waves) { best_waves = w; cfg = c; wg_ks = ks; }
-            if (w >= 1024) { cfg = c; wg_ks = ks; found = true; break; }
+            if (w >= want_waves) { cfg = c; wg_ks = ks; found = true; break; }
         }
     }
     // throughput mode (many streams): workgroup-tiled kernel with the activation tile shared through LDS
