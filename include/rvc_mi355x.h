@@ -116,6 +116,20 @@ rvc_status rvc_resampler_process(rvc_resampler *r, const float *in, size_t n_in,
 /* device-resident variant (HIP device pointers, engine's stream; no sync unless sync != 0) */
 rvc_status rvc_resampler_process_device(rvc_resampler *r, const void *d_in, void *d_out, int sync);
 
+/* ---- the plugin's per-chunk state machine as one call (SURVEY.md section 8 rows f1-f3 chained, all buffers resident in HBM) ---- */
+/* `create`/`update` + `process_one_frame` of the filter (obs-rvc/src/lib.rs:181-260, 659-795): host-rate ring, 16 kHz ring, both
+ * resamplers, RvcInfer::infer, RMS envelope mixing and SOLA.  One H2D copy (the new chunk), one D2H copy (the finished frame) and
+ * one synchronisation per chunk.  Lengths in seconds as in the plugin's settings; skip_inference != 0 = pass-through mode
+ * (lib.rs:224-227).  The engine must be in single-stream mode; destroy the session before the engine. */
+typedef struct rvc_session rvc_session;
+rvc_status rvc_session_create(rvc_engine *e, size_t sample_rate, double sample_length, double crossfade_length, double extra_inference_time,
+                              size_t model_output_sample_rate, int32_t pitch_shift, double rms_mix_rate, int skip_inference, rvc_session **out);
+void rvc_session_destroy(rvc_session *s);
+size_t rvc_session_frame_size(rvc_session *s);                 /* sample_frame_size: samples per process call, in and out */
+void rvc_session_set_params(rvc_session *s, int32_t pitch_shift, double rms_mix_rate);
+void rvc_session_geometry(rvc_session *s, int32_t out[10]);   /* the derived sizes of lib.rs:200-227 (see session.hip.h) */
+rvc_status rvc_session_process(rvc_session *s, const float *input_sample, size_t n, float *output, size_t cap, size_t *sola_offset);
+
 /* ---- measurement / debugging ---- */
 /* total milliseconds of the last infer measured with HIP events on the engine's stream */
 float rvc_last_gpu_ms(rvc_engine *e);

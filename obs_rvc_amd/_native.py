@@ -22,12 +22,13 @@ SYMBOLS = [
     "rvc_index_device_ptr", "rvc_device", "rvc_version", "rvc_envelop_mixing", "rvc_sola_step", "rvc_profile_last_knn",
     "rvc_resampler_create", "rvc_resampler_destroy", "rvc_resampler_input_frames_next", "rvc_resampler_output_frames_max",
     "rvc_resampler_reset", "rvc_resampler_process", "rvc_resampler_process_device",
+    "rvc_session_create", "rvc_session_destroy", "rvc_session_process", "rvc_session_frame_size", "rvc_session_set_params", "rvc_session_geometry",
 ]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950: the engine library and the rvc-rpc protocol-compatible executable."""
-    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "kernels.hip.h", "resample.hip.h", "blob.h")] + \
+    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "kernels.hip.h", "resample.hip.h", "session.hip.h", "blob.h")] + \
            [os.path.join(os.path.dirname(_HERE), "include", "rvc_mi355x.h")]
     newest = max(os.path.getmtime(s) for s in srcs)
     if force or not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < newest:
@@ -110,5 +111,15 @@ def lib():
     L.rvc_resampler_reset.restype = None
     L.rvc_resampler_process.argtypes = [vp, fp, sz, fp, sz, C.POINTER(sz)]
     L.rvc_resampler_process_device.argtypes = [vp, vp, vp, C.c_int]
+    L.rvc_session_create.argtypes = [vp, sz, C.c_double, C.c_double, C.c_double, sz, i32, C.c_double, C.c_int, C.POINTER(vp)]
+    L.rvc_session_destroy.argtypes = [vp]
+    L.rvc_session_destroy.restype = None
+    L.rvc_session_process.argtypes = [vp, fp, sz, fp, sz, C.POINTER(sz)]
+    L.rvc_session_frame_size.argtypes = [vp]
+    L.rvc_session_frame_size.restype = sz
+    L.rvc_session_set_params.argtypes = [vp, i32, C.c_double]
+    L.rvc_session_set_params.restype = None
+    L.rvc_session_geometry.argtypes = [vp, C.POINTER(i32)]
+    L.rvc_session_geometry.restype = None
     _LIB = L
     return L

@@ -2129,11 +2129,13 @@ rvc_status rvc_sola_step(rvc_engine *e, float *output, size_t output_len, float 
     return guarded(e, [&]() {
         if (search + 1 > 1024) throw ShapeError("sola search range too long");
         if (output_len < sola_len + search || output_len < search + frame + sola_len) throw PanicError("sola: output shorter than offset + frame + tail (the reference slices out of range)");
-        float *d_out, *d_sola, *d_frame; int *d_off;
+        float *d_out, *d_sola, *d_frame, *d_cor; int *d_off;
         HIPCHK(hipMalloc(&d_out, output_len * 4)); HIPCHK(hipMalloc(&d_sola, sola_len * 4)); HIPCHK(hipMalloc(&d_frame, frame * 4)); HIPCHK(hipMalloc(&d_off, 4));
+        HIPCHK(hipMalloc(&d_cor, (search + 1) * 4));
         HIPCHK(hipMemcpyAsync(d_out, output, output_len * 4, hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipMemcpyAsync(d_sola, sola_buffer, sola_len * 4, hipMemcpyHostToDevice, e->stream));
-        hipLaunchKernelGGL(post_sola_kernel, dim3(1), dim3(1024), 0, e->stream, d_out, d_sola, (int)sola_len, (int)search, (int)frame, d_frame, d_off);
+        hipLaunchKernelGGL(post_sola_corr_kernel, dim3((unsigned)(search + 4) / 4), dim3(256), 0, e->stream, d_out, d_sola, (int)sola_len, (int)search, d_cor);
+        hipLaunchKernelGGL(post_sola_kernel, dim3(1), dim3(1024), 0, e->stream, d_out, d_sola, (int)sola_len, (int)search, (int)frame, d_frame, d_off, d_cor);
         int off = 0;
         HIPCHK(hipMemcpyAsync(output, d_out, output_len * 4, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipMemcpyAsync(sola_buffer, d_sola, sola_len * 4, hipMemcpyDeviceToHost, e->stream));
@@ -2141,7 +2143,7 @@ rvc_status rvc_sola_step(rvc_engine *e, float *output, size_t output_len, float 
         HIPCHK(hipMemcpyAsync(&off, d_off, 4, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         if (sola_offset) *sola_offset = (size_t)off;
-        (void)hipFree(d_out); (void)hipFree(d_sola); (void)hipFree(d_frame); (void)hipFree(d_off);
+        (void)hipFree(d_out); (void)hipFree(d_sola); (void)hipFree(d_frame); (void)hipFree(d_off); (void)hipFree(d_cor);
         return RVC_OK;
     });
 }
@@ -2242,3 +2244,4 @@ rvc_status rvc_get_tap(rvc_engine *e, const char *name, float *out, size_t cap, 
 }  // extern "C"
 
 #include "resample.hip.h"
+#include "session.hip.h"

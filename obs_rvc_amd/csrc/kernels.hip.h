@@ -1879,16 +1879,28 @@ __global__ void post_mix_kernel(float *out, int n, const float *r1, int n1, cons
 }
 // rt_utils.rs:60-90 + lib.rs:768-794 in one workgroup: normalised cross-correlation over search+1 lags (last maximum wins),
 // sin^2 crossfade with the previous tail, new tail saved, first `frame` samples returned.
-__global__ __launch_bounds__(1024) void post_sola_kernel(float *output, float *sola, int sola_len, int search, int frame, float *frame_out, int *offset_out)
+// normalised cross-correlation of get_sola_offset (rt_utils.rs:60-77), one wave per lag: cor[l] = <out[l..], sola> / sqrt(<out[l..], out[l..]> + 1e-8)
+// with f64 accumulation (the reference's FFT convolution carries f32 rounding noise of the same order as an f32 direct sum)
+__global__ __launch_bounds__(256) void post_sola_corr_kernel(const float *output, const float *sola, int sola_len, int search, float *cor)
+{
+    const int lane = threadIdx.x & 63, l = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (l > search) return;
+    double nom = 0.0, den = 0.0;
+    for (int j = lane; j < sola_len; j += 64) { const double v = (double)output[l + j]; nom += v * (double)sola[j]; den += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { nom += __shfl_xor(nom, o, 64); den += __shfl_xor(den, o, 64); }
+    if (lane == 0) cor[l] = (float)nom / sqrtf((float)den + 1e-8f);
+}
+
+// arg-max with the reference's tie rule (the LAST maximum wins, rt_utils.rs:79-88), sin^2 crossfade with the previous tail, tail save and
+// frame extraction (lib.rs:768-794)
+__global__ __launch_bounds__(1024) void post_sola_kernel(float *output, float *sola, int sola_len, int search, int frame, float *frame_out, int *offset_out,
+                                                         const float *cor_g)
 {
     __shared__ float cor[1024];
     __shared__ int s_off;
     const int t = threadIdx.x;
-    for (int l = t; l <= search; l += 1024) {
-        double nom = 0.0, den = 0.0;
-        for (int j = 0; j < sola_len; j++) { const double v = (double)output[l + j]; nom += v * (double)sola[j]; den += v * v; }
-        cor[l] = (float)nom / sqrtf((float)den + 1e-8f);
-    }
+    for (int l = t; l <= search; l += 1024) cor[l] = cor_g[l];
     __syncthreads();
     if (t == 0) {
         int best = 0; float bv = cor[0];

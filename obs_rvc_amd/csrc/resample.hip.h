@@ -108,14 +108,29 @@ __global__ __launch_bounds__(1024) void resample_polyphase_kernel(ResampleP p)
             s[q] = (int)((m * p.P) / p.Q);        // < Lin
             acc[q] = 0.f;
         }
+        // row index (s[q] - n) mod Lin: no wrap while n <= s[0] (s ascends with q), always wrapped once n > s[3]; only the few
+        // taps in between need the generic form -- the two long segments run with plain descending addresses
+        const int nA = s[0] + 1 < p.fft_in ? s[0] + 1 : p.fft_in, nB = s[3] + 1 < p.fft_in ? s[3] + 1 : p.fft_in;
+        const float *r0 = row + s[0], *r1 = row + s[1], *r2 = row + s[2], *r3 = row + s[3];
+        int n = lane;
 #pragma unroll 4
-        for (int n = lane; n < p.fft_in; n += 64) {
+        for (; n < nA; n += 64) {
+            const float xvn = xv[n];
+            acc[0] += xvn * r0[-n]; acc[1] += xvn * r1[-n]; acc[2] += xvn * r2[-n]; acc[3] += xvn * r3[-n];
+        }
+        for (; n < nB; n += 64) {
             const float xvn = xv[n];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 int i = s[q] - n; i += i < 0 ? p.Lin : 0;
                 acc[q] += xvn * row[i];
             }
+        }
+        r0 += p.Lin; r1 += p.Lin; r2 += p.Lin; r3 += p.Lin;
+#pragma unroll 4
+        for (; n < p.fft_in; n += 64) {
+            const float xvn = xv[n];
+            acc[0] += xvn * r0[-n]; acc[1] += xvn * r1[-n]; acc[2] += xvn * r2[-n]; acc[3] += xvn * r3[-n];
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {

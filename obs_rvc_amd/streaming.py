@@ -68,3 +68,47 @@ class StreamingSession:
         off, frame, self.sola_buffer = self.e.sola_step(out, self.sola_buffer, g.sola_search_frame_size, g.sample_frame_size)
         self.last_sola_offset = off
         return frame
+
+
+class NativeStreamingSession:
+    """The same state machine as one native call per chunk with every buffer resident in HBM (`rvc_session_*`,
+    csrc/session.hip.h): one H2D copy, one D2H copy and one synchronisation per chunk."""
+
+    def __init__(self, engine, sample_rate: int = 48000, sample_length: float = 0.30, crossfade_length: float = 0.07,
+                 extra_inference_time: float = 2.0, model_output_sample_rate: int = 40000, pitch_shift: int = 12,
+                 rms_mix_rate: float = 1.0, skip_inference: bool = False):
+        import ctypes as C
+        from . import _native
+        from .rvc_common import RvcInferError
+        self._C, self._err, self._L, self._engine = C, RvcInferError, _native.lib(), engine
+        h = C.c_void_p()
+        rc = self._L.rvc_session_create(engine._h, sample_rate, sample_length, crossfade_length, extra_inference_time, model_output_sample_rate,
+                                        pitch_shift, rms_mix_rate, 1 if skip_inference else 0, C.byref(h))
+        if rc != 0:
+            raise RvcInferError(rc, (self._L.rvc_last_error_message(engine._h) or b"").decode())
+        self._h = h
+        g = (C.c_int32 * 10)()
+        self._L.rvc_session_geometry(h, g)
+        (self.sample_frame_size, self.sample_frame_16k, self.input_buffer_size, self.input_buffer_16k_size, self.model_return_length,
+         self.model_return_size, self.skip_head, self.sola_buffer_frame_size, self.sola_search_frame_size, self.extra_frame_size) = [int(v) for v in g]
+        self.last_sola_offset = 0
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and getattr(self._engine, "_h", None):
+            self._L.rvc_session_destroy(h)
+
+    def set_params(self, pitch_shift: int, rms_mix_rate: float) -> None:
+        self._L.rvc_session_set_params(self._h, pitch_shift, rms_mix_rate)
+
+    def process_one_frame(self, input_sample: np.ndarray) -> np.ndarray:
+        C = self._C
+        x = np.ascontiguousarray(input_sample, dtype=np.float32).reshape(-1)
+        out = np.empty(self.sample_frame_size, np.float32)
+        off = C.c_size_t(0)
+        fp = C.POINTER(C.c_float)
+        rc = self._L.rvc_session_process(self._h, x.ctypes.data_as(fp), x.size, out.ctypes.data_as(fp), out.size, C.byref(off))
+        if rc != 0:
+            raise self._err(rc, (self._L.rvc_last_error_message(self._engine._h) or b"").decode())
+        self.last_sola_offset = int(off.value)
+        return out

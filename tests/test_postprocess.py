@@ -142,3 +142,49 @@ def test_streaming_host_logic_with_oracle_backends():
     assert abs(rms(frames[-1]) - 0.3 / np.sqrt(2)) < 0.01
     with pytest.raises(ValueError):
         StreamingSession(ora, g, 12, 1.0, 4800, None)          # no converters but model rate != host rate
+
+
+@pytest.mark.gpu
+def test_native_session_matches_python_state_machine_and_oracle():
+    # rvc_session_process = the whole process_one_frame with device-resident rings; against the host-side state machine over the
+    # same engine kernels (tight) and against the all-CPU restatement (parity tolerance)
+    import time
+    from oracle import resample_oracle as RO
+    from obs_rvc_amd.resample import FftFixedInOut
+    from obs_rvc_amd.rvc import RvcInfer
+    from obs_rvc_amd.streaming import NativeStreamingSession, StreamingSession
+    g = derive(48000, 0.16, 0.07, 2.0, 4800)
+    z = zoo("tiny")
+
+    def engine():
+        e = RvcInfer(z["data"]); e.load_contentvec(2); e.load_f0(); e.load_model(z["model"]); e.set_noise_seed(3, 0)
+        return e
+    e1, e2 = engine(), engine()
+    ora = O.OracleRvcInfer(z["data"]); ora.load_contentvec(2); ora.load_f0(1); ora.load_model(z["model"]); ora.set_noise_seed(3, 0)
+    nat = NativeStreamingSession(e1, 48000, 0.16, 0.07, 2.0, 4800, 12, 0.6)
+    assert (nat.sample_frame_size, nat.sample_frame_16k, nat.input_buffer_size, nat.input_buffer_16k_size, nat.model_return_length,
+            nat.model_return_size, nat.skip_head) == (g.sample_frame_size, g.sample_frame_16k, g.input_buffer_size, g.input_buffer_16k_size,
+                                                      g.model_return_length, g.model_return_size, g.skip_head)
+    pys = StreamingSession(e2, g, 12, 0.6, 4800, lambda ri, ro, n: FftFixedInOut(e2, ri, ro, n))
+    ors = StreamingSession(ora, g, 12, 0.6, 4800, lambda ri, ro, n: RO.FftFixedInOut(ri, ro, n))
+    a = np.interp(np.arange(7680 * 16) / 48000.0, np.arange(2560 * 16) / 16000.0, voice_signal(2560 * 16, seed=10)).astype(np.float32)
+    t_nat = t_py = 0.0
+    for c in range(16):
+        ch = a[c * 7680:(c + 1) * 7680]
+        t0 = time.perf_counter(); fn = nat.process_one_frame(ch); t1 = time.perf_counter(); fp = pys.process_one_frame(ch); t2 = time.perf_counter()
+        fo = ors.process_one_frame(ch)
+        t_nat += t1 - t0; t_py += t2 - t1
+        assert fn.shape == (7680,) and nat.last_sola_offset == pys.last_sola_offset
+        assert np.abs(fn - fp).max() < 2e-5, (c, float(np.abs(fn - fp).max()))
+        assert rms(fn - fo) < 1e-3, (c, rms(fn - fo))
+    assert t_nat < t_py                               # fewer host round trips
+    with pytest.raises(Exception):
+        nat.process_one_frame(a[:100])
+    wrong = NativeStreamingSession(e1, 48000, 0.16, 0.07, 2.0, 40000)   # the loaded (tiny) synthesizer runs at 4.8 kHz, not 40 kHz
+    with pytest.raises(Exception):
+        wrong.process_one_frame(a[:7680])
+    assert NativeStreamingSession(e1, 44100, 0.16, 0.07, 2.0, 40000).sample_frame_size == 7056
+    sk = NativeStreamingSession(e1, 48000, 0.16, 0.07, 2.0, 4800, 12, 1.0, skip_inference=True)
+    tone = (0.3 * np.sin(2 * np.pi * 300.0 * np.arange(7680 * 8) / 48000.0)).astype(np.float32)
+    last = [sk.process_one_frame(tone[c * 7680:(c + 1) * 7680]) for c in range(8)][-1]
+    assert abs(rms(last) - 0.3 / np.sqrt(2)) < 0.01
