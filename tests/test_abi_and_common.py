@@ -96,3 +96,13 @@ def test_shard_streams_round_robin():
     assert [len(s) for s in sh] == [64] * 8 and sh[3][:3] == [3, 11, 19]
     assert sorted(sum(dist.shard_streams(13, 4), [])) == list(range(13))
     assert dist.local_streams(5, 1, 2) == [1, 3]
+
+
+def test_header_is_plain_c(tmp_path):
+    # the boundary is a C ABI: the header must compile as C99 (no C++-isms outside the extern "C" guards)
+    import shutil, subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not found")
+    src = tmp_path / "abi_check.c"
+    src.write_text('#include "rvc_mi355x.h"\nint main(void) { rvc_engine *e = 0; rvc_session *s = 0; rvc_resampler *r = 0; (void)e; (void)s; (void)r; return (int)RVC_OK; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(src)])
