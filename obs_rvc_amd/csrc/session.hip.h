@@ -64,7 +64,7 @@ rvc_status rvc_session_create(rvc_engine *e, size_t sample_rate, double sample_l
 {
     if (out) *out = nullptr;
     return guarded(e, [&]() {
-        if (!out || sample_rate < 8000 || sample_rate % 100 != 0 || sample_rate > 384000 || model_output_sample_rate % 100 != 0 || model_output_sample_rate == 0)
+        if (!out || sample_rate < 1000 || sample_rate % 100 != 0 || sample_rate > 384000 || model_output_sample_rate % 100 != 0 || model_output_sample_rate == 0)
             throw ShapeError("session: unsupported sample rate");
         if (e->n_streams != 1) throw ShapeError("session: the engine must be in single-stream mode");
         std::unique_ptr<rvc_session> sp(new rvc_session());

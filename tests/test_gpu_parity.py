@@ -323,3 +323,31 @@ def test_linearity_of_retrieval_free_feature_path_properties():
     b1 = eng2.infer(x, 2560, 12, 200, 21)
     assert a1.shape == (10080,) and np.array_equal(a1, b1) and not np.array_equal(a1, a2)
     assert np.abs(a1).max() <= 1.0 and np.isfinite(a1).all()
+
+
+def test_plain_c_client_links_and_runs(tmp_path):
+    # examples/c_smoke.c is compiled with gcc as C99 against include/rvc_mi355x.h and linked to the shared library: the boundary is a
+    # C ABI, not a Python extension.  Its infer output must equal the ctypes path's (same seed, same input).
+    import shutil, subprocess
+    from obs_rvc_amd import _native
+    from obs_rvc_amd.rvc import RvcInfer
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not found")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_smoke")
+    libdir = os.path.dirname(_native.SO_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_smoke.c"),
+                           "-L", libdir, "-lrvc_mi355x", "-Wl,-rpath," + libdir, "-lm", "-o", exe])
+    z = zoo("tiny")
+    out = subprocess.run([exe, z["data"], z["model"]], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[-1].startswith("ok ") and "gfx950" in lines[-1]
+    n, r = int(lines[0].split()[1]), float(lines[0].split("rms")[1].split(",")[0])
+    eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"]); eng.set_noise_seed(1234, 0)
+    i = np.arange(35840)
+    x = (np.float32(0.1) * np.sin(2.0 * 3.14159265358979 * 180.0 * i / 16000.0).astype(np.float32) + np.float32(0.05) * np.sin(2.0 * 3.14159265358979 * 360.0 * i / 16000.0).astype(np.float32)).astype(np.float32)
+    y = eng.infer(x, 2560, 12, 200, 21)
+    assert n == y.size == 1008 and abs(rms(y) - r) < 1e-5 * max(r, 1e-3) + 2e-6
+    assert "small buffer: status 5 (expected 5), required 1008" in out.stdout
+    assert "session: frame 768 samples" in out.stdout
