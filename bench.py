@@ -169,20 +169,23 @@ def main():
     # the whole plugin-side chain as one native call (rvc_session_process: 48 kHz chunk in -> resample -> infer -> resample ->
     # envelope -> SOLA -> 48 kHz frame out, rings resident in HBM); reported next to `value`, never as `value`
     chain_ms = None
-    if rank == 0 and S == 1 and args.preset == "full" and not args.index:
+    if rank == 0 and args.preset == "full" and not args.index:
         from obs_rvc_amd.streaming import NativeStreamingSession
         ses = NativeStreamingSession(eng, 48000, 0.16, 0.07, 2.0, 48000, 12, 0.75)
-        x48 = np.interp(np.arange(ses.sample_frame_size * 34) / 48000.0, np.arange(chunk * 34) / 16000.0, voice_signal(chunk * 34, seed=99)).astype(np.float32)
+        F, n_ch = ses.sample_frame_size, 34 if S == 1 else 12
+        x48 = np.stack([np.interp(np.arange(F * n_ch) / 48000.0, np.arange(chunk * n_ch) / 16000.0, voice_signal(chunk * n_ch, seed=99 + s)).astype(np.float32)
+                        for s in range(S)])
         ts = []
-        for i in range(34):
+        for i in range(n_ch):
+            xin = x48[:, i * F:(i + 1) * F] if S > 1 else x48[0, i * F:(i + 1) * F]
             h0 = time.perf_counter()
             try:
-                ses.process_one_frame(x48[i * ses.sample_frame_size:(i + 1) * ses.sample_frame_size])
+                ses.process_one_frame(np.ascontiguousarray(xin))
             except Exception as ex:      # while the 2.24 s ring is still mostly zeros the synthetic RMVPE weights can hit the
                 if "Panic" not in str(ex):   # reference's out-of-range decode (rmvpe.rs:124): reported as RVC_PANIC after the
                     raise                    # chunk has run, so its time is still a valid sample
             ts.append(time.perf_counter() - h0)
-        chain_ms = round(float(np.median(ts[6:])) * 1e3, 4)
+        chain_ms = round(float(np.median(ts[n_ch // 5:])) * 1e3, 4)
         del ses
 
     cpu = None

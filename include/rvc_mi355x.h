@@ -120,7 +120,8 @@ rvc_status rvc_resampler_process_device(rvc_resampler *r, const void *d_in, void
 /* `create`/`update` + `process_one_frame` of the filter (obs-rvc/src/lib.rs:181-260, 659-795): host-rate ring, 16 kHz ring, both
  * resamplers, RvcInfer::infer, RMS envelope mixing and SOLA.  One H2D copy (the new chunk), one D2H copy (the finished frame) and
  * one synchronisation per chunk.  Lengths in seconds as in the plugin's settings; skip_inference != 0 = pass-through mode
- * (lib.rs:224-227).  The engine must be in single-stream mode; destroy the session before the engine. */
+ * (lib.rs:224-227).  The session covers every stream of the engine (rvc_set_streams before rvc_session_create): process then takes
+ * input [streams][n] and writes output [streams][cap], sola_offset [streams].  Destroy the session before the engine. */
 typedef struct rvc_session rvc_session;
 rvc_status rvc_session_create(rvc_engine *e, size_t sample_rate, double sample_length, double crossfade_length, double extra_inference_time,
                               size_t model_output_sample_rate, int32_t pitch_shift, double rms_mix_rate, int skip_inference, rvc_session **out);

@@ -2113,9 +2113,9 @@ rvc_status rvc_envelop_mixing(rvc_engine *e, const float *input, float *output, 
         HIPCHK(hipMalloc(&d_in, output_len * 4)); HIPCHK(hipMalloc(&d_out, output_len * 4)); HIPCHK(hipMalloc(&d_r, (size_t)2 * nf * 4));
         HIPCHK(hipMemcpyAsync(d_in, input, output_len * 4, hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipMemcpyAsync(d_out, output, output_len * 4, hipMemcpyHostToDevice, e->stream));
-        hipLaunchKernelGGL(post_rms_kernel, dim3(nf), dim3(256), 0, e->stream, d_in, n, frame, hop, d_r);
-        hipLaunchKernelGGL(post_rms_kernel, dim3(nf), dim3(256), 0, e->stream, d_out, n, frame, hop, d_r + nf);
-        hipLaunchKernelGGL(post_mix_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, d_out, n, d_r, nf, d_r + nf, nf, (float)(1.0 - mix_rate));
+        hipLaunchKernelGGL(post_rms_kernel, dim3(nf), dim3(256), 0, e->stream, d_in, n, frame, hop, d_r, 0LL, 0LL);
+        hipLaunchKernelGGL(post_rms_kernel, dim3(nf), dim3(256), 0, e->stream, d_out, n, frame, hop, d_r + nf, 0LL, 0LL);
+        hipLaunchKernelGGL(post_mix_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, d_out, n, d_r, nf, d_r + nf, nf, (float)(1.0 - mix_rate), 0LL, 0LL);
         HIPCHK(hipMemcpyAsync(output, d_out, output_len * 4, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_r);
@@ -2134,8 +2134,8 @@ rvc_status rvc_sola_step(rvc_engine *e, float *output, size_t output_len, float 
         HIPCHK(hipMalloc(&d_cor, (search + 1) * 4));
         HIPCHK(hipMemcpyAsync(d_out, output, output_len * 4, hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipMemcpyAsync(d_sola, sola_buffer, sola_len * 4, hipMemcpyHostToDevice, e->stream));
-        hipLaunchKernelGGL(post_sola_corr_kernel, dim3((unsigned)(search + 4) / 4), dim3(256), 0, e->stream, d_out, d_sola, (int)sola_len, (int)search, d_cor);
-        hipLaunchKernelGGL(post_sola_kernel, dim3(1), dim3(1024), 0, e->stream, d_out, d_sola, (int)sola_len, (int)search, (int)frame, d_frame, d_off, d_cor);
+        hipLaunchKernelGGL(post_sola_corr_kernel, dim3((unsigned)(search + 4) / 4), dim3(256), 0, e->stream, d_out, d_sola, (int)sola_len, (int)search, d_cor, 0LL, 0LL, 0LL);
+        hipLaunchKernelGGL(post_sola_kernel, dim3(1), dim3(1024), 0, e->stream, d_out, d_sola, (int)sola_len, (int)search, (int)frame, d_frame, d_off, d_cor, 0LL, 0LL, 0LL, 0LL);
         int off = 0;
         HIPCHK(hipMemcpyAsync(output, d_out, output_len * 4, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipMemcpyAsync(sola_buffer, d_sola, sola_len * 4, hipMemcpyDeviceToHost, e->stream));

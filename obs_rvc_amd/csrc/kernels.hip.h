@@ -1844,9 +1844,11 @@ __global__ void knn_queries_kernel(const float *cv, int cv_cs, long long cv_bs, 
 // caller-side post-processing (reference: obs-rvc/src/rt_utils.rs:60-132, lib.rs:758-794)
 // ------------------------------------------------------------------------------------
 // rt_utils.rs:94-103: zero-pad frame/2, square, windowed mean (window frame, step hop), sqrt.  One workgroup per frame.
-__global__ __launch_bounds__(256) void post_rms_kernel(const float *y, int n, int frame, int hop, float *out)
+// (all post-processing kernels take a stream index in blockIdx.y -- blockIdx.x for post_sola_kernel -- and per-stream strides)
+__global__ __launch_bounds__(256) void post_rms_kernel(const float *y, int n, int frame, int hop, float *out, long long y_bs, long long out_bs)
 {
     __shared__ float red[16];
+    y += blockIdx.y * y_bs; out += blockIdx.y * out_bs;
     const int f = blockIdx.x, pad = frame / 2;
     float s = 0.f;
     for (int j = threadIdx.x; j < frame; j += 256) {
@@ -1869,10 +1871,11 @@ __device__ __forceinline__ float lerp_align_corners_at(const float *in, int n_in
     return in[fl] * (1.0f - fr) + in[ce] * fr;
 }
 // rt_utils.rs:119-132
-__global__ void post_mix_kernel(float *out, int n, const float *r1, int n1, const float *r2, int n2, float mix_power)
+__global__ void post_mix_kernel(float *out, int n, const float *r1, int n1, const float *r2, int n2, float mix_power, long long out_bs, long long r_bs)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    out += blockIdx.y * out_bs; r1 += blockIdx.y * r_bs; r2 += blockIdx.y * r_bs;
     const float a = lerp_align_corners_at(r1, n1, n + 1, i);
     const float b = fmaxf(lerp_align_corners_at(r2, n2, n + 1, i), 1e-3f);
     out[i] = out[i] * powf(a / b, mix_power);
@@ -1881,10 +1884,12 @@ __global__ void post_mix_kernel(float *out, int n, const float *r1, int n1, cons
 // sin^2 crossfade with the previous tail, new tail saved, first `frame` samples returned.
 // normalised cross-correlation of get_sola_offset (rt_utils.rs:60-77), one wave per lag: cor[l] = <out[l..], sola> / sqrt(<out[l..], out[l..]> + 1e-8)
 // with f64 accumulation (the reference's FFT convolution carries f32 rounding noise of the same order as an f32 direct sum)
-__global__ __launch_bounds__(256) void post_sola_corr_kernel(const float *output, const float *sola, int sola_len, int search, float *cor)
+__global__ __launch_bounds__(256) void post_sola_corr_kernel(const float *output, const float *sola, int sola_len, int search, float *cor,
+                                                             long long out_bs, long long sola_bs, long long cor_bs)
 {
     const int lane = threadIdx.x & 63, l = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (l > search) return;
+    output += blockIdx.y * out_bs; sola += blockIdx.y * sola_bs; cor += blockIdx.y * cor_bs;
     double nom = 0.0, den = 0.0;
     for (int j = lane; j < sola_len; j += 64) { const double v = (double)output[l + j]; nom += v * (double)sola[j]; den += v * v; }
 #pragma unroll
@@ -1895,11 +1900,12 @@ __global__ __launch_bounds__(256) void post_sola_corr_kernel(const float *output
 // arg-max with the reference's tie rule (the LAST maximum wins, rt_utils.rs:79-88), sin^2 crossfade with the previous tail, tail save and
 // frame extraction (lib.rs:768-794)
 __global__ __launch_bounds__(1024) void post_sola_kernel(float *output, float *sola, int sola_len, int search, int frame, float *frame_out, int *offset_out,
-                                                         const float *cor_g)
+                                                         const float *cor_g, long long out_bs, long long sola_bs, long long frame_bs, long long cor_bs)
 {
     __shared__ float cor[1024];
     __shared__ int s_off;
     const int t = threadIdx.x;
+    output += blockIdx.x * out_bs; sola += blockIdx.x * sola_bs; frame_out += blockIdx.x * frame_bs; cor_g += blockIdx.x * cor_bs; offset_out += blockIdx.x;
     for (int l = t; l <= search; l += 1024) cor[l] = cor_g[l];
     __syncthreads();
     if (t == 0) {

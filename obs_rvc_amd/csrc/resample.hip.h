@@ -70,9 +70,10 @@ struct ResampleP {
     float *ov_new;           // [fft_out]
     float *out;              // [fft_out]
     int fft_in, fft_out, Lin, P, Q, splits, x_in_lds;
+    long long x_bs, out_bs;     // stream strides (blockIdx.z = stream); the overlap buffers are [streams][fft_out]
 };
 
-// grid = (splits, Q): workgroup (s, a) owns the outputs m = a + t*Q, t in its share of [0, ceil((Lout - a)/Q)); they all use
+// grid = (splits, Q, streams): workgroup (s, a) owns the outputs m = a + t*Q, t in its share of [0, ceil((Lout - a)/Q)); they all use
 // polyphase row (a*P) mod Q.  Row and chunk live in LDS; one wave per group of 4 outputs (they share the x reads), lanes along n.
 __global__ __launch_bounds__(1024) void resample_polyphase_kernel(ResampleP p)
 {
@@ -81,6 +82,8 @@ __global__ __launch_bounds__(1024) void resample_polyphase_kernel(ResampleP p)
     const int a = blockIdx.y, Lout = 2 * p.fft_out;
     const int r = (int)(((long long)a * p.P) % p.Q);
     const float *rsrc = p.table + (long long)r * p.Lin;
+    const float *xg = p.x + blockIdx.z * p.x_bs, *ovo = p.ov_old + (long long)blockIdx.z * p.fft_out;
+    float *ovn = p.ov_new + (long long)blockIdx.z * p.fft_out, *og = p.out + blockIdx.z * p.out_bs;
     {
         // staging in batches of 4 independent 16-byte loads per thread (latency: one round trip per batch, not per element)
         const int n4 = p.Lin / 4, step = (int)blockDim.x;
@@ -92,10 +95,10 @@ __global__ __launch_bounds__(1024) void resample_polyphase_kernel(ResampleP p)
             for (int u = 0; u < 4; u++) if (i0 + u * step < n4) reinterpret_cast<f32x4 *>(row)[i0 + u * step] = v[u];
         }
         for (int i = n4 * 4 + threadIdx.x; i < p.Lin; i += step) row[i] = rsrc[i];
-        if (p.x_in_lds) for (int i = threadIdx.x; i < p.fft_in; i += step) xs[i] = p.x[i];
+        if (p.x_in_lds) for (int i = threadIdx.x; i < p.fft_in; i += step) xs[i] = xg[i];
     }
     __syncthreads();
-    const float *xv = p.x_in_lds ? xs : p.x;
+    const float *xv = p.x_in_lds ? xs : xg;
     const int n_t = a < Lout ? (Lout - a + p.Q - 1) / p.Q : 0;               // outputs of this residue class
     const int per = (n_t + p.splits - 1) / p.splits;
     const int t0 = blockIdx.x * per, t1 = (t0 + per < n_t) ? t0 + per : n_t;
@@ -138,8 +141,8 @@ __global__ __launch_bounds__(1024) void resample_polyphase_kernel(ResampleP p)
             const int t = tb + q;
             if (lane == 0 && t < t1) {
                 const int m = a + t * p.Q;
-                if (m < p.fft_out) p.out[m] = v + p.ov_old[m];
-                else p.ov_new[m - p.fft_out] = v;
+                if (m < p.fft_out) og[m] = v + ovo[m];
+                else ovn[m - p.fft_out] = v;
             }
         }
     }
@@ -151,7 +154,7 @@ using namespace rvc;
 
 struct rvc_resampler {
     rvc_engine *e = nullptr;
-    int rate_in = 0, rate_out = 0, fft_in = 0, fft_out = 0, P = 1, Q = 1, Lin = 0;
+    int rate_in = 0, rate_out = 0, fft_in = 0, fft_out = 0, P = 1, Q = 1, Lin = 0, nb = 1;   // nb = streams converted per call
     float *d_table = nullptr, *d_ov[2] = {nullptr, nullptr}, *d_x = nullptr, *d_out = nullptr;
     int parity = 0;
 };
@@ -161,14 +164,14 @@ static long long gcd_ll(long long a, long long b) { while (b) { long long t = a 
 extern "C" {
 
 // FftFixedInOut::<f32>::new(sample_rate_input, sample_rate_output, chunk_size_in, 1)   (obs-rvc/src/lib.rs:236-242)
-rvc_status rvc_resampler_create(rvc_engine *e, size_t rate_in, size_t rate_out, size_t chunk_size_in, rvc_resampler **out)
+static rvc_status resampler_create_n(rvc_engine *e, size_t rate_in, size_t rate_out, size_t chunk_size_in, int nb, rvc_resampler **out)
 {
     if (out) *out = nullptr;
     return guarded(e, [&]() {
         if (!out || rate_in == 0 || rate_out == 0 || chunk_size_in == 0 || rate_in > (1u << 22) || rate_out > (1u << 22) || chunk_size_in > (1u << 20))
             throw ShapeError("resampler: bad rates / chunk size");
         std::unique_ptr<rvc_resampler> r(new rvc_resampler());
-        r->e = e; r->rate_in = (int)rate_in; r->rate_out = (int)rate_out;
+        r->e = e; r->rate_in = (int)rate_in; r->rate_out = (int)rate_out; r->nb = nb;
         const long long g = gcd_ll((long long)rate_in, (long long)rate_out);
         const int min_in = (int)(rate_in / g);
         // fft_chunks = ceil(chunk_size_in as f32 / min_chunk_in as f32)
@@ -203,8 +206,8 @@ rvc_status rvc_resampler_create(rvc_engine *e, size_t rate_in, size_t rate_out, 
         hipLaunchKernelGGL(resample_filter_spectrum_kernel, dim3((new_len + 63) / 64), dim3(64), 0, e->stream, d_h, fi, Lin, new_len, d_Fr, d_Fi);
         const long long tot = (long long)Lin * r->Q;
         hipLaunchKernelGGL(resample_table_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, e->stream, d_Fr, d_Fi, new_len, Lin, r->Q, r->d_table);
-        for (int i = 0; i < 2; i++) { HIPCHK(hipMalloc(&r->d_ov[i], (size_t)fo * 4)); HIPCHK(hipMemsetAsync(r->d_ov[i], 0, (size_t)fo * 4, e->stream)); }
-        HIPCHK(hipMalloc(&r->d_x, (size_t)fi * 4)); HIPCHK(hipMalloc(&r->d_out, (size_t)fo * 4));
+        for (int i = 0; i < 2; i++) { HIPCHK(hipMalloc(&r->d_ov[i], (size_t)nb * fo * 4)); HIPCHK(hipMemsetAsync(r->d_ov[i], 0, (size_t)nb * fo * 4, e->stream)); }
+        HIPCHK(hipMalloc(&r->d_x, (size_t)nb * fi * 4)); HIPCHK(hipMalloc(&r->d_out, (size_t)nb * fo * 4));
         HIPCHK(hipStreamSynchronize(e->stream));
         HIPCHK(hipGetLastError());
         (void)hipFree(d_h); (void)hipFree(d_Fr); (void)hipFree(d_Fi);
@@ -212,6 +215,11 @@ rvc_status rvc_resampler_create(rvc_engine *e, size_t rate_in, size_t rate_out, 
         *out = r.release();
         return RVC_OK;
     });
+}
+
+rvc_status rvc_resampler_create(rvc_engine *e, size_t rate_in, size_t rate_out, size_t chunk_size_in, rvc_resampler **out)
+{
+    return resampler_create_n(e, rate_in, rate_out, chunk_size_in, 1, out);
 }
 
 void rvc_resampler_destroy(rvc_resampler *r)
@@ -230,18 +238,19 @@ void rvc_resampler_reset(rvc_resampler *r)
 {
     if (!r) return;
     (void)guarded(r->e, [&]() {
-        for (int i = 0; i < 2; i++) HIPCHK(hipMemsetAsync(r->d_ov[i], 0, (size_t)r->fft_out * 4, r->e->stream));
+        for (int i = 0; i < 2; i++) HIPCHK(hipMemsetAsync(r->d_ov[i], 0, (size_t)r->nb * r->fft_out * 4, r->e->stream));
         HIPCHK(hipStreamSynchronize(r->e->stream));
         return RVC_OK;
     });
 }
 
-// queue one chunk on the engine's stream; d_in / d_out are device pointers
-static void resampler_launch(rvc_resampler *r, const float *d_in, float *d_out)
+// queue one chunk (of every stream) on the engine's stream; d_in / d_out are device pointers, stream b at d_in + b*in_bs / d_out + b*out_bs
+static void resampler_launch(rvc_resampler *r, const float *d_in, float *d_out, long long in_bs = 0, long long out_bs = 0)
 {
     ResampleP p{};
     p.x = d_in; p.table = r->d_table; p.ov_old = r->d_ov[r->parity]; p.ov_new = r->d_ov[r->parity ^ 1]; p.out = d_out;
     p.fft_in = r->fft_in; p.fft_out = r->fft_out; p.Lin = r->Lin; p.P = r->P; p.Q = r->Q;
+    p.x_bs = in_bs; p.out_bs = out_bs;
     p.x_in_lds = ((size_t)(r->Lin + r->fft_in) * sizeof(float) <= 152 * 1024) ? 1 : 0;
     const int Lout = 2 * r->fft_out, per_class = (Lout + r->Q - 1) / r->Q;
     // 32..64 outputs (8..16 waves x 4) per workgroup: the 100+ KiB of LDS staging is amortised and the grid still covers the chip
@@ -252,7 +261,7 @@ static void resampler_launch(rvc_resampler *r, const float *d_in, float *d_out)
     const int per_wg = (per_class + splits - 1) / splits;
     const int threads = std::min(1024, std::max(64, ((per_wg + 3) / 4) * 64));
     const size_t lds = (size_t)(r->Lin + (p.x_in_lds ? r->fft_in : 0)) * sizeof(float);
-    hipLaunchKernelGGL(resample_polyphase_kernel, dim3(splits, r->Q), dim3(threads), lds, r->e->stream, p);
+    hipLaunchKernelGGL(resample_polyphase_kernel, dim3(splits, r->Q, r->nb), dim3(threads), lds, r->e->stream, p);
     r->parity ^= 1;
 }
 

@@ -12,17 +12,20 @@
 namespace rvc {
 
 // out[i] = i < n - f ? in[i + f] : chunk[i - (n - f)]        (lib.rs:661-665 "move and append the last n samples")
+// (blockIdx.y = stream; rings are [streams][n], chunks [streams][f])
 __global__ void ring_shift_append_kernel(const float *in, float *out, int n, int f, const float *chunk)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    in += (long long)blockIdx.y * n; out += (long long)blockIdx.y * n; chunk += (long long)blockIdx.y * f;
     if (i < n) out[i] = i < n - f ? in[i + f] : chunk[i - (n - f)];
 }
 
 // 16 kHz ring (lib.rs:669-679): shift by f, then overwrite [copy_begin, n) with res[skip ..] (copy_begin = n - f - skip: the
 // converter's output re-writes the `skip` samples before the new chunk as well)
-__global__ void ring16_update_kernel(const float *in, float *out, int n, int f, const float *res, int skip, int copy_begin)
+__global__ void ring16_update_kernel(const float *in, float *out, int n, int f, const float *res, int skip, int copy_begin, long long res_bs)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    in += (long long)blockIdx.y * n; out += (long long)blockIdx.y * n; res += blockIdx.y * res_bs;
     if (i < n) out[i] = i >= copy_begin ? res[skip + i - copy_begin] : in[i + f];
 }
 
@@ -42,6 +45,8 @@ struct rvc_session {
     int par = 0, par16 = 0;
     float *d_chunk = nullptr, *d_down = nullptr, *d_model = nullptr, *d_up = nullptr, *d_rms = nullptr, *d_sola = nullptr, *d_frame = nullptr, *d_cor = nullptr;
     int *d_off = nullptr; int n_rms = 0;
+    int B = 1;                     // streams (= the engine's stream count at creation); every buffer below has a leading [B] axis
+    std::vector<int> h_off;
 };
 
 extern "C" {
@@ -58,7 +63,8 @@ void rvc_session_destroy(rvc_session *s)
 }
 
 // `create` / `update` of the filter (lib.rs:181-260): host sample rate, the three length settings (seconds), the synthesizer's output
-// rate; skip_inference != 0 is the plugin's pass-through mode (lib.rs:224-227, 697-699).  The engine must be in single-stream mode.
+// rate; skip_inference != 0 is the plugin's pass-through mode (lib.rs:224-227, 697-699).  The session covers every stream of the
+// engine (rvc_set_streams before creating it): all rings, converter states and SOLA tails get a leading [streams] axis.
 rvc_status rvc_session_create(rvc_engine *e, size_t sample_rate, double sample_length, double crossfade_length, double extra_inference_time,
                               size_t model_output_sample_rate, int32_t pitch_shift, double rms_mix_rate, int skip_inference, rvc_session **out)
 {
@@ -66,10 +72,9 @@ rvc_status rvc_session_create(rvc_engine *e, size_t sample_rate, double sample_l
     return guarded(e, [&]() {
         if (!out || sample_rate < 1000 || sample_rate % 100 != 0 || sample_rate > 384000 || model_output_sample_rate % 100 != 0 || model_output_sample_rate == 0)
             throw ShapeError("session: unsupported sample rate");
-        if (e->n_streams != 1) throw ShapeError("session: the engine must be in single-stream mode");
         std::unique_ptr<rvc_session> sp(new rvc_session());
         rvc_session *s = sp.get();
-        s->e = e; s->sample_rate = (int)sample_rate; s->pitch_shift = pitch_shift; s->rms_mix_rate = rms_mix_rate; s->skip_inference = skip_inference != 0;
+        s->e = e; s->B = e->n_streams; s->h_off.resize(s->B); s->sample_rate = (int)sample_rate; s->pitch_shift = pitch_shift; s->rms_mix_rate = rms_mix_rate; s->skip_inference = skip_inference != 0;
         const int zc = s->zc = (int)sample_rate / 100;                                                             // lib.rs:200
         const int sft = (int)llround(sample_length * (double)sample_rate / zc);                                     // lib.rs:202
         s->sample_frame_size = sft * zc; s->sample_frame_16k = sft * 160;                                           // lib.rs:203-205
@@ -85,9 +90,9 @@ rvc_status rvc_session_create(rvc_engine *e, size_t sample_rate, double sample_l
         s->skip_head = s->extra_frame_size / zc;                                                                    // lib.rs:694
         if (sft < 1 || s->sola_buffer_frame_size < 1 || s->sola_search_frame_size + 1 > 1024) throw ShapeError("session: unsupported length settings");
         // lib.rs:236-242
-        rvc_status rc = rvc_resampler_create(e, sample_rate, 16000, (size_t)s->sample_frame_size + 2 * zc, &s->down);
+        rvc_status rc = resampler_create_n(e, sample_rate, 16000, (size_t)s->sample_frame_size + 2 * zc, s->B, &s->down);
         if (rc != RVC_OK) return rc;
-        rc = rvc_resampler_create(e, (size_t)s->model_rate, sample_rate, (size_t)s->model_return_size, &s->up);
+        rc = resampler_create_n(e, (size_t)s->model_rate, sample_rate, (size_t)s->model_return_size, s->B, &s->up);
         if (rc != RVC_OK) { rvc_resampler_destroy(s->down); return rc; }
         s->up_out = s->up->fft_out;
         const bool ok = s->down->fft_in == s->sample_frame_size + 2 * zc && s->down->fft_out == s->sample_frame_16k + 320 && s->up->fft_in == s->model_return_size &&
@@ -96,14 +101,15 @@ rvc_status rvc_session_create(rvc_engine *e, size_t sample_rate, double sample_l
             rvc_resampler_destroy(s->down); rvc_resampler_destroy(s->up);
             throw ShapeError("session: chunk sizes are not multiples of the resampling ratios");
         }
-        auto dev = [&](float **p, size_t n) { HIPCHK(hipMalloc(p, std::max<size_t>(n, 4) * 4)); HIPCHK(hipMemsetAsync(*p, 0, std::max<size_t>(n, 4) * 4, e->stream)); };
+        const size_t NB = (size_t)s->B;
+        auto dev = [&](float **p, size_t n) { n = std::max<size_t>(n, 4) * NB; HIPCHK(hipMalloc(p, n * 4)); HIPCHK(hipMemsetAsync(*p, 0, n * 4, e->stream)); };
         for (int i = 0; i < 2; i++) { dev(&s->d_in[i], s->input_buffer_size); dev(&s->d_in16[i], s->input_buffer_16k_size); }
         dev(&s->d_chunk, s->sample_frame_size); dev(&s->d_down, s->down->fft_out); dev(&s->d_model, s->model_return_size); dev(&s->d_up, s->up_out);
         const int frame = 4 * zc, hop = zc;
         s->n_rms = (s->up_out + 2 * (frame / 2) - frame) / hop + 1;
         dev(&s->d_rms, (size_t)2 * s->n_rms); dev(&s->d_sola, s->sola_buffer_frame_size); dev(&s->d_frame, s->sample_frame_size);
         dev(&s->d_cor, (size_t)s->sola_search_frame_size + 1);
-        HIPCHK(hipMalloc(&s->d_off, 4));
+        HIPCHK(hipMalloc(&s->d_off, 4 * NB));
         HIPCHK(hipStreamSynchronize(e->stream));
         *out = sp.release();
         return RVC_OK;
@@ -123,33 +129,35 @@ void rvc_session_geometry(rvc_session *s, int32_t out[10])
     for (int i = 0; i < 10; i++) out[i] = v[i];
 }
 
-// process_one_frame (lib.rs:659-795): n = sample_frame_size samples in at the host rate, sample_frame_size samples out
+// process_one_frame (lib.rs:659-795) for every stream of the engine: input_sample [B][n] with n = sample_frame_size samples at the host
+// rate, output [B][cap_per_stream] (sample_frame_size samples each), sola_offset [B] (may be NULL).  B = 1 is the plugin's case.
 rvc_status rvc_session_process(rvc_session *s, const float *input_sample, size_t n, float *output, size_t cap, size_t *sola_offset)
 {
     if (!s) return RVC_BACKEND;
     rvc_engine *e = s->e;
     return guarded(e, [&]() {
         if (n != (size_t)s->sample_frame_size || cap < (size_t)s->sample_frame_size || !input_sample || !output) throw ShapeError("session: wrong chunk size");
-        if (e->n_streams != 1) throw ShapeError("session: the engine must be in single-stream mode");
+        if (e->n_streams != s->B) throw ShapeError("session: the engine's stream count changed since the session was created");
         hipStream_t st = e->stream;
-        const int T = 256;
-        HIPCHK(hipMemcpyAsync(s->d_chunk, input_sample, n * 4, hipMemcpyHostToDevice, st));
+        const int T = 256, B = s->B;
+        HIPCHK(hipMemcpyAsync(s->d_chunk, input_sample, (size_t)B * n * 4, hipMemcpyHostToDevice, st));
         // lib.rs:661-665
-        hipLaunchKernelGGL(ring_shift_append_kernel, dim3((s->input_buffer_size + T - 1) / T), dim3(T), 0, st, s->d_in[s->par], s->d_in[s->par ^ 1],
+        hipLaunchKernelGGL(ring_shift_append_kernel, dim3((s->input_buffer_size + T - 1) / T, B), dim3(T), 0, st, s->d_in[s->par], s->d_in[s->par ^ 1],
                            s->input_buffer_size, s->sample_frame_size, s->d_chunk);
         s->par ^= 1;
         const float *ring = s->d_in[s->par];
         // lib.rs:669-683: the converter sees the new chunk plus the 2*zc samples before it; its first 160 outputs are dropped
         const int down_start = s->input_buffer_size - s->sample_frame_size - 2 * s->sample_rate / 100;
-        resampler_launch(s->down, ring + down_start, s->d_down);
+        resampler_launch(s->down, ring + down_start, s->d_down, s->input_buffer_size, s->down->fft_out);
         const int copy_begin = s->input_buffer_16k_size - (s->sample_frame_size / (s->sample_rate / 100) + 1) * 160;
-        hipLaunchKernelGGL(ring16_update_kernel, dim3((s->input_buffer_16k_size + T - 1) / T), dim3(T), 0, st, s->d_in16[s->par16], s->d_in16[s->par16 ^ 1],
-                           s->input_buffer_16k_size, s->sample_frame_16k, s->d_down, 160, copy_begin);
+        hipLaunchKernelGGL(ring16_update_kernel, dim3((s->input_buffer_16k_size + T - 1) / T, B), dim3(T), 0, st, s->d_in16[s->par16], s->d_in16[s->par16 ^ 1],
+                           s->input_buffer_16k_size, s->sample_frame_16k, s->d_down, 160, copy_begin, (long long)s->down->fft_out);
         s->par16 ^= 1;
         const float *ring16 = s->d_in16[s->par16];
         // lib.rs:694-707
         if (s->skip_inference) {
-            HIPCHK(hipMemcpyAsync(s->d_model, ring16 + (s->input_buffer_16k_size - s->model_return_size), (size_t)s->model_return_size * 4, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpy2DAsync(s->d_model, (size_t)s->model_return_size * 4, ring16 + (s->input_buffer_16k_size - s->model_return_size),
+                                    (size_t)s->input_buffer_16k_size * 4, (size_t)s->model_return_size * 4, B, hipMemcpyDeviceToDevice, st));
         } else {
             size_t got = 0;
             rvc_status rc = infer_common(e, ring16, true, (size_t)s->input_buffer_16k_size, (size_t)s->sample_frame_16k, s->pitch_shift, (uint32_t)s->skip_head,
@@ -158,25 +166,26 @@ rvc_status rvc_session_process(rvc_session *s, const float *input_sample, size_t
             if (got != (size_t)s->model_return_size) throw ShapeError("session: the loaded synthesizer's output rate does not match model_output_sample_rate");
         }
         // lib.rs:742-756
-        resampler_launch(s->up, s->d_model, s->d_up);
+        resampler_launch(s->up, s->d_model, s->d_up, s->model_return_size, s->up_out);
         // lib.rs:758-765
+        const long long up_bs = s->up_out;
         if (s->rms_mix_rate < 1.0) {
             const int nn = s->up_out, frame = 4 * s->zc, hop = s->zc, nf = s->n_rms;
-            hipLaunchKernelGGL(post_rms_kernel, dim3(nf), dim3(256), 0, st, ring + s->extra_frame_size, nn, frame, hop, s->d_rms);
-            hipLaunchKernelGGL(post_rms_kernel, dim3(nf), dim3(256), 0, st, s->d_up, nn, frame, hop, s->d_rms + nf);
-            hipLaunchKernelGGL(post_mix_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, s->d_up, nn, s->d_rms, nf, s->d_rms + nf, nf, (float)(1.0 - s->rms_mix_rate));
+            hipLaunchKernelGGL(post_rms_kernel, dim3(nf, B), dim3(256), 0, st, ring + s->extra_frame_size, nn, frame, hop, s->d_rms, (long long)s->input_buffer_size, 2LL * nf);
+            hipLaunchKernelGGL(post_rms_kernel, dim3(nf, B), dim3(256), 0, st, s->d_up, nn, frame, hop, s->d_rms + nf, up_bs, 2LL * nf);
+            hipLaunchKernelGGL(post_mix_kernel, dim3((nn + 255) / 256, B), dim3(256), 0, st, s->d_up, nn, s->d_rms, nf, s->d_rms + nf, nf, (float)(1.0 - s->rms_mix_rate), up_bs, 2LL * nf);
         }
         // lib.rs:768-794
-        hipLaunchKernelGGL(post_sola_corr_kernel, dim3((unsigned)(s->sola_search_frame_size + 4) / 4), dim3(256), 0, st, s->d_up, s->d_sola,
-                           s->sola_buffer_frame_size, s->sola_search_frame_size, s->d_cor);
-        hipLaunchKernelGGL(post_sola_kernel, dim3(1), dim3(1024), 0, st, s->d_up, s->d_sola, s->sola_buffer_frame_size, s->sola_search_frame_size,
-                           s->sample_frame_size, s->d_frame, s->d_off, s->d_cor);
-        int off = 0;
-        HIPCHK(hipMemcpyAsync(output, s->d_frame, (size_t)s->sample_frame_size * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(&off, s->d_off, 4, hipMemcpyDeviceToHost, st));
+        const long long cor_bs = s->sola_search_frame_size + 1;
+        hipLaunchKernelGGL(post_sola_corr_kernel, dim3((unsigned)(s->sola_search_frame_size + 4) / 4, B), dim3(256), 0, st, s->d_up, s->d_sola,
+                           s->sola_buffer_frame_size, s->sola_search_frame_size, s->d_cor, up_bs, (long long)s->sola_buffer_frame_size, cor_bs);
+        hipLaunchKernelGGL(post_sola_kernel, dim3(B), dim3(1024), 0, st, s->d_up, s->d_sola, s->sola_buffer_frame_size, s->sola_search_frame_size,
+                           s->sample_frame_size, s->d_frame, s->d_off, s->d_cor, up_bs, (long long)s->sola_buffer_frame_size, (long long)s->sample_frame_size, cor_bs);
+        HIPCHK(hipMemcpy2DAsync(output, cap * 4, s->d_frame, (size_t)s->sample_frame_size * 4, (size_t)s->sample_frame_size * 4, B, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(s->h_off.data(), s->d_off, 4 * (size_t)B, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
-        if (sola_offset) *sola_offset = (size_t)off;
+        if (sola_offset) for (int b = 0; b < B; b++) sola_offset[b] = (size_t)s->h_off[b];
         return s->skip_inference ? RVC_OK : check_status(e);
     });
 }

@@ -87,6 +87,7 @@ class NativeStreamingSession:
         if rc != 0:
             raise RvcInferError(rc, (self._L.rvc_last_error_message(engine._h) or b"").decode())
         self._h = h
+        self.n_streams = int(getattr(engine, "n_streams", 1))
         g = (C.c_int32 * 10)()
         self._L.rvc_session_geometry(h, g)
         (self.sample_frame_size, self.sample_frame_16k, self.input_buffer_size, self.input_buffer_16k_size, self.model_return_length,
@@ -102,13 +103,19 @@ class NativeStreamingSession:
         self._L.rvc_session_set_params(self._h, pitch_shift, rms_mix_rate)
 
     def process_one_frame(self, input_sample: np.ndarray) -> np.ndarray:
+        """One chunk of one stream (shape (sample_frame_size,)) or of every stream of the engine ((streams, sample_frame_size))."""
         C = self._C
-        x = np.ascontiguousarray(input_sample, dtype=np.float32).reshape(-1)
-        out = np.empty(self.sample_frame_size, np.float32)
-        off = C.c_size_t(0)
+        x = np.ascontiguousarray(input_sample, dtype=np.float32)
+        single = x.ndim == 1
+        x = x.reshape(1, -1) if single else x
+        if x.shape != (self.n_streams, self.sample_frame_size):
+            raise self._err(5, "expected %d stream(s) of %d samples" % (self.n_streams, self.sample_frame_size))
+        out = np.empty((x.shape[0], self.sample_frame_size), np.float32)
+        off = (C.c_size_t * x.shape[0])()
         fp = C.POINTER(C.c_float)
-        rc = self._L.rvc_session_process(self._h, x.ctypes.data_as(fp), x.size, out.ctypes.data_as(fp), out.size, C.byref(off))
+        rc = self._L.rvc_session_process(self._h, x.ctypes.data_as(fp), x.shape[1], out.ctypes.data_as(fp), out.shape[1], off)
         if rc != 0:
             raise self._err(rc, (self._L.rvc_last_error_message(self._engine._h) or b"").decode())
-        self.last_sola_offset = int(off.value)
-        return out
+        self.last_sola_offsets = [int(v) for v in off]
+        self.last_sola_offset = self.last_sola_offsets[0]
+        return out[0] if single else out

@@ -188,3 +188,35 @@ def test_native_session_matches_python_state_machine_and_oracle():
     tone = (0.3 * np.sin(2 * np.pi * 300.0 * np.arange(7680 * 8) / 48000.0)).astype(np.float32)
     last = [sk.process_one_frame(tone[c * 7680:(c + 1) * 7680]) for c in range(8)][-1]
     assert abs(rms(last) - 0.3 / np.sqrt(2)) < 0.01
+
+
+@pytest.mark.gpu
+def test_native_session_batches_streams():
+    # 3 streams through ONE batched session (rings / converter states / SOLA tails with a leading stream axis, one infer_batch per tick)
+    # must equal 3 independent single-stream sessions
+    from obs_rvc_amd.rvc import RvcInfer
+    from obs_rvc_amd.streaming import NativeStreamingSession
+    z = zoo("tiny")
+
+    def engine(streams, sid0):
+        e = RvcInfer(z["data"]); e.load_contentvec(2); e.load_f0(); e.load_model(z["model"]); e.set_streams(streams); e.set_noise_seed(3, sid0)
+        return e
+    S = 3
+    eb = engine(S, 0)
+    batched = NativeStreamingSession(eb, 48000, 0.16, 0.07, 2.0, 4800, 12, 0.6)
+    singles = []
+    for sidx in range(S):
+        e1 = engine(1, sidx)
+        singles.append((e1, NativeStreamingSession(e1, 48000, 0.16, 0.07, 2.0, 4800, 12, 0.6)))
+    F = batched.sample_frame_size
+    audio = [np.interp(np.arange(F * 10) / 48000.0, np.arange(2560 * 10) / 16000.0, voice_signal(2560 * 10, seed=30 + sidx)).astype(np.float32) for sidx in range(S)]
+    for c in range(10):
+        x = np.stack([a[c * F:(c + 1) * F] for a in audio])
+        yb = batched.process_one_frame(x)
+        assert yb.shape == (S, F)
+        for sidx in range(S):
+            y1 = singles[sidx][1].process_one_frame(x[sidx])
+            assert np.abs(yb[sidx] - y1).max() < 2e-5, (c, sidx, float(np.abs(yb[sidx] - y1).max()))
+            assert batched.last_sola_offsets[sidx] == singles[sidx][1].last_sola_offset
+    with pytest.raises(Exception):
+        batched.process_one_frame(x[0])               # one stream handed to a 3-stream session
