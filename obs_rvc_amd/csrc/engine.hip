@@ -1000,7 +1000,8 @@ struct rvc_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
     size_t last_knn_rows = 0;
-    std::vector<int> h_status;
+    int *h_status = nullptr;        // pinned, one word per stream (up to 4096)
+    bool status_queued = false;     // an async copy of the status words is already in the stream in front of the caller's sync
 };
 
 namespace rvc {
@@ -1695,19 +1696,26 @@ static void push_call_params(rvc_engine *e, int32_t pitch_shift)
     HIPCHK(hipMemcpyAsync(e->d_cp, e->h_cp, sizeof(CallParams), hipMemcpyHostToDevice, e->stream));
 }
 
+// Status words of all streams (0 ok, 6 = the reference would have panicked at rmvpe.rs:124, 7 = GRU hand-off time-out): one strided
+// copy into pinned memory, queued in front of the call's final synchronisation so that reading them costs no extra round trip.
+static void queue_status(rvc_engine *e)
+{
+    HIPCHK(hipMemcpy2DAsync(e->h_status, sizeof(int), (char *)e->d_state + offsetof(StreamState, status), sizeof(StreamState), sizeof(int), (size_t)e->n_streams,
+                            hipMemcpyDeviceToHost, e->stream));
+    e->status_queued = true;
+}
+
 static rvc_status check_status(rvc_engine *e)
 {
-    // the decode kernel raises status 6 where the reference would panic (rmvpe.rs:124)
-    e->h_status.resize(e->n_streams);
-    std::vector<StreamState> st(e->n_streams);
-    // only the small tail of each state is needed, but states are tiny (4 KB) -- copy the status words
-    for (int b = 0; b < e->n_streams; b++)
-        HIPCHK(hipMemcpy(&e->h_status[b], (char *)(e->d_state + b) + offsetof(StreamState, status), sizeof(int), hipMemcpyDeviceToHost));
+    if (!e->status_queued) { queue_status(e); HIPCHK(hipStreamSynchronize(e->stream)); }
+    e->status_queued = false;
     for (int b = 0; b < e->n_streams; b++)
         if (e->h_status[b] != 0) {
+            const int code = e->h_status[b];
             int zero = 0;
-            HIPCHK(hipMemcpy((char *)(e->d_state + b) + offsetof(StreamState, status), &zero, sizeof(int), hipMemcpyHostToDevice));
-            if (e->h_status[b] == 7) { e->err = "GRU hand-off timed out (multi-CU recurrence)"; return RVC_BACKEND; }
+            for (int c = b; c < e->n_streams; c++)
+                if (e->h_status[c] != 0) HIPCHK(hipMemcpy((char *)(e->d_state + c) + offsetof(StreamState, status), &zero, sizeof(int), hipMemcpyHostToDevice));
+            if (code == 7) { e->err = "GRU hand-off timed out (multi-CU recurrence)"; return RVC_BACKEND; }
             e->err = "to_local_average_cents: index out of bounds (argmax bin >= 348), the reference panics here";
             return RVC_PANIC;
         }
@@ -1759,6 +1767,7 @@ rvc_status rvc_create(const char *data_path, int device, rvc_engine **out)
         HIPCHK(hipEventCreate(&e->ev0)); HIPCHK(hipEventCreate(&e->ev1));
         HIPCHK(hipMalloc(&e->d_cp, sizeof(CallParams)));
         HIPCHK(hipHostMalloc((void **)&e->h_cp, sizeof(CallParams)));
+        HIPCHK(hipHostMalloc((void **)&e->h_status, 4096 * sizeof(int)));
         init_constants(e);
         alloc_state(e);
     } catch (const std::exception &x) {
@@ -1788,6 +1797,7 @@ void rvc_destroy(rvc_engine *e)
     if (e->d_state) (void)hipFree(e->d_state);
     if (e->d_cp) (void)hipFree(e->d_cp);
     if (e->h_cp) (void)hipHostFree(e->h_cp);
+    if (e->h_status) (void)hipHostFree(e->h_status);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     for (int i = 0; i < 3; i++) {
@@ -1895,6 +1905,7 @@ rvc_status rvc_pitch(rvc_engine *e, const float *input, size_t n, int32_t pitch_
         if (cap < (size_t)pl->Tm) return RVC_SHAPE;
         run_single_input(e, pl, input, n, pitch_shift);
         HIPCHK(hipMemcpyAsync(out, pl->d_f0, (size_t)pl->Tm * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        queue_status(e);
         HIPCHK(hipStreamSynchronize(e->stream));
         return check_status(e);
     });
@@ -1917,6 +1928,7 @@ static rvc_status infer_common(rvc_engine *e, const void *input, bool input_on_d
                             out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream));
     e->last_knn_rows = pl->with_index ? return_length : 0;
     if (!sync) return RVC_OK;
+    queue_status(e);
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1));
     return check_status(e);

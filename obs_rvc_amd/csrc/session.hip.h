@@ -183,6 +183,7 @@ rvc_status rvc_session_process(rvc_session *s, const float *input_sample, size_t
                            s->sample_frame_size, s->d_frame, s->d_off, s->d_cor, up_bs, (long long)s->sola_buffer_frame_size, (long long)s->sample_frame_size, cor_bs);
         HIPCHK(hipMemcpy2DAsync(output, cap * 4, s->d_frame, (size_t)s->sample_frame_size * 4, (size_t)s->sample_frame_size * 4, B, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(s->h_off.data(), s->d_off, 4 * (size_t)B, hipMemcpyDeviceToHost, st));
+        if (!s->skip_inference) queue_status(e);
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
         if (sola_offset) for (int b = 0; b < B; b++) sola_offset[b] = (size_t)s->h_off[b];
