@@ -424,6 +424,13 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
         });
         return;
     }
+    if (const char *f = getenv("RVC_TUNE")) {        // tuning aid: "M,K:cfg,ks;M,K:cfg,ks;..." overrides the tile choice of matching layers
+        for (const char *q = f; q && *q; ) {
+            int tm = 0, tk = 0, tc = 0, tks = 1;
+            if (sscanf(q, "%d,%d:%d,%d", &tm, &tk, &tc, &tks) == 4 && tm == p.M && tk == p.K) { cfg = tc; wg_ks = tks; }
+            q = strchr(q, ';'); if (q) q++;
+        }
+    }
     if (const char *f = getenv("RVC_FORCE_CFG")) {   // tuning aid: "cfg,ks[,mfast]"
         int fc = 0, fk = 1; if (sscanf(f, "%d,%d", &fc, &fk) >= 1) { cfg = fc; wg_ks = fk; }
     }
