@@ -141,12 +141,12 @@ def main():
         # "source" note) -- PMC counters cannot be collected inside this process
         traffic = {}
         try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json" if S == 1 else "r01_pmc_traffic_%dstreams.json" % S)))
         except Exception:
             pass
         roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 5),
-                "traffic": (traffic.get("igemm_all_instantiations", {}).get("hbm_read_bytes_per_launch") if S == 1 else None),
+                "traffic": traffic.get("igemm_all_instantiations", {}).get("hbm_read_bytes_per_launch"),
                 "kernel": "rvc::igemm_kernel<MF,NF> (all instantiations)", "launches_per_step": n_l // reps,
                 "avg_launch_us": round(tot_ms * 1e3 / max(n_l, 1), 3), "flops_per_step": tot_fl / reps}
         if k_n:
