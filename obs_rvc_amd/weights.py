@@ -228,6 +228,11 @@ SYNTH_PRESETS = {
                     flow_n=4, wn_layers=3, wn_k=5, gin=256, up_init=512, n_ups=4,
                     up_rates=(10, 10, 2, 2), up_kernels=(16, 16, 4, 4),
                     rb_k=(3, 7, 11), rb_d=(1, 3, 5), sr=40000),
+    # five upsampling stages and three ResBlock kernels at toy width (upstream's 32 kHz v1 layout is 10*4*2*2*2)
+    "tiny5": dict(inter=16, hidden=16, filter=32, heads=2, enc_layers=1, enc_k=3, window=4,
+                  flow_n=3, wn_layers=2, wn_k=5, gin=8, up_init=64, n_ups=5,
+                  up_rates=(4, 2, 2, 2, 2), up_kernels=(8, 4, 4, 4, 4),
+                  rb_k=(3, 7, 11), rb_d=(1, 3, 5), sr=6400),
     "tiny": dict(inter=16, hidden=16, filter=32, heads=2, enc_layers=2, enc_k=3, window=4,
                  flow_n=2, wn_layers=2, wn_k=5, gin=8, up_init=32, n_ups=4,
                  up_rates=(4, 3, 2, 2), up_kernels=(8, 7, 4, 4),

@@ -325,6 +325,20 @@ def test_linearity_of_retrieval_free_feature_path_properties():
     assert np.abs(a1).max() <= 1.0 and np.isfinite(a1).all()
 
 
+def test_five_stage_synthesizer_with_odd_flow_count():
+    # a synthesizer family the zoo does not otherwise cover: 5 upsampling stages (upstream's 32 kHz v1 layout), 3 ResBlock kernels at
+    # toy width, an ODD number of flows (the folded channel flips then need one materialised flip at the end)
+    from oracle import oracle as O
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("tiny", 2, "tiny5")
+    ora = O.OracleRvcInfer(z["data"]); ora.load_contentvec(2); ora.load_f0(1); ora.load_model(z["model"]); ora.set_noise_seed(4, 1)
+    eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"]); eng.set_noise_seed(4, 1)
+    x = voice_signal(g.input_buffer_16k_size, seed=17)
+    for _ in range(2):
+        yo, ye = ora.infer(x, 2560, 3, 200, 21), eng.infer(x, 2560, 3, 200, 21)
+        assert ye.shape == yo.shape == (21 * 64,) and rms(ye - yo) < PCM_TOL, rms(ye - yo)
+
+
 def test_plain_c_client_links_and_runs(tmp_path):
     # examples/c_smoke.c is compiled with gcc as C99 against include/rvc_mi355x.h and linked to the shared library: the boundary is a
     # C ABI, not a Python extension.  Its infer output must equal the ctypes path's (same seed, same input).
