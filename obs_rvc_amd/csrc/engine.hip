@@ -645,6 +645,12 @@ static void add_layernorm(Plan &pl, const T1 &x, const float *g, const float *b)
     dim3 grid((x.T + 3) / 4, x.B);
     if (x.C > 1024) throw ShapeError("layernorm: more than 1024 channels");
     const bool small = x.C <= 256;
+    if (x.B >= 16 && x.C > 256 && (size_t)x.C * 33 * 4 <= 150 * 1024 && !getenv("RVC_NO_LN_TILE")) {
+        dim3 tg((x.T + 31) / 32, x.B);
+        const size_t lds = (size_t)x.C * 33 * sizeof(float);
+        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(layernorm_tile_kernel, tg, dim3(256), lds, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs); });
+        return;
+    }
     pl.ops.push_back([=](hipStream_t s) {
         if (small) hipLaunchKernelGGL((layernorm_ct_kernel<4>), grid, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
         else hipLaunchKernelGGL((layernorm_ct_kernel<16>), grid, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
@@ -1021,6 +1027,7 @@ static void init_kernel_attrs()
     if (done) return;
     done = true;
     HIPCHK(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)layernorm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));   // + 1.3 KB static
     HIPCHK(hipFuncSetAttribute((const void *)gru_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)knn_select_blend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));   // + ~5 KB static
     HIPCHK(hipFuncSetAttribute((const void *)knn_dot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -679,6 +679,44 @@ __global__ __launch_bounds__(256) void layernorm_ct_kernel(const float *x, float
     }
 }
 
+// Throughput-mode LayerNorm (many streams): a workgroup owns 32 time steps x ALL channels of one stream.  Rows are read and written as
+// full 128-byte lines (the 4-step kernel above touches 16-byte slivers of lines that other workgroups -- on other XCDs -- fetch again:
+// 156 MB of HBM/MALL reads per launch for 22 MB of data at 64 streams); the tile sits in LDS ([C][33]) for the two-pass statistics.
+__global__ __launch_bounds__(256) void layernorm_tile_kernel(const float *x, float *y, const float *g, const float *bta,
+                                                             int C, int T, int x_cs, long long x_bs, int y_cs, long long y_bs)
+{
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [C][33]
+    __shared__ float red[8][32], s_mean[32], s_inv[32];
+    const int t0 = blockIdx.x * 32, b = blockIdx.y, tid = threadIdx.x, tx = tid & 31, part = tid >> 5;
+    const float *xb = x + (long long)b * x_bs + t0;
+    const bool ok = t0 + tx < T;
+    for (int c0 = part; c0 < C; c0 += 8 * 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int c = c0 + 8 * u; v[u] = (ok && c < C) ? xb[(long long)c * x_cs + tx] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int c = c0 + 8 * u; if (c < C) tile[c * 33 + tx] = v[u]; }
+    }
+    __syncthreads();
+    float s = 0.f;
+    for (int c = part; c < C; c += 8) s += tile[c * 33 + tx];
+    red[part][tx] = s;
+    __syncthreads();
+    if (part == 0) { float m = 0.f; for (int q = 0; q < 8; q++) m += red[q][tx]; s_mean[tx] = m / (float)C; }
+    __syncthreads();
+    const float mean = s_mean[tx];
+    float qv = 0.f;
+    for (int c = part; c < C; c += 8) { const float d = tile[c * 33 + tx] - mean; qv += d * d; }
+    red[part][tx] = qv;
+    __syncthreads();
+    if (part == 0) { float m = 0.f; for (int q = 0; q < 8; q++) m += red[q][tx]; s_inv[tx] = 1.0f / sqrtf(m / (float)C + 1e-5f); }
+    __syncthreads();
+    if (!ok) return;
+    const float inv = s_inv[tx];
+    float *yb = y + (long long)b * y_bs + t0;
+    for (int c = part; c < C; c += 8) yb[(long long)c * y_cs + tx] = (tile[c * 33 + tx] - mean) * inv * g[c] + bta[c];
+}
+
 // GroupNorm with one group per channel (= per-channel normalisation over time) + GELU, in place.
 __global__ __launch_bounds__(256) void groupnorm_gelu_kernel(float *x, const float *g, const float *bta, int T, int cs, long long bs)
 {

@@ -298,6 +298,24 @@ def test_batched_streams_full_size_throughput_kernels():
             assert rms(ye[s] - yo) < PCM_TOL, (c, s, rms(ye[s] - yo))
 
 
+def test_many_streams_full_size_take_the_throughput_paths():
+    # 18 streams: past every small-batch special case (no CU partition above 4 streams, generic GRU above 8, unfused ResBlock chains,
+    # tile LayerNorm and LDS-tiled GEMMs from 16) -- BASELINE config 4's code paths at a size the oracle can still check
+    from oracle import oracle as O
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("full")
+    S = 18
+    eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"])
+    eng.set_streams(S); eng.set_noise_seed(6, 200)
+    xin = np.stack([voice_signal(g.input_buffer_16k_size, seed=70 + s) for s in range(S)])
+    ye = eng.infer_batch(xin, g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+    assert ye.shape == (S, g.model_return_size) and np.isfinite(ye).all()
+    for s in (0, 9, 17):
+        o = O.OracleRvcInfer(z["data"]); o.load_contentvec(2); o.load_f0(1); o.load_model(z["model"]); o.set_noise_seed(6, 200 + s)
+        yo = o.infer(xin[s], g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+        assert rms(ye[s] - yo) < PCM_TOL, (s, rms(ye[s] - yo))
+
+
 def test_graph_replay_equals_eager_and_device_api():
     import torch
     z, ora, eng = _pair("tiny")
