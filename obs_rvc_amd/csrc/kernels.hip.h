@@ -1639,12 +1639,12 @@ __global__ __launch_bounds__(256) void knn_merge_blend_kernel(KnnBlendP p)
         int s = (p.skip_head + r) / 2; s = s < p.T - 1 ? s : p.T - 1;
         if (s - p.first_raw != j) continue;
         if (threadIdx.x < KNN_K) {
-            p.out_idx[((long long)b * p.R + r) * KNN_K + threadIdx.x] = si[threadIdx.x];
+            p.out_idx[((long long)b * p.R + r) * KNN_K + threadIdx.x] = si[threadIdx.x] == 0x7fffffff ? -1 : si[threadIdx.x];
             p.out_dist[((long long)b * p.R + r) * KNN_K + threadIdx.x] = sd[threadIdx.x];
         }
         for (int c = threadIdx.x; c < p.dim; c += 256) {
             float acc = 0.f;
-            for (int k = 0; k < KNN_K; k++) acc += (w[k] / ws) * p.index[(long long)si[k] * p.dim + c];
+            for (int k = 0; k < KNN_K; k++) if (si[k] >= 0 && si[k] != 0x7fffffff) acc += (w[k] / ws) * p.index[(long long)si[k] * p.dim + c];   // no valid hit for a non-finite query
             p.phone[(long long)b * p.ph_bs + (long long)c * p.ph_cs + r] = p.rate * acc + (1.0f - p.rate) * qv[c];
         }
     }
@@ -1857,13 +1857,13 @@ __global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p)
         int s = (p.skip_head + r) / 2; s = s < p.T - 1 ? s : p.T - 1;
         if (s - p.first_raw != j) continue;
         if (tid < KNN_K) {
-            p.out_idx[((long long)b * p.R + r) * KNN_K + tid] = si[tid];
+            p.out_idx[((long long)b * p.R + r) * KNN_K + tid] = si[tid] == 0x7fffffff ? -1 : si[tid];   // -1: no hit (non-finite query)
             p.out_dist[((long long)b * p.R + r) * KNN_K + tid] = sd[tid];
         }
         for (int c = tid; c < p.dim; c += 1024) {
             float acc = 0.f;
 #pragma unroll
-            for (int k = 0; k < KNN_K; k++) acc += (w[k] / ws) * p.index[(long long)si[k] * p.dim + c];
+            for (int k = 0; k < KNN_K; k++) if (si[k] >= 0 && si[k] != 0x7fffffff) acc += (w[k] / ws) * p.index[(long long)si[k] * p.dim + c];   // no valid hit for a non-finite query
             p.phone[(long long)b * p.ph_bs + (long long)c * p.ph_cs + r] = p.rate * acc + (1.0f - p.rate) * qv[c];
         }
     }

@@ -383,3 +383,22 @@ def test_plain_c_client_links_and_runs(tmp_path):
     assert n == y.size == 1008 and abs(rms(y) - r) < 1e-5 * max(r, 1e-3) + 2e-6
     assert "small buffer: status 5 (expected 5), required 1008" in out.stdout
     assert "session: frame 768 samples" in out.stdout
+
+
+def test_non_finite_input_is_contained():
+    # NaN / Inf samples (a glitching capture device) must not fault the GPU or poison later chunks: with retrieval on, a non-finite
+    # query has no nearest neighbour (hits report index -1) and the chunk's output is NaN; the next clean chunk is clean again
+    z = zoo("tiny")
+    from obs_rvc_amd.rvc import RvcInfer
+    eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"])
+    eng.load_index(W.make_index(2000, 48, seed=1)); eng.set_index_rate(0.5)
+    x = voice_signal(g.input_buffer_16k_size, seed=1)
+    for bad in (np.where(np.arange(x.size) % 1000 == 0, np.nan, x), np.where(np.arange(x.size) % 777 == 0, np.inf, x)):
+        y = eng.infer(bad.astype(np.float32), 2560, 12, 200, 21)
+        assert y.shape == (1008,) and not np.isfinite(y).all()
+        idx, dist = eng.knn()
+        assert (idx == -1).all()
+    y = eng.infer((x * 1e30).astype(np.float32), 2560, 12, 200, 21)
+    assert y.shape == (1008,)
+    y = eng.infer(x, 2560, 12, 200, 21)
+    assert np.isfinite(y).all() and (eng.knn()[0] >= 0).all()
