@@ -402,3 +402,31 @@ def test_non_finite_input_is_contained():
     assert y.shape == (1008,)
     y = eng.infer(x, 2560, 12, 200, 21)
     assert np.isfinite(y).all() and (eng.knn()[0] >= 0).all()
+
+
+def test_edge_case_sweep_leaves_the_engine_usable():
+    # sizes at and past the edges (see tests/tools/fuzz_probe.py, which runs each case in its own process to catch GPU faults):
+    # every call either returns a finite result of the expected size or raises the mapped error, and the engine keeps working
+    z = zoo("tiny")
+    from obs_rvc_amd.rvc import RvcInfer
+    eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"])
+    x = voice_signal(g.input_buffer_16k_size, seed=1)
+    ok = [(lambda: eng.infer(x[:5120], 2560, 12, 0, 1), (48,)), (lambda: eng.infer(x[:35001], 2560, 12, 200, 17), (816,)),
+          (lambda: eng.infer(x, 2560, 12, 0, 223), (10704,)), (lambda: eng.infer(x, 0, 12, 200, 21), (1008,)),
+          (lambda: eng.infer(x, 2560, 1200, 200, 21), (1008,)), (lambda: eng.infer(x, 2560, -1200, 200, 21), (1008,)),
+          (lambda: eng.pitch(x, 12, 30000), (224,)), (lambda: eng.hubert(x[:400]), (1, 48, 1))]
+    for fn, shape in ok:
+        y = fn()
+        assert y.shape == shape and np.isfinite(y).all()
+    bad = [(lambda: eng.infer(x[:400], 2560, 12, 0, 1), "Panic"), (lambda: eng.infer(x, 2560, 12, 200, 100), "Panic"),
+           (lambda: eng.infer(x, 2560, 12, 200, 0), "NdarrayShapeError"), (lambda: eng.infer(x, 10 ** 6, 12, 200, 21), "Panic"),
+           (lambda: eng.load_index(W.make_index(3, 48, seed=1)), "NdarrayShapeError"), (lambda: eng.set_streams(0), "NdarrayShapeError"),
+           (lambda: eng.infer(np.concatenate([x] * 6), 2560, 12, 200, 21), "Panic")]
+    for fn, kind in bad:
+        with pytest.raises(RvcInferError) as ei:
+            fn()
+        assert ei.value.kind == kind
+        assert np.isfinite(eng.infer(x, 2560, 12, 200, 21)).all()
+    eng.set_streams(300)                                   # far more streams than CUs' worth of workgroups in the small kernels
+    yb = eng.infer_batch(np.stack([x] * 300), 2560, 12, 200, 21)
+    assert yb.shape == (300, 1008) and np.isfinite(yb).all()
