@@ -1140,8 +1140,8 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
     add_tap(pl, "cv.pos", h2);
     T1 qkv = make_t1(A, B, 3 * E, T, 0), att = make_t1(A, B, E, T, 0), ff = make_t1(A, B, m.ffn, T, 0);
     const int hd = E / m.heads, Tp = T | 1;
-    const size_t attn_lds = ((size_t)((2 * hd * Tp + 3) & ~3) + 16 * Tp + 16 * hd) * sizeof(float);
-    if (attn_lds > 160 * 1024) throw ShapeError("ContentVec attention: window too long for the LDS-resident kernel (T <= ~300)");
+    const size_t attn_lds = ((size_t)((hd * Tp + 3) & ~3) + 16 * Tp + 16 * hd) * sizeof(float);
+    if (attn_lds > 160 * 1024) throw ShapeError("ContentVec attention: window too long for the LDS-resident kernel (T <= ~490 at head size 64)");
     HIPCHK(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     for (int l = 0; l < m.run_layers; l++) {
         ModelCV::Layer &Ly = m.layers[l];
@@ -1348,7 +1348,7 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
     add_tap(pl, "sy.emb", x);
     T1 qkv = make_t1(A, B, 3 * H, R, 0), att = make_t1(A, B, H, R, 0), ff = make_t1(A, B, F, R, HALO);
     const int kc = H / m.heads, Tp = R | 1;
-    const size_t attn_lds = ((size_t)((2 * kc * Tp + 3) & ~3) + 16 * Tp + 16 * kc) * sizeof(float);
+    const size_t attn_lds = ((size_t)((kc * Tp + 3) & ~3) + 16 * Tp + 16 * kc) * sizeof(float);
     if (attn_lds > 160 * 1024) throw ShapeError("synth attention: return_length too long for the LDS-resident kernel");
     for (int l = 0; l < m.enc_layers; l++) {
         ModelSY::Layer &Ly = m.layers[l];

@@ -761,16 +761,12 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnP p)
     const int hd = p.E / p.heads, T = p.T, Tp = T | 1;
     const int qtiles = (T + 15) / 16;
     const int h = blockIdx.x / qtiles, qt = blockIdx.x - h * qtiles, b = blockIdx.y;
-    float *Ks = smem;                                   // [hd][Tp]
-    float *Vs = Ks + hd * Tp;                           // [hd][Tp]
-    float *Ps = smem + ((2 * hd * Tp + 3) & ~3);        // [4 waves][Tp][4]
+    float *KVs = smem;                                  // [hd][Tp]: K during the score pass, then V (one buffer: long windows fit)
+    float *Ps = smem + ((hd * Tp + 3) & ~3);            // [4 waves][Tp][4]
     float *Qs = Ps + 16 * Tp;                           // [4 waves][hd][4]
     const float *base = p.qkv + (long long)b * p.bs;
-    for (int i = threadIdx.x; i < hd * T; i += 256) {
-        int d = i / T, t = i - d * T;
-        Ks[d * Tp + t] = base[(long long)(p.E + h * hd + d) * p.cs + t];
-        Vs[d * Tp + t] = base[(long long)(2 * p.E + h * hd + d) * p.cs + t];
-    }
+    for (int d = threadIdx.x >> 6; d < hd; d += 4)
+        for (int t = threadIdx.x & 63; t < T; t += 64) KVs[d * Tp + t] = base[(long long)(p.E + h * hd + d) * p.cs + t];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *P = Ps + wave * 4 * Tp, *Q = Qs + wave * 4 * hd;
     const int t1 = qt * 16 + wave * 4;
@@ -781,36 +777,36 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnP p)
         *reinterpret_cast<f32x4 *>(Q + d * 4) = qv;
     }
     __syncthreads();
-    if (t1 >= T) return;
+    const bool active = t1 < T;                          // idle waves of the last tile still take part in the barriers below
     const int W = p.window;
-    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    for (int t2 = lane; t2 < T; t2 += 64) {
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        for (int d = 0; d < hd; d++) {
-            const float kv = Ks[d * Tp + t2];
-            const f32x4 qv = *reinterpret_cast<const f32x4 *>(Q + d * 4);
-            a[0] += qv[0] * kv; a[1] += qv[1] * kv; a[2] += qv[2] * kv; a[3] += qv[3] * kv;
-        }
-        if (p.rel_k) {
+    float inv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int t2 = lane; t2 < T; t2 += 64) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            for (int d = 0; d < hd; d++) {
+                const float kv = KVs[d * Tp + t2];
+                const f32x4 qv = *reinterpret_cast<const f32x4 *>(Q + d * 4);
+                a[0] += qv[0] * kv; a[1] += qv[1] * kv; a[2] += qv[2] * kv; a[3] += qv[3] * kv;
+            }
+            if (p.rel_k) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int rr = t2 - (t1 + r);
-                if (rr >= -W && rr <= W) {
-                    float ra = 0.f;
-                    const float *rk = p.rel_k + (rr + W) * hd;
-                    for (int d = 0; d < hd; d++) ra += Q[d * 4 + r] * rk[d];
-                    a[r] += ra;
+                for (int r = 0; r < 4; r++) {
+                    const int rr = t2 - (t1 + r);
+                    if (rr >= -W && rr <= W) {
+                        float ra = 0.f;
+                        const float *rk = p.rel_k + (rr + W) * hd;
+                        for (int d = 0; d < hd; d++) ra += Q[d * 4 + r] * rk[d];
+                        a[r] += ra;
+                    }
                 }
             }
+            *reinterpret_cast<f32x4 *>(P + t2 * 4) = a;
+#pragma unroll
+            for (int r = 0; r < 4; r++) mx[r] = fmaxf(mx[r], a[r]);
         }
-        *reinterpret_cast<f32x4 *>(P + t2 * 4) = a;
 #pragma unroll
-        for (int r = 0; r < 4; r++) mx[r] = fmaxf(mx[r], a[r]);
-    }
-    float inv[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) mx[r] = wave_max(mx[r]);
-    {
+        for (int r = 0; r < 4; r++) mx[r] = wave_max(mx[r]);
         float sum[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t2 = lane; t2 < T; t2 += 64) {
             f32x4 e = *reinterpret_cast<const f32x4 *>(P + t2 * 4);
@@ -830,10 +826,14 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnP p)
             }
         }
     }
-    wave_lds_sync();
+    __syncthreads();                                     // every wave is done with K
+    for (int d = threadIdx.x >> 6; d < hd; d += 4)
+        for (int t = threadIdx.x & 63; t < T; t += 64) KVs[d * Tp + t] = base[(long long)(2 * p.E + h * hd + d) * p.cs + t];
+    __syncthreads();
+    if (!active) return;
     for (int d = lane; d < hd; d += 64) {
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        const float *vr = Vs + d * Tp;
+        const float *vr = KVs + d * Tp;
         for (int t2 = 0; t2 < T; t2++) {
             const float vv = vr[t2];
             const f32x4 pr = *reinterpret_cast<const f32x4 *>(P + t2 * 4);

@@ -12,8 +12,8 @@
 // c at u = (mP mod Q)/Q + integer: a POLYPHASE filter with Q rows of Lin taps, row[r][i] = c((r + i*Q)/Q), and
 //     y[m] = sum_n x[n] * row[mP mod Q][(floor(mP/Q) - n) mod Lin].
 // The table is built once per converter ON THE GPU in fp64 (two brute-force DFTs with exact integer phase reduction: no FFT
-// library, ~1e8..3e10 terms); per chunk one kernel runs the polyphase sum with the row (<= 112 KiB) and the chunk resident in the
-// 160 KiB LDS of each CU: no general-length (2^a 3^b 5^c 7^d) FFT on the per-chunk path, one launch, LDS-bandwidth bound
+// library, ~1e8..3e10 terms); per chunk one kernel runs the polyphase sum with the row (up to 150 KiB; longer chunks -- the plugin allows
+// 1.5 s -- read it from L2) and the chunk resident in the 160 KiB LDS of each CU: no general-length (2^a 3^b 5^c 7^d) FFT on the per-chunk path, one launch, LDS-bandwidth bound
 // (fft_in * Lout MACs: 50 M for 48k->16k at 160 ms).  Same result as the FFT form up to fp32 rounding (tests: 2e-5 abs).
 #pragma once
 
@@ -69,7 +69,7 @@ struct ResampleP {
     const float *ov_old;     // [fft_out]
     float *ov_new;           // [fft_out]
     float *out;              // [fft_out]
-    int fft_in, fft_out, Lin, P, Q, splits, x_in_lds;
+    int fft_in, fft_out, Lin, P, Q, splits, x_in_lds, row_in_lds;
     long long x_bs, out_bs;     // stream strides (blockIdx.z = stream); the overlap buffers are [streams][fft_out]
 };
 
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(1024) void resample_polyphase_kernel(ResampleP p)
     const float *rsrc = p.table + (long long)r * p.Lin;
     const float *xg = p.x + blockIdx.z * p.x_bs, *ovo = p.ov_old + (long long)blockIdx.z * p.fft_out;
     float *ovn = p.ov_new + (long long)blockIdx.z * p.fft_out, *og = p.out + blockIdx.z * p.out_bs;
-    {
+    if (p.row_in_lds) {
         // staging in batches of 4 independent 16-byte loads per thread (latency: one round trip per batch, not per element)
         const int n4 = p.Lin / 4, step = (int)blockDim.x;
         for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * step) {
@@ -95,10 +95,12 @@ __global__ __launch_bounds__(1024) void resample_polyphase_kernel(ResampleP p)
             for (int u = 0; u < 4; u++) if (i0 + u * step < n4) reinterpret_cast<f32x4 *>(row)[i0 + u * step] = v[u];
         }
         for (int i = n4 * 4 + threadIdx.x; i < p.Lin; i += step) row[i] = rsrc[i];
-        if (p.x_in_lds) for (int i = threadIdx.x; i < p.fft_in; i += step) xs[i] = xg[i];
     }
+    if (p.x_in_lds) { float *xd = p.row_in_lds ? xs : smem; for (int i = threadIdx.x; i < p.fft_in; i += (int)blockDim.x) xd[i] = xg[i]; }
     __syncthreads();
-    const float *xv = p.x_in_lds ? xs : xg;
+    // long chunks (plugin sample_length up to 1.5 s): the polyphase row stays in global memory / L2, only the chunk sits in LDS
+    const float *xv = p.x_in_lds ? (p.row_in_lds ? xs : smem) : xg;
+    const float *rowp = p.row_in_lds ? row : rsrc;
     const int n_t = a < Lout ? (Lout - a + p.Q - 1) / p.Q : 0;               // outputs of this residue class
     const int per = (n_t + p.splits - 1) / p.splits;
     const int t0 = blockIdx.x * per, t1 = (t0 + per < n_t) ? t0 + per : n_t;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(1024) void resample_polyphase_kernel(ResampleP p)
         // row index (s[q] - n) mod Lin: no wrap while n <= s[0] (s ascends with q), always wrapped once n > s[3]; only the few
         // taps in between need the generic form -- the two long segments run with plain descending addresses
         const int nA = s[0] + 1 < p.fft_in ? s[0] + 1 : p.fft_in, nB = s[3] + 1 < p.fft_in ? s[3] + 1 : p.fft_in;
-        const float *r0 = row + s[0], *r1 = row + s[1], *r2 = row + s[2], *r3 = row + s[3];
+        const float *r0 = rowp + s[0], *r1 = rowp + s[1], *r2 = rowp + s[2], *r3 = rowp + s[3];
         int n = lane;
 #pragma unroll 4
         for (; n < nA; n += 64) {
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(1024) void resample_polyphase_kernel(ResampleP p)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 int i = s[q] - n; i += i < 0 ? p.Lin : 0;
-                acc[q] += xvn * row[i];
+                acc[q] += xvn * rowp[i];
             }
         }
         r0 += p.Lin; r1 += p.Lin; r2 += p.Lin; r3 += p.Lin;
@@ -179,7 +181,7 @@ static rvc_status resampler_create_n(rvc_engine *e, size_t rate_in, size_t rate_
         r->fft_in = (int)((long long)chunks * (long long)rate_in / g); r->fft_out = (int)((long long)chunks * (long long)rate_out / g);
         r->P = min_in; r->Q = (int)(rate_out / g); r->Lin = 2 * r->fft_in;
         const int fi = r->fft_in, fo = r->fft_out, Lin = r->Lin;
-        if ((size_t)Lin * sizeof(float) > 150 * 1024) throw ShapeError("resampler: chunk too long for the LDS-resident polyphase row (fft_in <= 19200)");
+        if (fi > (1 << 18)) throw ShapeError("resampler: chunk too long");
         if ((long long)Lin * r->Q > (1ll << 28)) throw ShapeError("resampler: polyphase table too large (rates with a tiny common divisor)");
         // filter taps in f32 as the crate computes them: window^2 * sinc, normalised to unit sum, then / (2 fft_in)
         float cutoff = powf(0.4f, 16.0f / (float)fi);
@@ -251,16 +253,17 @@ static void resampler_launch(rvc_resampler *r, const float *d_in, float *d_out, 
     p.x = d_in; p.table = r->d_table; p.ov_old = r->d_ov[r->parity]; p.ov_new = r->d_ov[r->parity ^ 1]; p.out = d_out;
     p.fft_in = r->fft_in; p.fft_out = r->fft_out; p.Lin = r->Lin; p.P = r->P; p.Q = r->Q;
     p.x_bs = in_bs; p.out_bs = out_bs;
-    p.x_in_lds = ((size_t)(r->Lin + r->fft_in) * sizeof(float) <= 152 * 1024) ? 1 : 0;
+    p.row_in_lds = ((size_t)r->Lin * sizeof(float) <= 150 * 1024) ? 1 : 0;
+    p.x_in_lds = ((size_t)((p.row_in_lds ? r->Lin : 0) + r->fft_in) * sizeof(float) <= 152 * 1024) ? 1 : 0;
     const int Lout = 2 * r->fft_out, per_class = (Lout + r->Q - 1) / r->Q;
     // 32..64 outputs (8..16 waves x 4) per workgroup: the 100+ KiB of LDS staging is amortised and the grid still covers the chip
-    const int per_target = r->Q == 1 ? 32 : 64;      // measured: 21 us (48k->16k), 65 us (48k->48k), 23 us (44.1k->16k) per call
+    const int per_target = r->Q == 1 ? 32 : 64;      // measured: 14 us (48k->16k), 40 us (48k->48k), 13 us (44.1k->16k) per call
     int splits = std::max(1, (per_class + per_target - 1) / per_target);
-    while (splits > 1 && (long long)splits * r->Q > 1024) splits = (splits + 1) / 2;
+    while (splits > 1 && (long long)splits * r->Q > 4096) splits = (splits + 1) / 2;
     p.splits = splits;
     const int per_wg = (per_class + splits - 1) / splits;
     const int threads = std::min(1024, std::max(64, ((per_wg + 3) / 4) * 64));
-    const size_t lds = (size_t)(r->Lin + (p.x_in_lds ? r->fft_in : 0)) * sizeof(float);
+    const size_t lds = (size_t)((p.row_in_lds ? r->Lin : 0) + (p.x_in_lds ? r->fft_in : 0)) * sizeof(float);
     hipLaunchKernelGGL(resample_polyphase_kernel, dim3(splits, r->Q, r->nb), dim3(threads), lds, r->e->stream, p);
     r->parity ^= 1;
 }

@@ -430,3 +430,36 @@ def test_edge_case_sweep_leaves_the_engine_usable():
     eng.set_streams(300)                                   # far more streams than CUs' worth of workgroups in the small kernels
     yb = eng.infer_batch(np.stack([x] * 300), 2560, 12, 200, 21)
     assert yb.shape == (300, 1008) and np.isfinite(yb).all()
+
+
+def test_plugin_maximum_settings():
+    # the plugin's sliders at their upper ends (obs-rvc/src/lib.rs:396-413): 1.5 s chunks, 0.15 s crossfade, 5 s of extra context at a
+    # 48 kHz host -> a 6.66 s window (L = 106 560, ContentVec T = 332: the attention falls back to the one-buffer LDS kernel),
+    # R = 155 frames (text-encoder attention past the small-T kernel), Tm = 160 mel frames
+    from oracle import oracle as O
+    from obs_rvc_amd.rvc import RvcInfer
+    gg = derive(48000, 1.5, 0.15, 5.0, 48000)
+    assert (gg.input_buffer_16k_size, gg.sample_frame_16k, gg.model_return_length, gg.skip_head) == (106560, 24000, 155, 500)
+    # full-size ContentVec on the long window
+    z = zoo("full")
+    ora = O.OracleRvcInfer(z["data"]); ora.load_contentvec(2); ora.load_f0(1); ora.load_model(z["model"]); ora.set_noise_seed(8, 0)
+    eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"]); eng.set_noise_seed(8, 0)
+    x = voice_signal(gg.input_buffer_16k_size, seed=23)
+    ho, he = ora.hubert(x), eng.hubert(x)
+    assert he.shape == ho.shape == (1, 768, 332) and rel_rms(he, ho) < 1e-4
+    # with the synthetic full-size RMVPE weights some of the 160 frames decode to a bin >= 348, where the reference indexes out of
+    # bounds (rmvpe.rs:124) and panics: both sides must report exactly that
+    with pytest.raises(Exception) as eo:
+        ora.infer(x, gg.sample_frame_16k, 7, gg.skip_head, gg.model_return_length)
+    with pytest.raises(RvcInferError) as ee:
+        eng.infer(x, gg.sample_frame_16k, 7, gg.skip_head, gg.model_return_length)
+    assert "Panic" in str(eo.value) and ee.value.kind == "Panic"
+    # the whole chunk at these sizes on the small model (same code paths, well-behaved salience)
+    z = zoo("tiny")
+    ora = O.OracleRvcInfer(z["data"]); ora.load_contentvec(2); ora.load_f0(1); ora.load_model(z["model"]); ora.set_noise_seed(8, 0)
+    eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"]); eng.set_noise_seed(8, 0)
+    for _ in range(2):
+        yo = ora.infer(x, gg.sample_frame_16k, 7, gg.skip_head, gg.model_return_length)
+        ye = eng.infer(x, gg.sample_frame_16k, 7, gg.skip_head, gg.model_return_length)
+        assert ye.shape == yo.shape == (155 * 48,) and rms(ye - yo) < PCM_TOL, rms(ye - yo)
+    assert np.allclose(eng.pitch_cache(), ora.pitch_cache(), rtol=1e-5, atol=1e-3)

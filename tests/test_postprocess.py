@@ -220,3 +220,42 @@ def test_native_session_batches_streams():
             assert batched.last_sola_offsets[sidx] == singles[sidx][1].last_sola_offset
     with pytest.raises(Exception):
         batched.process_one_frame(x[0])               # one stream handed to a 3-stream session
+
+
+@pytest.mark.gpu
+def test_native_session_at_the_plugin_maximum_settings():
+    # 1.5 s chunks: the 72 960-sample downsampler chunk no longer fits the LDS-resident polyphase row (global-memory row fallback);
+    # native session vs the host-side state machine over a second engine (tight), and vs the all-CPU chain while the SOLA offsets
+    # agree (a near-tie in the 480-lag search may legitimately flip between fp32 summation orders)
+    from oracle import resample_oracle as RO
+    from obs_rvc_amd.resample import FftFixedInOut
+    from obs_rvc_amd.rvc import RvcInfer
+    from obs_rvc_amd.streaming import NativeStreamingSession, StreamingSession
+    g = derive(48000, 1.5, 0.15, 5.0, 4800)
+    z = zoo("tiny")
+
+    def engine():
+        e = RvcInfer(z["data"]); e.load_contentvec(2); e.load_f0(); e.load_model(z["model"]); e.set_noise_seed(3, 0)
+        return e
+    e1, e2 = engine(), engine()
+    ora = O.OracleRvcInfer(z["data"]); ora.load_contentvec(2); ora.load_f0(1); ora.load_model(z["model"]); ora.set_noise_seed(3, 0)
+    nat = NativeStreamingSession(e1, 48000, 1.5, 0.15, 5.0, 4800, 12, 0.6)
+    assert (nat.sample_frame_size, nat.input_buffer_size, nat.model_return_length) == (72000, 319680, 155)
+    pys = StreamingSession(e2, g, 12, 0.6, 4800, lambda ri, ro, n: FftFixedInOut(e2, ri, ro, n))
+    ors = StreamingSession(ora, g, 12, 0.6, 4800, lambda ri, ro, n: RO.FftFixedInOut(ri, ro, n))
+    a = np.interp(np.arange(72000 * 3) / 48000.0, np.arange(24000 * 3) / 16000.0, voice_signal(24000 * 3, seed=12)).astype(np.float32)
+    agree = 0
+    for c in range(3):
+        ch = a[c * 72000:(c + 1) * 72000]
+        fn, fp, fo = nat.process_one_frame(ch), pys.process_one_frame(ch), ors.process_one_frame(ch)
+        assert fn.shape == fo.shape == (72000,) and nat.last_sola_offset == pys.last_sola_offset
+        assert np.abs(fn - fp).max() < 5e-5, (c, float(np.abs(fn - fp).max()))
+        assert np.abs(pys.input_buffer_16k - ors.input_buffer_16k).max() < 5e-5
+        # the decode's arg-max over 360 salience bins is a discrete decision: on a near-tie (flat synthetic salience) the two fp32
+        # summation orders may pick neighbouring bins, the f0 of that frame moves by 20 cents and stays in the pitch cache --
+        # compare audio only while every decision agreed
+        same_decisions = np.abs(e1.pitch_cache() - ora.pitch_cache()).max() < 0.5 and nat.last_sola_offset == ors.last_sola_offset
+        if same_decisions:
+            agree += 1
+            assert rms(fn - fo) < 1e-3, (c, rms(fn - fo))
+    assert agree >= 1

@@ -10,7 +10,8 @@ from oracle import resample_oracle as RO
 
 # (rate_in, rate_out, chunk_size_in): the plugin's down/up-sampler shapes at 48 kHz and 44.1 kHz hosts, 160 / 300 ms chunks
 CASES = [(48000, 16000, 7680 + 960), (48000, 48000, 10080), (40000, 48000, 14000), (48000, 44100, 10080),
-         (44100, 16000, 7056 + 882), (32000, 48000, 6720), (16000, 48000, 3360)]
+         (44100, 16000, 7056 + 882), (32000, 48000, 6720), (16000, 48000, 3360),
+         (48000, 16000, 72000 + 960), (48000, 44100, 25600)]        # past the LDS-resident row: sample_length 1.5 s; 48k->44.1k at 0.5 s
 
 
 def test_fft_sizes_follow_the_rate_ratio():
