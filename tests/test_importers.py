@@ -274,3 +274,147 @@ def test_checkpoint_files_and_cli(tmp_path):
         IM.main(["contentvec", onnx, out, "--version", "2"])  # default pos_groups 16 does not fit this 48-wide toy model
     cfg, t = IM.import_contentvec(IM.load_named_tensors(onnx), heads=4, pos_groups=4)
     assert cfg["embed"] == 48 and "cv.l1.ff2.w" in t
+
+
+def _upstream_rmvpe(en_out=4, n_blocks=2, levels=5, inter=2, hidden=32, seed=0):
+    """RMVPE's E2E network written as upstream structures it (module and parameter names as in its rmvpe.py, from the public
+    architecture): DeepUnet(Encoder / Intermediate / Decoder of ConvBlockRes) -> Conv2d(.., 3) -> BiGRU -> Linear -> Sigmoid."""
+    import torch
+    import torch.nn as nn
+
+    class ConvBlockRes(nn.Module):
+        def __init__(self, ci, co):
+            super().__init__()
+            self.conv = nn.Sequential(nn.Conv2d(ci, co, 3, 1, 1, bias=False), nn.BatchNorm2d(co, momentum=0.01), nn.ReLU(),
+                                      nn.Conv2d(co, co, 3, 1, 1, bias=False), nn.BatchNorm2d(co, momentum=0.01), nn.ReLU())
+            self.is_shortcut = ci != co
+            if self.is_shortcut:
+                self.shortcut = nn.Conv2d(ci, co, 1)
+
+        def forward(self, x):
+            return self.conv(x) + (self.shortcut(x) if self.is_shortcut else x)
+
+    class ResEncoderBlock(nn.Module):
+        def __init__(self, ci, co, pool, nb):
+            super().__init__()
+            self.conv = nn.ModuleList([ConvBlockRes(ci, co)] + [ConvBlockRes(co, co) for _ in range(nb - 1)])
+            self.pool = nn.AvgPool2d(2) if pool else None
+
+        def forward(self, x):
+            for c in self.conv:
+                x = c(x)
+            return (x, self.pool(x)) if self.pool is not None else x
+
+    class Encoder(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.bn = nn.BatchNorm2d(1, momentum=0.01)
+            self.layers = nn.ModuleList()
+            ci, co = 1, en_out
+            for _ in range(levels):
+                self.layers.append(ResEncoderBlock(ci, co, True, n_blocks)); ci, co = co, co * 2
+            self.out_channel = co
+
+        def forward(self, x):
+            skips = []
+            x = self.bn(x)
+            for l in self.layers:
+                t, x = l(x); skips.append(t)
+            return x, skips
+
+    class Intermediate(nn.Module):
+        def __init__(self, ci, co):
+            super().__init__()
+            self.layers = nn.ModuleList([ResEncoderBlock(ci, co, False, n_blocks)] + [ResEncoderBlock(co, co, False, n_blocks) for _ in range(inter - 1)])
+
+        def forward(self, x):
+            for l in self.layers:
+                x = l(x)
+            return x
+
+    class ResDecoderBlock(nn.Module):
+        def __init__(self, ci, co):
+            super().__init__()
+            self.conv1 = nn.Sequential(nn.ConvTranspose2d(ci, co, 3, 2, 1, 1, bias=False), nn.BatchNorm2d(co, momentum=0.01), nn.ReLU())
+            self.conv2 = nn.ModuleList([ConvBlockRes(co * 2, co)] + [ConvBlockRes(co, co) for _ in range(n_blocks - 1)])
+
+        def forward(self, x, skip):
+            x = torch.cat((self.conv1(x), skip), dim=1)
+            for c in self.conv2:
+                x = c(x)
+            return x
+
+    class Decoder(nn.Module):
+        def __init__(self, ci):
+            super().__init__()
+            self.layers = nn.ModuleList()
+            for _ in range(levels):
+                self.layers.append(ResDecoderBlock(ci, ci // 2)); ci //= 2
+
+        def forward(self, x, skips):
+            for i, l in enumerate(self.layers):
+                x = l(x, skips[-1 - i])
+            return x
+
+    class DeepUnet(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = Encoder()
+            self.intermediate = Intermediate(self.encoder.out_channel // 2, self.encoder.out_channel)
+            self.decoder = Decoder(self.encoder.out_channel)
+
+        def forward(self, x):
+            x, skips = self.encoder(x)
+            return self.decoder(self.intermediate(x), skips)
+
+    class BiGRU(nn.Module):
+        def __init__(self, i, h):
+            super().__init__()
+            self.gru = nn.GRU(i, h, num_layers=1, batch_first=True, bidirectional=True)
+
+        def forward(self, x):
+            return self.gru(x)[0]
+
+    class E2E(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.unet = DeepUnet()
+            self.cnn = nn.Conv2d(en_out, 3, 3, padding=1)
+            self.fc = nn.Sequential(BiGRU(3 * 128, hidden), nn.Linear(2 * hidden, 360), nn.Dropout(0.25), nn.Sigmoid())
+
+        def forward(self, mel):                       # mel (B, 128, T)
+            x = self.cnn(self.unet(mel.transpose(-1, -2).unsqueeze(1))).transpose(1, 2).flatten(-2)
+            return self.fc(x)                         # (B, T, 360)
+
+    torch.manual_seed(seed)
+    m = E2E().eval()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, nn.BatchNorm2d):       # non-trivial running statistics and affine
+                mod.running_mean.normal_(0, 0.2); mod.running_var.uniform_(0.5, 1.5); mod.weight.uniform_(0.7, 1.3); mod.bias.normal_(0, 0.1)
+        m.unet.encoder.bn.running_mean.fill_(-4.0); m.unet.encoder.bn.running_var.fill_(9.0)   # log-mel is roughly in [-12, 2]
+    return m
+
+
+def test_rmvpe_import_is_checked_against_an_upstream_structured_module(tmp_path):
+    # import_rmvpe (names, BatchNorm folding, concat order, GRU gate layout) checked end to end: an nn.Module with upstream's
+    # structure and parameter names -> state dict -> blob -> oracle forward  ==  the module's own forward on the oracle's log-mel
+    import torch
+    from oracle import oracle as O
+    m = _upstream_rmvpe()
+    named = {k: v.detach().numpy() for k, v in m.state_dict().items() if "num_batches_tracked" not in k}
+    cfg, tens = IM.import_rmvpe(named)
+    assert (cfg["en_out"], cfg["levels"], cfg["n_blocks"], cfg["inter_layers"], cfg["gru_hidden"], cfg["n_out"]) == (4, 5, 2, 2, 32, 360)
+    d = tmp_path / "data"
+    os.makedirs(d / "f0"); os.makedirs(d / "contentvec")
+    W.write_blob(str(d / "f0" / "rmvpe.rvcw"), cfg, tens)
+    ora = O.OracleRvcInfer(str(d)); ora.load_f0(1); ora.enable_taps(True)
+    try:
+        ora.pitch(voice_signal(35840, seed=4), 0, 2560)
+    except Exception as ex:                            # an untrained head may decode to a bin where the reference panics: taps are still there
+        assert "Panic" in str(ex)
+    mel = ora.tap("rm.mel").reshape(128, 32)
+    got = ora.tap("rm.sal").reshape(32, 360)
+    with torch.no_grad():
+        ref = m(torch.from_numpy(np.ascontiguousarray(mel))[None])[0].numpy()
+    assert ref.shape == got.shape and rel_rms(got, ref) < 5e-5, rel_rms(got, ref)
