@@ -12,8 +12,9 @@ Tensor names follow the upstream state dicts (fairseq HubertModel or transformer
 norm parameters and biases but stores `nn.Linear` weights as anonymous transposed MatMul operands: `load_named_tensors`
 re-attaches them through the graph (MatMul -> Add whose bias initializer is `<layer>.bias`).  Exports whose initializers were
 renamed wholesale (e.g. Conv+BatchNorm fused by the exporter's constant folding) cannot be mapped by name; the importer then
-fails with the list of missing tensors instead of guessing.  PARITY UNPINNED for the synthesizer / RMVPE name tables (no real
-file in this image); the ContentVec table is pinned against transformers.HubertModel (tests/test_importers.py).
+fails with the list of missing tensors instead of guessing.  No real checkpoint exists in this image: the ContentVec table is pinned
+against transformers.HubertModel, the RMVPE and synthesizer tables are checked end to end against nn.Modules written with upstream's
+structure and parameter names (tests/test_importers.py) -- a real file may still differ in details these tests cannot see.
 
 CLI:  python -m obs_rvc_amd.importers contentvec|rmvpe|synth <input> <output.rvcw> [--version 2] [--sid 0] [--sr 48000]
 """

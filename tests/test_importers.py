@@ -418,3 +418,220 @@ def test_rmvpe_import_is_checked_against_an_upstream_structured_module(tmp_path)
     with torch.no_grad():
         ref = m(torch.from_numpy(np.ascontiguousarray(mel))[None])[0].numpy()
     assert ref.shape == got.shape and rel_rms(got, ref) < 5e-5, rel_rms(got, ref)
+
+
+def _upstream_synth(phone_dim=48, inter=16, hidden=16, filt=32, heads=2, layers=2, k=3, window=4, n_flows=2, wn_layers=2, gin=8,
+                    up_init=32, rates=(4, 3, 2, 2), kernels=(8, 7, 4, 4), rb_k=(3, 5), rb_d=(1, 3), n_spk=3, seed=0):
+    """RVC's SynthesizerTrnMs768NSFsid written as upstream structures it (module / parameter names of infer_pack's models.py,
+    attentions.py, modules.py, from the public architecture; the relative-position attention is written directly from its definition).
+    Returns (module, helpers) where the decoder takes the harmonic source as an input (upstream draws it from SineGen)."""
+    import math
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from torch.nn.utils import weight_norm
+
+    class LayerNorm(nn.Module):
+        def __init__(self, c):
+            super().__init__()
+            self.gamma, self.beta = nn.Parameter(torch.ones(c)), nn.Parameter(torch.zeros(c))
+
+        def forward(self, x):
+            return F.layer_norm(x.transpose(1, -1), (x.shape[1],), self.gamma, self.beta, 1e-5).transpose(1, -1)
+
+    class MultiHeadAttention(nn.Module):
+        def __init__(self, c, n_heads, window_size):
+            super().__init__()
+            self.n_heads, self.k_channels, self.w = n_heads, c // n_heads, window_size
+            self.conv_q, self.conv_k, self.conv_v, self.conv_o = (nn.Conv1d(c, c, 1) for _ in range(4))
+            self.emb_rel_k = nn.Parameter(torch.randn(1, 2 * window_size + 1, self.k_channels) * self.k_channels ** -0.5)
+            self.emb_rel_v = nn.Parameter(torch.randn(1, 2 * window_size + 1, self.k_channels) * self.k_channels ** -0.5)
+
+        def forward(self, x, c):
+            b, d, t = x.shape
+            q, kk, v = (f(x).view(b, self.n_heads, self.k_channels, t).transpose(2, 3) for f in (self.conv_q, self.conv_k, self.conv_v))
+            q = q / math.sqrt(self.k_channels)
+            scores = q @ kk.transpose(-2, -1)
+            rel = torch.arange(t)[None, :] - torch.arange(t)[:, None]                 # j - i
+            inside = (rel.abs() <= self.w)
+            idx = (rel + self.w).clamp(0, 2 * self.w)
+            rk, rv = self.emb_rel_k[0][idx], self.emb_rel_v[0][idx]                       # (t, t, kc)
+            scores = scores + torch.einsum("bhid,ijd->bhij", q, rk) * inside
+            p = F.softmax(scores, dim=-1)
+            out = p @ v + torch.einsum("bhij,ijd->bhid", p * inside, rv)
+            return self.conv_o(out.transpose(2, 3).contiguous().view(b, d, t))
+
+    class FFN(nn.Module):
+        def __init__(self, c, f, ks):
+            super().__init__()
+            self.ks = ks
+            self.conv_1, self.conv_2 = nn.Conv1d(c, f, ks), nn.Conv1d(f, c, ks)
+
+        def forward(self, x, mask):
+            pad = ((self.ks - 1) // 2, self.ks // 2)
+            x = torch.relu(self.conv_1(F.pad(x * mask, pad)))
+            return self.conv_2(F.pad(x * mask, pad)) * mask
+
+    class Encoder(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.attn_layers = nn.ModuleList(MultiHeadAttention(hidden, heads, window) for _ in range(layers))
+            self.norm_layers_1 = nn.ModuleList(LayerNorm(hidden) for _ in range(layers))
+            self.ffn_layers = nn.ModuleList(FFN(hidden, filt, k) for _ in range(layers))
+            self.norm_layers_2 = nn.ModuleList(LayerNorm(hidden) for _ in range(layers))
+
+        def forward(self, x, mask):
+            x = x * mask
+            for a, n1, f, n2 in zip(self.attn_layers, self.norm_layers_1, self.ffn_layers, self.norm_layers_2):
+                x = n1(x + a(x, x))
+                x = n2(x + f(x, mask))
+            return x * mask
+
+    class TextEncoder(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.emb_phone, self.emb_pitch = nn.Linear(phone_dim, hidden), nn.Embedding(256, hidden)
+            self.encoder, self.proj = Encoder(), nn.Conv1d(hidden, inter * 2, 1)
+
+        def forward(self, phone, pitch):
+            x = F.leaky_relu((self.emb_phone(phone) + self.emb_pitch(pitch)) * math.sqrt(hidden), 0.1).transpose(1, -1)
+            mask = torch.ones(1, 1, x.shape[-1])
+            x = self.encoder(x, mask)
+            return torch.split(self.proj(x) * mask, inter, dim=1)
+
+    class WN(nn.Module):
+        def __init__(self, ks):
+            super().__init__()
+            self.in_layers = nn.ModuleList(weight_norm(nn.Conv1d(hidden, 2 * hidden, ks, padding=(ks - 1) // 2)) for _ in range(wn_layers))
+            self.res_skip_layers = nn.ModuleList(weight_norm(nn.Conv1d(hidden, 2 * hidden if i < wn_layers - 1 else hidden, 1)) for i in range(wn_layers))
+            self.cond_layer = weight_norm(nn.Conv1d(gin, 2 * hidden * wn_layers, 1))
+
+        def forward(self, x, mask, g):
+            out = torch.zeros_like(x)
+            g = self.cond_layer(g)
+            for i in range(wn_layers):
+                a = self.in_layers[i](x) + g[:, i * 2 * hidden:(i + 1) * 2 * hidden]
+                acts = torch.tanh(a[:, :hidden]) * torch.sigmoid(a[:, hidden:])
+                rs = self.res_skip_layers[i](acts)
+                if i < wn_layers - 1:
+                    x = (x + rs[:, :hidden]) * mask; out = out + rs[:, hidden:]
+                else:
+                    out = out + rs
+            return out * mask
+
+    class ResidualCouplingLayer(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.pre, self.enc, self.post = nn.Conv1d(inter // 2, hidden, 1), WN(5), nn.Conv1d(hidden, inter // 2, 1)
+
+        def forward(self, x, mask, g, reverse):
+            x0, x1 = torch.split(x, [inter // 2] * 2, 1)
+            m = self.post(self.enc(self.pre(x0) * mask, mask, g)) * mask
+            x1 = (x1 - m) * mask if reverse else m + x1 * mask
+            return torch.cat([x0, x1], 1)
+
+    class Flip(nn.Module):
+        def forward(self, x, mask, g, reverse):
+            return torch.flip(x, [1])
+
+    class ResidualCouplingBlock(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.flows = nn.ModuleList()
+            for _ in range(n_flows):
+                self.flows.append(ResidualCouplingLayer()); self.flows.append(Flip())
+
+        def forward(self, x, mask, g, reverse=True):
+            for f in (reversed(self.flows) if reverse else self.flows):
+                x = f(x, mask, g, reverse)
+            return x
+
+    class ResBlock1(nn.Module):
+        def __init__(self, ch, ks):
+            super().__init__()
+            self.convs1 = nn.ModuleList(weight_norm(nn.Conv1d(ch, ch, ks, 1, dilation=d, padding=(ks * d - d) // 2)) for d in rb_d)
+            self.convs2 = nn.ModuleList(weight_norm(nn.Conv1d(ch, ch, ks, 1, dilation=1, padding=(ks - 1) // 2)) for _ in rb_d)
+
+        def forward(self, x):
+            for c1, c2 in zip(self.convs1, self.convs2):
+                x = c2(F.leaky_relu(c1(F.leaky_relu(x, 0.1)), 0.1)) + x
+            return x
+
+    class SourceModuleHnNSF(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l_linear = nn.Linear(1, 1)
+
+    class GeneratorNSF(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.m_source = SourceModuleHnNSF()
+            self.conv_pre = nn.Conv1d(inter, up_init, 7, 1, padding=3)
+            self.ups, self.noise_convs, self.resblocks = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+            ch = up_init
+            for i, (u, kk) in enumerate(zip(rates, kernels)):
+                self.ups.append(weight_norm(nn.ConvTranspose1d(ch, ch // 2, kk, u, padding=(kk - u) // 2)))
+                ch //= 2
+                if i + 1 < len(rates):
+                    sf = int(np.prod(rates[i + 1:]))
+                    self.noise_convs.append(nn.Conv1d(1, ch, kernel_size=sf * 2, stride=sf, padding=sf // 2))
+                else:
+                    self.noise_convs.append(nn.Conv1d(1, ch, kernel_size=1))
+                for ks in rb_k:
+                    self.resblocks.append(ResBlock1(ch, ks))
+            self.conv_post = nn.Conv1d(ch, 1, 7, 1, padding=3, bias=False)
+            self.cond = nn.Conv1d(gin, up_init, 1)
+
+        def forward(self, x, har_source, g):           # har_source (1, 1, T * upp): upstream computes it as m_source(f0, upp)
+            x = self.conv_pre(x) + self.cond(g)
+            nk = len(rb_k)
+            for i in range(len(rates)):
+                x = self.ups[i](F.leaky_relu(x, 0.1)) + self.noise_convs[i](har_source)
+                x = sum(self.resblocks[i * nk + j](x) for j in range(nk)) / nk
+            return torch.tanh(self.conv_post(F.leaky_relu(x)))
+
+    class Synth(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.enc_p, self.dec, self.flow, self.emb_g = TextEncoder(), GeneratorNSF(), ResidualCouplingBlock(), nn.Embedding(n_spk, gin)
+
+    torch.manual_seed(seed)
+    m = Synth().eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    return m
+
+
+def test_synth_import_is_checked_against_an_upstream_structured_module(tmp_path):
+    # import_synth (names, weight-norm folding, baked speaker row, flow order and flips, rel-pos tables, noise-conv geometry) checked
+    # end to end: upstream-structured nn.Module -> state dict -> blob -> oracle forward == the module's forward, stage by stage, on
+    # the oracle's own phone / pitch / prior noise / harmonic source
+    import torch
+    from oracle import oracle as O
+    m = _upstream_synth()
+    sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    assert any(k.endswith("weight_g") or "parametrizations" in k for k in sd)          # weight-normed layers are exported as pairs
+    cfg, tens = IM.import_synth(sd, sid=1, sr=4800, up_rates=[4, 3, 2, 2], heads=2)
+    model = str(tmp_path / "upstream.rvcw")
+    W.write_blob(model, cfg, tens)
+    z = zoo("tiny")
+    ora = O.OracleRvcInfer(z["data"]); ora.load_contentvec(2); ora.load_f0(1); ora.load_model(model); ora.set_noise_seed(3, 1); ora.enable_taps(True)
+    R = 21
+    audio = ora.infer(voice_signal(35840, seed=4), 2560, 12, 200, R)
+    phone = torch.from_numpy(np.ascontiguousarray(ora.tap("phone").reshape(R, -1)))[None]
+    pitch = torch.from_numpy(ora.tap("pitch").astype(np.int64))[None]
+    I = 16
+    with torch.no_grad():
+        g = m.emb_g(torch.tensor([1])).unsqueeze(-1)
+        mp, logs = m.enc_p(phone, pitch)
+        stats = torch.cat([mp, logs], 1)[0].numpy()
+        assert rel_rms(ora.tap("sy.stats").reshape(stats.shape), stats) < 5e-5
+        eps = torch.from_numpy(O.philox_normal(3, 1, 0, 0, I * R).reshape(I, R))[None]
+        zp = mp + torch.exp(logs) * eps * 0.66666
+        mask = torch.ones(1, 1, R)
+        zz = m.flow(zp, mask, g, reverse=True)
+        assert rel_rms(ora.tap("sy.z").reshape(I, R), zz[0].numpy()) < 5e-5
+        src = torch.from_numpy(np.ascontiguousarray(ora.tap("sy.src")).reshape(1, 1, -1))
+        ref = m.dec(zz, src, g)[0, 0].numpy()
+    assert ref.shape == audio.shape and np.sqrt(np.mean((ref - audio) ** 2)) < 5e-5
