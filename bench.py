@@ -193,13 +193,21 @@ def main():
         # CPU baseline: the C oracle (a port of the reference's path; the reference itself -- Rust + ONNX Runtime -- cannot
         # run here) on this node's host cores, bounded sample of the same workload
         from oracle import oracle as O
-        threads = min(os.cpu_count() or 1, 32)
-        O.set_threads(threads)
+        # 16 OpenMP threads is this restatement's optimum on the 256-CPU host (1: 1158, 8: 358, 16: 297, 32: 550, 64: 1100 ms/chunk --
+        # its parallel loops are per layer and short, so more threads only add barrier cost); the single-thread figure is reported too
+        threads = min(os.cpu_count() or 1, 16)
         ora = O.OracleRvcInfer(z["data"])
         ora.load_contentvec(2); ora.load_f0(1); ora.load_model(z["model"]); ora.set_noise_seed(1234, 0)
         if args.index:
             ora.load_index(W.make_index()); ora.set_index_rate(0.75)
-        n_cpu = 24
+        O.set_threads(1)
+        ora.infer(rings[0, 0], chunk, 12, g.skip_head, g.model_return_length)
+        c0 = time.perf_counter()
+        for i in range(3):
+            ora.infer(rings[i % n_rings, 0], chunk, 12, g.skip_head, g.model_return_length)
+        one_thread_ms = (time.perf_counter() - c0) / 3 * 1e3
+        O.set_threads(threads)
+        n_cpu = 40
         ora.infer(rings[0, 0], chunk, 12, g.skip_head, g.model_return_length)
         c0 = time.perf_counter()
         for i in range(n_cpu):
@@ -207,7 +215,7 @@ def main():
         ct = time.perf_counter() - c0
         cpu = {"value": round(FRAMES_PER_CHUNK * n_cpu / ct, 2), "unit": "frames/s", "cores": threads, "kind": "port",
                "sample": "%d chunks of stream 0 (same rings, same weights), C oracle with OpenMP, %.1f s" % (n_cpu, ct),
-               "ms_per_chunk": round(ct / n_cpu * 1e3, 2)}
+               "ms_per_chunk": round(ct / n_cpu * 1e3, 2), "one_thread_ms_per_chunk": round(one_thread_ms, 1)}
 
     if rank == 0:
         total_streams = S * world
