@@ -91,6 +91,10 @@ rvc_status rvc_infer_device(rvc_engine *e, const void *d_input, size_t n, size_t
                             uint32_t skip_head, uint32_t return_length, void *d_out, size_t cap_per_stream, size_t *out_len, int sync);
 rvc_status rvc_synchronize(rvc_engine *e);
 void rvc_set_use_graph(rvc_engine *e, int on);    /* replay the per-chunk launch sequence from a hipGraph */
+/* Offline throughput mode (no counterpart in the reference, whose protocol is one request at a time): with on != 0, consecutive
+ * rvc_infer_device(..., sync = 0) calls overlap chunk i+1's ContentVec / f0 branches with chunk i's synthesizer (two plan slots).
+ * Results are identical to the serial order; every call needs its own output buffer until rvc_synchronize. */
+void rvc_set_pipeline(rvc_engine *e, int on);
 
 /* ---- caller-side post-processing of the plugin, same host-buffer convention ---- */
 /* envelop_mixing (obs-rvc/src/rt_utils.rs:119-132): output[i] *= (rms(input)/max(rms(output),1e-3))^(1-mix_rate) */

@@ -295,12 +295,15 @@ struct Plan {
     std::vector<float *> owned_dev;   // plan-time repacked weights
     // timeline probe (RVC_STAMPS=1): one device timestamp per section boundary
     unsigned long long *d_stamps = nullptr; std::vector<std::string> stamp_names;
+    // chunk pipelining (rvc_set_pipeline): plans alternate between two slots; ev_done marks the end of this plan's previous chunk
+    int slot = 0; hipEvent_t ev_done = nullptr; bool ev_done_valid = false;
     // graph
     hipGraphExec_t graph_exec = nullptr;
     ~Plan()
     {
         for (float *p : owned_dev) (void)hipFree(p);
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (ev_done) (void)hipEventDestroy(ev_done);
         for (auto &e : prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     }
 };
@@ -1010,6 +1013,10 @@ struct rvc_engine {
     std::vector<std::unique_ptr<Plan>> plans;
     Plan *last_plan = nullptr;
     bool taps_on = false, profile_on = false, use_graph = false;
+    // offline throughput mode: consecutive unsynchronised infer_device calls overlap chunk i+1's two front branches with chunk i's
+    // synthesizer (two plan slots; the branch streams are ordered by events instead of forking from the main stream)
+    bool pipeline = false, pipe_now = false; int pipe_slot = 0; hipEvent_t ev_in = nullptr; const void *pipe_input = nullptr; size_t pipe_input_bytes = 0;
+    float pushed_uppower = -1.f; uint32_t pushed_seed = 0; bool pushed_valid = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
     size_t last_knn_rows = 0;
@@ -1488,17 +1495,18 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
 }
 
 // ------------------------------- plan -------------------------------------------------
-static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32_t skip_head, uint32_t R)
+static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32_t skip_head, uint32_t R, int slot = 0)
 {
     const int B = e->n_streams;
     const bool with_index = mode == 0 && e->d_index && e->index_rate > 0.f;
     for (auto &p : e->plans)
         if (p->mode == mode && p->L == L && p->frame16k == frame16k && p->skip_head == skip_head && p->R == R && p->B == B &&
-            p->with_index == with_index && p->with_taps == e->taps_on)
+            p->with_index == with_index && p->with_taps == e->taps_on && p->slot == slot)
             return p.get();
     std::unique_ptr<Plan> up(new Plan());
     Plan &pl = *up;
     pl.mode = mode; pl.L = L; pl.frame16k = frame16k; pl.skip_head = skip_head; pl.R = R; pl.B = B; pl.with_index = with_index; pl.with_taps = e->taps_on;
+    pl.slot = slot;
     pl.d_in = pl.arena.floats((size_t)B * L + 64);
     T1 sal0, src0; float *d_pitchf0 = nullptr; int *d_pitch0 = nullptr;
     size_t rm_begin = 0, rm_end = 0;
@@ -1651,7 +1659,7 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
     }
     HIPCHK(hipDeviceSynchronize());
     // bounded plan cache (each geometry owns its activation arena and graph): evict the oldest
-    while (e->plans.size() >= 6) { if (e->last_plan == e->plans.front().get()) e->last_plan = nullptr; e->plans.erase(e->plans.begin()); }
+    while (e->plans.size() >= 8) { if (e->last_plan == e->plans.front().get()) e->last_plan = nullptr; e->plans.erase(e->plans.begin()); }
     e->plans.push_back(std::move(up));
     return e->plans.back().get();
 }
@@ -1666,6 +1674,7 @@ static void issue_ops(rvc_engine *e, Plan &pl, bool capturing)
         const int sid = pl.ops.sid[i];
         hipStream_t st = sid == 0 ? e->stream : e->aux[sid - 1];
         if (pl.ops.kind[i] == 1) {
+            if (e->pipe_now && (sid == 1 || sid == 3)) continue;      // pipelined: the front branches are ordered by events, not by the main stream
             HIPCHK(hipEventRecord(e->ev_fork[sid - 1], e->stream));
             HIPCHK(hipStreamWaitEvent(st, e->ev_fork[sid - 1], 0));
         } else if (pl.ops.kind[i] == 2) {
@@ -1704,6 +1713,13 @@ static float uppower(int32_t pitch_shift) { return ldexpf(1.0f, pitch_shift / 12
 
 static void push_call_params(rvc_engine *e, int32_t pitch_shift)
 {
+    const float up = uppower(pitch_shift);
+    if (e->pipeline) {
+        // the f0 branch of the next chunk may already be running: only touch the parameter block when it changes, and then drain first
+        if (e->pushed_valid && e->pushed_uppower == up && e->pushed_seed == e->seed) return;
+        HIPCHK(hipDeviceSynchronize());
+    }
+    e->pushed_uppower = up; e->pushed_seed = e->seed; e->pushed_valid = true;
     e->h_cp->uppower = uppower(pitch_shift);
     e->h_cp->seed = e->seed;
     e->h_cp->chunk_base = 0;
@@ -1779,6 +1795,7 @@ rvc_status rvc_create(const char *data_path, int device, rvc_engine **out)
         e->partition_ok = !getenv("RVC_NO_CUMASK");
         configure_aux_streams(e);
         HIPCHK(hipEventCreate(&e->ev0)); HIPCHK(hipEventCreate(&e->ev1));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
         HIPCHK(hipMalloc(&e->d_cp, sizeof(CallParams)));
         HIPCHK(hipHostMalloc((void **)&e->h_cp, sizeof(CallParams)));
         HIPCHK(hipHostMalloc((void **)&e->h_status, 4096 * sizeof(int)));
@@ -1814,6 +1831,7 @@ void rvc_destroy(rvc_engine *e)
     if (e->h_status) (void)hipHostFree(e->h_status);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->ev_in) (void)hipEventDestroy(e->ev_in);
     for (int i = 0; i < 3; i++) {
         if (e->ev_fork[i]) (void)hipEventDestroy(e->ev_fork[i]);
         if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
@@ -1931,15 +1949,31 @@ static rvc_status infer_common(rvc_engine *e, const void *input, bool input_on_d
     if (!e->sy) return RVC_MODEL_NOT_LOADED;             // rvc.rs:141-143
     if (!e->cv) return RVC_CONTENTVEC_NOT_LOADED;        // rvc.rs:85-88 (via extract_feature at rvc.rs:151)
     if (!e->rm) return RVC_F0_NOT_LOADED;                // reference: unreachable!() at rvc.rs:125
-    Plan *pl = get_plan(e, 0, n, frame16k, skip_head, return_length);
+    const bool pipe = e->pipeline && !sync && input_on_device && out_on_device && e->partitioned && !e->use_graph && !e->profile_on && !e->taps_on;
+    Plan *pl = get_plan(e, 0, n, frame16k, skip_head, return_length, pipe ? (e->pipe_slot ^= 1) : 0);
     if (out_len) *out_len = pl->N;
     if (cap < pl->N) return RVC_SHAPE;
     const int B = pl->B;
-    HIPCHK(hipMemcpyAsync(pl->d_in, input, (size_t)B * n * sizeof(float), input_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
     push_call_params(e, pitch_shift);
+    if (pipe) {
+        // chunk pipelining: the two front branches of this chunk start as soon as THEIR previous work and this plan slot's previous
+        // chunk are done -- not after the previous chunk's synthesizer on the main stream
+        hipStream_t cvs = e->aux[2], rms = e->aux[0];
+        if (pl->ev_done_valid) { HIPCHK(hipStreamWaitEvent(cvs, pl->ev_done, 0)); HIPCHK(hipStreamWaitEvent(rms, pl->ev_done, 0)); }
+        HIPCHK(hipMemcpyAsync(pl->d_in, input, (size_t)B * n * sizeof(float), hipMemcpyDeviceToDevice, cvs));
+        HIPCHK(hipEventRecord(e->ev_in, cvs));
+        HIPCHK(hipStreamWaitEvent(rms, e->ev_in, 0));
+    } else {
+        HIPCHK(hipMemcpyAsync(pl->d_in, input, (size_t)B * n * sizeof(float), input_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+    }
+    e->pipe_now = pipe;
     run_plan(e, *pl);
+    e->pipe_now = false;
     HIPCHK(hipMemcpy2DAsync(out, cap * sizeof(float), pl->audio.p, pl->N * sizeof(float), pl->N * sizeof(float), B,
                             out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream));
+    if (!pl->ev_done) HIPCHK(hipEventCreateWithFlags(&pl->ev_done, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(pl->ev_done, e->stream));
+    pl->ev_done_valid = true;
     e->last_knn_rows = pl->with_index ? return_length : 0;
     if (!sync) return RVC_OK;
     queue_status(e);
@@ -1992,6 +2026,11 @@ rvc_status rvc_set_streams(rvc_engine *e, int n_streams)
 }
 
 void rvc_set_use_graph(rvc_engine *e, int on) { if (e) e->use_graph = on != 0; }
+void rvc_set_pipeline(rvc_engine *e, int on)
+{
+    if (!e) return;
+    (void)guarded(e, [&]() { HIPCHK(hipDeviceSynchronize()); e->pipeline = on != 0; e->pushed_valid = false; return RVC_OK; });
+}
 void rvc_set_profile(rvc_engine *e, int on) { if (e) e->profile_on = on != 0; }
 void rvc_enable_taps(rvc_engine *e, int on) { if (e) e->taps_on = on != 0; }
 float rvc_last_gpu_ms(rvc_engine *e) { return e ? e->last_ms : 0.f; }

@@ -148,6 +148,10 @@ class RvcInfer:
                                            int(return_length), C.c_void_p(d_out_ptr), int(cap_per_stream), C.byref(nn), 1 if sync else 0))
         return nn.value
 
+    def set_pipeline(self, on: bool = True):
+        """Offline throughput mode: unsynchronised infer_device calls overlap across chunks (rvc_set_pipeline)."""
+        self._L.rvc_set_pipeline(self._h, 1 if on else 0)
+
     def synchronize(self):
         self._chk(self._L.rvc_synchronize(self._h))
 

@@ -463,3 +463,26 @@ def test_plugin_maximum_settings():
         ye = eng.infer(x, gg.sample_frame_16k, 7, gg.skip_head, gg.model_return_length)
         assert ye.shape == yo.shape == (155 * 48,) and rms(ye - yo) < PCM_TOL, rms(ye - yo)
     assert np.allclose(eng.pitch_cache(), ora.pitch_cache(), rtol=1e-5, atol=1e-3)
+
+
+def test_pipelined_chunks_equal_serial_chunks():
+    # offline throughput mode: unsynchronised infer_device calls overlap chunk i+1's front branches with chunk i's synthesizer
+    # (two plan slots); per-stream state (pitch cache, noise counters) must evolve exactly as in the serial order
+    import torch
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("full")
+    L, chunk, N = g.input_buffer_16k_size, g.sample_frame_16k, g.model_return_size
+    audio = voice_signal(chunk * 24, seed=31)
+    rings = torch.from_numpy(np.stack(list(chunk_stream(audio, L, chunk))[-8:])).cuda()
+
+    def run(pipelined):
+        eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"]); eng.set_noise_seed(11, 0)
+        eng.set_pipeline(pipelined)
+        outs = torch.zeros((8, N), device="cuda")
+        for i in range(8):
+            eng.infer_device(rings[i].data_ptr(), L, chunk, 12, g.skip_head, g.model_return_length, outs[i].data_ptr(), N, sync=not pipelined)
+        eng.synchronize()
+        return outs.cpu().numpy(), eng.pitch_cache()
+    ys, cs = run(False)
+    yp, cp = run(True)
+    assert np.isfinite(ys).all() and np.array_equal(ys, yp) and np.array_equal(cs, cp)
