@@ -249,7 +249,7 @@ struct ConvOpts {
     bool glu = false;            // GLU-packed weight rows, gate fused into the epilogue (ModelSY flows)
 };
 
-struct ProfEvent { hipEvent_t a, b; double flops; double bytes; };   // bytes > 0: HBM-bound retrieval scan (flops = 0)
+struct ProfEvent { hipEvent_t a, b; double flops; double bytes; int desc = -1; };   // bytes > 0: HBM-bound retrieval scan (flops = 0)
 
 struct Plan;
 typedef std::function<void(hipStream_t)> Op;
@@ -289,6 +289,7 @@ struct Plan {
     // profiling
     bool profile = false;
     std::vector<ProfEvent> prof;
+    std::vector<std::string> descs;   // per-op description for rvc_debug_profile_dump
     size_t prof_used = 0;
     double igemm_flops = 0;
     int n_igemm = 0;
@@ -344,9 +345,13 @@ static void launch_igemm(int cfg, int ks, bool pre, const IgemmP &p, dim3 grid, 
 #undef RVC_KS
 }
 
+static unsigned long long *g_kprobe = nullptr;   // tuning build (-DRVC_KPROBE): destination of the per-wave phase stamps
+static int g_last_waves = 0, g_last_wgs = 0;
+
 // generic: the caller fills geometry (N, NW, strides, koff, phases); this picks the tile + split-K and queues the op
 static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases)
 {
+    p.probe = g_kprobe;
     // table entries become non-negative byte offsets; the kernel moves the base pointer back by koff_bias bytes
     std::vector<int> kb(koff);
     int kmin = 0;
@@ -412,11 +417,13 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
         pl.igemm_flops += flops; pl.n_igemm++;
         Plan *plp = &pl;
         const int lc = lds_cfg;
+        { char d[160]; snprintf(d, sizeof d, "lds M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%u", p.M, p.N, p.K, B, p.nphase, bm, bn, grid.x, grid.y); pl.descs.push_back(d); }
+        const int desc_id = (int)pl.descs.size() - 1;
         pl.ops.push_back([=](hipStream_t s) {
             ProfEvent *pe = nullptr;
             if (plp->profile) {
                 if (plp->prof_used == plp->prof.size()) { ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; e.bytes = 0; plp->prof.push_back(e); }
-                pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0;
+                pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
             }
             hipEvent_t ea = pe ? pe->a : nullptr, eb = pe ? pe->b : nullptr;
 #define RVC_LG1(K) { if (ea) hipExtLaunchKernelGGL((K), grid, dim3(256), (uint32_t)lds, s, ea, eb, 0, p); else hipLaunchKernelGGL((K), grid, dim3(256), lds, s, p); }
@@ -457,10 +464,13 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     const int ntiles = weight_heavy ? p.m_fast * p.ntn : p.ntm * p.ntn;
     dim3 grid(wg_ks > 1 ? ntiles : (ntiles + 3) / 4, B * p.nphase * ksplit);
     dim3 egrid((unsigned)(((long long)p.M * p.N + 255) / 256), B * p.nphase);
+    g_last_wgs = (int)(grid.x * grid.y); g_last_waves = wg_ks > 1 ? wg_ks : 4;
     const double flops = 2.0 * p.M * (double)p.N * ksum * B;
     pl.igemm_flops += flops;
     pl.n_igemm++;
     Plan *plp = &pl;
+    { char d[200]; snprintf(d, sizeof d, "reg M=%d N=%d K=%d B=%d nph=%d tile=%dx%d ks=%d mfast=%d grid=%ux%u pre=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, 16 * kMF[cfg], 16 * kNF[cfg], wg_ks, p.m_fast, grid.x, grid.y, (int)pre, ksum); pl.descs.push_back(d); }
+    const int desc_id = (int)pl.descs.size() - 1;
     pl.ops.push_back([=](hipStream_t s) {
         ProfEvent *pe = nullptr;
         if (plp->profile) {
@@ -468,7 +478,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
                 ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; e.bytes = 0; plp->prof.push_back(e);
             }
             pe = &plp->prof[plp->prof_used++];
-            pe->flops = flops; pe->bytes = 0;
+            pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
             if (ksplit > 1) HIPCHK(hipEventRecord(pe->a, s));
         }
         if (pe && ksplit == 1) launch_igemm(cfg, wg_ks, pre, p, grid, s, pe->a, pe->b);
@@ -967,6 +977,9 @@ struct ModelSY {
         dec_post = prep_conv(b.w("sy.dec.post.w"), nullptr, 1, c, 7, 1);
         src_w = b.w("sy.src")[0]; src_b = b.w("sy.src")[1];
         weight_bytes = b.bytes();
+        // the f0 / feature frame rate is 100 Hz (rvc.rs:153, 160 samples @16 kHz): a synthesizer whose hop is not sr / 100 would
+        // return audio of the wrong length without any error (e.g. an import that guessed the first upsample rate)
+        if (sr != 100 * upp()) throw std::runtime_error(fmt("synthesizer: sr %d", sr) + fmt(" != 100 * prod(upsample rates) = %d", 100 * upp()));
     }
     ~ModelSY()
     {
@@ -1007,7 +1020,8 @@ struct rvc_engine {
     // streams
     int n_streams = 1;
     StreamState *d_state = nullptr;
-    CallParams *d_cp = nullptr, *h_cp = nullptr;
+    CallParams *d_cp = nullptr, *h_cp = nullptr;   // h_cp: ring of 64 pinned blocks, one per call (an async copy reads its block later)
+    unsigned cp_slot = 0; hipEvent_t ev_cp = nullptr;
     uint32_t seed = 0, stream_id0 = 0;
     // plans (keyed by geometry)
     std::vector<std::unique_ptr<Plan>> plans;
@@ -1089,7 +1103,8 @@ static void reset_state(rvc_engine *e)
 static void configure_aux_streams(rvc_engine *e)
 {
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, e->device));
-    const int ncu = prop.multiProcessorCount, nf0 = ncu / 8;
+    int ncu = prop.multiProcessorCount, nf0 = ncu / 8;
+    if (const char *f = getenv("RVC_F0_CUS")) { const int v = atoi(f); if (v >= 8 && v < ncu) nf0 = v; }   // tuning aid
     bool want = e->partition_ok && ncu >= 64 && ncu <= 1024 && e->n_streams <= 4;
     if (e->aux[0] && want == e->partitioned) return;
     for (int i = 0; i < 3; i++) if (e->aux[i]) { HIPCHK(hipStreamDestroy(e->aux[i])); e->aux[i] = nullptr; }
@@ -1720,10 +1735,19 @@ static void push_call_params(rvc_engine *e, int32_t pitch_shift)
         HIPCHK(hipDeviceSynchronize());
     }
     e->pushed_uppower = up; e->pushed_seed = e->seed; e->pushed_valid = true;
-    e->h_cp->uppower = uppower(pitch_shift);
-    e->h_cp->seed = e->seed;
-    e->h_cp->chunk_base = 0;
-    HIPCHK(hipMemcpyAsync(e->d_cp, e->h_cp, sizeof(CallParams), hipMemcpyHostToDevice, e->stream));
+    // every call writes its own pinned block: an unsynchronised call's copy may still be pending when the next call arrives
+    // (64 blocks: far more calls than the stream can hold unfinished copies for would have to be queued to wrap around)
+    CallParams *h = e->h_cp + (e->cp_slot++ & 63u);
+    h->uppower = up;
+    h->seed = e->seed;
+    h->chunk_base = 0;
+    HIPCHK(hipMemcpyAsync(e->d_cp, h, sizeof(CallParams), hipMemcpyHostToDevice, e->stream));
+    if (e->pipeline) {
+        // pipelined calls do not fork the front branches from the main stream: order them behind the parameter copy explicitly
+        HIPCHK(hipEventRecord(e->ev_cp, e->stream));
+        HIPCHK(hipStreamWaitEvent(e->aux[0], e->ev_cp, 0));
+        HIPCHK(hipStreamWaitEvent(e->aux[2], e->ev_cp, 0));
+    }
 }
 
 // Status words of all streams (0 ok, 6 = the reference would have panicked at rmvpe.rs:124, 7 = GRU hand-off time-out): one strided
@@ -1797,7 +1821,8 @@ rvc_status rvc_create(const char *data_path, int device, rvc_engine **out)
         HIPCHK(hipEventCreate(&e->ev0)); HIPCHK(hipEventCreate(&e->ev1));
         HIPCHK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
         HIPCHK(hipMalloc(&e->d_cp, sizeof(CallParams)));
-        HIPCHK(hipHostMalloc((void **)&e->h_cp, sizeof(CallParams)));
+        HIPCHK(hipHostMalloc((void **)&e->h_cp, 64 * sizeof(CallParams)));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_cp, hipEventDisableTiming));
         HIPCHK(hipHostMalloc((void **)&e->h_status, 4096 * sizeof(int)));
         init_constants(e);
         alloc_state(e);
@@ -1832,6 +1857,7 @@ void rvc_destroy(rvc_engine *e)
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+    if (e->ev_cp) (void)hipEventDestroy(e->ev_cp);
     for (int i = 0; i < 3; i++) {
         if (e->ev_fork[i]) (void)hipEventDestroy(e->ev_fork[i]);
         if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
@@ -1851,6 +1877,7 @@ rvc_status rvc_load_contentvec(rvc_engine *e, int model_version)
         const int dim = model_version == RVC_VERSION_V1 ? 256 : 768, layer = model_version == RVC_VERSION_V1 ? 9 : 12;   // enums.rs:10-23
         char name[64]; snprintf(name, sizeof name, "vec-%d-layer-%d.rvcw", dim, layer);
         Blob b(e->data_path + "/contentvec/" + name);
+        HIPCHK(hipDeviceSynchronize());      // unsynchronised calls may still be running on the plans freed below
         e->plans.clear(); e->last_plan = nullptr;
         e->cv.reset(new ModelCV(b));
         return RVC_OK;
@@ -1861,6 +1888,7 @@ rvc_status rvc_load_model(rvc_engine *e, const char *model_path)
 {
     return guarded(e, [&]() {
         Blob b(native_path(model_path ? model_path : ""));
+        HIPCHK(hipDeviceSynchronize());      // unsynchronised calls may still be running on the plans freed below
         e->plans.clear(); e->last_plan = nullptr;
         e->sy.reset(new ModelSY(b));
         return RVC_OK;
@@ -1872,6 +1900,7 @@ rvc_status rvc_load_f0(rvc_engine *e, int pitch_algorithm)
     (void)pitch_algorithm;   // only Rmvpe exists (enums.rs:26-28); unknown values map to it (enums.rs:96-103)
     return guarded(e, [&]() {
         Blob b(e->data_path + "/f0/rmvpe.rvcw");
+        HIPCHK(hipDeviceSynchronize());      // unsynchronised calls may still be running on the plans freed below
         e->plans.clear(); e->last_plan = nullptr;
         e->rm.reset(new ModelRM(b));
         return RVC_OK;
@@ -2260,6 +2289,46 @@ double rvc_debug_conv_bench(rvc_engine *e, int M, int Cin, int KW, int dil, int 
     return us;
 }
 
+// tuning build only (-DRVC_KPROBE): one launch of a Conv1d with per-wave phase stamps (device wall clock, 10 ns ticks):
+// out[wave][16]; returns the number of waves (workgroups * waves per workgroup), *event_us = the dispatch's own begin..end time
+int rvc_debug_conv_probe(rvc_engine *e, int M, int Cin, int KW, int dil, int N, unsigned long long *out, size_t cap_waves, double *event_us, int *waves_per_wg)
+{
+    int nw = -1;
+    (void)guarded(e, [&]() {
+        std::vector<float> w((size_t)M * Cin * KW), bias(M, 0.1f);
+        for (size_t i = 0; i < w.size(); i++) w[i] = (float)((i * 2654435761u) % 1000) / 1000.0f - 0.5f;
+        ConvW cw = prep_conv(w.data(), bias.data(), M, Cin, KW, 1);
+        Plan pl; pl.B = 1;
+        const int pad = (KW - 1) * dil / 2;
+        T1 x = make_t1(pl.arena, 1, Cin, N, (pad + 3) / 4 * 4), y = make_t1(pl.arena, 1, M, N, 0);
+        std::vector<float> hx((size_t)Cin * x.ld, 0.25f);
+        HIPCHK(hipMemcpy(x.p - x.halo, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        unsigned long long *d_probe; const size_t pbytes = (size_t)1 << 24;
+        HIPCHK(hipMalloc(&d_probe, pbytes)); HIPCHK(hipMemset(d_probe, 0, pbytes));
+        g_kprobe = d_probe;
+        add_conv1d(pl, cw, x, y, 1, pad, dil);
+        g_kprobe = nullptr;
+        HIPCHK(hipDeviceSynchronize());
+        for (int i = 0; i < 5; i++) for (auto &op : pl.ops.v) op(e->stream);
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemset(d_probe, 0, pbytes));
+        HIPCHK(hipDeviceSynchronize());
+        pl.profile = true; pl.prof_used = 0;
+        for (auto &op : pl.ops.v) op(e->stream);
+        HIPCHK(hipDeviceSynchronize());
+        float t = 0.f; HIPCHK(hipEventElapsedTime(&t, pl.prof[0].a, pl.prof[0].b));
+        if (event_us) *event_us = t * 1e3;
+        nw = g_last_wgs * g_last_waves;
+        if (waves_per_wg) *waves_per_wg = g_last_waves;
+        if ((size_t)nw <= cap_waves && (size_t)nw * 128 <= pbytes) HIPCHK(hipMemcpy(out, d_probe, (size_t)nw * 128, hipMemcpyDeviceToHost));
+        else nw = -2;
+        (void)hipFree(d_probe);
+        free_conv(cw);
+        return RVC_OK;
+    });
+    return nw;
+}
+
 rvc_status rvc_profile_last_knn(rvc_engine *e, int *launches, double *kernel_ms, double *bytes)
 {
     return guarded(e, [&]() {
@@ -2273,6 +2342,25 @@ rvc_status rvc_profile_last_knn(rvc_engine *e, int *launches, double *kernel_ms,
         if (bytes) *bytes = by;
         return RVC_OK;
     });
+}
+
+// tuning aid: one line per profiled launch of the last call: "<us> <gflop> <description>"
+int rvc_debug_profile_dump(rvc_engine *e, char *buf, size_t cap)
+{
+    if (!e || !e->last_plan) return 0;
+    Plan &pl = *e->last_plan;
+    if (hipDeviceSynchronize() != hipSuccess) return 0;
+    std::string out;
+    for (size_t i = 0; i < pl.prof_used; i++) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, pl.prof[i].a, pl.prof[i].b) != hipSuccess) continue;
+        char ln[320];
+        snprintf(ln, sizeof ln, "%.2f %.4f %s\n", t * 1e3, pl.prof[i].flops * 1e-9, pl.prof[i].desc >= 0 ? pl.descs[pl.prof[i].desc].c_str() : (pl.prof[i].bytes > 0 ? "knn_dot" : "?"));
+        out += ln;
+    }
+    if (out.size() + 1 > cap) return -1;
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return (int)pl.prof_used;
 }
 
 rvc_status rvc_get_tap(rvc_engine *e, const char *name, float *out, size_t cap, size_t *n)

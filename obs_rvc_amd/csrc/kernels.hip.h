@@ -66,6 +66,7 @@ struct IgemmP {
     int koff_bias;           // bytes: the koff table holds (offset - min offset) * 4, the base pointer is moved back by this
     int glu;                 // WaveNet gate fused into the epilogue: rows are GLU-packed (see glu_store), output has M/2 channels
     int res_nogroup;         // residual channel = m (a tensor shared by all phases) instead of m + y_c0
+    unsigned long long *probe;   // tuning build only (-DRVC_KPROBE): per-wave phase timestamps
     int m_fast;              // XCD-aware tile order: >0 = ntm rounded up to 8, m fastest (workgroup b runs on XCD b%8, so all
                              // n-tiles of one weight-row block share one XCD's L2); 0 = n fastest (activation-heavy layers)
 };
@@ -150,10 +151,16 @@ __device__ __forceinline__ void lds_only_barrier()
 //   The workgroup's slice of the koff table is staged in LDS once; weights and gathered activations are
 //   register-prefetched D chunks (of 16 k) ahead; the koff entries of the next chunk are read from LDS
 //   one stage early so the LDS latency is off the critical path.
+#ifdef RVC_KPROBE
+#define RVC_KP(i) do { if (p.probe && (threadIdx.x & 63) == 0) p.probe[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define RVC_KP(i)
+#endif
 template <int MF, int NF, int D, int KS, bool PRE>
 __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
 {
     constexpr int WAVES = KS > 1 ? KS : 4;
+    RVC_KP(0);
     constexpr int NACC = (MF * NF == 1) ? 2 : 1;   // a lone fragment alternates two accumulators (MFMA dependency)
     constexpr int TE = MF * NF * 256;              // elements of one tile
     constexpr int PE = (KS > 1) ? ((TE + WAVES * 64 - 1) / (WAVES * 64)) : 1;
@@ -176,6 +183,7 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
         int4 *dst = reinterpret_cast<int4 *>(s_koff);
         for (int i = threadIdx.x; i < gn * 4; i += WAVES * 64) dst[i] = src[i];
     }
+    RVC_KP(8);
     int tn, tm;
     if (p.m_fast) { tm = tile % p.m_fast; tn = tile / p.m_fast; }
     else { tn = tile % p.ntn; tm = tile / p.ntn; }
@@ -203,6 +211,7 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
                         pre_w[mf][nf][r] = epi_prefetch(p, ph, b, tm * 16 * MF + mf * 16 + kq * 4 + r, tn * 16 * NF + nf * 16 + li);
         }
     }
+    RVC_KP(9);
     // (the barrier that publishes the koff slice comes after the weight loads of the first D stages have been issued:
     //  they do not depend on it, so their latency overlaps the table's round trip)
     // this wave's chunk range inside the workgroup's slice
@@ -248,6 +257,7 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
 #pragma unroll
             for (int nf = 0; nf < NF; nf++) acc[a][mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    RVC_KP(10);
     f32x4 a_st[D][MF];
     float b_st[D][NF][4];
 #define RVC_LOAD_A(S, C)                                                                               \
@@ -282,12 +292,15 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
         for (int s = 0; s < D; s++)
             if (s < nc) RVC_LOAD_A(s, s)
     }
+    RVC_KP(11);
     lds_only_barrier();        // not __syncthreads(): its vmcnt(0) would drain the weight loads just issued
+    RVC_KP(1);
     if (!live) return;
     int4 ko_nx = nc > 0 ? kol[0] : make_int4(0, 0, 0, 0);
 #pragma unroll
     for (int s = 0; s < D; s++)
         if (s < nc) RVC_LOAD_B(s, s)
+    RVC_KP(2);
     int c = 0;
     for (; c + 2 * D <= nc; c += D) {
 #pragma unroll
@@ -317,6 +330,7 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
 #pragma unroll
             for (int nf = 0; nf < NF; nf++) acc[0][mf][nf] += acc[NACC - 1][mf][nf];
     }
+    RVC_KP(3);
 
     if (KS > 1) {
         // fixed-order reduction of the KS partial tiles through LDS, then every thread finishes its share of the tile
@@ -327,7 +341,9 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
             for (int nf = 0; nf < NF; nf++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) red[wave * TE + ((mf * NF + nf) * 4 + r) * 64 + lane] = acc[0][mf][nf][r];
+        RVC_KP(4);
         __syncthreads();
+        RVC_KP(5);
 #pragma unroll
         for (int q = 0; q < PE; q++) {
             const int e = threadIdx.x + q * WAVES * 64;
@@ -350,6 +366,7 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
             else if (m < p.M && n < p.N)
                 p.part[(((long long)(b * p.nphase + phase) * p.ksplit + ks) * p.M + m) * (long long)p.N + n] = v;
         }
+        RVC_KP(6);
         return;
     }
     // D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
@@ -374,6 +391,7 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
                     if (PF) epi_finish(p, ph, b, m, n, acc[0][mf][nf][r], pre_w[PF ? mf : 0][PF ? nf : 0][r]);
                     else epilogue_store(p, ph, b, m, n, acc[0][mf][nf][r]);
                 }
+        RVC_KP(6);
     } else {
         // partial sums: part[((b*nphase + phase)*ksplit + ks)][M][N]
         float *pp = p.part + ((long long)(b * p.nphase + phase) * p.ksplit + ks) * (long long)p.M * p.N;

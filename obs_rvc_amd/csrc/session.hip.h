@@ -72,7 +72,9 @@ rvc_status rvc_session_create(rvc_engine *e, size_t sample_rate, double sample_l
     return guarded(e, [&]() {
         if (!out || sample_rate < 1000 || sample_rate % 100 != 0 || sample_rate > 384000 || model_output_sample_rate % 100 != 0 || model_output_sample_rate == 0)
             throw ShapeError("session: unsupported sample rate");
-        std::unique_ptr<rvc_session> sp(new rvc_session());
+        // destroyed through rvc_session_destroy on every failure path (a throwing hipMalloc part-way through included): both converters
+        // and every device buffer allocated so far are released
+        std::unique_ptr<rvc_session, void (*)(rvc_session *)> sp(new rvc_session(), rvc_session_destroy);
         rvc_session *s = sp.get();
         s->e = e; s->B = e->n_streams; s->h_off.resize(s->B); s->sample_rate = (int)sample_rate; s->pitch_shift = pitch_shift; s->rms_mix_rate = rms_mix_rate; s->skip_inference = skip_inference != 0;
         const int zc = s->zc = (int)sample_rate / 100;                                                             // lib.rs:200
@@ -93,12 +95,11 @@ rvc_status rvc_session_create(rvc_engine *e, size_t sample_rate, double sample_l
         rvc_status rc = resampler_create_n(e, sample_rate, 16000, (size_t)s->sample_frame_size + 2 * zc, s->B, &s->down);
         if (rc != RVC_OK) return rc;
         rc = resampler_create_n(e, (size_t)s->model_rate, sample_rate, (size_t)s->model_return_size, s->B, &s->up);
-        if (rc != RVC_OK) { rvc_resampler_destroy(s->down); return rc; }
+        if (rc != RVC_OK) return rc;
         s->up_out = s->up->fft_out;
         const bool ok = s->down->fft_in == s->sample_frame_size + 2 * zc && s->down->fft_out == s->sample_frame_16k + 320 && s->up->fft_in == s->model_return_size &&
                         s->up_out >= s->sola_buffer_frame_size + s->sola_search_frame_size + s->sample_frame_size;
         if (!ok) {   // rubato would return WrongNumberOfInputFrames on the first chunk and the plugin would panic (lib.rs:680-682)
-            rvc_resampler_destroy(s->down); rvc_resampler_destroy(s->up);
             throw ShapeError("session: chunk sizes are not multiples of the resampling ratios");
         }
         const size_t NB = (size_t)s->B;

@@ -6,7 +6,9 @@ retrieval needs exactly that matrix, so `read_index` returns the (ntotal, d) flo
 
 Faiss is not installed here and the reference holds no index file: the layout below restates faiss/impl/index_write.cpp /
 index_read.cpp (IndexFlat "IxF2" / "IxFI" / "IxFl", IndexIVFFlat "IwFl" with "ilar" inverted lists, IndexIDMap "IxMp").
-PARITY UNPINNED against a real file; `write_flat` / `write_ivf_flat` emit the same layout for the tests."""
+PARITY UNPINNED against a file written by Faiss itself; pinned at byte level against tests/golden/faiss_*.index, which a separate
+C restatement of index_write.cpp's WRITE1 / WRITEVECTOR / WRITEXBVECTOR sequence produces (tests/golden/make_faiss_fixture.c);
+`write_flat` / `write_ivf_flat` emit the same layout for the round-trip tests."""
 from __future__ import annotations
 
 import struct
@@ -79,9 +81,9 @@ def _read(r: _R) -> Tuple[np.ndarray, Optional[np.ndarray]]:
         r.vec(np.int64)
         if dm_type == 2:
             n = r.u64(); r.raw(n * 16)
-        code_size = r.u64()
-        if code_size != 4 * d:
-            raise IndexFormatError("IVFFlat code size %d != 4 * d" % code_size)
+        # write_index for IndexIVFFlat emits write_ivf_header + write_InvertedLists only: unlike IwSq / IwPQ there is NO code_size
+        # field here (read_index sets code_size = d * sizeof(float)); the value inside the "ilar" header is checked against it
+        code_size = 4 * d
         il = r.fourcc()
         if il == "il00":
             return np.zeros((0, d), np.float32), np.zeros(0, np.int64)
@@ -89,7 +91,7 @@ def _read(r: _R) -> Tuple[np.ndarray, Optional[np.ndarray]]:
             raise IndexFormatError("unsupported inverted-list container %r" % il)
         nl2, cs2 = r.u64(), r.u64()
         if nl2 != nlist or cs2 != code_size:
-            raise IndexFormatError("inverted lists disagree with the IVF header")
+            raise IndexFormatError("inverted lists (nlist %d, code size %d) disagree with the IVF header (nlist %d, 4 * d = %d)" % (nl2, cs2, nlist, code_size))
         lt = r.fourcc()
         if lt == "full":
             sizes = r.vec(np.uint64).astype(np.int64)
@@ -150,7 +152,6 @@ def write_ivf_flat(path: str, vectors: np.ndarray, centroids: np.ndarray, sparse
         f.write(struct.pack("<QQ", c.shape[0], 1))
         write_flat(f, c)
         f.write(struct.pack("<B", 0)); f.write(struct.pack("<Q", 0))            # direct map: NoMap, empty array
-        f.write(struct.pack("<Q", 4 * d))
         f.write(b"ilar"); f.write(struct.pack("<QQ", c.shape[0], 4 * d))
         sizes = np.bincount(assign, minlength=c.shape[0]).astype(np.uint64)
         if sparse_sizes:

@@ -17,6 +17,7 @@ against transformers.HubertModel, the RMVPE and synthesizer tables are checked e
 structure and parameter names (tests/test_importers.py) -- a real file may still differ in details these tests cannot see.
 
 CLI:  python -m obs_rvc_amd.importers contentvec|rmvpe|synth <input> <output.rvcw> [--version 2] [--sid 0] [--sr 48000]
+                                      [--up-rates 10,10,2,2]
 """
 from __future__ import annotations
 
@@ -37,6 +38,19 @@ class ImportError_(ValueError):
 
 
 # --------------------------------------------------------------------------------------------- loading
+def load_checkpoint_config(path: str) -> Optional[list]:
+    """The hyper-parameter list an RVC model .pth carries next to its weights ({"weight": sd, "config": [...], "sr": ..}): upstream
+    order [spec_channels, segment_size, inter, hidden, filter, n_heads, n_layers, kernel_size, p_dropout, resblock,
+    resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates, upsample_initial_channel, upsample_kernel_sizes,
+    spk_embed_dim, gin_channels, sr].  None for formats that have no such entry (ONNX, safetensors, bare state dicts)."""
+    if os.path.splitext(path)[1].lower() in (".onnx", ".safetensors"):
+        return None
+    import torch
+    obj = torch.load(path, map_location="cpu", weights_only=True)
+    cfg = obj.get("config") if isinstance(obj, dict) else None
+    return list(cfg) if isinstance(cfg, (list, tuple)) and len(cfg) >= 18 else None
+
+
 def load_named_tensors(path: str) -> Named:
     ext = os.path.splitext(path)[1].lower()
     if ext == ".onnx":
@@ -242,10 +256,25 @@ def import_rmvpe(named: Named) -> Tuple[dict, Named]:
 
 # --------------------------------------------------------------------------------------------- synthesizer
 def import_synth(named: Named, sid: int = 0, sr: Optional[int] = None, up_rates: Optional[List[int]] = None,
-                 heads: int = 2, window: int = 10) -> Tuple[dict, Named]:
+                 heads: Optional[int] = None, window: int = 10, config: Optional[list] = None) -> Tuple[dict, Named]:
     """RVC `SynthesizerTrnMs{256,768}NSFsid` state dict (the "weight" entry of a model .pth) -> (cfg, tensors) of weights.make_synth.
     The speaker embedding row `emb_g.weight[sid]` is baked, as in the reference's 3-input export (rvc/src/rvc.rs:186-203).
-    Upsample rates follow from the kernel sizes (HiFiGAN: kernel = 2 * rate) unless given; `sr` defaults to 100 * prod(rates)."""
+
+    Upsample rates cannot be read off the weights (official configs pair kernel 16 with rate 10 *and* with rate 8): they come from,
+    in this order, `up_rates`, the checkpoint's `config` list (entries 12 / 14 / 17 = upsample_rates / upsample_kernel_sizes / sr,
+    see load_checkpoint_config), or `sr` (the noise convs pin every rate but the first: rate0 = (sr / 100) / prod(rates[1:])).
+    Without any of the three the import fails instead of guessing.  The result always satisfies sr == 100 * prod(rates), which the
+    engine checks at load."""
+    if config is not None:
+        if up_rates is None:
+            up_rates = [int(r) for r in config[12]]
+        if sr is None:
+            s_ = config[17]
+            sr = int({"32k": 32000, "40k": 40000, "48k": 48000}.get(s_, s_)) if not isinstance(s_, (int, float)) else int(s_)
+        if heads is None:
+            heads = int(config[5])
+    if heads is None:
+        heads = 2
     s = _Src(named, ("", "weight."))
     t: Named = {}
     t["sy.g"] = s.get("emb_g.weight")[sid] if s.has("emb_g.weight") else s.get("emb_g.weight")
@@ -306,11 +335,27 @@ def import_synth(named: Named, sid: int = 0, sr: Optional[int] = None, up_rates:
                 rb_k.append(int(t[q + "c1_0.w"].shape[-1]))
     t["sy.dec.post.w"] = s.get("dec.conv_post.weight")
     s.check("synthesizer")
+    # the noise conv of stage i spans 2 * prod(rates after i) samples (kernel): that pins every rate but the first
+    tail = [int(t["sy.dec.nc%d.w" % i].shape[-1]) // 2 for i in range(n_ups - 1)]      # prod(rates[i+1:])
+    tail_rates = [tail[i] // (tail[i + 1] if i + 1 < len(tail) else 1) for i in range(len(tail))]
     if up_rates is None:
-        # the noise conv of stage i spans 2 * prod(rates after i) samples (kernel) -- that pins every rate but the first, which
-        # follows from the transposed-conv kernel (HiFiGAN configs use kernel = 2 * rate)
-        tail = [int(t["sy.dec.nc%d.w" % i].shape[-1]) // 2 for i in range(n_ups - 1)]      # prod(rates[i+1:])
-        up_rates = [kernels[0] // 2] + [tail[i] // (tail[i + 1] if i + 1 < len(tail) else 1) for i in range(len(tail))]
+        if not sr:
+            raise ImportError_("synthesizer: the first upsample rate is not recoverable from the weights (kernel %d is used with rate %d "
+                               "and other rates in official configs); pass up_rates, the checkpoint's config list or sr" % (kernels[0], kernels[0] // 2))
+        tp = int(np.prod(tail_rates)) if tail_rates else 1
+        if sr % (100 * tp) != 0:
+            raise ImportError_("synthesizer: sr %d is not 100 * (a multiple of the tail rates' product %d)" % (sr, tp))
+        up_rates = [sr // (100 * tp)] + tail_rates
+    up_rates = [int(r) for r in up_rates]
+    if len(up_rates) != n_ups or up_rates[1:] != tail_rates:
+        raise ImportError_("synthesizer: upsample rates %s do not match the noise-conv geometry of the weights (rates after the first: %s)" % (up_rates, tail_rates))
+    for i in range(n_ups):
+        if kernels[i] < up_rates[i] or (kernels[i] - up_rates[i]) % 2 != 0:
+            raise ImportError_("synthesizer: upsample kernel %d / rate %d of stage %d is not a HiFiGAN pair (padding (k - r) / 2)" % (kernels[i], up_rates[i], i))
+    if config is not None and [int(k) for k in config[14]] != kernels:
+        raise ImportError_("synthesizer: config upsample_kernel_sizes %s != kernels in the weights %s" % (list(config[14]), kernels))
+    if sr and int(sr) != 100 * int(np.prod(up_rates)):
+        raise ImportError_("synthesizer: sr %d != 100 * prod(upsample rates %s) -- the f0 frame rate is 100 Hz" % (sr, up_rates))
     rb_d = [1, 3, 5][:n_rbd]
     Hd, I = int(t["sy.enc.phone.w"].shape[0]), int(t["sy.enc.proj.w"].shape[0]) // 2
     cfg = dict(kind=3, phone_dim=int(t["sy.enc.phone.w"].shape[1]), n_rb=n_rb, n_rbd=n_rbd, inter=I, hidden=Hd,
@@ -329,6 +374,8 @@ def import_synth(named: Named, sid: int = 0, sr: Optional[int] = None, up_rates:
 
 def convert(kind: str, src: str, dst: str, **kw) -> None:
     named = load_named_tensors(src)
+    if kind == "synth" and kw.get("config") is None:
+        kw["config"] = load_checkpoint_config(src)
     cfg, t = {"contentvec": import_contentvec, "rmvpe": import_rmvpe, "synth": import_synth}[kind](named, **kw)
     W.write_blob(dst, cfg, {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in t.items()})
 
@@ -338,8 +385,10 @@ def main(argv=None):
     ap.add_argument("kind", choices=["contentvec", "rmvpe", "synth"])
     ap.add_argument("src"); ap.add_argument("dst")
     ap.add_argument("--version", type=int, default=2); ap.add_argument("--sid", type=int, default=0); ap.add_argument("--sr", type=int, default=None)
+    ap.add_argument("--up-rates", default=None, help="synthesizer upsample rates, e.g. 10,10,2,2 (default: the checkpoint's config list, else from --sr)")
     a = ap.parse_args(argv)
-    kw = dict(version=a.version) if a.kind == "contentvec" else (dict(sid=a.sid, sr=a.sr) if a.kind == "synth" else {})
+    ur = [int(v) for v in a.up_rates.split(",")] if a.up_rates else None
+    kw = dict(version=a.version) if a.kind == "contentvec" else (dict(sid=a.sid, sr=a.sr, up_rates=ur) if a.kind == "synth" else {})
     convert(a.kind, a.src, a.dst, **kw)
     print("wrote", a.dst)
 

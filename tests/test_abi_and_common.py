@@ -71,6 +71,15 @@ def test_geometry_matches_plugin_formulas():
     assert d.sola_buffer_frame_size == 1920 and d.sola_search_frame_size == 480
 
 
+def test_geometry_rounds_halves_away_from_zero():
+    # lib.rs:202 uses f64::round(): 0.125 s at 48 kHz is 12.5 hops -> 13 (Python's round() would give 12); the native session
+    # uses llround() (tests/test_postprocess.py compares the two on the GPU)
+    g = geometry.derive(48000, 0.125, 0.065, 2.005, 48000)
+    assert g.sample_frame_size == 13 * 480 and g.sample_frame_16k == 13 * 160
+    assert g.crossfade_frame_size == 7 * 480 and g.extra_frame_size == 201 * 480
+    assert geometry.derive(48000, 0.16, 0.07, 2.0, 48000) == geometry.BASELINE_160MS
+
+
 def test_blob_roundtrip(tmp_path):
     t = {"a.w": np.arange(24, dtype=np.float32).reshape(2, 3, 4), "b": np.array([1.5], np.float32)}
     p = str(tmp_path / "x.rvcw")

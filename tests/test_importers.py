@@ -168,8 +168,13 @@ def test_synth_import_round_trip_in_upstream_naming():
         assert t2[k].shape == t[k].shape and np.allclose(t2[k], t[k], rtol=2e-6, atol=1e-7), k
     for k in cfg:
         assert float(c2[k]) == float(cfg[k]), k
-    c3, _ = IM.import_synth(sd, sid=2)
-    assert [c3["up_rate%d" % i] for i in range(1, 4)] == rates[1:]
+    # without explicit rates the first one follows from sr (the noise convs pin the others); with nothing to go on the import fails
+    c3, _ = IM.import_synth(sd, sid=2, sr=int(cfg["sr"]))
+    assert [c3["up_rate%d" % i] for i in range(4)] == rates and c3["sr"] == cfg["sr"]
+    with pytest.raises(IM.ImportError_):
+        IM.import_synth(sd, sid=2)
+    with pytest.raises(IM.ImportError_):
+        IM.import_synth(sd, sid=2, sr=int(cfg["sr"]) * 2, up_rates=rates)       # sr must be 100 * prod(rates)
     with pytest.raises(IM.ImportError_):
         IM.import_synth({k: v for k, v in sd.items() if "resblocks.3.convs2.0" not in k}, sid=0)
 
@@ -244,6 +249,54 @@ def test_faiss_index_reader(tmp_path):
     open(str(tmp_path / "pq.index"), "wb").write(b"IxPq" + raw[4:])
     with pytest.raises(FI.IndexFormatError):
         FI.read_index(str(tmp_path / "pq.index"))
+
+
+def test_faiss_reader_against_independent_fixture():
+    # tests/golden/faiss_*.index are written by tests/golden/make_faiss_fixture.c, a separate C restatement of faiss's
+    # index_write.cpp macro sequence (IndexFlatL2; IndexIVFFlat with "full" and with "sprs" list sizes, ids stored out of order,
+    # and -- unlike IwSq / IwPQ -- no code_size field between the direct map and the inverted lists)
+    from obs_rvc_amd import faiss_index as FI
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    exp = np.array([[(i * 7 + j * 3) % 11 - 5 + 0.25 * j for j in range(4)] for i in range(7)], np.float32)
+    for name in ("faiss_flat.index", "faiss_ivf.index", "faiss_ivf_sparse.index"):
+        got = FI.read_index(os.path.join(gold, name))
+        assert got.dtype == np.float32 and np.array_equal(got, exp), name
+    raw = open(os.path.join(gold, "faiss_ivf.index"), "rb").read()
+    # byte-level: header (33) + nlist, nprobe (16) + quantizer IxF2 (4 + 33 + 8 + 3*4*4) + direct map (1 + 8) + "ilar" nlist code_size (20)
+    # + "full" + sizes vector (4 + 8 + 24) + 7 * (16 + 8)
+    assert len(raw) == 4 + 33 + 16 + (4 + 33 + 8 + 48) + 9 + 20 + 36 + 7 * 24
+    assert raw[4 + 33 + 16 + 93 + 9:][:4] == b"ilar"
+
+
+def test_synth_import_of_official_rate_kernel_pairs(tmp_path):
+    # 40 kHz v1/v2 models pair upsample kernels [16, 16, 4, 4] with rates [10, 10, 2, 2] (NOT kernel = 2 * rate): the rates must
+    # come from the checkpoint's config list (entries 12 / 14 / 17) or from sr, never from the kernel size
+    import torch
+    m = _upstream_synth(up_init=32, rates=(10, 10, 2, 2), kernels=(16, 16, 4, 4))
+    sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    config = [1025, 32, 16, 16, 32, 2, 2, 3, 0.0, "1", [3, 5], [[1, 3], [1, 3]], [10, 10, 2, 2], 32, [16, 16, 4, 4], 3, 8, 40000]
+    c1, _ = IM.import_synth(sd, sid=0, config=config)
+    assert [c1["up_rate%d" % i] for i in range(4)] == [10, 10, 2, 2] and c1["sr"] == 40000 and c1["heads"] == 2
+    c2, _ = IM.import_synth(sd, sid=0, sr=40000)
+    assert [c2["up_rate%d" % i] for i in range(4)] == [10, 10, 2, 2]
+    with pytest.raises(IM.ImportError_):
+        IM.import_synth(sd, sid=0)                                   # nothing pins the first rate
+    with pytest.raises(IM.ImportError_):
+        IM.import_synth(sd, sid=0, up_rates=[8, 10, 2, 2], sr=40000)  # (16 - 8) / 2 is a valid padding, but sr is not 100 * prod
+    # the same through the files users have: {"weight": sd, "config": [...]} + the CLI, no --sr / --up-rates given
+    pth, out = str(tmp_path / "voice40k.pth"), str(tmp_path / "voice40k.rvcw")
+    torch.save({"weight": {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, "config": config, "version": "v2", "sr": "40k"}, pth)
+    assert IM.load_checkpoint_config(pth)[12] == [10, 10, 2, 2]
+    IM.main(["synth", pth, out])
+    cfg, _ = W.read_blob(out)
+    assert [int(cfg["up_rate%d" % i]) for i in range(4)] == [10, 10, 2, 2] and int(cfg["sr"]) == 40000
+    # a bare state dict (no config entry) needs --sr or --up-rates
+    bare = str(tmp_path / "bare.pth")
+    torch.save({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, bare)
+    with pytest.raises(IM.ImportError_):
+        IM.main(["synth", bare, out])
+    IM.main(["synth", bare, out, "--up-rates", "10,10,2,2"])
+    assert int(W.read_blob(out)[0]["sr"]) == 40000
 
 
 def test_checkpoint_files_and_cli(tmp_path):
