@@ -311,38 +311,45 @@ struct Plan {
 
 // Profile mode times a kernel with the start / stop events of hipExtLaunchKernelGGL: they carry the dispatch's own begin / end
 // timestamps (what rocprofv3 --kernel-trace reports), not the time between two event-record packets around it.
-template <int MF, int NF, int D, int KS, bool PRE> static void launch_igemm_t(const IgemmP &p, dim3 grid, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
+template <typename K> static void launch_k(K kern, const IgemmP &p, dim3 grid, dim3 block, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
 {
-    // LDS: this workgroup's slice of the koff table + the KS partial tiles of the in-workgroup K split
-    const size_t lds = (size_t)p.chunks_per_split * 16 * sizeof(int) + (KS > 1 ? (size_t)KS * MF * NF * 256 * sizeof(float) : 0);
-    if (ea) hipExtLaunchKernelGGL((igemm_kernel<MF, NF, D, KS, PRE>), grid, dim3((KS > 1 ? KS : 4) * 64), (uint32_t)lds, s, ea, eb, 0, p);
-    else hipLaunchKernelGGL((igemm_kernel<MF, NF, D, KS, PRE>), grid, dim3((KS > 1 ? KS : 4) * 64), lds, s, p);
+    if (ea) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, s, ea, eb, 0, p);
+    else hipLaunchKernelGGL(kern, grid, block, lds, s, p);
 }
 
 // tile configurations: index -> (MF, NF); every tile exists with KS in {1, 4, 8, 16}
 static const int kMF[5] = {1, 1, 1, 2, 2}, kNF[5] = {1, 2, 4, 2, 4};
 
-static void launch_igemm(int cfg, int ks, bool pre, const IgemmP &p, dim3 grid, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr)
+// lean kernel (igemm2): 2-D tile grid, LDS = offset table (none for LIN layers) + the KS partial tiles
+static void launch_igemm2(int cfg, int ks, bool pre, bool lin, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr)
 {
-#define RVC_KS(MF, NF, D, PRE)                                                       \
-        switch (ks) {                                                                \
-        case 1: launch_igemm_t<MF, NF, D, 1, PRE>(p, grid, s, ea, eb); return;               \
-        case 4: launch_igemm_t<MF, NF, D, 4, PRE>(p, grid, s, ea, eb); return;               \
-        case 8: launch_igemm_t<MF, NF, D, 8, PRE>(p, grid, s, ea, eb); return;               \
-        default: launch_igemm_t<MF, NF, (D > 8 ? 8 : D), 16, PRE>(p, grid, s, ea, eb); return; \
+#define RVC_KS2(MF, NF, D, PRE, LIN)                                                                                   \
+        switch (ks) {                                                                                                  \
+        case 1: launch_k(igemm2_kernel<MF, NF, D, 1, PRE, LIN>, p, grid, dim3(256), lds, s, ea, eb); return;           \
+        case 4: launch_k(igemm2_kernel<MF, NF, D, 4, PRE, LIN>, p, grid, dim3(256), lds, s, ea, eb); return;           \
+        case 8: launch_k(igemm2_kernel<MF, NF, D, 8, PRE, LIN>, p, grid, dim3(512), lds, s, ea, eb); return;           \
+        default: launch_k(igemm2_kernel<MF, NF, (D > 8 ? 8 : D), 16, PRE, LIN>, p, grid, dim3(1024), lds, s, ea, eb); return; \
         }
-#define RVC_CASE(C, MF, NF, D)                                                       \
-    case C:                                                                          \
-        if (pre) { RVC_KS(MF, NF, D, true) } else { RVC_KS(MF, NF, D, false) }
+#define RVC_CASE2(C, MF, NF, D)                                                                                        \
+    case C:                                                                                                            \
+        if (lin) { RVC_KS2(MF, NF, D, false, true) } else if (pre) { RVC_KS2(MF, NF, D, true, false) } else { RVC_KS2(MF, NF, D, false, false) }
     switch (cfg) {
-        RVC_CASE(0, 1, 1, 12)
-        RVC_CASE(1, 1, 2, 8)
-        RVC_CASE(2, 1, 4, 5)
-        RVC_CASE(3, 2, 2, 6)
-        RVC_CASE(4, 2, 4, 4)
+        RVC_CASE2(0, 1, 1, 12)
+        RVC_CASE2(1, 1, 2, 8)
+        RVC_CASE2(2, 1, 4, 5)
+        RVC_CASE2(3, 2, 2, 6)
+        RVC_CASE2(4, 2, 4, 4)
     }
-#undef RVC_CASE
-#undef RVC_KS
+#undef RVC_CASE2
+#undef RVC_KS2
+}
+
+// the first-generation kernel remains for the two-stage grid-level split-K (offset table too long for LDS): 16x16 tiles only
+static void launch_igemm(bool pre, const IgemmP &p, dim3 grid, hipStream_t s)
+{
+    const size_t lds = (size_t)p.chunks_per_split * 16 * sizeof(int);
+    if (pre) hipLaunchKernelGGL((igemm_kernel<1, 1, 12, 1, true>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((igemm_kernel<1, 1, 12, 1, false>), grid, dim3(256), lds, s, p);
 }
 
 static unsigned long long *g_kprobe = nullptr;   // tuning build (-DRVC_KPROBE): destination of the per-wave phase stamps
@@ -464,12 +471,25 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     const int ntiles = weight_heavy ? p.m_fast * p.ntn : p.ntm * p.ntn;
     dim3 grid(wg_ks > 1 ? ntiles : (ntiles + 3) / 4, B * p.nphase * ksplit);
     dim3 egrid((unsigned)(((long long)p.M * p.N + 255) / 256), B * p.nphase);
-    g_last_wgs = (int)(grid.x * grid.y); g_last_waves = wg_ks > 1 ? wg_ks : 4;
+    // lean kernel: x = fast tile axis (m when m_fast, else n; 4 tiles per workgroup without the in-workgroup K split), y = slow axis
+    const bool lean = ksplit == 1 && !getenv("RVC_OLD_IGEMM");
+    const bool lin = lean && p.lin_cs4 != 0 && p.nphase == 1 && !pre && !getenv("RVC_NO_LIN");
+    size_t lds2 = 0;
+    if (lean) {
+        const int fast_n = weight_heavy ? p.ntm : p.ntn, slow_n = weight_heavy ? p.ntn : p.ntm;
+        unsigned gx = (unsigned)(wg_ks > 1 ? fast_n : (fast_n + 3) / 4);
+        if (weight_heavy) gx = (gx + 7) / 8 * 8;           // workgroup (x, y) runs on XCD x % 8 when gridDim.x is a multiple of 8
+        grid = dim3(gx, (unsigned)slow_n, (unsigned)(B * p.nphase));
+        if (grid.y > 65535 || grid.z > 65535) throw ShapeError("implicit GEMM grid too large");
+        p.nbatch = B;
+        lds2 = (lin ? 0 : (size_t)nchunks * 64) + (wg_ks > 1 ? (size_t)wg_ks * kMF[cfg] * kNF[cfg] * 1024 : 0);
+    }
+    g_last_wgs = (int)(grid.x * grid.y * grid.z); g_last_waves = wg_ks > 1 ? wg_ks : 4;
     const double flops = 2.0 * p.M * (double)p.N * ksum * B;
     pl.igemm_flops += flops;
     pl.n_igemm++;
     Plan *plp = &pl;
-    { char d[200]; snprintf(d, sizeof d, "reg M=%d N=%d K=%d B=%d nph=%d tile=%dx%d ks=%d mfast=%d grid=%ux%u pre=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, 16 * kMF[cfg], 16 * kNF[cfg], wg_ks, p.m_fast, grid.x, grid.y, (int)pre, ksum); pl.descs.push_back(d); }
+    { char d[200]; snprintf(d, sizeof d, "reg M=%d N=%d K=%d B=%d nph=%d tile=%dx%d ks=%d mfast=%d grid=%ux%ux%u pre=%d lin=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, 16 * kMF[cfg], 16 * kNF[cfg], wg_ks, p.m_fast, grid.x, grid.y, grid.z, (int)pre, (int)lin, ksum); pl.descs.push_back(d); }
     const int desc_id = (int)pl.descs.size() - 1;
     pl.ops.push_back([=](hipStream_t s) {
         ProfEvent *pe = nullptr;
@@ -481,8 +501,8 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
             pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
             if (ksplit > 1) HIPCHK(hipEventRecord(pe->a, s));
         }
-        if (pe && ksplit == 1) launch_igemm(cfg, wg_ks, pre, p, grid, s, pe->a, pe->b);
-        else launch_igemm(cfg, wg_ks, pre, p, grid, s);
+        if (lean) launch_igemm2(cfg, wg_ks, pre, lin, p, grid, lds2, s, pe ? pe->a : nullptr, pe ? pe->b : nullptr);
+        else launch_igemm(pre, p, grid, s);
         if (ksplit > 1) hipLaunchKernelGGL(splitk_epilogue_kernel, egrid, dim3(256), 0, s, p);
         if (pe && ksplit > 1) HIPCHK(hipEventRecord(pe->b, s));
     });
@@ -515,6 +535,8 @@ static void add_conv1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int 
     p.NW = y.T; p.x_hs = 0; p.x_ws = stride; p.y_hm = 0; p.y_ws = 1; p.OW = y.T;
     p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.ld; p.y_rs = 0;
     fill_epilogue(p, cw, o);
+    // 1x1 convolution with a whole number of 16-row chunks: operand row k sits at k * channel stride, no offset table (igemm2 LIN)
+    if (KW == 1 && cw.groups == 1 && pad == 0 && cw.K == cw.Kp) p.lin_cs4 = x.ld * 4;
     if (cw.groups > 1 && (o.m_off != 0 || o.m_cnt >= 0)) throw std::runtime_error("row sub-range on grouped conv");
     std::vector<int> koff(cw.Kp, 0);
     for (int ci = 0; ci < cig; ci++) for (int k = 0; k < KW; k++) koff[ci * KW + k] = ci * x.ld + k * dil - pad;

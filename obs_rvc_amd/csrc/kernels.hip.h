@@ -69,6 +69,8 @@ struct IgemmP {
     unsigned long long *probe;   // tuning build only (-DRVC_KPROBE): per-wave phase timestamps
     int m_fast;              // XCD-aware tile order: >0 = ntm rounded up to 8, m fastest (workgroup b runs on XCD b%8, so all
                              // n-tiles of one weight-row block share one XCD's L2); 0 = n fastest (activation-heavy layers)
+    int nbatch;              // igemm2: streams in the launch (grid z = batch * nphase + phase)
+    int lin_cs4;             // igemm2 LIN layers (1x1 conv on a 1-D tensor): input channel stride in BYTES, k-th operand row = k * lin_cs4
 };
 
 __device__ __forceinline__ void epilogue_store(const IgemmP &p, const PhaseD &ph, int b, int m, int n, float acc)
@@ -152,7 +154,7 @@ __device__ __forceinline__ void lds_only_barrier()
 //   register-prefetched D chunks (of 16 k) ahead; the koff entries of the next chunk are read from LDS
 //   one stage early so the LDS latency is off the critical path.
 #ifdef RVC_KPROBE
-#define RVC_KP(i) do { if (p.probe && (threadIdx.x & 63) == 0) p.probe[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (i)] = wall_clock64(); } while (0)
+#define RVC_KP(i) do { if (p.probe && (threadIdx.x & 63) == 0) p.probe[((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define RVC_KP(i)
 #endif
@@ -405,6 +407,329 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
                     if (m < p.M && n < p.N) pp[(long long)m * p.N + n] = acc[0][mf][nf][r];
                 }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// igemm2_kernel -- the same tile computation as igemm_kernel with a lean launch prologue / epilogue for the one-stream
+// latency chain (measured with tests/tools/kprobe.py: of the 16 us a 0.5 GFLOP ContentVec GEMM took, 2.0 us went from wave
+// entry to the first barrier -- scalar divisions for the tile index, a dependent global -> LDS copy of the offset table,
+// 64-bit address arithmetic -- and 1.3 us into a branchy per-element epilogue):
+//   * tile coordinates come from a 2-D grid (x = fast axis, y = slow axis, z = batch * nphase + phase): no divisions.  With
+//     m_fast the fast axis is m and gridDim.x is a multiple of 8, so workgroup (x, y) still runs on XCD x % 8;
+//   * the offset table is requested FIRST and written to LDS only after the index arithmetic, the epilogue operand requests
+//     and the first D weight loads have been issued; with KS > 1 every wave stages just its own K slice (no workgroup barrier);
+//   * LIN layers (1x1 convolution on a 1-D tensor = every Linear of the transformers) need no table at all: the k-th operand
+//     row is k * channel stride, so the activation gathers leave together with the weight loads;
+//   * epilogue addresses are 32-bit element offsets from per-batch bases, the activation is dispatched once per tile.
+// Grid-level split-K (a table too long for LDS) stays on igemm_kernel.
+template <int ACT> __device__ __forceinline__ float act_t(float v, float slope)
+{
+    if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (ACT == ACT_LRELU) return v > 0.f ? v : v * slope;
+    if (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (ACT == ACT_TANH) return tanhf(v);
+    if (ACT == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+struct Epi2 { float bias, res, yold; int yo; };
+__device__ __forceinline__ Epi2 epi2_prefetch(const IgemmP &p, const PhaseD &ph, const float *resb, const float *yb, int m, int n)
+{
+    Epi2 e = {0.f, 0.f, 0.f, -1};
+    if (m >= p.M || n >= p.N) return e;
+    int nh = 0, nw = n;
+    if (p.y_hm) { nh = n / p.NW; nw = n - nh * p.NW; }
+    const int ow = nw * p.y_ws + ph.y_pos, oh = nh * p.y_hm + ph.y_h0;
+    if (ow < 0 || ow >= p.OW) return e;
+    const int ch = m + ph.y_c0;
+    e.yo = ch * p.y_cs + oh * p.y_rs + ow;
+    if (p.bias) e.bias = p.bias[ph.bias_off + m];
+    if (resb) e.res = resb[(p.res_nogroup ? m : ch) * p.res_cs + oh * p.res_rs + ow];
+    if (p.accumulate) e.yold = yb[e.yo];
+    return e;
+}
+template <int ACT> __device__ __forceinline__ void epi2_finish(const IgemmP &p, float *yb, float acc, const Epi2 &e)
+{
+    if (e.yo < 0) return;
+    float v = act_t<ACT>(acc + e.bias, p.slope);
+    v += e.res;
+    v *= p.scale;
+    v += e.yold;
+    yb[e.yo] = v;
+}
+#define RVC_ACT_DISPATCH(STMT)                                                   \
+    switch (p.act) {                                                             \
+    case ACT_RELU: { constexpr int A_ = ACT_RELU; STMT } break;                  \
+    case ACT_LRELU: { constexpr int A_ = ACT_LRELU; STMT } break;                \
+    case ACT_GELU: { constexpr int A_ = ACT_GELU; STMT } break;                  \
+    case ACT_TANH: { constexpr int A_ = ACT_TANH; STMT } break;                  \
+    case ACT_SIGMOID: { constexpr int A_ = ACT_SIGMOID; STMT } break;            \
+    default: { constexpr int A_ = ACT_NONE; STMT } break;                        \
+    }
+
+template <int MF, int NF, int D, int KS, bool PRE, bool LIN>
+__global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p)
+{
+    constexpr int WAVES = KS > 1 ? KS : 4;
+    constexpr int NACC = (MF * NF == 1) ? 2 : 1;
+    constexpr int TE = MF * NF * 256;
+    constexpr int PE = (KS > 1) ? ((TE + WAVES * 64 - 1) / (WAVES * 64)) : 1;
+    constexpr bool PF = (KS > 1) || (MF * NF <= 4);
+    constexpr int KR = 2;                         // offset-table entries (int4) a thread can hold between request and LDS write
+    extern __shared__ __attribute__((aligned(16))) int s_koff[];
+    RVC_KP(0);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int fast = KS > 1 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave, slow = (int)blockIdx.y;
+    const int tm = p.m_fast ? fast : slow, tn = p.m_fast ? slow : fast;
+    int phase = 0, b = 0;
+    {
+        const int z = (int)blockIdx.z;
+        if (p.nphase == 1) b = z;
+        else if (p.nbatch == 1) phase = z;
+        else { b = z / p.nphase; phase = z - b * p.nphase; }
+    }
+    PhaseD ph = p.ph0;
+    if (phase) ph = p.ph[phase];
+    const int nchunks = ph.nchunks;
+    // this wave's chunk range (KS > 1: the waves of the workgroup split K)
+    int c0 = 0, nc = nchunks;
+    if (KS > 1) {
+        const int cpw = (nchunks + KS - 1) / KS;
+        c0 = wave * cpw;
+        int c1 = c0 + cpw;
+        c1 = c1 < nchunks ? c1 : nchunks;
+        nc = c1 > c0 ? c1 - c0 : 0;
+    }
+    // 1. request the offset-table slice (KS > 1: this wave's; KS == 1: the workgroup's) -- consumed after everything else is in flight
+    int4 kr[KR];
+    const int kt_n = LIN ? 0 : (KS > 1 ? nc * 4 : nchunks * 4);          // int4 entries to stage
+    const int kt_i = KS > 1 ? lane : (int)threadIdx.x;
+    constexpr int KT_STRIDE = KS > 1 ? 64 : WAVES * 64;
+    const int4 *ksrc = reinterpret_cast<const int4 *>(p.koff + ph.koff_off) + (KS > 1 ? c0 * 4 : 0);
+    int4 *kdst = reinterpret_cast<int4 *>(s_koff) + (KS > 1 ? c0 * 4 : 0);
+    if (!LIN) {
+#pragma unroll
+        for (int r = 0; r < KR; r++) { const int i = kt_i + r * KT_STRIDE; if (i < kt_n) kr[r] = ksrc[i]; }
+    }
+    RVC_KP(8);
+    const bool live = tm < p.ntm && tn < p.ntn;
+    const int li = lane & 15, kq = lane >> 4;
+    const float *resb = p.res ? p.res + (long long)b * p.res_bs : nullptr;
+    float *yb = p.y + (long long)b * p.y_bs;
+
+    // 2. epilogue operands, requested up front
+    Epi2 pre_w[(KS > 1 || !PF) ? 1 : MF][(KS > 1 || !PF) ? 1 : NF][4];
+    Epi2 pre_r[PE];
+    if (PF && live && !p.glu) {
+        if (KS > 1) {
+#pragma unroll
+            for (int q = 0; q < PE; q++) {
+                const int e = threadIdx.x + q * WAVES * 64;
+                const int l = e & 63, r = (e >> 6) & 3, f = e >> 8, mf = f / NF, nf = f - mf * NF;
+                pre_r[q] = (e < TE) ? epi2_prefetch(p, ph, resb, yb, tm * 16 * MF + mf * 16 + (l >> 4) * 4 + r, tn * 16 * NF + nf * 16 + (l & 15)) : Epi2{0.f, 0.f, 0.f, -1};
+            }
+        } else {
+#pragma unroll
+            for (int mf = 0; mf < ((KS > 1 || !PF) ? 1 : MF); mf++)
+#pragma unroll
+                for (int nf = 0; nf < ((KS > 1 || !PF) ? 1 : NF); nf++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        pre_w[mf][nf][r] = epi2_prefetch(p, ph, resb, yb, tm * 16 * MF + mf * 16 + kq * 4 + r, tn * 16 * NF + nf * 16 + li);
+        }
+    }
+    RVC_KP(9);
+    // gathered-activation addressing: wave-uniform base + unsigned 32-bit BYTE offset per lane
+    const char *xb = reinterpret_cast<const char *>(p.x + (long long)b * p.x_bs + ph.x_off) - (LIN ? 0 : p.koff_bias);
+    unsigned xo[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; nf++) {
+        int n = tn * 16 * NF + nf * 16 + li;
+        n = n < p.N ? n : p.N - 1;
+        int nh = 0, nw = n;
+        if (p.x_hs) { nh = n / p.NW; nw = n - nh * p.NW; }
+        xo[nf] = (unsigned)(nh * p.x_hs + nw * p.x_ws) * 4u;
+        if (LIN) xo[nf] += (unsigned)((c0 * 16 + kq * 4) * p.lin_cs4);
+    }
+    // weights: MFMA-fragment order [m_tile][chunk][lane][4]
+    const float *wrow[MF];
+    const int mtiles = (p.M + 15) >> 4;
+#pragma unroll
+    for (int mf = 0; mf < MF; mf++) {
+        int mt = tm * MF + mf;
+        mt = mt < mtiles ? mt : mtiles - 1;
+        wrow[mf] = p.w + ph.w_off + ((long long)mt * nchunks + c0) * 256 + lane * 4;
+    }
+    const int4 *kol = reinterpret_cast<const int4 *>(s_koff) + c0 * 4 + kq;
+    const float pre_slope = p.pre_slope;
+    const unsigned lin1 = (unsigned)p.lin_cs4, lin16 = 16u * (unsigned)p.lin_cs4;
+
+    f32x4 acc[NACC][MF][NF];
+#pragma unroll
+    for (int a = 0; a < NACC; a++)
+#pragma unroll
+        for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+            for (int nf = 0; nf < NF; nf++) acc[a][mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    RVC_KP(10);
+
+    f32x4 a_st[D][MF];
+    float b_st[D][NF][4];
+    int4 ko_nx = make_int4(0, 0, 0, 0);
+#define RVC_LOAD_A(S, C)                                                                               \
+    {                                                                                                  \
+        _Pragma("unroll") for (int mf = 0; mf < MF; mf++) a_st[S][mf] = *reinterpret_cast<const f32x4 *>(wrow[mf] + (C) * 256); \
+    }
+#define RVC_LOAD_B(S, C)                                                                               \
+    {                                                                                                  \
+        const int cc_ = (C);                                                                           \
+        int4 ko_;                                                                                      \
+        if (LIN) { const unsigned kb_ = (unsigned)cc_ * lin16; ko_ = make_int4((int)kb_, (int)(kb_ + lin1), (int)(kb_ + 2u * lin1), (int)(kb_ + 3u * lin1)); } \
+        else { ko_ = ko_nx; ko_nx = kol[(cc_ + 1 < nc ? cc_ + 1 : cc_) * 4]; }                         \
+        _Pragma("unroll") for (int nf = 0; nf < NF; nf++) {                                            \
+            b_st[S][nf][0] = *reinterpret_cast<const float *>(xb + (xo[nf] + (unsigned)ko_.x));        \
+            b_st[S][nf][1] = *reinterpret_cast<const float *>(xb + (xo[nf] + (unsigned)ko_.y));        \
+            b_st[S][nf][2] = *reinterpret_cast<const float *>(xb + (xo[nf] + (unsigned)ko_.z));        \
+            b_st[S][nf][3] = *reinterpret_cast<const float *>(xb + (xo[nf] + (unsigned)ko_.w));        \
+        }                                                                                              \
+    }
+#define RVC_COMPUTE_STAGE(S)                                                                          \
+    {                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; j++)                                                  \
+            _Pragma("unroll") for (int nf = 0; nf < NF; nf++) {                                        \
+                const float bv_ = PRE ? fmaxf(b_st[S][nf][j], b_st[S][nf][j] * pre_slope) : b_st[S][nf][j]; \
+                _Pragma("unroll") for (int mf = 0; mf < MF; mf++)                                      \
+                    acc[j % NACC][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[S][mf][j], bv_, acc[j % NACC][mf][nf], 0, 0, 0); \
+            }                                                                                          \
+    }
+#define RVC_LOAD_STAGE(S, C) { RVC_LOAD_A(S, C) RVC_LOAD_B(S, C) }
+    // 3. first D stages: weights (and, without a table, the activations) leave now
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < D; s++)
+            if (s < nc) { RVC_LOAD_A(s, s) if (LIN) RVC_LOAD_B(s, s) }
+    }
+    RVC_KP(11);
+    if (!LIN) {
+        // 4. publish the offset table: registers -> LDS (the rare long tables finish with a plain copy loop)
+#pragma unroll
+        for (int r = 0; r < KR; r++) { const int i = kt_i + r * KT_STRIDE; if (i < kt_n) kdst[i] = kr[r]; }
+        for (int i = kt_i + KR * KT_STRIDE; i < kt_n; i += KT_STRIDE) kdst[i] = ksrc[i];
+        if (KS > 1) __builtin_amdgcn_s_waitcnt(0xC07F);      // wave-private slice: LDS writes done (lgkmcnt(0)), no barrier
+        else lds_only_barrier();
+    }
+    RVC_KP(1);
+    if (!live) { if (KS > 1) { /* whole workgroup is dead: uniform */ } return; }
+    if (!LIN) {
+        ko_nx = nc > 0 ? kol[0] : make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < D; s++)
+            if (s < nc) RVC_LOAD_B(s, s)
+    }
+    RVC_KP(2);
+    int c = 0;
+    for (; c + 2 * D <= nc; c += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            RVC_COMPUTE_STAGE(s)
+            __builtin_amdgcn_sched_barrier(0);
+            RVC_LOAD_STAGE(s, c + s + D)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    for (; c < nc; c += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            if (c + s < nc) {
+                RVC_COMPUTE_STAGE(s)
+                if (c + s + D < nc) RVC_LOAD_STAGE(s, c + s + D)
+            }
+        }
+    }
+#undef RVC_COMPUTE_STAGE
+#undef RVC_LOAD_STAGE
+#undef RVC_LOAD_A
+#undef RVC_LOAD_B
+    if (NACC == 2) {
+#pragma unroll
+        for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+            for (int nf = 0; nf < NF; nf++) acc[0][mf][nf] += acc[NACC - 1][mf][nf];
+    }
+    RVC_KP(3);
+
+    if (KS > 1) {
+        // fixed-order reduction of the KS partial tiles through LDS, then every thread finishes its share of the tile
+        float *red = reinterpret_cast<float *>(s_koff + (LIN ? 0 : nchunks * 16));     // [KS][TE]
+#pragma unroll
+        for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+            for (int nf = 0; nf < NF; nf++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) red[wave * TE + ((mf * NF + nf) * 4 + r) * 64 + lane] = acc[0][mf][nf][r];
+        RVC_KP(4);
+        __syncthreads();
+        RVC_KP(5);
+        if (p.glu) {
+#pragma unroll
+            for (int q = 0; q < PE; q++) {
+                const int e = threadIdx.x + q * WAVES * 64;
+                if (e >= TE) break;
+                const int l = e & 63, r = (e >> 6) & 3, f = e >> 8, mf = f / NF, nf = f - mf * NF;
+                if (r >= 2) continue;
+                float v = 0.f, v2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < KS; w++) { v += red[w * TE + e]; v2 += red[w * TE + e + 128]; }
+                glu_store(p, ph, b, tm * 16 * MF + mf * 16 + (l >> 4) * 4 + r, tn * 16 * NF + nf * 16 + (l & 15), v, v2);
+            }
+            return;
+        }
+        float vsum[PE];
+#pragma unroll
+        for (int q = 0; q < PE; q++) {
+            const int e = threadIdx.x + q * WAVES * 64;
+            float v = 0.f;
+            if (e < TE) {
+#pragma unroll
+                for (int w = 0; w < KS; w++) v += red[w * TE + e];
+            }
+            vsum[q] = v;
+        }
+        RVC_ACT_DISPATCH(
+            _Pragma("unroll") for (int q = 0; q < PE; q++) epi2_finish<A_>(p, yb, vsum[q], pre_r[q]);
+        )
+        RVC_KP(6);
+        return;
+    }
+    // D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
+    if (p.glu) {
+#pragma unroll
+        for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+            for (int nf = 0; nf < NF; nf++)
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+                    glu_store(p, ph, b, tm * 16 * MF + mf * 16 + kq * 4 + r, tn * 16 * NF + nf * 16 + li, acc[0][mf][nf][r], acc[0][mf][nf][r + 2]);
+        return;
+    }
+    if (PF) {
+        RVC_ACT_DISPATCH(
+            _Pragma("unroll") for (int mf = 0; mf < MF; mf++)
+                _Pragma("unroll") for (int nf = 0; nf < NF; nf++)
+                    _Pragma("unroll") for (int r = 0; r < 4; r++)
+                        epi2_finish<A_>(p, yb, acc[0][mf][nf][r], pre_w[PF ? mf : 0][PF ? nf : 0][r]);
+        )
+    } else {
+        RVC_ACT_DISPATCH(
+            _Pragma("unroll") for (int mf = 0; mf < MF; mf++)
+                _Pragma("unroll") for (int nf = 0; nf < NF; nf++)
+                    _Pragma("unroll") for (int r = 0; r < 4; r++) {
+                        const Epi2 e_ = epi2_prefetch(p, ph, resb, yb, tm * 16 * MF + mf * 16 + kq * 4 + r, tn * 16 * NF + nf * 16 + li);
+                        epi2_finish<A_>(p, yb, acc[0][mf][nf][r], e_);
+                    }
+        )
+    }
+    RVC_KP(6);
 }
 
 // Throughput-mode implicit GEMM (many streams batched: N = B*T is large).  Classic CDNA anatomy: a 256-thread
