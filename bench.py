@@ -4,265 +4,477 @@
 Metric (BASELINE.json): audio frames/s (+ p99 per-chunk latency), 160 ms chunks @16 kHz.
 A "step" is one 160 ms chunk of every stream of this rank through the whole per-chunk hot path
 (ContentVec -> RMVPE f0 -> [retrieval] -> NSF-HiFiGAN); one chunk = 16 new 10 ms frames.
-Workload at N=1: BASELINE configs[1] (1 stream, v2/768 ContentVec + RMVPE + v2-48k synthesizer,
-retrieval off).  With --gpus N every rank runs its own stream(s) (streams are independent, no per-chunk
-collective; RCCL is used only for the barrier/max and, with --index, the index broadcast at load).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--index] [--graph] [--no-cpu]
+Headline (`value`): BASELINE configs[1] on every GPU -- 1 stream, v2/768 ContentVec + RMVPE + v2-48k synthesizer, retrieval off,
+inputs resident in HBM, every chunk synchronised (per-chunk latency is the product).  Streams are independent, so with N GPUs every
+rank runs the same per-GPU work (weak scaling, no per-chunk collective).  The same run also measures, as `sub_configs`:
+  index100k  BASELINE configs[2]: + 100k x 768 flat-L2 retrieval (k = 4, rate 0.75); with N > 1 the index reaches every rank through
+             the engine's own RCCL broadcast (rvc_index_broadcast)
+  streams64  BASELINE configs[3] (N = 1) / configs[4] (N > 1: 64 streams per GPU, stream s of the job on rank s mod N, shared index
+             broadcast over RCCL): throughput mode, every stage batched over the streams
+and the host-buffer boundary of the reference (`latency_ms_host_buffer`: rvc_infer with H2D + D2H inside the call).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--index] [--only-headline] [--no-cpu] [--dry-launch]
+
+N > 1: either started by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / LOCAL_RANK / WORLD_SIZE
+in the environment) or, without those variables, bench.py spawns the N ranks itself (one process per GPU, 127.0.0.1 rendezvous).
+--dry-launch runs the launcher, the rendezvous (gloo), the stream sharding and the reduction of the per-rank results without
+touching a GPU (CPU test of the multi-rank plumbing).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
+
+# hardware queues of the HIP runtime: must be in the environment before the runtime initialises (engine.hip, rvc_runtime_defaults)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+HBM_PEAK_GBS = 8000.0
 FRAMES_PER_CHUNK = 16              # 160 ms chunk = 16 hops of 10 ms (SURVEY.md section 8d)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=1, help="concurrent streams per GPU (BASELINE config 4: 64)")
-    ap.add_argument("--index", action="store_true", help="BASELINE config 3: 100k x 768 flat-L2 retrieval, k=4, rate 0.75")
+    ap.add_argument("--streams", type=int, default=1, help="streams per GPU of the HEADLINE leg (default 1 = BASELINE configs[1])")
+    ap.add_argument("--index", action="store_true", help="headline leg with the 100k x 768 index (BASELINE configs[2])")
+    ap.add_argument("--only-headline", action="store_true", help="skip the sub_configs / informational legs")
     ap.add_argument("--graph", action="store_true", help="replay each chunk from a hipGraph (default: eager launches with interleaved branch submission, measured faster)")
     ap.add_argument("--no-graph", action="store_true", help="accepted for compatibility: eager launches are the default")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--dry-launch", action="store_true", help="multi-rank plumbing only (gloo, no GPU work)")
     ap.add_argument("--preset", default="full")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+# ------------------------------------------------------------------------------------------------------------ launcher
+def spawn_ranks(args, argv):
+    """`bench.py --gpus N` without a torchrun environment: one child process per GPU, rank r on device r."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), RVC_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("bench.py: rank exit codes %s" % rcs)
 
-    from common import BASELINE_160MS as g, chunk_stream, voice_signal, zoo
-    from obs_rvc_amd import weights as W
-    from obs_rvc_amd.rvc import RvcInfer
 
-    if rank == 0:
-        z = zoo(args.preset)
-    if world > 1:
-        dist.barrier()
-    z = zoo(args.preset)
+# ------------------------------------------------------------------------------------------------------------ helpers
+def pct(lat, q):
+    return round(float(np.percentile(lat, q)) * 1e3, 4)
 
-    S = args.streams
-    eng = RvcInfer(z["data"], device=local_rank)
-    eng.load_contentvec(2); eng.load_f0(1); eng.load_model(z["model"])
-    eng.set_streams(S)
-    eng.set_noise_seed(1234, rank * S)
-    if args.index:
-        from obs_rvc_amd import dist as rdist
-        rdist.load_shared_index(eng, W.make_index() if rank == 0 else None, 100000, 768, rank, world)
-        eng.set_index_rate(0.75)
-    eng.set_use_graph(args.graph and not args.no_graph)
 
-    # synthetic 16 kHz input: stream s of rank r uses audio seed r*S + s; the ring states are precomputed and
-    # made resident in HBM before the timed region (the chunk's H2D is outside `value`, see DESIGN.md)
+class Job:
+    """Rank / world bookkeeping + the two reductions the bench needs (max of a time, concatenation of latency samples)."""
+
+    def __init__(self, dry):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dry = dry
+        if not dry:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+            torch.cuda.set_device(self.local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if dry:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
+        self.dev = "cpu" if dry else "cuda"
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        if not self.dry:
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, v):
+        if self.world == 1:
+            return float(v)
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, values):
+        """every rank's list of floats (equal lengths) -> list of per-rank arrays, on every rank"""
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device=self.dev)
+        if self.world == 1:
+            return [t.cpu().numpy()]
+        gl = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(gl, t)
+        return [g.cpu().numpy() for g in gl]
+
+    def close(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def make_rings(S, stream_ids, n_rings, g):
+    from common import chunk_stream, voice_signal
     L, chunk = g.input_buffer_16k_size, g.sample_frame_16k
-    n_rings = 8
     rings = np.zeros((n_rings, S, L), np.float32)
     for s in range(S):
-        audio = voice_signal(chunk * (n_rings + 14), seed=rank * S + s)
+        audio = voice_signal(chunk * (n_rings + 14), seed=stream_ids[s])
         rs = list(chunk_stream(audio, L, chunk))[-n_rings:]
         for i in range(n_rings):
             rings[i, s] = rs[i]
-    d_rings = torch.from_numpy(rings).cuda()
-    N = g.model_return_size
-    d_out = torch.empty((S, N), dtype=torch.float32, device="cuda")
+    return rings
 
-    def step(i, sync):
-        eng.infer_device(d_rings[i % n_rings].data_ptr(), L, chunk, 12, g.skip_head, g.model_return_length, d_out.data_ptr(), N, sync=sync)
 
-    for i in range(args.warmup):
-        step(i, True)
+def timed_leg(job, eng, d_rings, d_out, g, steps, warmup):
+    """W warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; every step synchronised so that the
+    per-chunk latency is observed.  -> (elapsed seconds = max over ranks, this rank's per-step latencies)"""
+    L, chunk, N = g.input_buffer_16k_size, g.sample_frame_16k, g.model_return_size
+    n_rings = d_rings.shape[0]
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def step(i):
+        eng.infer_device(d_rings[i % n_rings].data_ptr(), L, chunk, 12, g.skip_head, g.model_return_length, d_out.data_ptr(), N, sync=True)
 
-    # timed region: exactly K steps; each step is synchronised so that per-chunk latency is observed
-    barrier()
+    for i in range(warmup):
+        step(i)
+    job.barrier()
     lat = []
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         t1 = time.perf_counter()
-        step(i, True)
+        step(i)
         lat.append(time.perf_counter() - t1)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        lt = torch.tensor(sorted(lat), dtype=torch.float64, device="cuda")
-        gl = [torch.empty_like(lt) for _ in range(world)]
-        dist.all_gather(gl, lt)
-        lat = torch.cat(gl).cpu().numpy().tolist()
-    lat = np.array(lat)
+    job.torch.cuda.synchronize()
+    job.barrier()
+    elapsed = job.max_over_ranks(time.perf_counter() - t0)
+    return elapsed, lat, step
 
-    # roofline of the dominant kernel class (implicit-GEMM on the fp32 matrix cores): per-launch HIP events
-    # on the engine's own stream over a few chunks, eager launches (same kernels, same shapes)
-    roof = None
-    if rank == 0:
-        eng.set_profile(True)
-        tot_ms = tot_fl = 0.0
-        n_l = 0
-        reps = 5
-        k_ms = k_by = 0.0
-        k_n = 0
-        for i in range(reps):
-            step(i, True)
-            nl, ms, fl = eng.profile_last()
-            tot_ms += ms; tot_fl += fl; n_l += nl
-            kn, kms, kby = eng.profile_last_knn()
-            k_n += kn; k_ms += kms; k_by += kby
-        eng.set_profile(False)
-        achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-        # HBM traffic per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, gfx950 x2 correction; see the file's
-        # "source" note) -- PMC counters cannot be collected inside this process
-        traffic = {}
-        try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json" if S == 1 else "r01_pmc_traffic_%dstreams.json" % S)))
-        except Exception:
-            pass
-        roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 5),
-                "traffic": traffic.get("igemm_all_instantiations", {}).get("hbm_read_bytes_per_launch"),
-                "kernel": "rvc::igemm_kernel<MF,NF> (all instantiations)", "launches_per_step": n_l // reps,
-                "avg_launch_us": round(tot_ms * 1e3 / max(n_l, 1), 3), "flops_per_step": tot_fl / reps}
-        if k_n:
-            ach = k_by / (k_ms * 1e-3) / 1e9
-            roof["retrieval_scan"] = {"bound": "hbm", "kernel": "rvc::knn_dot_kernel", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                                      "frac": round(ach / 8000.0, 4), "bytes_per_launch": k_by / k_n, "avg_launch_us": round(k_ms * 1e3 / k_n, 2),
-                                      "traffic": (traffic.get("knn_dot_kernel", {}).get("hbm_read_bytes_per_launch") if S == 1 else None)}
 
-    # offline throughput mode (rvc_set_pipeline): K unsynchronised chunks, consecutive chunks overlap on the GPU; reported next to
-    # `value` (which keeps the streaming semantics: one chunk in flight, synchronised per chunk), never as `value`
-    pipe_fps = None
-    if rank == 0 and S <= 4 and args.preset == "full" and not args.graph:
-      try:
-        outs = torch.empty((n_rings, S, N), dtype=torch.float32, device="cuda")
-        eng.set_pipeline(True)
+def roofline_of(eng, step, S, reps=5):
+    """Dominant kernel class (implicit GEMM on the fp32 matrix cores): per-launch HIP events on the stream each kernel is launched on
+    (hipExtLaunchKernelGGL start/stop = the dispatch's own begin/end), eager launches of the same kernels and shapes."""
+    eng.set_profile(True)
+    tot_ms = tot_fl = k_ms = k_by = 0.0
+    n_l = k_n = 0
+    wall = []
+    for i in range(reps):
+        t0 = time.perf_counter()
+        step(i)
+        wall.append(time.perf_counter() - t0)
+        nl, ms, fl = eng.profile_last()
+        tot_ms += ms; tot_fl += fl; n_l += nl
+        kn, kms, kby = eng.profile_last_knn()
+        k_n += kn; k_ms += kms; k_by += kby
+    eng.set_profile(False)
+    achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    # HBM traffic per launch: PMC counters cannot be collected inside this process -- the figure comes from a committed
+    # `rocprofv3 --pmc FETCH_SIZE` pass of the same command (gfx950 x2 correction applied, see the file's "source" note)
+    tname = "r01_pmc_traffic.json" if S == 1 else "r01_pmc_traffic_%dstreams.json" % S
+    traffic = {}
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", tname)))
+    except Exception:
+        tname = None
+    roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 5),
+            "traffic": traffic.get("igemm_all_instantiations", {}).get("hbm_read_bytes_per_launch"),
+            "traffic_source": ("static: profiles/%s (separate rocprofv3 --pmc pass, not measured in this run)" % tname) if tname else None,
+            "kernel": "rvc::igemm2_kernel / igemm_lds_kernel (all instantiations)", "launches_per_step": n_l // reps,
+            "avg_launch_us": round(tot_ms * 1e3 / max(n_l, 1), 3), "flops_per_step": tot_fl / reps,
+            "sum_kernel_ms": round(tot_ms / reps, 4),
+            "note": "achieved = flops / SUM of per-launch durations; the ContentVec and f0 branches overlap on disjoint CU sets, so the sum exceeds the step's wall time -- frac_by_wall in the enclosing record uses the step's wall clock"}
+    if k_n:
+        ach = k_by / (k_ms * 1e-3) / 1e9
+        roof["retrieval_scan"] = {"bound": "hbm", "kernel": "rvc::knn_dot_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": k_by / k_n, "avg_launch_us": round(k_ms * 1e3 / k_n, 2),
+                                  "traffic": (traffic.get("knn_dot_kernel", {}).get("hbm_read_bytes_per_launch") if S == 1 else None),
+                                  "traffic_source": ("static: profiles/%s" % tname) if (tname and S == 1) else None}
+    return roof
+
+
+def run_config(job, z, g, S, with_index, steps, warmup, graph, index_vecs, want_roofline=True):
+    """One configuration on every rank: S streams per GPU, retrieval on/off.  -> record (rank 0) / None"""
+    from obs_rvc_amd import dist as rdist
+    from obs_rvc_amd.rvc import RvcInfer
+    torch = job.torch
+    eng = RvcInfer(z["data"], device=job.local_rank)
+    eng.load_contentvec(2); eng.load_f0(1); eng.load_model(z["model"])
+    eng.set_streams(S)
+    # stream s of this rank is stream (s * world + rank) of the job: round-robin sharding (SURVEY.md section 8e)
+    stream_ids = [s * job.world + job.rank for s in range(S)]
+    eng.set_noise_seed(1234, job.rank * S)
+    bcast_ms = None
+    if with_index:
+        b0 = time.perf_counter()
+        rdist.load_shared_index(eng, index_vecs if job.rank == 0 else None, 100000, 768, job.rank, job.world)
+        bcast_ms = round((time.perf_counter() - b0) * 1e3, 2)
+        eng.set_index_rate(0.75)
+    eng.set_use_graph(graph)
+    n_rings = 8 if S <= 8 else 4
+    rings = make_rings(S, stream_ids, n_rings, g)
+    d_rings = torch.from_numpy(rings).cuda()
+    d_out = torch.empty((S, g.model_return_size), dtype=torch.float32, device="cuda")
+    elapsed, lat, step = timed_leg(job, eng, d_rings, d_out, g, steps, warmup)
+    lat_all = job.gather(lat)
+    per_rank = [FRAMES_PER_CHUNK * steps * S / float(np.sum(l)) for l in lat_all]
+    rec = None
+    roof = roofline_of(eng, step, S) if (job.rank == 0 and want_roofline) else None
+    if job.rank == 0:
+        allat = np.concatenate(lat_all)
+        value = FRAMES_PER_CHUNK * steps * S * job.world / elapsed
+        ms = elapsed / steps * 1e3
+        rec = {"frames_per_s": round(value, 2), "ms_per_step": round(ms, 4), "streams_per_gpu": S, "streams_total": S * job.world, "n_gpus": job.world,
+               "retrieval": "100k x768 flat-L2 k=4 rate 0.75" if with_index else "off",
+               "latency_ms": {"p50": pct(allat, 50), "p99": pct(allat, 99), "max": round(float(allat.max()) * 1e3, 4)},
+               "rtf": round(float(np.percentile(allat, 99)) / 0.160, 5),
+               "per_rank_frames_per_s": [round(v, 1) for v in per_rank]}
+        if with_index:
+            rec["index_broadcast"] = {"via": "rvc_index_broadcast (ncclBroadcast, librccl over xGMI)", "rccl_ranks": job.world, "bytes": 100000 * 768 * 4,
+                                      "ms_incl_comm_init": bcast_ms}
+        if roof:
+            roof["frac_by_wall"] = round(roof["flops_per_step"] / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 5)
+            rec["roofline"] = roof
+    return rec, eng, rings, d_rings
+
+
+def host_buffer_leg(eng, rings, g, steps):
+    """The reference's boundary hands over host buffers (`RvcInfer::infer(ArrayView1<f32>) -> Array1<f32>`, rvc.rs:133-220): the same
+    chunk through the host-pointer C ABI -- H2D 143 KB + kernels + D2H 40 KB + one synchronisation inside the call (SURVEY.md 8d:
+    latency from request bytes available to reply bytes complete)."""
+    ts = []
+    n = min(max(steps, 30), 200)
+    for i in range(n + 5):
+        h0 = time.perf_counter()
+        eng.infer(rings[i % rings.shape[0], 0], g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+        ts.append(time.perf_counter() - h0)
+    ts = np.array(ts[5:])
+    return {"p50": pct(ts, 50), "p99": pct(ts, 99), "max": round(float(ts.max()) * 1e3, 4), "samples": int(n),
+            "frames_per_s": round(FRAMES_PER_CHUNK * n / float(ts.sum()), 2), "api": "rvc_infer (host pointers: H2D + D2H + sync inside the call)"}
+
+
+def pipelined_leg(job, eng, d_rings, g, S, steps):
+    """Offline throughput mode (rvc_set_pipeline): K unsynchronised chunks, consecutive chunks overlap on the GPU."""
+    torch = job.torch
+    L, chunk, N = g.input_buffer_16k_size, g.sample_frame_16k, g.model_return_size
+    n_rings = d_rings.shape[0]
+    outs = torch.empty((n_rings, S, N), dtype=torch.float32, device="cuda")
+    eng.set_pipeline(True)
+    try:
         for i in range(6):
             eng.infer_device(d_rings[i % n_rings].data_ptr(), L, chunk, 12, g.skip_head, g.model_return_length, outs[i % n_rings].data_ptr(), N, sync=False)
         eng.synchronize()
         p0 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(steps):
             eng.infer_device(d_rings[i % n_rings].data_ptr(), L, chunk, 12, g.skip_head, g.model_return_length, outs[i % n_rings].data_ptr(), N, sync=False)
         eng.synchronize()
-        pt = time.perf_counter() - p0
-        eng.set_pipeline(False)
-        pipe_fps = round(FRAMES_PER_CHUNK * args.steps * S / pt, 2)
-      except Exception as ex:          # informational leg: never lose the headline line over it
-        print("bench: offline-pipelined leg failed: %s" % ex, file=sys.stderr)
+        return round(FRAMES_PER_CHUNK * steps * S / (time.perf_counter() - p0), 2)
+    finally:
         eng.set_pipeline(False)
 
-    # the reference's boundary hands over host buffers: the same chunk through the host-pointer C ABI (H2D 143 KB + D2H 40 KB
-    # + sync inside the call); reported separately, never as `value`
-    host_ms = None
-    if rank == 0 and S == 1:
-      try:
-        ts = []
-        for i in range(30):
-            h0 = time.perf_counter()
-            eng.infer(rings[i % n_rings, 0], chunk, 12, g.skip_head, g.model_return_length)
-            ts.append(time.perf_counter() - h0)
-        host_ms = round(float(np.median(ts[5:])) * 1e3, 4)
-      except Exception as ex:
-        print("bench: host-buffer leg failed: %s" % ex, file=sys.stderr)
 
-    # the whole plugin-side chain as one native call (rvc_session_process: 48 kHz chunk in -> resample -> infer -> resample ->
-    # envelope -> SOLA -> 48 kHz frame out, rings resident in HBM); reported next to `value`, never as `value`
-    chain_ms = None
-    if rank == 0 and args.preset == "full" and not args.index:
-      try:
-        from obs_rvc_amd.streaming import NativeStreamingSession
-        ses = NativeStreamingSession(eng, 48000, 0.16, 0.07, 2.0, 48000, 12, 0.75)
-        F, n_ch = ses.sample_frame_size, 34 if S == 1 else 12
-        x48 = np.stack([np.interp(np.arange(F * n_ch) / 48000.0, np.arange(chunk * n_ch) / 16000.0, voice_signal(chunk * n_ch, seed=99 + s)).astype(np.float32)
-                        for s in range(S)])
-        ts = []
-        for i in range(n_ch):
-            xin = x48[:, i * F:(i + 1) * F] if S > 1 else x48[0, i * F:(i + 1) * F]
-            h0 = time.perf_counter()
+def chain_leg(eng, S, g):
+    """The whole plugin-side chain as one native call (rvc_session_process: 48 kHz chunk in -> resample -> infer -> resample ->
+    envelope -> SOLA -> 48 kHz frame out, rings resident in HBM).  A chunk on which the reference would panic (RVC_PANIC: the
+    synthetic RMVPE weights can hit rmvpe.rs:124 while the 2.24 s ring is still mostly zeros) is COUNTED, not hidden."""
+    from common import voice_signal
+    from obs_rvc_amd.rvc_common import RvcInferError
+    from obs_rvc_amd.streaming import NativeStreamingSession
+    chunk = g.sample_frame_16k
+    ses = NativeStreamingSession(eng, 48000, 0.16, 0.07, 2.0, 48000, 12, 0.75)
+    F, n_ch = ses.sample_frame_size, 34 if S == 1 else 12
+    x48 = np.stack([np.interp(np.arange(F * n_ch) / 48000.0, np.arange(chunk * n_ch) / 16000.0, voice_signal(chunk * n_ch, seed=99 + s)).astype(np.float32)
+                    for s in range(S)])
+    ts, panics = [], 0
+    for i in range(n_ch):
+        xin = x48[:, i * F:(i + 1) * F] if S > 1 else x48[0, i * F:(i + 1) * F]
+        h0 = time.perf_counter()
+        try:
+            ses.process_one_frame(np.ascontiguousarray(xin))
+        except RvcInferError as ex:
+            if "Panic" not in str(ex):
+                raise
+            panics += 1            # reported after the chunk has run: its time is still a valid sample
+        ts.append(time.perf_counter() - h0)
+    del ses
+    return {"ms_per_chunk": round(float(np.median(ts[n_ch // 5:])) * 1e3, 4), "chunks": n_ch, "panic_chunks": panics}
+
+
+def cpu_baseline_leg(z, rings, g, with_index, index_vecs):
+    """CPU baseline: the C oracle (a port of the reference's path; the reference itself -- Rust + ONNX Runtime -- cannot run here)
+    on this node's host cores, bounded sample of the same workload."""
+    from oracle import oracle as O
+    # 16 OpenMP threads is this restatement's optimum on the 256-CPU host (1: 1158, 8: 358, 16: 297, 32: 550, 64: 1100 ms/chunk --
+    # its parallel loops are per layer and short, so more threads only add barrier cost); the single-thread figure is reported too
+    threads = min(os.cpu_count() or 1, 16)
+    chunk = g.sample_frame_16k
+    ora = O.OracleRvcInfer(z["data"])
+    ora.load_contentvec(2); ora.load_f0(1); ora.load_model(z["model"]); ora.set_noise_seed(1234, 0)
+    if with_index:
+        ora.load_index(index_vecs); ora.set_index_rate(0.75)
+    O.set_threads(1)
+    ora.infer(rings[0, 0], chunk, 12, g.skip_head, g.model_return_length)
+    c0 = time.perf_counter()
+    for i in range(3):
+        ora.infer(rings[i % rings.shape[0], 0], chunk, 12, g.skip_head, g.model_return_length)
+    one_thread_ms = (time.perf_counter() - c0) / 3 * 1e3
+    O.set_threads(threads)
+    n_cpu = 40
+    ora.infer(rings[0, 0], chunk, 12, g.skip_head, g.model_return_length)
+    c0 = time.perf_counter()
+    for i in range(n_cpu):
+        ora.infer(rings[i % rings.shape[0], 0], chunk, 12, g.skip_head, g.model_return_length)
+    ct = time.perf_counter() - c0
+    return {"value": round(FRAMES_PER_CHUNK * n_cpu / ct, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d chunks of stream 0 (same rings, same weights), C oracle with OpenMP, %.1f s" % (n_cpu, ct),
+            "ms_per_chunk": round(ct / n_cpu * 1e3, 2), "one_thread_ms_per_chunk": round(one_thread_ms, 1), "host_cpus": os.cpu_count()}
+
+
+# ------------------------------------------------------------------------------------------------------------ dry launch
+def dry_launch(args):
+    """No GPU: the launcher, the gloo rendezvous, the stream sharding and the reductions, with a stand-in step."""
+    from obs_rvc_amd import dist as rdist
+    job = Job(dry=True)
+    S = args.streams
+    total = S * job.world
+    mine = rdist.local_streams(total, job.rank, job.world)
+    assert mine == [s * job.world + job.rank for s in range(S)]
+    lat = []
+    job.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        time.sleep(0.001)
+        lat.append(time.perf_counter() - t1)
+    job.barrier()
+    elapsed = job.max_over_ranks(time.perf_counter() - t0)
+    lat_all = job.gather(lat)
+    owned = job.gather([float(len(mine))] + [float(s) for s in mine])
+    if job.rank == 0:
+        streams = sorted(int(v) for o in owned for v in o[1:])
+        print(json.dumps({"metric": "dry launch (no GPU work)", "dry_launch": True, "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup,
+                          "streams_total": total, "streams_covered": streams == list(range(total)),
+                          "per_rank_streams": [[int(v) for v in o[1:]] for o in owned],
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "latency_samples": int(sum(len(l) for l in lat_all))}))
+    job.close()
+
+
+# ------------------------------------------------------------------------------------------------------------ main
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)
+    if args.dry_launch:
+        return dry_launch(args)
+    job = Job(dry=False)
+    if job.world != args.gpus and job.rank == 0:
+        print("bench: --gpus %d but WORLD_SIZE=%d: running the %d ranks that exist" % (args.gpus, job.world, job.world), file=sys.stderr)
+    from common import BASELINE_160MS as g, zoo
+    from obs_rvc_amd import weights as W
+    if job.rank == 0:
+        z = zoo(args.preset)
+    job.barrier()
+    z = zoo(args.preset)
+    graph = bool(args.graph and not args.no_graph)
+    full = args.preset == "full"
+    index_vecs = W.make_index() if (job.rank == 0 and full) else None      # only rank 0 ever holds the host copy
+
+    # ---- headline: BASELINE configs[1] (or what --streams / --index ask for) on every rank
+    S = args.streams
+    head, eng, rings, d_rings = run_config(job, z, g, S, args.index and full, args.steps, args.warmup, graph, index_vecs)
+    extra = {}
+    if job.rank == 0 and not args.only_headline:
+        skip = os.environ.get("RVC_BENCH_SKIP", "").split(",")     # debugging aid: leg names to leave out
+
+        def informational(name, fn):                       # informational legs never cost the headline line
+            if name in skip:
+                return
             try:
-                ses.process_one_frame(np.ascontiguousarray(xin))
-            except Exception as ex:      # while the 2.24 s ring is still mostly zeros the synthetic RMVPE weights can hit the
-                if "Panic" not in str(ex):   # reference's out-of-range decode (rmvpe.rs:124): reported as RVC_PANIC after the
-                    raise                    # chunk has run, so its time is still a valid sample
-            ts.append(time.perf_counter() - h0)
-        chain_ms = round(float(np.median(ts[n_ch // 5:])) * 1e3, 4)
-        del ses
-      except Exception as ex:
-        print("bench: plugin-chain leg failed: %s" % ex, file=sys.stderr)
-
+                extra[name] = fn()
+            except Exception as ex:
+                print("bench: %s leg failed: %s" % (name, ex), file=sys.stderr)
+                extra[name] = None
+        if S == 1:
+            informational("latency_ms_host_buffer", lambda: host_buffer_leg(eng, rings, g, args.steps))
+        if S <= 4 and full and not graph:
+            informational("offline_pipelined_frames_per_s", lambda: pipelined_leg(job, eng, d_rings, g, S, args.steps))
+        if full and not args.index:
+            informational("plugin_chain", lambda: chain_leg(eng, S, g))
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        # CPU baseline: the C oracle (a port of the reference's path; the reference itself -- Rust + ONNX Runtime -- cannot
-        # run here) on this node's host cores, bounded sample of the same workload
-        from oracle import oracle as O
-        # 16 OpenMP threads is this restatement's optimum on the 256-CPU host (1: 1158, 8: 358, 16: 297, 32: 550, 64: 1100 ms/chunk --
-        # its parallel loops are per layer and short, so more threads only add barrier cost); the single-thread figure is reported too
-        threads = min(os.cpu_count() or 1, 16)
-        ora = O.OracleRvcInfer(z["data"])
-        ora.load_contentvec(2); ora.load_f0(1); ora.load_model(z["model"]); ora.set_noise_seed(1234, 0)
-        if args.index:
-            ora.load_index(W.make_index()); ora.set_index_rate(0.75)
-        O.set_threads(1)
-        ora.infer(rings[0, 0], chunk, 12, g.skip_head, g.model_return_length)
-        c0 = time.perf_counter()
-        for i in range(3):
-            ora.infer(rings[i % n_rings, 0], chunk, 12, g.skip_head, g.model_return_length)
-        one_thread_ms = (time.perf_counter() - c0) / 3 * 1e3
-        O.set_threads(threads)
-        n_cpu = 40
-        ora.infer(rings[0, 0], chunk, 12, g.skip_head, g.model_return_length)
-        c0 = time.perf_counter()
-        for i in range(n_cpu):
-            ora.infer(rings[i % n_rings, 0], chunk, 12, g.skip_head, g.model_return_length)
-        ct = time.perf_counter() - c0
-        cpu = {"value": round(FRAMES_PER_CHUNK * n_cpu / ct, 2), "unit": "frames/s", "cores": threads, "kind": "port",
-               "sample": "%d chunks of stream 0 (same rings, same weights), C oracle with OpenMP, %.1f s" % (n_cpu, ct),
-               "ms_per_chunk": round(ct / n_cpu * 1e3, 2), "one_thread_ms_per_chunk": round(one_thread_ms, 1)}
+    if job.rank == 0 and job.world == 1 and not args.no_cpu:
+        cpu = cpu_baseline_leg(z, rings, g, args.index and full, index_vecs)
+    del eng, d_rings
+    job.torch.cuda.empty_cache()
 
-    if rank == 0:
-        total_streams = S * world
-        value = FRAMES_PER_CHUNK * args.steps * total_streams / elapsed
+    # ---- sub-configurations: every rank takes part (the timed regions are bracketed by barriers)
+    sub = {}
+    if not args.only_headline and full and S == 1 and not args.index:
+        try:
+            rec, e2, _, d2 = run_config(job, z, g, 1, True, args.steps, args.warmup, graph, index_vecs)
+            sub["index100k"] = rec
+            del e2, d2
+            job.torch.cuda.empty_cache()
+            k64 = max(10, min(args.steps, 20))
+            rec, e3, _, d3 = run_config(job, z, g, 64, job.world > 1, k64, 3, graph, index_vecs)
+            if rec:
+                rec["steps"] = k64
+                rec["config"] = "BASELINE configs[%d]" % (4 if job.world > 1 else 3)
+            sub["streams64"] = rec
+            del e3, d3
+        except Exception as ex:
+            if job.world > 1:
+                raise                                        # a rank that left a collective would hang the others: fail loudly
+            print("bench: sub-configuration leg failed: %s" % ex, file=sys.stderr)
+
+    if job.rank == 0:
         out = {
-            "metric": "audio frames/sec (10 ms hops of new input, 160 ms chunks @16 kHz)", "value": round(value, 2), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "metric": "audio frames/sec (10 ms hops of new input, 160 ms chunks @16 kHz)", "value": head["frames_per_s"], "unit": "frames/s",
+            "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: %d stream(s)/GPU, ContentVec v2-768 + RMVPE + NSF-HiFiGAN v2-48k, retrieval %s, preset %s"
                                    % (2 if args.index else (1 if S == 1 else 3), S, "100k x768 flat-L2 k=4" if args.index else "off", args.preset),
-                       "streams_per_gpu": S, "chunk_ms": 160, "input_samples_16k": L, "output_samples": N, "hip_graph": bool(args.graph and not args.no_graph)},
-            "latency_ms": {"p50": round(float(np.percentile(lat, 50)) * 1e3, 4), "p99": round(float(np.percentile(lat, 99)) * 1e3, 4),
-                           "max": round(float(lat.max()) * 1e3, 4)},
-            "rtf": round(float(np.percentile(lat, 99)) / 0.160, 5), "host_buffer_api_ms_per_chunk": host_ms, "plugin_chain_ms_per_chunk": chain_ms, "offline_pipelined_frames_per_s": pipe_fps,
-            "roofline": roof, "cpu_baseline": cpu,
+                       "streams_per_gpu": S, "streams_total": S * job.world, "chunk_ms": 160, "input_samples_16k": g.input_buffer_16k_size,
+                       "output_samples": g.model_return_size, "hip_graph": graph,
+                       "timed_api": "rvc_infer_device: inputs resident in HBM when the timed region starts, one synchronisation per chunk; the host-buffer boundary (H2D + D2H inside the call) is latency_ms_host_buffer"},
+            "latency_ms": head["latency_ms"], "rtf": head["rtf"], "rccl_ranks": job.world, "per_rank_frames_per_s": head["per_rank_frames_per_s"],
+            "latency_ms_host_buffer": extra.get("latency_ms_host_buffer"),
+            "host_buffer_api_ms_per_chunk": (extra.get("latency_ms_host_buffer") or {}).get("p50"),
+            "plugin_chain": extra.get("plugin_chain"),
+            "plugin_chain_ms_per_chunk": (extra.get("plugin_chain") or {}).get("ms_per_chunk"),
+            "offline_pipelined_frames_per_s": extra.get("offline_pipelined_frames_per_s"),
+            "roofline": head.get("roofline"), "cpu_baseline": cpu, "sub_configs": sub or None,
         }
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        if args.index and head.get("index_broadcast"):
+            out["index_broadcast"] = head["index_broadcast"]
+        # librccl prints a version banner through C stdio when its first communicator is created: push it out now so that the
+        # JSON line below is the LAST line on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+    job.close()
 
 
 if __name__ == "__main__":

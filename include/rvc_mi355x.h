@@ -79,6 +79,17 @@ rvc_status rvc_get_knn(rvc_engine *e, int32_t *idx, float *dist, size_t cap_rows
 void rvc_set_noise_seed(rvc_engine *e, uint32_t seed, uint32_t stream_id);
 void rvc_reset_state(rvc_engine *e);     /* zero the 1024-entry pitch cache and the chunk counter */
 
+/* ---- multi-GPU (BASELINE configs[4]; no counterpart in the reference: one RvcInfer per process, rvc.rs:133-134) ---- */
+/* Streams shard across GPUs with NO per-chunk collective: one process + one engine per GPU, stream s on rank s mod world.  The one
+ * exchange step is at load: the shared retrieval index travels from rank 0 into every rank's HBM with ONE ncclBroadcast over
+ * RCCL / xGMI.  Rank 0 calls rvc_rccl_unique_id and hands the 128 bytes to the other ranks by any host-side means (pipe, file,
+ * TCP store); then EVERY rank calls rvc_index_broadcast with the same id.  Rank 0 passes the (n, dim) fp32 matrix (or NULL to
+ * send the index its engine already holds); the other ranks pass vectors = NULL and n = dim = 0 (or the shape they expect, which
+ * is then checked).  librccl is loaded lazily (dlopen; RVC_RCCL_LIB overrides the name): single-GPU use never touches it. */
+#define RVC_RCCL_UNIQUE_ID_BYTES 128
+rvc_status rvc_rccl_unique_id(void *id128);
+rvc_status rvc_index_broadcast(rvc_engine *e, const void *unique_id128, int rank, int world, const float *vectors, size_t n, size_t dim);
+
 /* ---- many concurrent streams on one GPU (BASELINE configs 4-5) ---- */
 /* The engine then holds n_streams independent stream states (pitch cache, noise counters) that share weights. */
 rvc_status rvc_set_streams(rvc_engine *e, int n_streams);

@@ -22,23 +22,54 @@ SYMBOLS = [
     "rvc_index_device_ptr", "rvc_device", "rvc_version", "rvc_envelop_mixing", "rvc_sola_step", "rvc_profile_last_knn",
     "rvc_resampler_create", "rvc_resampler_destroy", "rvc_resampler_input_frames_next", "rvc_resampler_output_frames_max",
     "rvc_resampler_reset", "rvc_resampler_process", "rvc_resampler_process_device",
+    "rvc_rccl_unique_id", "rvc_index_broadcast",
     "rvc_session_create", "rvc_session_destroy", "rvc_session_process", "rvc_session_frame_size", "rvc_session_set_params", "rvc_session_geometry",
 ]
 
 
+SOURCES = ("engine.hip", "kernels.hip.h", "resample.hip.h", "session.hip.h", "rccl_bcast.hip.h", "blob.h", "rvc_rpc.cpp")
+
+
+def source_hash() -> str:
+    """sha256 over the library's sources (+ the public header), first 16 hex digits.  It is compiled into the binary
+    (`rvc_version()` ends in "src:<hash>"), so a tested .so can be tied to the sources it was built from."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in [os.path.join(CSRC, n) for n in SOURCES] + [os.path.join(os.path.dirname(_HERE), "include", "rvc_mi355x.h")]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def binary_hash(path: str = None) -> str:
+    """The source hash embedded in a built library ("" if the file is missing or predates the scheme); read from the file's bytes,
+    so no GPU and no dlopen is needed."""
+    path = path or SO_PATH
+    if not os.path.exists(path):
+        return ""
+    with open(path, "rb") as fh:
+        blob = fh.read()
+    i = blob.find(b"rvc-mi355x-src:")
+    return blob[i + 15:i + 31].decode("ascii", "replace") if i >= 0 else ""
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950: the engine library and the rvc-rpc protocol-compatible executable."""
-    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "kernels.hip.h", "resample.hip.h", "session.hip.h", "blob.h")] + \
-           [os.path.join(os.path.dirname(_HERE), "include", "rvc_mi355x.h")]
-    newest = max(os.path.getmtime(s) for s in srcs)
-    if force or not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < newest:
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               os.path.join(CSRC, "engine.hip"), "-o", SO_PATH]
+    """hipcc --offload-arch=gfx950: the engine library and the rvc-rpc protocol-compatible executable.  A library is reused only
+    if the source hash compiled into it equals the hash of the sources on disk (never by modification time)."""
+    want = source_hash()
+    have = binary_hash()
+    if force or have != want:
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", '-DRVC_SRC_HASH="%s"' % want,
+               os.path.join(CSRC, "engine.hip"), "-o", SO_PATH, "-ldl"]
         if verbose:
+            print("source hash %s, binary %s -> rebuilding" % (want, have or "(none)"))
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    elif verbose:
+        print("librvc_mi355x.so carries source hash %s = sources on disk: up to date" % have)
     rpc_src = os.path.join(CSRC, "rvc_rpc.cpp")
-    if os.path.exists(rpc_src) and (force or not os.path.exists(RPC_PATH) or os.path.getmtime(RPC_PATH) < max(newest, os.path.getmtime(rpc_src))):
+    if force or have != want or not os.path.exists(RPC_PATH) or os.path.getmtime(RPC_PATH) < os.path.getmtime(rpc_src):
         cmd = ["hipcc", "-O2", "-std=c++17", rpc_src, "-o", RPC_PATH, "-L" + CSRC, "-lrvc_mi355x", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
@@ -52,7 +83,7 @@ def lib():
         return _LIB
     if not os.path.exists(SO_PATH):
         raise RuntimeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % SO_PATH)
-    L = C.CDLL(SO_PATH)
+    L = C.CDLL(os.environ.get("RVC_LIB_OVERRIDE") or SO_PATH)     # override: A/B timing of an older build (tuning aid)
     vp, fp, sz, i32, u32 = C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_int32, C.c_uint32
     L.rvc_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     L.rvc_destroy.argtypes = [vp]
@@ -113,6 +144,9 @@ def lib():
     L.rvc_resampler_reset.restype = None
     L.rvc_resampler_process.argtypes = [vp, fp, sz, fp, sz, C.POINTER(sz)]
     L.rvc_resampler_process_device.argtypes = [vp, vp, vp, C.c_int]
+    if hasattr(L, "rvc_rccl_unique_id") or not os.environ.get("RVC_LIB_OVERRIDE"):
+        L.rvc_rccl_unique_id.argtypes = [vp]
+        L.rvc_index_broadcast.argtypes = [vp, vp, C.c_int, C.c_int, fp, sz, sz]
     L.rvc_session_create.argtypes = [vp, sz, C.c_double, C.c_double, C.c_double, sz, i32, C.c_double, C.c_int, C.POINTER(vp)]
     L.rvc_session_destroy.argtypes = [vp]
     L.rvc_session_destroy.restype = None

@@ -15,8 +15,16 @@
 #include <cstddef>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
+
+// The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The engine runs four
+// streams concurrently per chunk; a second engine in the process, or the streams an RCCL communicator leaves behind, then share
+// queues with them and the per-chunk latency rises by 5-20 % (measured: 2.38 -> 2.84 ms for an engine created after a communicator;
+// flat 2.38 ms with 16 queues).  The variable is read when the runtime initialises, so a default is planted when this library is
+// loaded -- it does not override a value the host has set, and a host that has already initialised HIP should set it itself.
+__attribute__((constructor)) static void rvc_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 namespace rvc {
 
@@ -478,7 +486,10 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     if (lean) {
         const int fast_n = weight_heavy ? p.ntm : p.ntn, slow_n = weight_heavy ? p.ntn : p.ntm;
         unsigned gx = (unsigned)(wg_ks > 1 ? fast_n : (fast_n + 3) / 4);
-        if (weight_heavy) gx = (gx + 7) / 8 * 8;           // workgroup (x, y) runs on XCD x % 8 when gridDim.x is a multiple of 8
+        // workgroup (x, y) runs on XCD x % 8 when gridDim.x is a multiple of 8: all tiles of one weight-row block then share one
+        // XCD's L2.  Only when the padding is cheap and every XCD still gets live workgroups (a short axis padded to 8 would park
+        // all the work on a few XCDs: measured 3.6x slower at 64 streams)
+        if (weight_heavy && (wg_ks > 1 || gx >= 16)) gx = (gx + 7) / 8 * 8;
         grid = dim3(gx, (unsigned)slow_n, (unsigned)(B * p.nphase));
         if (grid.y > 65535 || grid.z > 65535) throw ShapeError("implicit GEMM grid too large");
         p.nbatch = B;
@@ -1122,6 +1133,47 @@ static void reset_state(rvc_engine *e)
 // CU partition for the two concurrent branches of a chunk at low stream counts: the f0 branch (RMVPE: ~140 short weight-streaming
 // kernels) gets 1/8 of the CUs, ContentVec the rest.  Sharing CUs slows the f0 branch by ~35 % (measured).  With
 // many streams every kernel fills the chip and the streams are plain.
+//
+// CU-masked streams are never destroyed: the runtime recycles the hardware queue of a destroyed stream, mask included, for the next
+// stream it creates -- an engine created after another one had been destroyed then ran its MAIN stream on a partition (measured:
+// 2.41 -> 2.79-3.1 ms per chunk for the second engine of a process; no effect without masks).  Masked pairs live in a per-device
+// pool for the life of the process; engines borrow a pair and hand it back.
+struct MaskedPair { int device; hipStream_t f0, cv; bool in_use; };
+static std::mutex g_pool_mu;
+static std::vector<MaskedPair> g_pool;
+
+static bool acquire_masked_pair(int device, int ncu, int nf0, hipStream_t *f0, hipStream_t *cv)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto &m : g_pool)
+        if (m.device == device && !m.in_use) { m.in_use = true; *f0 = m.f0; *cv = m.cv; return true; }
+    MaskedPair m{device, nullptr, nullptr, true};
+    for (int i = 0; i < 2; i++) {
+        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+        for (int c = 0; c < ncu; c++) if ((c < nf0) == (i == 0)) mask[c / 32] |= 1u << (c % 32);
+        hipStream_t *dst = i == 0 ? &m.f0 : &m.cv;
+        if (hipExtStreamCreateWithCUMask(dst, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;          // (a first stream that did get created stays allocated: it must not be destroyed either)
+        }
+    }
+    g_pool.push_back(m);
+    *f0 = m.f0; *cv = m.cv;
+    return true;
+}
+static void release_masked_pair(hipStream_t f0)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto &m : g_pool) if (m.f0 == f0) m.in_use = false;
+}
+
+static void release_aux_streams(rvc_engine *e)
+{
+    if (e->partitioned && e->aux[0]) { release_masked_pair(e->aux[0]); e->aux[0] = nullptr; e->aux[2] = nullptr; }
+    for (int i = 0; i < 3; i++) if (e->aux[i]) { (void)hipStreamDestroy(e->aux[i]); e->aux[i] = nullptr; }
+    e->partitioned = false;
+}
+
 static void configure_aux_streams(rvc_engine *e)
 {
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, e->device));
@@ -1129,18 +1181,13 @@ static void configure_aux_streams(rvc_engine *e)
     if (const char *f = getenv("RVC_F0_CUS")) { const int v = atoi(f); if (v >= 8 && v < ncu) nf0 = v; }   // tuning aid
     bool want = e->partition_ok && ncu >= 64 && ncu <= 1024 && e->n_streams <= 4;
     if (e->aux[0] && want == e->partitioned) return;
-    for (int i = 0; i < 3; i++) if (e->aux[i]) { HIPCHK(hipStreamDestroy(e->aux[i])); e->aux[i] = nullptr; }
-    for (int i = 0; i < 3; i++) {
-        if (want && i != 1) {
-            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-            for (int c = 0; c < ncu; c++) if ((c < nf0) == (i == 0)) mask[c / 32] |= 1u << (c % 32);
-            if (hipExtStreamCreateWithCUMask(&e->aux[i], (uint32_t)mask.size(), mask.data()) == hipSuccess) continue;
-            (void)hipGetLastError(); want = false; e->partition_ok = false;
-            if (i == 2) { HIPCHK(hipStreamDestroy(e->aux[0])); HIPCHK(hipStreamCreateWithFlags(&e->aux[0], hipStreamNonBlocking)); }
-        }
-        HIPCHK(hipStreamCreateWithFlags(&e->aux[i], hipStreamNonBlocking));
+    release_aux_streams(e);
+    if (want) {
+        if (acquire_masked_pair(e->device, ncu, nf0, &e->aux[0], &e->aux[2])) e->partitioned = true;
+        else { want = false; e->partition_ok = false; }
     }
-    e->partitioned = want;
+    for (int i = 0; i < 3; i++)
+        if (!e->aux[i]) HIPCHK(hipStreamCreateWithFlags(&e->aux[i], hipStreamNonBlocking));
 }
 
 static void alloc_state(rvc_engine *e)
@@ -1822,7 +1869,11 @@ static std::string native_path(const std::string &p)
 // ---------------------------------------------------------------------------------------
 extern "C" {
 
-const char *rvc_version(void) { return "rvc-mi355x 0.1 (gfx950)"; }
+#ifndef RVC_SRC_HASH
+#define RVC_SRC_HASH "unhashed"
+#endif
+// "... rvc-mi355x-src:<sha256[:16] of the sources this binary was compiled from>" (obs_rvc_amd/_native.py source_hash / binary_hash)
+const char *rvc_version(void) { return "rvc-mi355x 0.2 (gfx950) rvc-mi355x-src:" RVC_SRC_HASH; }
 
 rvc_status rvc_create(const char *data_path, int device, rvc_engine **out)
 {
@@ -1883,8 +1934,8 @@ void rvc_destroy(rvc_engine *e)
     for (int i = 0; i < 3; i++) {
         if (e->ev_fork[i]) (void)hipEventDestroy(e->ev_fork[i]);
         if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
-        if (e->aux[i]) (void)hipStreamDestroy(e->aux[i]);
     }
+    release_aux_streams(e);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -2420,3 +2471,4 @@ rvc_status rvc_get_tap(rvc_engine *e, const char *name, float *out, size_t cap, 
 
 #include "resample.hip.h"
 #include "session.hip.h"
+#include "rccl_bcast.hip.h"

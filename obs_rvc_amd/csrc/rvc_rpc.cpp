@@ -26,9 +26,13 @@ static bool read_exact(FILE *f, void *buf, size_t n) { return n == 0 || fread(bu
 
 int main(int argc, char **argv)
 {
-    if (argc < 5) {   // main.rs:14-22 reads args[1..=4]
+    if (argc < 4) {   // main.rs:14-17: `args.len() < 4` prints the usage and returns (exit status 0)
         fprintf(stderr, "Usage: rvc-rpc <version> <f0_algorithm> <model> <data>\n");
         return 0;
+    }
+    if (argc < 5) {   // exactly three arguments pass that check and then main.rs:22 indexes args[4]: panic, exit status 101
+        fprintf(stderr, "rvc-rpc: index out of bounds: the len is %d but the index is 4 (main.rs:22)\n", argc);
+        return 101;
     }
     // RvcModelVersion::from(&str): "v1" -> V1, anything else -> V2 (enums.rs:66-74); PitchAlgorithm: always Rmvpe (enums.rs:126-133)
     const int version = strcmp(argv[1], "v1") == 0 ? RVC_VERSION_V1 : RVC_VERSION_V2;
@@ -61,6 +65,11 @@ int main(int argc, char **argv)
             !read_exact(stdin, &return_length, 4))
             return 101;
         size_t n_out = 0;
+        // the reply holds return_length 10 ms hops at the model rate (<= 480 samples each at 48 kHz; 1024 leaves room for any
+        // synthesizer hop).  A wire value no chunk of the plugin can produce (its slider tops out at a few hundred hops; infer itself
+        // rejects skip_head + return_length > 2T + 1) must not size a multi-gigabyte buffer: the reference would panic inside infer
+        // (rvc.rs:155 slice out of range) -> exit 101
+        if (return_length > (1u << 16)) { fprintf(stderr, "rvc-rpc: return_length %u out of range\n", return_length); return 101; }
         out.resize((size_t)return_length * 1024 + 16);
         rc = rvc_infer(e, in.data(), in.size(), frame, 1, pitch_shift, skip_head, return_length, out.data(), out.size(), &n_out);
         if (rc != RVC_OK) die(e, "infer", rc);                                                         // main.rs:93 unwrap

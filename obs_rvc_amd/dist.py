@@ -1,8 +1,10 @@
 """Multi-GPU layer: streams are independent units, so the per-chunk path has NO collective.
 
 * stream s -> rank s mod G (round-robin, BASELINE config 5: 512 streams -> 64 per GPU);
-* the only exchange step is at load: the shared retrieval index is broadcast from rank 0 with
-  torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+* the only exchange step is at load: the shared retrieval index is broadcast from rank 0 with ONE ncclBroadcast issued by the
+  engine itself (rvc_index_broadcast in the C ABI: librccl over xGMI, no Python needed by a Rust / C host).  The host's only job
+  is to hand rank 0's 128-byte unique id to the other ranks; here that goes through torch.distributed's object broadcast.
+  `broadcast_index` is the host-side equivalent on torch tensors ("gloo" in the CPU tests).
 The reference has no multi-stream or multi-GPU mode (one RvcInfer per process, rvc.rs:133-134)."""
 from __future__ import annotations
 
@@ -34,13 +36,20 @@ def broadcast_index(vecs: Optional[np.ndarray], n: int, dim: int, rank: int, wor
     return t
 
 
-def load_shared_index(eng, vecs: Optional[np.ndarray], n: int, dim: int, rank: int, world: int) -> None:
-    """Broadcast over RCCL (device to device) and hand the HBM-resident copy to the engine."""
-    import torch
+def exchange_unique_id(eng, rank: int, world: int) -> bytes:
+    """Rank 0 asks the engine (librccl) for a unique id; every rank returns the same 128 bytes."""
+    box = [eng.rccl_unique_id() if rank == 0 else None]
+    if world > 1:
+        import torch.distributed as dist
+        dist.broadcast_object_list(box, src=0)
+    return box[0]
 
-    t = broadcast_index(vecs, n, dim, rank, world, device="cuda")
-    torch.cuda.synchronize()
-    rc = eng._L.rvc_load_index_device(eng._h, C.c_void_p(t.data_ptr()), n, dim)
-    if rc != 0:
-        from .rvc_common import RvcInferError
-        raise RvcInferError(rc, "rvc_load_index_device")
+
+def load_shared_index(eng, vecs: Optional[np.ndarray], n: int, dim: int, rank: int, world: int) -> None:
+    """Every rank ends up with the same HBM-resident index: rank 0 uploads it once and the engine broadcasts it over RCCL / xGMI
+    (with world == 1 the call still goes through RCCL, a one-rank communicator)."""
+    uid = exchange_unique_id(eng, rank, world)
+    eng.index_broadcast(uid, rank, world, vecs if rank == 0 else None)
+    p, nbytes = eng.index_device_ptr()
+    if nbytes != n * dim * 4:
+        raise RuntimeError("index broadcast delivered %d bytes, expected %d" % (nbytes, n * dim * 4))

@@ -110,6 +110,22 @@ class RvcInfer:
         v, vp = _f32(vectors)
         self._chk(self._L.rvc_load_index(self._h, vp, v.shape[0], v.shape[1]))
 
+    def rccl_unique_id(self) -> bytes:
+        """rvc_rccl_unique_id: rank 0 creates the 128-byte ncclUniqueId the host then hands to the other ranks."""
+        buf = C.create_string_buffer(128)
+        self._chk(self._L.rvc_rccl_unique_id(buf))
+        return buf.raw
+
+    def index_broadcast(self, unique_id: bytes, rank: int, world: int, vectors=None):
+        """rvc_index_broadcast: ONE ncclBroadcast of the shared retrieval index from rank 0 into this rank's HBM (RCCL over xGMI).
+        Rank 0 passes the (n, dim) matrix (or None to send the index it already holds); the other ranks pass None."""
+        assert len(unique_id) == 128
+        if vectors is not None:
+            v, vp = _f32(vectors)
+            self._chk(self._L.rvc_index_broadcast(self._h, unique_id, int(rank), int(world), vp, v.shape[0], v.shape[1]))
+        else:
+            self._chk(self._L.rvc_index_broadcast(self._h, unique_id, int(rank), int(world), None, 0, 0))
+
     def set_index_rate(self, rate: float):
         self._L.rvc_set_index_rate(self._h, float(rate))
 

@@ -31,6 +31,12 @@ def test_header_symbols_exported():
     assert b"gfx950" in lib.rvc_version()
 
 
+def test_library_carries_the_hash_of_its_sources():
+    # build() never reuses a binary by modification time: the source hash compiled into rvc_version() must equal the sources on disk
+    assert _native.binary_hash() == _native.source_hash()
+    assert _native.lib().rvc_version().decode().endswith("rvc-mi355x-src:" + _native.source_hash())
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():
@@ -115,3 +121,40 @@ def test_header_is_plain_c(tmp_path):
     src = tmp_path / "abi_check.c"
     src.write_text('#include "rvc_mi355x.h"\nint main(void) { rvc_engine *e = 0; rvc_session *s = 0; rvc_resampler *r = 0; (void)e; (void)s; (void)r; return (int)RVC_OK; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(src)])
+
+
+def _c_decls(text):
+    """name -> parameter count of every function declared in the C header (comments stripped)."""
+    import re
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(rvc_\w+)\s*\(([^;{]*?)\)\s*;", text):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
+def test_rust_ffi_matches_header():
+    # bindings/rust/rvc/src/ffi.rs is hand-written (no Rust toolchain in the image): every extern "C" item must exist in
+    # include/rvc_mi355x.h with the same number of parameters, and every header entry point must be declared there
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = _c_decls(open(os.path.join(root, "include", "rvc_mi355x.h")).read())
+    ffi = open(os.path.join(root, "bindings", "rust", "rvc", "src", "ffi.rs")).read()
+    rust = {}
+    for m in re.finditer(r"pub fn (rvc_\w+)\s*\((.*?)\)\s*(?:->\s*[^;]+)?;", ffi, flags=re.S):
+        args = m.group(2).strip()
+        rust[m.group(1)] = 0 if not args else len([a for a in args.split(",") if a.strip()])
+    assert set(hdr) == set(_native.SYMBOLS), set(hdr) ^ set(_native.SYMBOLS)
+    assert set(rust) == set(hdr), set(rust) ^ set(hdr)
+    for name, n in hdr.items():
+        assert rust[name] == n, (name, rust[name], n)
+    # the shim keeps the nine public methods of rvc/src/rvc.rs:30-220 with the reference's signatures
+    shim = open(os.path.join(root, "bindings", "rust", "rvc", "src", "rvc.rs")).read()
+    for sig in ("pub fn new(data_path: PathBuf) -> Self", "pub fn load_contentvec(&mut self, model_version: RvcModelVersion)",
+                "pub fn load_model(&mut self, model_path: PathBuf)", "pub fn load_f0(&mut self, pitch_algorithm: PitchAlgorithm)",
+                "pub fn unload_model(&mut self)", "pub fn hubert(&self, input: ArrayView1<f32>) -> Result<Array3<f32>, RvcInferError>",
+                "pub fn extract_feature(&self, input: ArrayView1<f32>) -> Result<Array3<f32>, RvcInferError>",
+                "pub fn pitch(&mut self, input: ArrayView1<f32>, pitch_shift: i32, sample_frame_16k_size: usize) -> Result<Array1<f32>, RvcInferError>",
+                "pub fn infer("):
+        assert sig in shim, sig

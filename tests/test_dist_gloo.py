@@ -41,3 +41,36 @@ def test_gloo_broadcast_and_sharding(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "rank 0 ok [0, 2, 4, 6, 8]" in outs[0] and "rank 1 ok [1, 3, 5, 7]" in outs[1]
+
+
+def _last_json(text):
+    import json
+    for ln in reversed(text.strip().splitlines()):
+        if ln.startswith("{"):
+            return json.loads(ln)
+    raise AssertionError("no JSON line in: " + text)
+
+
+def test_bench_launcher_spawns_ranks_dry():
+    # `bench.py --gpus 2` with no torchrun environment spawns the two ranks itself (one process per GPU, 127.0.0.1 rendezvous);
+    # --dry-launch replaces the GPU work by a stand-in so the launcher, the rendezvous, the round-robin sharding (stream s of the
+    # job on rank s mod N) and the reductions run here.  BASELINE configs[4] shape: 64 streams per rank.
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "4", "--streams", "64"],
+                       env=env, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    j = _last_json(r.stdout.decode())
+    assert j["dry_launch"] is True and j["n_gpus"] == 2 and j["streams_total"] == 128 and j["streams_covered"] is True
+    assert j["per_rank_streams"][0][:3] == [0, 2, 4] and j["per_rank_streams"][1][:3] == [1, 3, 5] and j["latency_samples"] == 8
+
+
+def test_bench_under_torchrun_dry():
+    # the driver's own launch line: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "3"],
+                       env=env, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    j = _last_json(r.stdout.decode())
+    assert j["n_gpus"] == 2 and j["streams_covered"] is True and j["per_rank_streams"] == [[0], [1]]

@@ -1,0 +1,104 @@
+"""GPU tests of BASELINE configs[3] / [4]: 64 full-size streams on one GPU and the RCCL index broadcast behind the C ABI
+(SURVEY.md section 8e).  The 8-GPU run itself is the driver's; what one GPU can show is the per-rank work of configs[4] -- 64 streams,
+index delivered by rvc_index_broadcast through a real RCCL communicator -- and the launcher with one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from common import BASELINE_160MS as g, ROOT, rms, voice_signal, zoo
+from obs_rvc_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+PCM_TOL = 1e-3          # BASELINE.json north_star: +-1e-3 RMS on the float PCM output
+
+
+def _oracle(z, seed, stream):
+    from oracle import oracle as O
+    o = O.OracleRvcInfer(z["data"]); o.load_contentvec(2); o.load_f0(1); o.load_model(z["model"]); o.set_noise_seed(seed, stream)
+    return o
+
+
+def test_64_full_size_streams_throughput_mode():
+    # BASELINE configs[3] at its stated size: 64 concurrent streams, full v2-768 + RMVPE + v2-48k, batched per stage.
+    # finite + shapes, determinism across two engines, per-stream state advance, and three streams against the oracle
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("full")
+    S = 64
+    xin = np.stack([voice_signal(g.input_buffer_16k_size, seed=300 + s) for s in range(S)])
+    outs = []
+    for rep in range(2):
+        eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"])
+        eng.set_streams(S); eng.set_noise_seed(11, 1000)
+        y0 = eng.infer_batch(xin, g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+        y1 = eng.infer_batch(xin, g.sample_frame_16k, 12, g.skip_head, g.model_return_length)     # second chunk: counters / pitch cache moved
+        assert y0.shape == (S, g.model_return_size) and np.isfinite(y0).all() and np.isfinite(y1).all()
+        assert not np.array_equal(y0, y1)
+        outs.append((y0, y1))
+        if rep == 0:
+            cache5 = eng.pitch_cache(5)
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])       # bitwise reproducible
+    assert len({outs[0][0][s].tobytes() for s in range(S)}) == S                                   # 64 different streams, 64 different outputs
+    for s in (0, 31, 63):
+        o = _oracle(z, 11, 1000 + s)
+        yo0 = o.infer(xin[s], g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+        yo1 = o.infer(xin[s], g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+        assert rms(outs[0][0][s] - yo0) < PCM_TOL and rms(outs[0][1][s] - yo1) < PCM_TOL, s
+    o5 = _oracle(z, 11, 1005)
+    for _ in range(2):
+        o5.infer(xin[5], g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+    assert np.allclose(cache5, o5.pitch_cache(), rtol=1e-5, atol=1e-3)       # per-stream state (stream 5's pitch cache) after two chunks
+
+
+def test_index_broadcast_through_rccl_one_rank():
+    # rvc_rccl_unique_id + rvc_index_broadcast with a ONE-rank communicator: librccl is loaded (dlopen), ncclCommInitRank,
+    # two ncclBroadcast calls (header, matrix) and ncclCommDestroy really run; the engine then retrieves exactly as after rvc_load_index
+    from obs_rvc_amd import dist as rdist
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("tiny")
+    cfg, _ = W.read_blob(os.path.join(z["data"], "contentvec", "vec-768-layer-12.rvcw"))
+    dim = int(cfg["out_dim"])
+    vecs = W.make_index(3000, dim, seed=5)
+    x = voice_signal(g.input_buffer_16k_size, seed=41)
+    a = RvcInfer(z["data"]); a.load_contentvec(2); a.load_f0(); a.load_model(z["model"]); a.set_noise_seed(3, 0)
+    a.load_index(vecs); a.set_index_rate(0.75)
+    ya = a.infer(x, 2560, 12, 200, 21); ia, da = a.knn()
+    b = RvcInfer(z["data"]); b.load_contentvec(2); b.load_f0(); b.load_model(z["model"]); b.set_noise_seed(3, 0)
+    uid = b.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    rdist.load_shared_index(b, vecs, 3000, dim, 0, 1)
+    b.set_index_rate(0.75)
+    yb = b.infer(x, 2560, 12, 200, 21); ib, db = b.knn()
+    assert np.array_equal(ia, ib) and np.array_equal(da, db) and np.array_equal(ya, yb)
+    # rank 0 may also re-send the index its engine already holds (vectors = NULL)
+    b.index_broadcast(b.rccl_unique_id(), 0, 1, None)
+    assert np.array_equal(b.infer(x, 2560, 12, 200, 21).shape, ya.shape)
+    from obs_rvc_amd.rvc_common import RvcInferError
+    c = RvcInfer(z["data"])
+    with pytest.raises(RvcInferError):
+        c.index_broadcast(c.rccl_unique_id(), 0, 1, None)          # rank 0 with nothing to send
+    with pytest.raises(RvcInferError):
+        c.index_broadcast(uid, 3, 2, None)                         # rank outside the world
+
+
+def test_bench_line_single_rank_smoke():
+    # the bench contract on the tiny preset: one JSON line, the keys the driver reads, n_gpus = ranks that ran
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--preset", "tiny", "--steps", "5", "--warmup", "2", "--no-cpu"],
+                       capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 5 and j["value"] > 0 and j["roofline"]["frac"] > 0 and j["roofline"]["sum_kernel_ms"] > 0
+
+
+def test_binary_was_built_from_these_sources():
+    # build provenance: the loaded library reports the hash of the sources on disk
+    from obs_rvc_amd import _native
+    v = _native.lib().rvc_version().decode()
+    assert v.endswith("rvc-mi355x-src:" + _native.source_hash()), v

@@ -26,6 +26,10 @@ def test_rpc_binary_usage_line():
     import subprocess
     r = subprocess.run([_native.RPC_PATH, "v2", "rmvpe"], capture_output=True, timeout=30)
     assert r.returncode == 0 and b"Usage: rvc-rpc <version> <f0_algorithm> <model> <data>" in r.stderr
+    # the reference checks `args.len() < 4` but reads args[4] (rvc-rpc/src/main.rs:14,22): three arguments pass the usage check
+    # and then panic on the index -> exit status 101, no usage line
+    r = subprocess.run([_native.RPC_PATH, "v2", "rmvpe", "model.onnx"], capture_output=True, timeout=30)
+    assert r.returncode == 101 and b"Usage" not in r.stderr
 
 
 @pytest.mark.gpu
