@@ -244,18 +244,100 @@ def test_native_session_at_the_plugin_maximum_settings():
     pys = StreamingSession(e2, g, 12, 0.6, 4800, lambda ri, ro, n: FftFixedInOut(e2, ri, ro, n))
     ors = StreamingSession(ora, g, 12, 0.6, 4800, lambda ri, ro, n: RO.FftFixedInOut(ri, ro, n))
     a = np.interp(np.arange(72000 * 3) / 48000.0, np.arange(24000 * 3) / 16000.0, voice_signal(24000 * 3, seed=12)).astype(np.float32)
-    agree = 0
+    report = []
     for c in range(3):
         ch = a[c * 72000:(c + 1) * 72000]
         fn, fp, fo = nat.process_one_frame(ch), pys.process_one_frame(ch), ors.process_one_frame(ch)
         assert fn.shape == fo.shape == (72000,) and nat.last_sola_offset == pys.last_sola_offset
         assert np.abs(fn - fp).max() < 5e-5, (c, float(np.abs(fn - fp).max()))
         assert np.abs(pys.input_buffer_16k - ors.input_buffer_16k).max() < 5e-5
-        # the decode's arg-max over 360 salience bins is a discrete decision: on a near-tie (flat synthetic salience) the two fp32
-        # summation orders may pick neighbouring bins, the f0 of that frame moves by 20 cents and stays in the pitch cache --
-        # compare audio only while every decision agreed
-        same_decisions = np.abs(e1.pitch_cache() - ora.pitch_cache()).max() < 0.5 and nat.last_sola_offset == ors.last_sola_offset
-        if same_decisions:
-            agree += 1
+        # Two steps of the chain are discrete decisions: the decode's arg-max over 360 salience bins and the SOLA lag search.  On a
+        # near-tie (flat synthetic salience) two fp32 summation orders may pick neighbouring bins; that frame's f0 then moves by one
+        # 20-cent bin and stays in the pitch cache.  Every chunk is judged: either all decisions agree and the audio matches to the
+        # parity tolerance, or each disagreement is NAMED and must be exactly such a one-bin / voicing-threshold move.
+        ce, co = e1.pitch_cache(), ora.pitch_cache()
+        flips = np.nonzero(np.abs(ce - co) >= 0.5)[0]
+        sola_flip = nat.last_sola_offset != ors.last_sola_offset
+        if flips.size == 0 and not sola_flip:
             assert rms(fn - fo) < 1e-3, (c, rms(fn - fo))
-    assert agree >= 1
+            report.append((c, "all decisions agree"))
+            continue
+        named = []
+        for i in flips:
+            if ce[i] > 0 and co[i] > 0:
+                cents = abs(1200.0 * np.log2(ce[i] / co[i]))
+                assert cents < 25.0, "chunk %d: pitch cache[%d] differs by %.1f cents (engine %.3f Hz, oracle %.3f Hz): more than one salience bin" % (c, i, cents, ce[i], co[i])
+                named.append("cache[%d] one-bin arg-max flip (%.1f cents)" % (i, cents))
+            else:
+                named.append("cache[%d] voicing-threshold flip (%.3f vs %.3f Hz)" % (i, ce[i], co[i]))
+        if sola_flip:
+            named.append("SOLA offset %d vs %d" % (nat.last_sola_offset, ors.last_sola_offset))
+        assert flips.size <= 4, "chunk %d: %d pitch-cache entries differ -- not isolated near-ties: %s" % (c, flips.size, named)
+        report.append((c, named))
+    assert report[0][1] == "all decisions agree", report          # the first 1.5 s chunk has had no earlier decision to inherit
+    print("decision report:", report)
+
+
+@pytest.mark.gpu
+def test_native_session_full_size_v2_48k_matches_oracle_chain():
+    # rvc_session_process on the FULL model (v2-768 ContentVec + RMVPE + v2-48k synthesizer, BASELINE's 160 ms geometry): the whole
+    # plugin-side chain as one native call against the all-CPU chain (oracle infer + numpy/scipy resamplers + reference post-processing)
+    from oracle import resample_oracle as RO
+    from obs_rvc_amd.rvc import RvcInfer
+    from obs_rvc_amd.streaming import NativeStreamingSession, StreamingSession
+    g = derive(48000, 0.16, 0.07, 2.0, 48000)
+    z = zoo("full")
+    eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"]); eng.set_noise_seed(5, 0)
+    ora = O.OracleRvcInfer(z["data"]); ora.load_contentvec(2); ora.load_f0(1); ora.load_model(z["model"]); ora.set_noise_seed(5, 0)
+    nat = NativeStreamingSession(eng, 48000, 0.16, 0.07, 2.0, 48000, 12, 0.75)
+    assert (nat.sample_frame_size, nat.input_buffer_16k_size, nat.model_return_length, nat.model_return_size, nat.skip_head) == (7680, 35840, 21, 10080, 200)
+    ors = StreamingSession(ora, g, 12, 0.75, 48000, lambda ri, ro, n: RO.FftFixedInOut(ri, ro, n))
+    n_ch = 18                         # the 2.24 s ring is full of audio from chunk 14 on
+    a = np.interp(np.arange(7680 * n_ch) / 48000.0, np.arange(2560 * n_ch) / 16000.0, voice_signal(2560 * n_ch, seed=21)).astype(np.float32)
+    from obs_rvc_amd.rvc_common import RvcInferError
+    compared = full = settle = 0
+    prev_same = False
+    for c in range(n_ch):
+        ch = a[c * 7680:(c + 1) * 7680]
+        try:
+            fn = nat.process_one_frame(ch)
+            pe = None
+        except RvcInferError as ex:
+            pe = ex
+        try:
+            fo = ors.process_one_frame(ch)
+            po = None
+        except Exception as ex:
+            po = ex
+        # a chunk on which the reference would panic (rmvpe.rs:124, flat synthetic salience on a mostly-zero ring) must do so on both sides
+        assert (pe is None) == (po is None), (c, pe, po)
+        if pe is not None:
+            # the reference process dies here and the plugin respawns it with fresh state (obs-rvc/src/lib.rs:716-727); the engine
+            # reports RVC_PANIC after the chunk has run, so its pitch cache / chunk counter have moved: restart both sides' state
+            assert "Panic" in str(pe)
+            eng.reset_state(); ora.reset_state()
+            prev_same = False
+            settle = 2        # the native chain ran to its end on that chunk (converter overlap, SOLA tail), the CPU chain stopped at infer
+            continue
+        if settle:
+            settle -= 1
+            continue
+        assert fn.shape == fo.shape == (7680,)
+        if np.abs(eng.pitch_cache() - ora.pitch_cache()).max() >= 0.5:
+            continue                                   # an arg-max near-tie flipped (see the maximum-settings test): audio not comparable
+        # The synthetic synthesizer emits noise-like audio, so the 480-lag SOLA search has no dominant peak and the two fp32 summation
+        # orders rarely pick the same lag.  Everything else is compared exactly where it must agree: the frame is
+        # output[off .. off + 7680] of the envelope-mixed, upsampled model output, cross-faded over its first sola_buffer_frame_size
+        # samples -- behind the cross-fade the two frames are the same signal shifted by the difference of the two offsets.
+        oe, oo, xf = nat.last_sola_offset, ors.last_sola_offset, g.sola_buffer_frame_size
+        d = oo - oe
+        a_e = fn[xf + max(d, 0):7680 + min(d, 0)]
+        a_o = fo[xf + max(-d, 0):7680 + min(-d, 0)]
+        assert a_e.shape == a_o.shape and a_e.size > 4000
+        assert rms(a_e - a_o) < 1e-3, (c, oe, oo, rms(a_e - a_o), rms(a_o))
+        compared += 1
+        if oe == oo and prev_same:
+            assert rms(fn - fo) < 1e-3, (c, rms(fn - fo))         # same lag twice in a row: the cross-faded head agrees too
+            full += 1
+        prev_same = oe == oo
+    assert compared >= 10, (compared, full)
