@@ -367,6 +367,18 @@ static int g_last_waves = 0, g_last_wgs = 0;
 static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases)
 {
     p.probe = g_kprobe;
+    // many streams: fold them into the N axis (one launch-wide column index instead of a grid dimension), so that tiles are cut from
+    // B * N columns -- the ContentVec window (N = 111), the text encoder (N = 21) or RMVPE's deep levels (N = 4..64) no longer pad
+    // every stream up to a tile.  All offsets stay below 2^31 bytes / elements for every geometry the plugin can ask for (checked).
+    const int streams = B;
+    if (B > 1 && !getenv("RVC_NO_FOLD")) {
+        const long long lim = (1LL << 29);
+        if ((long long)B * p.x_bs < lim && (long long)B * p.y_bs < lim && (long long)B * (p.res ? p.res_bs : 0) < lim && (long long)B * p.N < (1LL << 30) &&
+            (size_t)(p.K / 16) * 64 <= 60 * 1024) {      // (the two-stage grid split-K fallback keeps the batch as a grid dimension)
+            p.fold_n = p.N; p.N = B * p.N; B = 1;
+        }
+    }
+    (void)streams;
     // table entries become non-negative byte offsets; the kernel moves the base pointer back by koff_bias bytes
     std::vector<int> kb(koff);
     int kmin = 0;
@@ -378,6 +390,10 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     std::vector<PhaseD> phv(phases);
     double ksum = 0;   // sum of the phases' K (phases of a fused launch may differ; p.K is the maximum)
     for (PhaseD &q : phv) { if (q.nchunks == 0) q.nchunks = p.K / 16; ksum += q.nchunks * 16.0; }
+    // phases of unequal length (the fused ResBlock chains: kernel sizes 3 / 7 / 11) are dispatched longest first: the grid's z axis
+    // is walked last, so the workgroups of phase 0 start first and the short phases fill the tail instead of the long one forming it
+    if (!getenv("RVC_NO_LPT"))
+        std::stable_sort(phv.begin(), phv.end(), [](const PhaseD &a, const PhaseD &b) { return a.nchunks > b.nchunks; });
     p.ph = pl.arena.upload(phv);
     p.nphase = (int)phv.size();
     p.ph0 = phv[0];
@@ -424,8 +440,9 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     }
     if (lds_cfg >= 0) {
         const int bm = lds_cfg == 0 ? 128 : (lds_cfg == 1 ? 64 : 32), bn = lds_cfg == 0 ? 128 : 256;
-        p.ksplit = 1; p.chunks_per_split = nchunks; p.m_fast = 0;
+        p.ksplit = 1; p.chunks_per_split = nchunks;
         p.ntm = (p.M + bm - 1) / bm; p.ntn = (p.N + bn - 1) / bn;
+        p.m_fast = p.fold_n ? p.ntm : 0;
         dim3 grid(p.ntm * p.ntn, B * p.nphase);
         const size_t lds = (size_t)nchunks * 64 + (size_t)2 * 16 * (bn + 4) * 4;
         const double flops = 2.0 * p.M * (double)p.N * ksum * B;
@@ -473,7 +490,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     if (ksplit > 1) p.part = pl.arena.floats((size_t)B * p.nphase * ksplit * p.M * p.N);
     // weight-heavy layers (short N: the transformer at T=111, RMVPE's deep levels, the synth encoder): keep all tiles that
     // read the same weight rows on one XCD so each weight byte crosses the fabric once (per-XCD L2s are private)
-    bool weight_heavy = p.N <= 512 && (long long)p.M * p.K >= 64 * 1024 && p.ntm >= 8;
+    bool weight_heavy = (p.N <= 512 && (long long)p.M * p.K >= 64 * 1024 && p.ntm >= 8) || (p.fold_n && p.ntm >= 2);
     if (const char *f = getenv("RVC_FORCE_MFAST")) weight_heavy = atoi(f) != 0;
     p.m_fast = weight_heavy ? (p.ntm + 7) / 8 * 8 : 0;
     const int ntiles = weight_heavy ? p.m_fast * p.ntn : p.ntm * p.ntn;
@@ -489,7 +506,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
         // workgroup (x, y) runs on XCD x % 8 when gridDim.x is a multiple of 8: all tiles of one weight-row block then share one
         // XCD's L2.  Only when the padding is cheap and every XCD still gets live workgroups (a short axis padded to 8 would park
         // all the work on a few XCDs: measured 3.6x slower at 64 streams)
-        if (weight_heavy && (wg_ks > 1 || gx >= 16)) gx = (gx + 7) / 8 * 8;
+        if (weight_heavy && ((wg_ks > 1 && gx >= 8) || gx >= 16)) gx = (gx + 7) / 8 * 8;
         grid = dim3(gx, (unsigned)slow_n, (unsigned)(B * p.nphase));
         if (grid.y > 65535 || grid.z > 65535) throw ShapeError("implicit GEMM grid too large");
         p.nbatch = B;
@@ -1753,9 +1770,11 @@ static void issue_ops(rvc_engine *e, Plan &pl, bool capturing)
     // fork/join through events; under stream capture the auxiliary streams become parallel branches of the hipGraph
     const std::vector<int> &ord = capturing ? pl.ops.order_graph : pl.ops.order_eager;
     const size_t n = pl.ops.v.size();
+    static const bool serial = getenv("RVC_SERIAL_BRANCHES") != nullptr;   // tuning aid: every op on the main stream (true per-kernel times)
     for (size_t k = 0; k < n; k++) {
-        const size_t i = k < ord.size() ? (size_t)ord[k] : k;      // ops queued after the reordered prefix keep their position
-        const int sid = pl.ops.sid[i];
+        const size_t i = (k < ord.size() && !serial) ? (size_t)ord[k] : k;      // ops queued after the reordered prefix keep their position
+        const int sid = serial ? 0 : pl.ops.sid[i];
+        if (serial && pl.ops.kind[i] != 0) continue;
         hipStream_t st = sid == 0 ? e->stream : e->aux[sid - 1];
         if (pl.ops.kind[i] == 1) {
             if (e->pipe_now && (sid == 1 || sid == 3)) continue;      // pipelined: the front branches are ordered by events, not by the main stream

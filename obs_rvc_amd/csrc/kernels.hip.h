@@ -70,12 +70,15 @@ struct IgemmP {
     int m_fast;              // XCD-aware tile order: >0 = ntm rounded up to 8, m fastest (workgroup b runs on XCD b%8, so all
                              // n-tiles of one weight-row block share one XCD's L2); 0 = n fastest (activation-heavy layers)
     int nbatch;              // igemm2: streams in the launch (grid z = batch * nphase + phase)
+    int fold_n;              // > 0: the streams of the launch are folded into the N axis: position n = stream (n / fold_n), local position
+                             // (n % fold_n); N = streams * fold_n and the launch has one batch (tiles may straddle streams, nothing is padded per stream)
     int lin_cs4;             // igemm2 LIN layers (1x1 conv on a 1-D tensor): input channel stride in BYTES, k-th operand row = k * lin_cs4
 };
 
 __device__ __forceinline__ void epilogue_store(const IgemmP &p, const PhaseD &ph, int b, int m, int n, float acc)
 {
     if (m >= p.M || n >= p.N) return;
+    if (p.fold_n) { b = n / p.fold_n; n -= b * p.fold_n; }
     int nh = 0, nw = n;
     if (p.y_hm) { nh = n / p.NW; nw = n - nh * p.NW; }
     const int ow = nw * p.y_ws + ph.y_pos, oh = nh * p.y_hm + ph.y_h0;
@@ -97,6 +100,7 @@ __device__ __forceinline__ void epilogue_store(const IgemmP &p, const PhaseD &ph
 __device__ __forceinline__ void glu_store(const IgemmP &p, const PhaseD &ph, int b, int m1, int n, float a1, float a2)
 {
     if (m1 >= p.M || n >= p.N) return;
+    if (p.fold_n) { b = n / p.fold_n; n -= b * p.fold_n; }
     const float ta = a1 + p.bias[ph.bias_off + m1], sa = a2 + p.bias[ph.bias_off + m1 + 2];
     const int ch = (m1 >> 4) * 8 + ((m1 & 15) >> 2) * 2 + (m1 & 1) + ph.y_c0;
     p.y[(long long)b * p.y_bs + (long long)ch * p.y_cs + n] = tanhf(ta) * (1.0f / (1.0f + expf(-sa)));
@@ -436,14 +440,16 @@ __device__ __forceinline__ Epi2 epi2_prefetch(const IgemmP &p, const PhaseD &ph,
 {
     Epi2 e = {0.f, 0.f, 0.f, -1};
     if (m >= p.M || n >= p.N) return e;
+    int bb = 0;
+    if (p.fold_n) { bb = n / p.fold_n; n -= bb * p.fold_n; }
     int nh = 0, nw = n;
     if (p.y_hm) { nh = n / p.NW; nw = n - nh * p.NW; }
     const int ow = nw * p.y_ws + ph.y_pos, oh = nh * p.y_hm + ph.y_h0;
     if (ow < 0 || ow >= p.OW) return e;
     const int ch = m + ph.y_c0;
-    e.yo = ch * p.y_cs + oh * p.y_rs + ow;
+    e.yo = bb * (int)p.y_bs + ch * p.y_cs + oh * p.y_rs + ow;
     if (p.bias) e.bias = p.bias[ph.bias_off + m];
-    if (resb) e.res = resb[(p.res_nogroup ? m : ch) * p.res_cs + oh * p.res_rs + ow];
+    if (resb) e.res = resb[bb * (int)p.res_bs + (p.res_nogroup ? m : ch) * p.res_cs + oh * p.res_rs + ow];
     if (p.accumulate) e.yold = yb[e.yo];
     return e;
 }
@@ -456,6 +462,43 @@ template <int ACT> __device__ __forceinline__ void epi2_finish(const IgemmP &p, 
     v += e.yold;
     yb[e.yo] = v;
 }
+// Column part of the output address (everything that depends on n only: stream, row, column, validity), computed once per MFMA
+// column instead of once per element -- with folded streams it holds an integer division.
+struct ColOut { int yo, ro; };          // yo < 0: column not stored
+__device__ __forceinline__ ColOut col_locate(const IgemmP &p, const PhaseD &ph, int n)
+{
+    ColOut c = {-1, 0};
+    if (n >= p.N) return c;
+    int bb = 0;
+    if (p.fold_n) { bb = n / p.fold_n; n -= bb * p.fold_n; }
+    int nh = 0, nw = n;
+    if (p.y_hm) { nh = n / p.NW; nw = n - nh * p.NW; }
+    const int ow = nw * p.y_ws + ph.y_pos, oh = nh * p.y_hm + ph.y_h0;
+    if (ow < 0 || ow >= p.OW) return c;
+    c.yo = bb * (int)p.y_bs + oh * p.y_rs + ow;
+    c.ro = bb * (int)p.res_bs + oh * p.res_rs + ow;
+    return c;
+}
+__device__ __forceinline__ Epi2 epi2_from_col(const IgemmP &p, const PhaseD &ph, const float *resb, const float *yb, const ColOut &c, int m)
+{
+    Epi2 e = {0.f, 0.f, 0.f, -1};
+    if (m >= p.M || c.yo < 0) return e;
+    const int ch = m + ph.y_c0;
+    e.yo = c.yo + ch * p.y_cs;
+    if (p.bias) e.bias = p.bias[ph.bias_off + m];
+    if (resb) e.res = resb[c.ro + (p.res_nogroup ? m : ch) * p.res_cs];
+    if (p.accumulate) e.yold = yb[e.yo];
+    return e;
+}
+// fused WaveNet gate on a located column (see glu_store)
+__device__ __forceinline__ void glu_from_col(const IgemmP &p, const PhaseD &ph, float *yb, const ColOut &c, int m1, float a1, float a2)
+{
+    if (m1 >= p.M || c.yo < 0) return;
+    const float ta = a1 + p.bias[ph.bias_off + m1], sa = a2 + p.bias[ph.bias_off + m1 + 2];
+    const int ch = (m1 >> 4) * 8 + ((m1 & 15) >> 2) * 2 + (m1 & 1) + ph.y_c0;
+    yb[c.yo + ch * p.y_cs] = tanhf(ta) * (1.0f / (1.0f + expf(-sa)));
+}
+
 #define RVC_ACT_DISPATCH(STMT)                                                   \
     switch (p.act) {                                                             \
     case ACT_RELU: { constexpr int A_ = ACT_RELU; STMT } break;                  \
@@ -530,12 +573,14 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
             }
         } else {
 #pragma unroll
-            for (int mf = 0; mf < ((KS > 1 || !PF) ? 1 : MF); mf++)
+            for (int nf = 0; nf < ((KS > 1 || !PF) ? 1 : NF); nf++) {
+                const ColOut col = col_locate(p, ph, tn * 16 * NF + nf * 16 + li);
 #pragma unroll
-                for (int nf = 0; nf < ((KS > 1 || !PF) ? 1 : NF); nf++)
+                for (int mf = 0; mf < ((KS > 1 || !PF) ? 1 : MF); mf++)
 #pragma unroll
                     for (int r = 0; r < 4; r++)
-                        pre_w[mf][nf][r] = epi2_prefetch(p, ph, resb, yb, tm * 16 * MF + mf * 16 + kq * 4 + r, tn * 16 * NF + nf * 16 + li);
+                        pre_w[mf][nf][r] = epi2_from_col(p, ph, resb, yb, col, tm * 16 * MF + mf * 16 + kq * 4 + r);
+            }
         }
     }
     RVC_KP(9);
@@ -546,9 +591,11 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
     for (int nf = 0; nf < NF; nf++) {
         int n = tn * 16 * NF + nf * 16 + li;
         n = n < p.N ? n : p.N - 1;
+        int bb = 0;
+        if (p.fold_n) { bb = n / p.fold_n; n -= bb * p.fold_n; }
         int nh = 0, nw = n;
         if (p.x_hs) { nh = n / p.NW; nw = n - nh * p.NW; }
-        xo[nf] = (unsigned)(nh * p.x_hs + nw * p.x_ws) * 4u;
+        xo[nf] = (unsigned)(bb * (int)p.x_bs + nh * p.x_hs + nw * p.x_ws) * 4u;
         if (LIN) xo[nf] += (unsigned)((c0 * 16 + kq * 4) * p.lin_cs4);
     }
     // weights: MFMA-fragment order [m_tile][chunk][lane][4]
@@ -628,6 +675,37 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
     }
     RVC_KP(2);
     int c = 0;
+#if !defined(RVC_EXP) || RVC_EXP == 2
+    // steady state: every operand register is reloaded right after its last use, so the loads of the next round are interleaved with
+    // the MFMAs of this one instead of forming a block during which the matrix pipe drains (measured at 64 streams: the 768 x 3072
+    // projection 75 -> 92 TF/s, the 768 x 768 one 61 -> 78 TF/s; no change at one stream)
+#define RVC_FUSED_STAGE(S, C)                                                                          \
+    {                                                                                                  \
+        const int cc_ = (C);                                                                           \
+        int4 ko_;                                                                                      \
+        if (LIN) { const unsigned kb_ = (unsigned)cc_ * lin16; ko_ = make_int4((int)kb_, (int)(kb_ + lin1), (int)(kb_ + 2u * lin1), (int)(kb_ + 3u * lin1)); } \
+        else { ko_ = ko_nx; ko_nx = kol[(cc_ + 1 < nc ? cc_ + 1 : cc_) * 4]; }                         \
+        const unsigned kov_[4] = {(unsigned)ko_.x, (unsigned)ko_.y, (unsigned)ko_.z, (unsigned)ko_.w}; \
+        f32x4 a_old_[MF];                                                                              \
+        _Pragma("unroll") for (int mf = 0; mf < MF; mf++) a_old_[mf] = a_st[S][mf];                    \
+        _Pragma("unroll") for (int mf = 0; mf < MF; mf++) a_st[S][mf] = *reinterpret_cast<const f32x4 *>(wrow[mf] + cc_ * 256); \
+        _Pragma("unroll") for (int j = 0; j < 4; j++)                                                  \
+            _Pragma("unroll") for (int nf = 0; nf < NF; nf++) {                                        \
+                const float bv_ = PRE ? fmaxf(b_st[S][nf][j], b_st[S][nf][j] * pre_slope) : b_st[S][nf][j]; \
+                _Pragma("unroll") for (int mf = 0; mf < MF; mf++)                                      \
+                    acc[j % NACC][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_old_[mf][j], bv_, acc[j % NACC][mf][nf], 0, 0, 0); \
+                b_st[S][nf][j] = *reinterpret_cast<const float *>(xb + (xo[nf] + kov_[j]));            \
+            }                                                                                          \
+    }
+    // (tiles of at least four fragments only: the lone-fragment tile with its two alternating accumulators produced wrong results in
+    //  this form on LIN layers -- cause not found, so it keeps the two-block loop below, which its 12-deep prefetch hides anyway)
+    if (MF * NF >= 4) {
+        for (; c + 2 * D <= nc; c += D) {
+#pragma unroll
+            for (int s = 0; s < D; s++) RVC_FUSED_STAGE(s, c + s + D)
+        }
+    }
+#undef RVC_FUSED_STAGE
     for (; c + 2 * D <= nc; c += D) {
 #pragma unroll
         for (int s = 0; s < D; s++) {
@@ -637,6 +715,21 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+#else
+    for (; c + 2 * D <= nc; c += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            RVC_COMPUTE_STAGE(s)
+#if !defined(RVC_EXP) || RVC_EXP != 1
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            RVC_LOAD_STAGE(s, c + s + D)
+#if !defined(RVC_EXP) || RVC_EXP != 1
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    }
+#endif
     for (; c < nc; c += D) {
 #pragma unroll
         for (int s = 0; s < D; s++) {
@@ -704,12 +797,14 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
     // D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
     if (p.glu) {
 #pragma unroll
-        for (int mf = 0; mf < MF; mf++)
+        for (int nf = 0; nf < NF; nf++) {
+            const ColOut col = col_locate(p, ph, tn * 16 * NF + nf * 16 + li);
 #pragma unroll
-            for (int nf = 0; nf < NF; nf++)
+            for (int mf = 0; mf < MF; mf++)
 #pragma unroll
                 for (int r = 0; r < 2; r++)
-                    glu_store(p, ph, b, tm * 16 * MF + mf * 16 + kq * 4 + r, tn * 16 * NF + nf * 16 + li, acc[0][mf][nf][r], acc[0][mf][nf][r + 2]);
+                    glu_from_col(p, ph, yb, col, tm * 16 * MF + mf * 16 + kq * 4 + r, acc[0][mf][nf][r], acc[0][mf][nf][r + 2]);
+        }
         return;
     }
     if (PF) {
@@ -720,11 +815,14 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
                         epi2_finish<A_>(p, yb, acc[0][mf][nf][r], pre_w[PF ? mf : 0][PF ? nf : 0][r]);
         )
     } else {
+        ColOut cols[NF];
+#pragma unroll
+        for (int nf = 0; nf < NF; nf++) cols[nf] = col_locate(p, ph, tn * 16 * NF + nf * 16 + li);
         RVC_ACT_DISPATCH(
             _Pragma("unroll") for (int mf = 0; mf < MF; mf++)
                 _Pragma("unroll") for (int nf = 0; nf < NF; nf++)
                     _Pragma("unroll") for (int r = 0; r < 4; r++) {
-                        const Epi2 e_ = epi2_prefetch(p, ph, resb, yb, tm * 16 * MF + mf * 16 + kq * 4 + r, tn * 16 * NF + nf * 16 + li);
+                        const Epi2 e_ = epi2_from_col(p, ph, resb, yb, cols[nf], tm * 16 * MF + mf * 16 + kq * 4 + r);
                         epi2_finish<A_>(p, yb, acc[0][mf][nf][r], e_);
                     }
         )
@@ -748,7 +846,9 @@ __global__ __launch_bounds__(256) void igemm_lds_kernel(IgemmP p)
     extern __shared__ __attribute__((aligned(16))) int s_mem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int tn = blockIdx.x % p.ntn, tm = blockIdx.x / p.ntn;
+    // m fastest when the streams are folded into N: consecutive workgroups (= consecutive XCDs) take the m-tiles of ONE activation
+    // tile, so a weight-row block stays in one XCD's L2 while the activations stream through once per XCD
+    const int tn = p.m_fast ? (int)blockIdx.x / p.ntm : (int)blockIdx.x % p.ntn, tm = p.m_fast ? (int)blockIdx.x % p.ntm : (int)blockIdx.x / p.ntn;
     int z = blockIdx.y;
     const int phase = z % p.nphase;
     const int b = z / p.nphase;
@@ -768,9 +868,11 @@ __global__ __launch_bounds__(256) void igemm_lds_kernel(IgemmP p)
     {
         int n = tn * BN + n_s;
         n = n < p.N ? n : p.N - 1;
+        int bb = 0;
+        if (p.fold_n) { bb = n / p.fold_n; n -= bb * p.fold_n; }
         int nh = 0, nw = n;
         if (p.x_hs) { nh = n / p.NW; nw = n - nh * p.NW; }
-        xo_s = (unsigned)(nh * p.x_hs + nw * p.x_ws) * 4u;
+        xo_s = (unsigned)(bb * (int)p.x_bs + nh * p.x_hs + nw * p.x_ws) * 4u;
     }
     const float *wrow[MF];
     const int mtiles = (p.M + 15) >> 4;
@@ -831,6 +933,11 @@ __global__ __launch_bounds__(256) void igemm_lds_kernel(IgemmP p)
         for (int mf = 0; mf < MF; mf++) a_cur[mf] = a_nxt[mf];
         __syncthreads();
     }
+    const float *resb = p.res ? p.res + (long long)b * p.res_bs : nullptr;
+    float *yb = p.y + (long long)b * p.y_bs;
+    ColOut cols[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; nf++) cols[nf] = col_locate(p, ph, tn * BN + (wn * NF + nf) * 16 + li);
     if (p.glu) {
 #pragma unroll
         for (int mf = 0; mf < MF; mf++)
@@ -838,16 +945,17 @@ __global__ __launch_bounds__(256) void igemm_lds_kernel(IgemmP p)
             for (int nf = 0; nf < NF; nf++)
 #pragma unroll
                 for (int r = 0; r < 2; r++)
-                    glu_store(p, ph, b, ((tm * WM + wm) * MF + mf) * 16 + kq * 4 + r, tn * BN + (wn * NF + nf) * 16 + li, acc[mf][nf][r], acc[mf][nf][r + 2]);
+                    glu_from_col(p, ph, yb, cols[nf], ((tm * WM + wm) * MF + mf) * 16 + kq * 4 + r, acc[mf][nf][r], acc[mf][nf][r + 2]);
         return;
     }
-#pragma unroll
-    for (int mf = 0; mf < MF; mf++)
-#pragma unroll
-        for (int nf = 0; nf < NF; nf++)
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                epilogue_store(p, ph, b, ((tm * WM + wm) * MF + mf) * 16 + kq * 4 + r, tn * BN + (wn * NF + nf) * 16 + li, acc[mf][nf][r]);
+    RVC_ACT_DISPATCH(
+        _Pragma("unroll") for (int mf = 0; mf < MF; mf++)
+            _Pragma("unroll") for (int nf = 0; nf < NF; nf++)
+                _Pragma("unroll") for (int r = 0; r < 4; r++) {
+                    const Epi2 e_ = epi2_from_col(p, ph, resb, yb, cols[nf], ((tm * WM + wm) * MF + mf) * 16 + kq * 4 + r);
+                    epi2_finish<A_>(p, yb, acc[mf][nf][r], e_);
+                }
+    )
 }
 
 // second stage of a split-K launch: fixed-order (deterministic) sum of the partials + epilogue

@@ -11,6 +11,7 @@ SHAPES = {  # name: (M, Cin, KW, dil, N)
 }
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     from obs_rvc_amd import _native
     L = _native.lib()
     L.rvc_debug_conv_bench.restype = C.c_double
