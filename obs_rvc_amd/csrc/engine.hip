@@ -436,10 +436,16 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
             // (M <= 64) weight panels, the register-direct kernel in between (cv_ff2 91 vs 73 TF/s, cv_o 77 vs 62, enc_ff1 24 vs 13)
             const bool lds_wins = p.M >= 2048 || p.M <= 64;
             if (wgs >= 384 && lds_wins) lds_cfg = bm == 128 ? 0 : (bm == 64 ? 1 : 2);
+            // 32x32x2 kernel (igemm32): RVC_GEMM32 = 0 off, 1 wherever the old workgroup-tiled kernel was chosen, 2 (default) for every
+            // layer with enough workgroups to fill the chip
+            static const int g32 = getenv("RVC_GEMM32") ? atoi(getenv("RVC_GEMM32")) : 2;
+            static const long long g32_min = getenv("RVC_GEMM32_MIN") ? atoll(getenv("RVC_GEMM32_MIN")) : 768;   // fewer workgroups balance badly over 256 CUs (measured: 336 -> slower)
+            if (g32 == 1 && lds_cfg >= 0) lds_cfg += 3;
+            else if (g32 >= 2 && wgs >= g32_min) lds_cfg = 3 + (bm == 128 ? 0 : (bm == 64 ? 1 : 2));
         }
     }
     if (lds_cfg >= 0) {
-        const int bm = lds_cfg == 0 ? 128 : (lds_cfg == 1 ? 64 : 32), bn = lds_cfg == 0 ? 128 : 256;
+        const int bm = lds_cfg % 3 == 0 ? 128 : (lds_cfg % 3 == 1 ? 64 : 32), bn = lds_cfg % 3 == 0 ? 128 : 256;
         p.ksplit = 1; p.chunks_per_split = nchunks;
         p.ntm = (p.M + bm - 1) / bm; p.ntn = (p.N + bn - 1) / bn;
         p.m_fast = p.fold_n ? p.ntm : 0;
@@ -449,7 +455,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
         pl.igemm_flops += flops; pl.n_igemm++;
         Plan *plp = &pl;
         const int lc = lds_cfg;
-        { char d[160]; snprintf(d, sizeof d, "lds M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%u", p.M, p.N, p.K, B, p.nphase, bm, bn, grid.x, grid.y); pl.descs.push_back(d); }
+        { char d[160]; snprintf(d, sizeof d, "%s M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%u", lds_cfg >= 3 ? "g32" : "lds", p.M, p.N, p.K, B, p.nphase, bm, bn, grid.x, grid.y); pl.descs.push_back(d); }
         const int desc_id = (int)pl.descs.size() - 1;
         pl.ops.push_back([=](hipStream_t s) {
             ProfEvent *pe = nullptr;
@@ -460,7 +466,10 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
             hipEvent_t ea = pe ? pe->a : nullptr, eb = pe ? pe->b : nullptr;
 #define RVC_LG1(K) { if (ea) hipExtLaunchKernelGGL((K), grid, dim3(256), (uint32_t)lds, s, ea, eb, 0, p); else hipLaunchKernelGGL((K), grid, dim3(256), lds, s, p); }
 #define RVC_LG(WM, WN, MF, NF) { if (pre) RVC_LG1((igemm_lds_kernel<WM, WN, MF, NF, true>)) else RVC_LG1((igemm_lds_kernel<WM, WN, MF, NF, false>)) }
-            if (lc == 0) RVC_LG(2, 2, 4, 4) else if (lc == 1) RVC_LG(1, 4, 4, 4) else RVC_LG(1, 4, 2, 4)
+#define RVC_LG32(WM, WN, MT, NT) { if (pre) RVC_LG1((igemm32_kernel<WM, WN, MT, NT, true>)) else RVC_LG1((igemm32_kernel<WM, WN, MT, NT, false>)) }
+            if (lc == 0) RVC_LG(2, 2, 4, 4) else if (lc == 1) RVC_LG(1, 4, 4, 4) else if (lc == 2) RVC_LG(1, 4, 2, 4)
+            else if (lc == 3) RVC_LG32(2, 2, 2, 2) else if (lc == 4) RVC_LG32(1, 4, 2, 2) else RVC_LG32(1, 4, 1, 2)
+#undef RVC_LG32
 #undef RVC_LG
 #undef RVC_LG1
         });

@@ -958,6 +958,158 @@ __global__ __launch_bounds__(256) void igemm_lds_kernel(IgemmP p)
     )
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// igemm32_kernel -- throughput-mode implicit GEMM on v_mfma_f32_32x32x2_f32 (many streams: N = streams * positions is large).
+// A 256-thread workgroup owns a (WM*MT*32) x (WN*NT*32) tile; every wave a (MT*32) x (NT*32) block of 32x32 accumulators
+// (16 registers each).  Per K step of 16:
+//   * the gathered activation tile [16][BN] goes global -> registers -> LDS once per workgroup (double-buffered, ONE barrier per
+//     step, fused input LeakyReLU applied once per element) and is read back as MFMA B operands by all four waves;
+//   * the weights stream global -> registers straight from the 16-row fragment packing the latency kernels use: for a 32-row
+//     MFMA the lane (row r, k-slot s) reads the float4 of fragment r>>4, quad q = 2u+s (u = 0, 1), so the eight MFMAs of a step
+//     take k = (2u+s)*4 + j -- A and B agree on that order, no repacking, no shuffles;
+//   * 32x32x2 halves the MFMA instruction count of the 16x16x4 form and has no dependent-issue gap (64-cycle issue = 64-cycle
+//     accumulator latency), so one wave per SIMD already saturates the pipe while the next step's loads are in flight.
+// Epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): a lane owns 16 rows of ONE column, so
+// the column part of the address (stream, row, validity) is computed once per 32-column block.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int WM, int WN, int MT, int NT, bool PRE>
+__global__ __launch_bounds__(256) void igemm32_kernel(IgemmP p)
+{
+    static_assert(WM * WN == 4, "four waves per workgroup");
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    constexpr int RS = BN + 4;                     // LDS row stride: k-slots 0 / 1 (4 rows apart) land 16 banks apart
+    constexpr int KR = 256 / BN > 0 ? 256 / BN : 1;    // k rows staged per pass of the 256 threads
+    constexpr int EPT = 16 / KR;                   // staged elements per thread per K step
+    static_assert(BN <= 256 && 256 % BN == 0, "BN must divide 256");
+    extern __shared__ __attribute__((aligned(16))) int s_mem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tn = p.m_fast ? (int)blockIdx.x / p.ntm : (int)blockIdx.x % p.ntn, tm = p.m_fast ? (int)blockIdx.x % p.ntm : (int)blockIdx.x / p.ntn;
+    int z = blockIdx.y;
+    const int phase = z % p.nphase;
+    const int b = z / p.nphase;
+    const PhaseD ph = p.nphase == 1 ? p.ph0 : p.ph[phase];
+    const int nchunks = ph.nchunks;
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(p.koff + ph.koff_off);
+        int4 *dst = reinterpret_cast<int4 *>(s_mem);
+        for (int i = threadIdx.x; i < nchunks * 4; i += 256) dst[i] = src[i];
+    }
+    float *bt = reinterpret_cast<float *>(s_mem + nchunks * 16);     // [2][16][RS]
+    const int c32 = lane & 31, ks = lane >> 5;                       // MFMA column (B) / row (A) and k-slot of this lane
+    const char *xb = reinterpret_cast<const char *>(p.x + (long long)b * p.x_bs + ph.x_off) - p.koff_bias;
+    // staging role: column n_s of the tile, k rows kr0, kr0 + KR, ...
+    const int n_s = threadIdx.x % BN, kr0 = threadIdx.x / BN;
+    unsigned xo_s;
+    {
+        int n = tn * BN + n_s;
+        n = n < p.N ? n : p.N - 1;
+        int bb = 0;
+        if (p.fold_n) { bb = n / p.fold_n; n -= bb * p.fold_n; }
+        int nh = 0, nw = n;
+        if (p.x_hs) { nh = n / p.NW; nw = n - nh * p.NW; }
+        xo_s = (unsigned)(bb * (int)p.x_bs + nh * p.x_hs + nw * p.x_ws) * 4u;
+    }
+    // weights: 16-row fragment packing [m_tile16][chunk][lane16x4][4]; this lane's float4 of quad q sits at ((q * 16 + r16) * 4)
+    const float *wrow[MT];
+    const int mtiles = (p.M + 15) >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        int t16 = ((tm * WM + wm) * MT + mt) * 2 + (c32 >> 4);
+        t16 = t16 < mtiles ? t16 : mtiles - 1;
+        wrow[mt] = p.w + ph.w_off + (long long)t16 * nchunks * 256 + (ks * 16 + (c32 & 15)) * 4;
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
+    const float pre_slope = p.pre_slope;
+    __syncthreads();
+    const int *kof = s_mem;
+    float sb[EPT];
+    f32x4 a_cur[MT][2], a_nxt[MT][2];
+#pragma unroll
+    for (int i = 0; i < EPT; i++) sb[i] = *reinterpret_cast<const float *>(xb + (xo_s + (unsigned)kof[kr0 + i * KR]));
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int u = 0; u < 2; u++) a_cur[mt][u] = *reinterpret_cast<const f32x4 *>(wrow[mt] + u * 128);
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const float v = sb[i];
+        bt[(kr0 + i * KR) * RS + n_s] = PRE ? fmaxf(v, v * pre_slope) : v;
+    }
+    __syncthreads();
+    // B operand of MFMA (u, j) for column block nt: row k = (2u + ks) * 4 + j of the staged tile
+    const float *br = bt + wn * NT * 32 + c32 + ks * 4 * RS;
+    for (int c = 0; c < nchunks; c++) {
+        const int cn = c + 1 < nchunks ? c + 1 : c;
+        const float *bcur = br + (c & 1) * 16 * RS;
+        float *bnxt = bt + ((c + 1) & 1) * 16 * RS;
+        // next K step: global -> registers
+#pragma unroll
+        for (int i = 0; i < EPT; i++) sb[i] = *reinterpret_cast<const float *>(xb + (xo_s + (unsigned)kof[cn * 16 + kr0 + i * KR]));
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) a_nxt[mt][u] = *reinterpret_cast<const f32x4 *>(wrow[mt] + cn * 256 + u * 128);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            float bv[NT][4];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) bv[nt][j] = bcur[(u * 8 + j) * RS + nt * 32];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][u][j], bv[nt][j], acc[mt][nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            const float v = sb[i];
+            bnxt[(kr0 + i * KR) * RS + n_s] = PRE ? fmaxf(v, v * pre_slope) : v;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) a_cur[mt][u] = a_nxt[mt][u];
+        __syncthreads();
+    }
+    const float *resb = p.res ? p.res + (long long)b * p.res_bs : nullptr;
+    float *yb = p.y + (long long)b * p.y_bs;
+    ColOut cols[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) cols[nt] = col_locate(p, ph, tn * BN + (wn * NT + nt) * 32 + c32);
+    const int row0 = (tm * WM + wm) * MT * 32 + ks * 4;          // + mt * 32 + (reg & 3) + 8 * (reg >> 2)
+    if (p.glu) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int r = 0; r < 2; r++)
+                        glu_from_col(p, ph, yb, cols[nt], row0 + mt * 32 + g * 8 + r, acc[mt][nt][g * 4 + r], acc[mt][nt][g * 4 + r + 2]);
+        return;
+    }
+    RVC_ACT_DISPATCH(
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++)
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++)
+                _Pragma("unroll") for (int r = 0; r < 16; r++) {
+                    const Epi2 e_ = epi2_from_col(p, ph, resb, yb, cols[nt], row0 + mt * 32 + (r & 3) + 8 * (r >> 2));
+                    epi2_finish<A_>(p, yb, acc[mt][nt][r], e_);
+                }
+    )
+}
+
 // second stage of a split-K launch: fixed-order (deterministic) sum of the partials + epilogue
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(IgemmP p)
 {
@@ -1025,48 +1177,77 @@ struct MelP {
     float bn_scale, bn_shift;
 };
 
+// One workgroup = one frame.  rmvpe.rs:159-205 restated for the GPU: reflect pad + periodic Hann while loading, a 1024-point
+// complex FFT as five radix-4 Stockham passes (every thread owns one 4-point butterfly per pass; ping-pong in LDS, five barriers
+// instead of the ten of a radix-2 pass structure), magnitudes of the 513 kept bins, then the mel projection as WAVEFRONT-SHUFFLE
+// reductions: a 16-lane group per filter strides over the filter's non-zero band and folds its partial sums with four xor-shuffles
+// (four filters per wave at a time, 128 filters over the four waves), log, and the RMVPE input affine.
+__device__ __forceinline__ void tw1024(const float *tw, int e, float &c, float &s)
+{
+    // W^e = exp(-2 pi i e / 1024) from the half table (e < 512); W^(e + 512) = -W^e
+    const int h = e & 511;
+    c = tw[2 * h]; s = tw[2 * h + 1];
+    if (e & 512) { c = -c; s = -s; }
+}
 __global__ __launch_bounds__(256) void mel_frontend_kernel(MelP p)
 {
-    __shared__ float re[1024], im[1024], mag[516];
+    __shared__ float bufr[2][1024], bufi[2][1024];
+    __shared__ float mag[516];
     const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const float *sig = p.audio + (long long)b * p.audio_bs + (p.n - p.frame);
     const int L = p.frame;
-    // frame t covers padded[t*160 .. t*160+1024), padded = reflect(sig, 512)
-    for (int j = tid; j < 1024; j += 256) {
+    // frame t covers padded[t*160 .. t*160+1024), padded = reflect(sig, 512); natural order (the Stockham passes sort as they go)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int j = tid + r * 256;
         int q = t * 160 + j - 512;            // index into the unpadded signal
         if (q < 0) q = -q;                     // left reflect: padded[512-i-1] = sig[i+1]
         if (q >= L) q = 2 * L - 2 - q;         // right reflect: padded[L+512+i] = sig[L-i-2]
-        float v = sig[q] * p.window[j];
-        // bit-reversed placement for the in-place radix-2 DIT
-        int r = __brev((unsigned)j) >> 22;
-        re[r] = v; im[r] = 0.f;
+        bufr[0][j] = sig[q] * p.window[j];
+        bufi[0][j] = 0.f;
     }
     __syncthreads();
-    for (int len = 2; len <= 1024; len <<= 1) {
-        const int half = len >> 1, step = 1024 / len;
-        for (int i = tid; i < 512; i += 256) {
-            int grp = i / half, k = i - grp * half;
-            int i0 = grp * len + k, i1 = i0 + half;
-            float wr = p.twiddle[2 * k * step], wi = p.twiddle[2 * k * step + 1];
-            float ur = re[i0], ui = im[i0];
-            float xr = re[i1], xi = im[i1];
-            float vr = xr * wr - xi * wi, vi = xr * wi + xi * wr;
-            re[i0] = ur + vr; im[i0] = ui + vi; re[i1] = ur - vr; im[i1] = ui - vi;
+    int cur = 0;
+#pragma unroll
+    for (int Ns = 1; Ns < 1024; Ns *= 4) {
+        const int k = tid & (Ns - 1);
+        const int estep = k * (256 / Ns);                         // exponent of the unit twiddle of this butterfly, in 1024ths of a turn
+        float vr[4], vi[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float xr = bufr[cur][tid + r * 256], xi = bufi[cur][tid + r * 256];
+            if (r == 0 || Ns == 1) { vr[r] = xr; vi[r] = xi; }
+            else { float c, sn; tw1024(p.twiddle, estep * r, c, sn); vr[r] = xr * c - xi * sn; vi[r] = xr * sn + xi * c; }
         }
+        const float a0r = vr[0] + vr[2], a0i = vi[0] + vi[2], a1r = vr[0] - vr[2], a1i = vi[0] - vi[2];
+        const float a2r = vr[1] + vr[3], a2i = vi[1] + vi[3];
+        const float a3r = vi[1] - vi[3], a3i = -(vr[1] - vr[3]);     // (v1 - v3) * (-i)
+        const int j0 = (tid / Ns) * Ns * 4 + k;
+        float *orr = bufr[cur ^ 1], *oi = bufi[cur ^ 1];
+        orr[j0] = a0r + a2r;          oi[j0] = a0i + a2i;
+        orr[j0 + Ns] = a1r + a3r;     oi[j0 + Ns] = a1i + a3i;
+        orr[j0 + 2 * Ns] = a0r - a2r; oi[j0 + 2 * Ns] = a0i - a2i;
+        orr[j0 + 3 * Ns] = a1r - a3r; oi[j0 + 3 * Ns] = a1i - a3i;
+        cur ^= 1;
         __syncthreads();
     }
-    for (int k = tid; k < 513; k += 256) mag[k] = sqrtf(re[k] * re[k] + im[k] * im[k]);
+    for (int k = tid; k < 513; k += 256) { const float xr = bufr[cur][k], xi = bufi[cur][k]; mag[k] = sqrtf(xr * xr + xi * xi); }
     __syncthreads();
-    // 128 mel bins: the triangular filters are sparse (a few to ~45 non-zero bins each), so one thread per filter walks only
-    // its non-zero range [lo, hi) -- ascending k, i.e. the dense k-ordered sum without the exact zeros
-    if (tid < 128) {
-        const int m = tid, lo = p.band[2 * m], hi = p.band[2 * m + 1];
+    // mel projection: filter m = wave * 32 + it * 4 + (lane >> 4); its 16 lanes stride over the band [lo, hi), xor-shuffle fold
+    const int lane = tid & 63, wave = tid >> 6, sub = lane >> 4, l16 = lane & 15;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int m = wave * 32 + it * 4 + sub;
+        const int lo = p.band[2 * m], hi = p.band[2 * m + 1];
         const float *br = p.basis + m * 513;
         float s = 0.f;
-        for (int k = lo; k < hi; k++) s += br[k] * mag[k];
-        const float lm = logf(fmaxf(s, 1e-5f));
-        p.mel[((long long)b * 128 + m) * p.Tm + t] = lm;
-        p.img[(long long)b * p.img_bs + (long long)t * p.img_ld + m] = lm * p.bn_scale + p.bn_shift;
+        for (int k = lo + l16; k < hi; k += 16) s += br[k] * mag[k];
+        s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+        if (l16 == 0) {
+            const float lm = logf(fmaxf(s, 1e-5f));
+            p.mel[((long long)b * 128 + m) * p.Tm + t] = lm;
+            p.img[(long long)b * p.img_bs + (long long)t * p.img_ld + m] = lm * p.bn_scale + p.bn_shift;
+        }
     }
 }
 
@@ -1421,7 +1602,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnP p)
 __global__ __launch_bounds__(256) void relpos_attention_small_kernel(AttnP p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NT = 256, U = 12;
+    constexpr int NT = 256;
     const int hd = p.E / p.heads, T = p.T, Tp = T | 1, W = p.window, NR = 2 * W + 1;
     const int qtiles = (T + 3) / 4;
     const int h = blockIdx.x / qtiles, qt = blockIdx.x - h * qtiles, b = blockIdx.y;
@@ -1430,30 +1611,52 @@ __global__ __launch_bounds__(256) void relpos_attention_small_kernel(AttnP p)
     float *Qs = Rv + NR * hd;                                      // [4][hd]
     float *S = Qs + 4 * hd;                                        // [4][64]
     const float *base = p.qkv + (long long)b * p.bs;
-    const int hT = hd * T, tot = 2 * hT, rtot = 2 * NR * hd, qtot = 4 * hd;
-    for (int i0 = 0; i0 < tot + rtot + qtot; i0 += NT * U) {
-        float v[U]; int dst[U];
+    // staging without integer divisions (the first version spent most of its 19 us on them: three per staged element): K / V rows
+    // are walked as (d, t) with t padded to a power of two, the relative-position tables are one contiguous copy, Q one row per pass
+    // All global loads are issued before the first LDS write (one memory round trip for the whole staging instead of one per loop
+    // iteration: the kernel was bound by exactly that serialisation).
+    const int tsh = T <= 32 ? 5 : 6, tmask = (1 << tsh) - 1;
+    constexpr int KV_IT = 16, RT_IT = 12;
+    const int kv_n = hd << tsh, rt_n = NR * hd;
+    float kk[KV_IT], vv[KV_IT], rk[RT_IT], rv[RT_IT], qq[4];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = i0 + u * NT + (int)threadIdx.x;
-            dst[u] = -1; v[u] = 0.f;
-            if (i < tot) {
-                const int which = i / hT, rem = i - which * hT, d = rem / T, t = rem - d * T;
-                v[u] = base[(long long)((which + 1) * p.E + h * hd + d) * p.cs + t];
-                dst[u] = which * hd * Tp + d * Tp + t;
-            } else if (i < tot + rtot) {
-                const int j = i - tot;
-                v[u] = j < NR * hd ? p.rel_k[j] : p.rel_v[j - NR * hd];
-                dst[u] = 2 * hd * Tp + j;
-            } else if (i < tot + rtot + qtot) {
-                const int j = i - tot - rtot, r = j / hd, d = j - r * hd, tq = qt * 4 + r;
-                v[u] = tq < T ? base[(long long)(h * hd + d) * p.cs + tq] * p.scale : 0.f;
-                dst[u] = 2 * hd * Tp + rtot + j;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) if (dst[u] >= 0) smem[dst[u]] = v[u];
+    for (int u = 0; u < KV_IT; u++) {
+        const int idx = threadIdx.x + u * NT, d = idx >> tsh, t = idx & tmask;
+        const bool ok = idx < kv_n && t < T;
+        kk[u] = ok ? base[(long long)(p.E + h * hd + d) * p.cs + t] : 0.f;
+        vv[u] = ok ? base[(long long)(2 * p.E + h * hd + d) * p.cs + t] : 0.f;
     }
+#pragma unroll
+    for (int u = 0; u < RT_IT; u++) {
+        const int j = threadIdx.x + u * NT;
+        rk[u] = j < rt_n ? p.rel_k[j] : 0.f;
+        rv[u] = j < rt_n ? p.rel_v[j] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int tq = qt * 4 + r;
+        qq[r] = (threadIdx.x < hd && tq < T) ? base[(long long)(h * hd + threadIdx.x) * p.cs + tq] * p.scale : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < KV_IT; u++) {
+        const int idx = threadIdx.x + u * NT, d = idx >> tsh, t = idx & tmask;
+        if (idx < kv_n && t < T) { Ks[d * Tp + t] = kk[u]; Vs[d * Tp + t] = vv[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < RT_IT; u++) {
+        const int j = threadIdx.x + u * NT;
+        if (j < rt_n) { Rk[j] = rk[u]; Rv[j] = rv[u]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) if (threadIdx.x < hd) Qs[r * hd + threadIdx.x] = qq[r];
+    // sizes beyond the unrolled staging (not reached by any official configuration: 2 heads x 96, window 10, T <= 64)
+    for (int idx = threadIdx.x + KV_IT * NT; idx < kv_n; idx += NT) {
+        const int d = idx >> tsh, t = idx & tmask;
+        if (t < T) { Ks[d * Tp + t] = base[(long long)(p.E + h * hd + d) * p.cs + t]; Vs[d * Tp + t] = base[(long long)(2 * p.E + h * hd + d) * p.cs + t]; }
+    }
+    for (int j = threadIdx.x + RT_IT * NT; j < rt_n; j += NT) { Rk[j] = p.rel_k[j]; Rv[j] = p.rel_v[j]; }
+    for (int d = threadIdx.x + NT; d < hd; d += NT)
+        for (int r = 0; r < 4; r++) { const int tq = qt * 4 + r; Qs[r * hd + d] = tq < T ? base[(long long)(h * hd + d) * p.cs + tq] * p.scale : 0.f; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = qt * 4 + wave;
