@@ -188,7 +188,7 @@ def roofline_of(eng, step, S, reps=5):
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     # HBM traffic per launch: PMC counters cannot be collected inside this process -- the figure comes from a committed
     # `rocprofv3 --pmc FETCH_SIZE` pass of the same command (gfx950 x2 correction applied, see the file's "source" note)
-    tname = "r01_pmc_traffic.json" if S == 1 else "r01_pmc_traffic_%dstreams.json" % S
+    tname = "r02_pmc_traffic.json" if S == 1 else "r02_pmc_traffic_%dstreams.json" % S
     traffic = {}
     try:
         traffic = json.load(open(os.path.join(ROOT, "profiles", tname)))
@@ -198,7 +198,7 @@ def roofline_of(eng, step, S, reps=5):
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 5),
             "traffic": traffic.get("igemm_all_instantiations", {}).get("hbm_read_bytes_per_launch"),
             "traffic_source": ("static: profiles/%s (separate rocprofv3 --pmc pass, not measured in this run)" % tname) if tname else None,
-            "kernel": "rvc::igemm2_kernel / igemm_lds_kernel (all instantiations)", "launches_per_step": n_l // reps,
+            "kernel": "rvc::igemm2_kernel / igemm32_kernel / igemm_lds_kernel (all instantiations)", "launches_per_step": n_l // reps,
             "avg_launch_us": round(tot_ms * 1e3 / max(n_l, 1), 3), "flops_per_step": tot_fl / reps,
             "sum_kernel_ms": round(tot_ms / reps, 4),
             "note": "achieved = flops / SUM of per-launch durations; the ContentVec and f0 branches overlap on disjoint CU sets, so the sum exceeds the step's wall time -- frac_by_wall in the enclosing record uses the step's wall clock"}
