@@ -11,8 +11,11 @@ Tensor names follow the upstream state dicts (fairseq HubertModel or transformer
 `SynthesizerTrnMs{256,768}NSFsid`; RMVPE's `E2E`).  An ONNX exporter keeps those names for Conv / ConvTranspose / Embedding /
 norm parameters and biases but stores `nn.Linear` weights as anonymous transposed MatMul operands: `load_named_tensors`
 re-attaches them through the graph (MatMul -> Add whose bias initializer is `<layer>.bias`).  Exports whose initializers were
-renamed wholesale (e.g. Conv+BatchNorm fused by the exporter's constant folding) cannot be mapped by name; the importer then
-fails with the list of missing tensors instead of guessing.  No real checkpoint exists in this image: the ContentVec table is pinned
+renamed wholesale (Conv + BatchNorm fused by the exporter's constant folding: the usual state of a public `rmvpe.onnx`) cannot be
+mapped by name: `import_rmvpe_structural` assigns them by graph topology and checks every assignment against the U-Net's channel
+algebra.  The reference's custom 3-input synthesizer export (rvc/src/rvc.rs:193-203, speaker row and conditioning folded into
+constants) is not covered: convert the `.pth` the ONNX file was exported from.  A name table that does not fit fails with the list
+of missing tensors instead of guessing.  No real checkpoint exists in this image: the ContentVec table is pinned
 against transformers.HubertModel, the RMVPE and synthesizer tables are checked end to end against nn.Modules written with upstream's
 structure and parameter names (tests/test_importers.py) -- a real file may still differ in details these tests cannot see.
 
@@ -254,6 +257,183 @@ def import_rmvpe(named: Named) -> Tuple[dict, Named]:
     return cfg, t
 
 
+def import_rmvpe_structural(inits: Named, nodes: List[dict]) -> Tuple[dict, Named]:
+    """RMVPE from an ONNX graph whose initializers carry NO usable names (public `rmvpe.onnx` exports: the exporter folds every
+    Conv + BatchNorm pair and names the result `onnx::Conv_123`, packs the GRU as `onnx::GRU_*` in ONNX's own gate order, stores
+    the Linear as an anonymous MatMul operand).  The tensors are assigned by TOPOLOGY instead: ONNX stores nodes in execution
+    order, and the order in which `E2E.forward` runs its weight-bearing ops is fixed by the architecture --
+
+        [BatchNormalization on the mel]  encoder: per level n_blocks x (conv3x3, conv3x3, [1x1 shortcut iff Cin != Cout])
+        intermediate layers (same blocks)  decoder: per level ConvTranspose 3x3 s2 then n_blocks blocks  conv3x3 (-> 3)  GRU  MatMul(+Add)
+
+    Levels = number of ConvTranspose nodes; a level starts at every block that carries a shortcut; the intermediate layers are the
+    blocks between the last encoder level and the first ConvTranspose.  Every assignment is checked against the channel algebra of
+    the U-Net (Cout doubles per encoder level, the decoder's first block of a level sees 2 x Cout inputs, ...); a graph that does
+    not fit raises instead of producing a silently wrong blob.  A Conv that still has its BatchNormalization behind it (an export
+    without constant folding) is folded here."""
+    producers = {}
+    for nd in nodes:
+        for o in nd["output"]:
+            producers[o] = nd
+    consumers: Dict[str, List[dict]] = {}
+    for nd in nodes:
+        for i in nd["input"]:
+            consumers.setdefault(i, []).append(nd)
+
+    def init_in(nd, k):
+        return inits[nd["input"][k]] if len(nd["input"]) > k and nd["input"][k] in inits else None
+
+    toks = []          # (kind, dict)
+    for nd in nodes:
+        op = nd["op_type"]
+        if op in ("Conv", "ConvTranspose"):
+            w = init_in(nd, 1)
+            if w is None or w.ndim != 4:
+                continue
+            b = init_in(nd, 2)
+            bn = None
+            for c in consumers.get(nd["output"][0], []):
+                if c["op_type"] == "BatchNormalization" and all(x in inits for x in c["input"][1:5]):
+                    bn = [inits[x] for x in c["input"][1:5]]
+            toks.append(("CT" if op == "ConvTranspose" else "C", dict(w=np.asarray(w, np.float32), b=None if b is None else np.asarray(b, np.float32), bn=bn)))
+        elif op == "BatchNormalization" and all(x in inits for x in nd["input"][1:5]):
+            src = producers.get(nd["input"][0])
+            if src is None or src["op_type"] not in ("Conv", "ConvTranspose"):
+                toks.append(("BN", dict(p=[np.asarray(inits[x], np.float32) for x in nd["input"][1:5]])))
+        elif op == "GRU":
+            toks.append(("GRU", dict(W=np.asarray(init_in(nd, 1), np.float32), R=np.asarray(init_in(nd, 2), np.float32), B=np.asarray(init_in(nd, 3), np.float32))))
+        elif op in ("MatMul", "Gemm"):
+            w = init_in(nd, 1)
+            if w is None or w.ndim != 2:
+                continue
+            b = init_in(nd, 2) if op == "Gemm" else None
+            if b is None:
+                for c in consumers.get(nd["output"][0], []):
+                    if c["op_type"] == "Add":
+                        for i in c["input"]:
+                            if i in inits and inits[i].ndim == 1:
+                                b = inits[i]
+            toks.append(("FC", dict(w=np.asarray(w, np.float32), b=None if b is None else np.asarray(b, np.float32), transposed=(op == "MatMul"))))
+
+    def fail(msg):
+        raise ImportError_("RMVPE (structural): " + msg)
+
+    def folded(tok, out_axis=0):
+        w, b, bn = tok["w"], tok["b"], tok["bn"]
+        if bn is not None:
+            return _fold_bn(w, b, bn[0], bn[1], bn[2], bn[3], out_axis=out_axis)
+        if b is None:
+            fail("a convolution has neither a bias nor a BatchNormalization behind it (BN neither folded nor present)")
+        return w, b
+
+    t: Named = {}
+    pos = 0
+    if toks and toks[0][0] == "BN":
+        g, b, m, v = toks[0][1]["p"]
+        sc = float(g[0]) / float(np.sqrt(v[0] + 1e-5))
+        t["rm.bn0"] = np.array([sc, float(b[0]) - float(m[0]) * sc], np.float32)
+        pos = 1
+    else:
+        fail("the graph does not start with the input BatchNormalization")
+    levels = sum(1 for k, _ in toks if k == "CT")
+    if levels < 1:
+        fail("no ConvTranspose nodes: not a U-Net")
+
+    def read_block(ci_expect):
+        nonlocal pos
+        if pos + 1 >= len(toks) or toks[pos][0] != "C" or toks[pos + 1][0] != "C":
+            fail("expected two 3x3 convolutions at weight-op %d" % pos)
+        a, b2 = toks[pos][1], toks[pos + 1][1]
+        if a["w"].shape[2:] != (3, 3) or b2["w"].shape[2:] != (3, 3):
+            fail("block at weight-op %d is not conv3x3 + conv3x3" % pos)
+        co, ci = int(a["w"].shape[0]), int(a["w"].shape[1])
+        if ci_expect is not None and ci != ci_expect:
+            fail("block at weight-op %d takes %d channels, the U-Net supplies %d" % (pos, ci, ci_expect))
+        if b2["w"].shape[:2] != (co, co):
+            fail("second convolution of the block at weight-op %d is %s, expected (%d, %d, 3, 3)" % (pos, b2["w"].shape, co, co))
+        pos += 2
+        sc = None
+        if ci != co:
+            if pos >= len(toks) or toks[pos][0] != "C" or toks[pos][1]["w"].shape != (co, ci, 1, 1):
+                fail("block with %d -> %d channels has no 1x1 shortcut behind it" % (ci, co))
+            sc = toks[pos][1]
+            pos += 1
+        return a, b2, sc, ci, co
+
+    def store(dst, blk):
+        a, b2, sc, _, _ = blk
+        t[dst + "c1.w"], t[dst + "c1.b"] = folded(a)
+        t[dst + "c2.w"], t[dst + "c2.b"] = folded(b2)
+        if sc is not None:
+            t[dst + "sc.w"], t[dst + "sc.b"] = _sq(sc["w"], 2), (sc["b"] if sc["b"] is not None else np.zeros(sc["w"].shape[0], np.float32))
+
+    first_ct = next(i for i, (k, _) in enumerate(toks) if k == "CT")
+    pre = []
+    c_in = 1
+    while pos < first_ct:
+        blk = read_block(c_in)
+        pre.append(blk)
+        c_in = blk[4]
+    starts = [i for i, blk in enumerate(pre) if blk[2] is not None]         # a level / the first intermediate layer starts at a shortcut
+    if len(starts) < levels + 1 or starts[0] != 0:
+        fail("%d blocks with a shortcut before the first ConvTranspose, expected at least %d (encoder levels + intermediate)" % (len(starts), levels + 1))
+    n_blocks = starts[1] - starts[0]
+    if any(starts[i + 1] - starts[i] != n_blocks for i in range(levels)) or (len(pre) - levels * n_blocks) % n_blocks != 0:
+        fail("blocks per level are not uniform")
+    inter = (len(pre) - levels * n_blocks) // n_blocks
+    for lv in range(levels):
+        for j in range(n_blocks):
+            store("rm.enc%d.b%d." % (lv, j), pre[lv * n_blocks + j])
+        if lv and pre[lv * n_blocks][4] != 2 * pre[(lv - 1) * n_blocks][4]:
+            fail("encoder level %d does not double the channel count" % lv)
+    for lv in range(inter):
+        for j in range(n_blocks):
+            store("rm.int%d.b%d." % (lv, j), pre[(levels + lv) * n_blocks + j])
+    for lv in range(levels):
+        if toks[pos][0] != "CT":
+            fail("expected the ConvTranspose of decoder level %d at weight-op %d" % (lv, pos))
+        up = toks[pos][1]
+        pos += 1
+        ci, co = int(up["w"].shape[0]), int(up["w"].shape[1])
+        if ci != c_in or up["w"].shape[2:] != (3, 3):
+            fail("decoder level %d upsamples %s, expected %d input channels, 3x3" % (lv, up["w"].shape, c_in))
+        t["rm.dec%d.up.w" % lv], t["rm.dec%d.up.b" % lv] = folded(up, out_axis=1)
+        c_in = 2 * co                                                       # concat with the encoder skip of the same size
+        for j in range(n_blocks):
+            blk = read_block(c_in)
+            store("rm.dec%d.b%d." % (lv, j), blk)
+            c_in = blk[4]
+    if pos >= len(toks) or toks[pos][0] != "C" or toks[pos][1]["w"].shape[1] != c_in:
+        fail("expected the final 3x3 convolution after the decoder")
+    t["rm.cnn.w"], t["rm.cnn.b"] = toks[pos][1]["w"], (toks[pos][1]["b"] if toks[pos][1]["b"] is not None else np.zeros(toks[pos][1]["w"].shape[0], np.float32))
+    pos += 1
+    if pos >= len(toks) or toks[pos][0] != "GRU":
+        fail("expected the GRU after the final convolution")
+    gru = toks[pos][1]
+    pos += 1
+    H = gru["R"].shape[2]
+    if gru["W"].shape[0] != 2 or gru["W"].shape[1] != 3 * H or gru["B"].shape != (2, 6 * H):
+        fail("GRU operands %s / %s / %s are not a bidirectional single layer" % (gru["W"].shape, gru["R"].shape, gru["B"].shape))
+
+    def zrh_to_rzn(a):          # ONNX gate order (z, r, h) -> PyTorch (r, z, n), along axis 0 of a [3H, ...] block
+        return np.concatenate([a[H:2 * H], a[0:H], a[2 * H:3 * H]], axis=0)
+    for d, name in enumerate(("f", "b")):                                   # direction 0 = forward, 1 = reverse
+        t["rm.gru.w_ih_" + name], t["rm.gru.w_hh_" + name] = zrh_to_rzn(gru["W"][d]), zrh_to_rzn(gru["R"][d])
+        t["rm.gru.b_ih_" + name], t["rm.gru.b_hh_" + name] = zrh_to_rzn(gru["B"][d, :3 * H]), zrh_to_rzn(gru["B"][d, 3 * H:])
+    if pos >= len(toks) or toks[pos][0] != "FC":
+        fail("expected the output Linear after the GRU")
+    fc = toks[pos][1]
+    w = fc["w"].T if (fc["transposed"] or fc["w"].shape[0] == 2 * H) and fc["w"].shape[0] == 2 * H else fc["w"]
+    if w.shape[1] != 2 * H or fc["b"] is None:
+        fail("output Linear is %s, expected (n_out, %d) with a bias" % (fc["w"].shape, 2 * H))
+    t["rm.fc.w"], t["rm.fc.b"] = np.ascontiguousarray(w), fc["b"]
+    cfg = dict(kind=2, en_out=int(t["rm.enc0.b0.c1.w"].shape[0]), levels=levels, n_blocks=n_blocks, inter_layers=inter,
+               n_mels=int(t["rm.gru.w_ih_f"].shape[1]) // 3, gru_hidden=int(H), n_out=int(t["rm.fc.w"].shape[0]))
+    if t["rm.cnn.w"].shape[0] * cfg["n_mels"] != t["rm.gru.w_ih_f"].shape[1]:
+        fail("GRU input width does not equal 3 x n_mels")
+    return cfg, t
+
+
 # --------------------------------------------------------------------------------------------- synthesizer
 def import_synth(named: Named, sid: int = 0, sr: Optional[int] = None, up_rates: Optional[List[int]] = None,
                  heads: Optional[int] = None, window: int = 10, config: Optional[list] = None) -> Tuple[dict, Named]:
@@ -376,6 +556,12 @@ def convert(kind: str, src: str, dst: str, **kw) -> None:
     named = load_named_tensors(src)
     if kind == "synth" and kw.get("config") is None:
         kw["config"] = load_checkpoint_config(src)
+    if kind == "rmvpe" and src.lower().endswith(".onnx") and not any(k.endswith("unet.encoder.bn.weight") for k in named):
+        # name-anonymised export (Conv + BN folded by the exporter, GRU / Linear operands renamed): assign by topology
+        inits, nodes = read_onnx(src)
+        cfg, t = import_rmvpe_structural(inits, nodes)
+        W.write_blob(dst, cfg, {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in t.items()})
+        return
     cfg, t = {"contentvec": import_contentvec, "rmvpe": import_rmvpe, "synth": import_synth}[kind](named, **kw)
     W.write_blob(dst, cfg, {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in t.items()})
 

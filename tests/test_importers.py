@@ -688,3 +688,130 @@ def test_synth_import_is_checked_against_an_upstream_structured_module(tmp_path)
         src = torch.from_numpy(np.ascontiguousarray(ora.tap("sy.src")).reshape(1, 1, -1))
         ref = m.dec(zz, src, g)[0, 0].numpy()
     assert ref.shape == audio.shape and np.sqrt(np.mean((ref - audio) ** 2)) < 5e-5
+
+
+def _anonymised_rmvpe_onnx(path, m, fold_bn=True):
+    """Write the graph a torch.onnx export of RMVPE `E2E` produces, as far as the importer can see it: nodes in execution order,
+    every Conv + BatchNorm pair folded into one Conv with anonymous operands (`onnx::Conv_<n>`) when fold_bn, the GRU packed as
+    ONNX packs it (W / R / B, gate order z, r, h, directions stacked), the Linear as MatMul(x, W^T) + Add."""
+    sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    inits, nodes, cnt = {}, [], [0]
+
+    def fresh(kind):
+        cnt[0] += 1
+        return "onnx::%s_%d" % (kind, 100 + 7 * cnt[0])
+
+    def bn_params(prefix):
+        return [sd[prefix + k] for k in ("weight", "bias", "running_mean", "running_var")]
+
+    def conv(x, wname, bnprefix=None, bias=None, transpose=False):
+        w = sd[wname]
+        op = "ConvTranspose" if transpose else "Conv"
+        if bnprefix is not None and fold_bn:
+            g, b, mu, var = bn_params(bnprefix)
+            sc = g / np.sqrt(var + 1e-5)
+            shape = [1, -1, 1, 1] if transpose else [-1, 1, 1, 1]
+            wf, bf = w * sc.reshape(shape), b + ((sd[bias] if bias else 0.0) - mu) * sc
+            wn, bn_ = fresh(op), fresh(op)
+            inits[wn], inits[bn_] = wf.astype(np.float32), bf.astype(np.float32)
+            y = "t%d" % len(nodes)
+            nodes.append({"op_type": op, "input": [x, wn, bn_], "output": [y]})
+            return y
+        wn = fresh(op)
+        inits[wn] = w
+        ins = [x, wn]
+        if bias:
+            bn_ = fresh(op); inits[bn_] = sd[bias]; ins.append(bn_)
+        y = "t%d" % len(nodes)
+        nodes.append({"op_type": op, "input": ins, "output": [y]})
+        if bnprefix is not None:
+            names = []
+            for k, arr in zip("gbmv", bn_params(bnprefix)):
+                n = fresh("BatchNormalization"); inits[n] = arr; names.append(n)
+            y2 = "t%d" % len(nodes)
+            nodes.append({"op_type": "BatchNormalization", "input": [y] + names, "output": [y2]})
+            y = y2
+        return y
+
+    def relu(x):
+        y = "t%d" % len(nodes); nodes.append({"op_type": "Relu", "input": [x], "output": [y]}); return y
+
+    def block(x, prefix):
+        y = relu(conv(x, prefix + ".conv.0.weight", prefix + ".conv.1."))
+        y = relu(conv(y, prefix + ".conv.3.weight", prefix + ".conv.4."))
+        if prefix + ".shortcut.weight" in sd:
+            sc = conv(x, prefix + ".shortcut.weight", None, prefix + ".shortcut.bias")
+        else:
+            sc = x
+        z = "t%d" % len(nodes); nodes.append({"op_type": "Add", "input": [y, sc], "output": [z]}); return z
+
+    names = []
+    for k, arr in zip("gbmv", bn_params("unet.encoder.bn.")):
+        n = fresh("BatchNormalization"); inits[n] = arr; names.append(n)
+    nodes.append({"op_type": "BatchNormalization", "input": ["input"] + names, "output": ["t0"]})
+    x = "t0"
+    levels = len(m.unet.encoder.layers)
+    nb = len(m.unet.encoder.layers[0].conv)
+    skips = []
+    for lv in range(levels):
+        for j in range(nb):
+            x = block(x, "unet.encoder.layers.%d.conv.%d" % (lv, j))
+        skips.append(x)
+        y = "t%d" % len(nodes); nodes.append({"op_type": "AveragePool", "input": [x], "output": [y]}); x = y
+    for lv in range(len(m.unet.intermediate.layers)):
+        for j in range(nb):
+            x = block(x, "unet.intermediate.layers.%d.conv.%d" % (lv, j))
+    for lv in range(levels):
+        p = "unet.decoder.layers.%d." % lv
+        x = relu(conv(x, p + "conv1.0.weight", p + "conv1.1.", transpose=True))
+        y = "t%d" % len(nodes); nodes.append({"op_type": "Concat", "input": [x, skips[levels - 1 - lv]], "output": [y]}); x = y
+        for j in range(nb):
+            x = block(x, p + "conv2.%d" % j)
+    x = conv(x, "cnn.weight", None, "cnn.bias")
+    H = sd["fc.0.gru.weight_hh_l0"].shape[1]
+
+    def rzn_to_zrh(a):
+        return np.concatenate([a[H:2 * H], a[0:H], a[2 * H:3 * H]], axis=0)
+    Wp = np.stack([rzn_to_zrh(sd["fc.0.gru.weight_ih_l0" + s_]) for s_ in ("", "_reverse")])
+    Rp = np.stack([rzn_to_zrh(sd["fc.0.gru.weight_hh_l0" + s_]) for s_ in ("", "_reverse")])
+    Bp = np.stack([np.concatenate([rzn_to_zrh(sd["fc.0.gru.bias_ih_l0" + s_]), rzn_to_zrh(sd["fc.0.gru.bias_hh_l0" + s_])]) for s_ in ("", "_reverse")])
+    gn = [fresh("GRU") for _ in range(3)]
+    inits[gn[0]], inits[gn[1]], inits[gn[2]] = Wp.astype(np.float32), Rp.astype(np.float32), Bp.astype(np.float32)
+    nodes.append({"op_type": "GRU", "input": [x] + gn, "output": ["gru_y"]})
+    mm = fresh("MatMul"); inits[mm] = np.ascontiguousarray(sd["fc.1.weight"].T)
+    ab = fresh("Add"); inits[ab] = sd["fc.1.bias"]
+    nodes.append({"op_type": "MatMul", "input": ["gru_y", mm], "output": ["mm_y"]})
+    nodes.append({"op_type": "Add", "input": [ab, "mm_y"], "output": ["lin_y"]})
+    nodes.append({"op_type": "Sigmoid", "input": ["lin_y"], "output": ["output"]})
+    OR.write_onnx(path, inits, nodes)
+
+
+def test_rmvpe_structural_import_of_a_name_anonymised_onnx(tmp_path):
+    # what a user's `rmvpe.onnx` looks like (BatchNorm folded by the exporter, anonymous operands, GRU in ONNX gate order): the
+    # name-based importer has nothing to hold on to, the structural one must produce the same blob as the named import of the
+    # checkpoint the graph was exported from -- with folded and with un-folded BatchNorm nodes
+    m = _upstream_rmvpe()
+    named = {k: v.detach().numpy() for k, v in m.state_dict().items() if "num_batches_tracked" not in k}
+    cfg0, t0 = IM.import_rmvpe(named)
+    for fold in (True, False):
+        p = str(tmp_path / ("rmvpe_%d.onnx" % fold))
+        _anonymised_rmvpe_onnx(p, m, fold_bn=fold)
+        inits, nodes = OR.read_onnx(p)
+        assert not any("unet" in k for k in inits)
+        with pytest.raises(IM.ImportError_):
+            IM.import_rmvpe(IM.load_named_tensors(p))                    # by name: nothing matches
+        cfg, t = IM.import_rmvpe_structural(inits, nodes)
+        assert cfg == cfg0, (cfg, cfg0)
+        assert set(t) == set(t0)
+        for k in t0:
+            assert t[k].shape == t0[k].shape and np.allclose(t[k], t0[k], rtol=2e-6, atol=1e-7), k
+    # the CLI route picks the structural importer by itself
+    out = str(tmp_path / "rmvpe.rvcw")
+    IM.main(["rmvpe", str(tmp_path / "rmvpe_1.onnx"), out])
+    c2, t2 = W.read_blob(out)
+    assert int(c2["levels"]) == cfg0["levels"] and np.allclose(t2["rm.gru.w_hh_b"], t0["rm.gru.w_hh_b"], rtol=2e-6, atol=1e-7)
+    # a graph that does not fit the U-Net's channel algebra is refused, not guessed at
+    inits, nodes = OR.read_onnx(str(tmp_path / "rmvpe_1.onnx"))
+    first_ct = next(i for i, nd in enumerate(nodes) if nd["op_type"] == "ConvTranspose")
+    with pytest.raises(IM.ImportError_):
+        IM.import_rmvpe_structural(inits, nodes[:first_ct - 6] + nodes[first_ct:])
