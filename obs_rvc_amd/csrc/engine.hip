@@ -717,6 +717,18 @@ static void add_layernorm(Plan &pl, const T1 &x, const float *g, const float *b)
     dim3 grid((x.T + 3) / 4, x.B);
     if (x.C > 1024) throw ShapeError("layernorm: more than 1024 channels");
     const bool small = x.C <= 256;
+    // many streams: 16-column strips held in registers (float4 rows; needs 16-byte aligned rows, which every plan tensor has: ld and
+    // halo are multiples of 4).  Reading the padding columns behind T is safe (inside the row), they are never written.
+    if (x.B >= 16 && x.ld % 4 == 0 && x.halo % 4 == 0 && ((x.T + 3) / 4 * 4 <= x.ld - x.halo) && !getenv("RVC_NO_LN_STRIP")) {
+        dim3 sg((x.T + 15) / 16, x.B);
+        const int nr = (x.C + 63) / 64;
+        pl.ops.push_back([=](hipStream_t s) {
+            if (nr <= 4) hipLaunchKernelGGL((layernorm_strip_kernel<4>), sg, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
+            else if (nr <= 12) hipLaunchKernelGGL((layernorm_strip_kernel<12>), sg, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
+            else hipLaunchKernelGGL((layernorm_strip_kernel<16>), sg, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
+        });
+        return;
+    }
     if (x.B >= 16 && x.C > 256 && (size_t)x.C * 33 * 4 <= 150 * 1024 && !getenv("RVC_NO_LN_TILE")) {
         dim3 tg((x.T + 31) / 32, x.B);
         const size_t lds = (size_t)x.C * 33 * sizeof(float);
