@@ -1278,6 +1278,7 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
         AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = E; ap.T = T; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;
         ap.scale = 1.0f / sqrtf((float)hd); ap.rel_k = nullptr; ap.rel_v = nullptr; ap.window = 0;
         dim3 ag(m.heads * ((T + 15) / 16), B);
+        if (B >= 16 && hd == 64 && T <= 256 && !getenv("RVC_ATTN_VALU") && !getenv("RVC_NO_QLOOP")) { ap.qloop = 1; ag = dim3(m.heads, B); }
         if (hd == 64 && T <= 128 && !getenv("RVC_ATTN_VALU")) {
             const size_t mfma_lds = ((size_t)16 * (2 * 64 + 1) + 128) * sizeof(float);
             pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL((attention_mfma_kernel<64, 2>), ag, dim3(256), mfma_lds, s, ap); });

@@ -1436,6 +1436,7 @@ struct AttnP {
     int o_cs; long long o_bs;
     float scale;
     const float *rel_k, *rel_v; int window;
+    int qloop;      // attention_mfma_kernel: one workgroup per (head, stream) walks all query tiles, keeping its K / V fragments in registers
 };
 
 // One workgroup = one head x 16 query rows; each wave owns 4 query rows and keeps 4 accumulators
@@ -1564,19 +1565,18 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnP p)
     constexpr int NC = KF * 16;                // t-chunks of 4 covered by the V registers
     const int T = p.T;
     const int qtiles = (T + 15) / 16, kfr = (T + 15) / 16;
-    const int h = blockIdx.x / qtiles, qt = blockIdx.x - h * qtiles, b = blockIdx.y;
+    // many streams (qloop): the K and V fragments of a head do not depend on the query tile, so one workgroup per (head, stream) loads them
+    // once and walks the query tiles (7 at T = 111): the K / V re-reads -- 5376 workgroups x 57 KB per layer at 64 streams -- drop 7-fold
+    const int h = p.qloop ? (int)blockIdx.x : (int)blockIdx.x / qtiles, qt_first = p.qloop ? 0 : (int)blockIdx.x - h * qtiles, b = blockIdx.y;
+    const int qt_last = p.qloop ? qtiles : qt_first + 1;
     const int Tq = KF * 64 + 1;
     float *Ps = smem;                         // [16][Tq]
     float *red = Ps + 16 * Tq;                // [4 waves][16 rows] x 2
     const float *base = p.qkv + (long long)b * p.bs;
     const float *qb = base + (long long)(h * HD) * p.cs, *kb = base + (long long)(p.E + h * HD) * p.cs, *vb = base + (long long)(2 * p.E + h * HD) * p.cs;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
-    const int t1 = qt * 16;
     float qa[HD / 4], kv[HD / 4][KF], vv[NC];
     {
-        const int tq = t1 + li < T ? t1 + li : T - 1;
-#pragma unroll
-        for (int c = 0; c < HD / 4; c++) qa[c] = qb[(long long)(c * 4 + kq) * p.cs + tq];
 #pragma unroll
         for (int f = 0; f < KF; f++) {
             int t2 = (wave + f * 4) * 16 + li; t2 = t2 < T ? t2 : T - 1;
@@ -1586,6 +1586,14 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnP p)
         const float *vr = vb + (long long)(wave * 16 + li) * p.cs + kq;
 #pragma unroll
         for (int c = 0; c < NC; c++) vv[c] = (wave * 16 < HD && c * 4 + kq < T) ? vr[c * 4] : 0.f;
+    }
+    for (int qt = qt_first; qt < qt_last; qt++) {
+    const int t1 = qt * 16;
+    if (qt != qt_first) __syncthreads();         // the previous tile's probabilities / statistics have been consumed
+    {
+        const int tq = t1 + li < T ? t1 + li : T - 1;
+#pragma unroll
+        for (int c = 0; c < HD / 4; c++) qa[c] = qb[(long long)(c * 4 + kq) * p.cs + tq];
     }
     f32x4 sacc[KF];
 #pragma unroll
@@ -1652,6 +1660,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnP p)
             const float inv = 1.0f / (red[64 + row] + red[64 + 16 + row] + red[64 + 32 + row] + red[64 + 48 + row]);
             if (tq < T) p.out[(long long)b * p.o_bs + (long long)(h * HD + wave * 16 + li) * p.o_cs + tq] = (o0[r] + o1[r]) * inv;
         }
+    }
     }
 }
 
