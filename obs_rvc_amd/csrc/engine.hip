@@ -780,6 +780,7 @@ struct ModelCV {
     int conv_k[7], conv_s[7];
     ConvW conv[7], proj, pos, final_proj;
     float *gn_g, *gn_b, *ln0_g, *ln0_b, *encln_g, *encln_b;
+    float *conv0_raw = nullptr;     // [conv_dim][conv_k0] row-major copy of the first conv (fused conv + GroupNorm + GELU kernel)
     struct Layer { ConvW qkv, o, ff1, ff2; float *ln1_g, *ln1_b, *ln2_g, *ln2_b; };
     std::vector<Layer> layers;
     std::vector<float *> owned;
@@ -795,6 +796,7 @@ struct ModelCV {
             cin = conv_dim;
         }
         auto own = [&](const std::string &n) { float *p = dv(b, n); owned.push_back(p); return p; };
+        conv0_raw = own("cv.conv0.w");
         gn_g = own("cv.gn.g"); gn_b = own("cv.gn.b"); ln0_g = own("cv.ln0.g"); ln0_b = own("cv.ln0.b");
         proj = prep_conv(b.w("cv.proj.w"), b.w("cv.proj.b"), embed, conv_dim, 1, 1);
         pos = prep_conv(b.w("cv.pos.w"), b.w("cv.pos.b"), embed, embed, pos_k, pos_groups);
@@ -1247,6 +1249,21 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
     for (int i = 0; i < 7; i++) {
         int To = (T - m.conv_k[i]) / m.conv_s[i] + 1;
         T1 y = make_t1(A, B, m.conv_dim, To, 0);
+        if (i == 0 && m.conv_k[0] <= 16 && To <= 32 * 256 && m.conv0_raw && !getenv("RVC_NO_CONV0_FUSE")) {
+            // first layer fused: conv (Cin = 1) + per-channel GroupNorm + GELU, outputs held in registers between the passes
+            dim3 grid(m.conv_dim, B);
+            const float *w0 = m.conv0_raw, *gg = m.gn_g, *bb = m.gn_b; const int kt = m.conv_k[0], st = m.conv_s[0];
+            const float *ain = x.p; const long long abs_ = x.bs;
+            const int nt = (To + 255) / 256;
+            pl.ops.push_back([=](hipStream_t s) {
+                if (nt <= 8) hipLaunchKernelGGL((conv0_gn_gelu_kernel<8>), grid, dim3(256), 0, s, ain, abs_, w0, kt, st, gg, bb, y.p, To, y.ld, y.bs);
+                else if (nt <= 16) hipLaunchKernelGGL((conv0_gn_gelu_kernel<16>), grid, dim3(256), 0, s, ain, abs_, w0, kt, st, gg, bb, y.p, To, y.ld, y.bs);
+                else hipLaunchKernelGGL((conv0_gn_gelu_kernel<32>), grid, dim3(256), 0, s, ain, abs_, w0, kt, st, gg, bb, y.p, To, y.ld, y.bs);
+            });
+            add_tap(pl, "cv.conv0", y);
+            x = y; T = To;
+            continue;
+        }
         ConvOpts o; o.act = i == 0 ? ACT_NONE : ACT_GELU;
         add_conv1d(pl, m.conv[i], x, y, m.conv_s[i], 0, 1, o);
         if (i == 0) {
