@@ -2460,6 +2460,58 @@ int rvc_debug_conv_probe(rvc_engine *e, int M, int Cin, int KW, int dil, int N, 
     return nw;
 }
 
+// test aid: one Conv1d(Cin -> M, KW taps, dilation dil, "same" padding, bias, optional input LeakyReLU) over N positions and `streams`
+// streams on deterministic data, through whatever tile configuration the planner (or RVC_FORCE_CFG) picks, against a double-precision
+// host evaluation.  Returns the largest |gpu - host| / (rms(host) + 1e-12); negative on failure.
+double rvc_debug_conv_check(rvc_engine *e, int M, int Cin, int KW, int dil, int N, int streams, int pre_act)
+{
+    double worst = -1.0;
+    (void)guarded(e, [&]() {
+        std::vector<float> w((size_t)M * Cin * KW), bias(M);
+        for (size_t i = 0; i < w.size(); i++) w[i] = (float)((i * 2654435761u) % 1000) / 1000.0f - 0.5f;
+        for (int m = 0; m < M; m++) bias[m] = 0.01f * (float)(m % 7) - 0.02f;
+        ConvW cw = prep_conv(w.data(), bias.data(), M, Cin, KW, 1);
+        Plan pl; pl.B = streams;
+        const int pad = (KW - 1) * dil / 2, halo = (pad + 3) / 4 * 4;
+        T1 x = make_t1(pl.arena, streams, Cin, N, halo), y = make_t1(pl.arena, streams, M, N, 0);
+        std::vector<float> hx((size_t)streams * Cin * N);
+        for (size_t i = 0; i < hx.size(); i++) hx[i] = (float)(((i * 40503u) ^ (i >> 3)) % 2001) / 1000.0f - 1.0f;
+        for (int b = 0; b < streams; b++)
+            for (int c = 0; c < Cin; c++)
+                HIPCHK(hipMemcpy(x.p + (long long)b * x.bs + (long long)c * x.ld, &hx[((size_t)b * Cin + c) * N], (size_t)N * 4, hipMemcpyHostToDevice));
+        ConvOpts o; if (pre_act) { o.pre_act = ACT_LRELU; o.pre_slope = 0.1f; }
+        add_conv1d(pl, cw, x, y, 1, pad, dil, o);
+        HIPCHK(hipDeviceSynchronize());
+        for (auto &op : pl.ops.v) op(e->stream);
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipGetLastError());
+        std::vector<float> hy((size_t)N);
+        double err = 0.0, ss = 0.0; size_t cnt = 0;
+        std::vector<double> ref((size_t)N);
+        for (int b = 0; b < streams; b++)
+            for (int m = 0; m < M; m++) {
+                HIPCHK(hipMemcpy(hy.data(), y.p + (long long)b * y.bs + (long long)m * y.ld, (size_t)N * 4, hipMemcpyDeviceToHost));
+                for (int n = 0; n < N; n++) {
+                    double a = bias[m];
+                    for (int c = 0; c < Cin; c++)
+                        for (int k = 0; k < KW; k++) {
+                            const int t = n + k * dil - pad;
+                            if (t < 0 || t >= N) continue;
+                            double v = hx[((size_t)b * Cin + c) * N + t];
+                            if (pre_act && v < 0) v *= 0.1f;
+                            a += (double)w[((size_t)m * Cin + c) * KW + k] * v;
+                        }
+                    ref[n] = a; ss += a * a; cnt++;
+                }
+                for (int n = 0; n < N; n++) err = std::max(err, std::fabs((double)hy[n] - ref[n]));
+            }
+        worst = err / (std::sqrt(ss / (double)std::max<size_t>(cnt, 1)) + 1e-12);
+        free_conv(cw);
+        return RVC_OK;
+    });
+    return worst;
+}
+
 rvc_status rvc_profile_last_knn(rvc_engine *e, int *launches, double *kernel_ms, double *bytes)
 {
     return guarded(e, [&]() {

@@ -513,7 +513,7 @@ template <int MF, int NF, int D, int KS, bool PRE, bool LIN>
 __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p)
 {
     constexpr int WAVES = KS > 1 ? KS : 4;
-    constexpr int NACC = (MF * NF == 1) ? 2 : 1;
+    constexpr int NACC = (MF * NF == 1) ? 2 : 1;   // a lone fragment alternates two accumulators (MFMA dependency)
     constexpr int TE = MF * NF * 256;
     constexpr int PE = (KS > 1) ? ((TE + WAVES * 64 - 1) / (WAVES * 64)) : 1;
     constexpr bool PF = (KS > 1) || (MF * NF <= 4);
@@ -675,7 +675,6 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
     }
     RVC_KP(2);
     int c = 0;
-#if !defined(RVC_EXP) || RVC_EXP == 2
     // steady state: every operand register is reloaded right after its last use, so the loads of the next round are interleaved with
     // the MFMAs of this one instead of forming a block during which the matrix pipe drains (measured at 64 streams: the 768 x 3072
     // projection 75 -> 92 TF/s, the 768 x 768 one 61 -> 78 TF/s; no change at one stream)
@@ -697,9 +696,16 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
                 b_st[S][nf][j] = *reinterpret_cast<const float *>(xb + (xo[nf] + kov_[j]));            \
             }                                                                                          \
     }
-    // (tiles of at least four fragments only: the lone-fragment tile with its two alternating accumulators produced wrong results in
-    //  this form on LIN layers -- cause not found, so it keeps the two-block loop below, which its 12-deep prefetch hides anyway)
-    if (MF * NF >= 4) {
+    // Not for the lone-fragment tile: with its two alternating accumulators (NACC = 2) this form computes garbage as soon as the loop is
+    // entered (K >= 24 chunks; `test_every_tile_configuration_computes_the_same_convolution` with -DRVC_FUSE_ALL), with or without
+    // scheduling barriers between the stages, while the same source with one accumulator per fragment is exact -- a code-generation
+    // problem of that instantiation as far as could be determined.  Its 12-deep prefetch hides the load block anyway.
+#ifdef RVC_FUSE_ALL
+    constexpr bool kFuse = true;      // investigation build only
+#else
+    constexpr bool kFuse = NACC == 1;
+#endif
+    if (kFuse) {
         for (; c + 2 * D <= nc; c += D) {
 #pragma unroll
             for (int s = 0; s < D; s++) RVC_FUSED_STAGE(s, c + s + D)
@@ -715,21 +721,6 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-#else
-    for (; c + 2 * D <= nc; c += D) {
-#pragma unroll
-        for (int s = 0; s < D; s++) {
-            RVC_COMPUTE_STAGE(s)
-#if !defined(RVC_EXP) || RVC_EXP != 1
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            RVC_LOAD_STAGE(s, c + s + D)
-#if !defined(RVC_EXP) || RVC_EXP != 1
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-        }
-    }
-#endif
     for (; c < nc; c += D) {
 #pragma unroll
         for (int s = 0; s < D; s++) {

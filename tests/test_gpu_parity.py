@@ -486,3 +486,35 @@ def test_pipelined_chunks_equal_serial_chunks():
     ys, cs = run(False)
     yp, cp = run(True)
     assert np.isfinite(ys).all() and np.array_equal(ys, yp) and np.array_equal(cs, cp)
+
+
+def test_every_tile_configuration_computes_the_same_convolution():
+    # the planner picks one of 5 tile shapes x 4 in-workgroup K splits (+ the two workgroup-tiled kernels at many streams) per layer;
+    # the model-level tests only ever see its choices.  Here every combination is forced onto small convolutions -- table-free 1x1
+    # layers (LIN), dilated multi-tap layers with the fused input LeakyReLU, K shorter and longer than the prefetch depth, ragged M / N
+    # -- and compared with a double-precision host evaluation (rvc_debug_conv_check)
+    import ctypes as C
+    from obs_rvc_amd import _native
+    L = _native.lib()
+    L.rvc_debug_conv_check.restype = C.c_double
+    L.rvc_debug_conv_check.argtypes = [C.c_void_p] + [C.c_int] * 7
+    h = C.c_void_p()
+    assert L.rvc_create(b"/tmp", 0, C.byref(h)) == 0
+    shapes = [(48, 48, 1, 1, 111, 0), (144, 48, 1, 1, 111, 0), (96, 384, 1, 1, 37, 0), (40, 32, 7, 3, 300, 1), (64, 512, 3, 1, 50, 0), (33, 16, 11, 1, 130, 1)]
+    try:
+        for cfg in range(5):
+            for ks in (1, 4, 8, 16):
+                os.environ["RVC_FORCE_CFG"] = "%d,%d" % (cfg, ks)
+                for (M, Cin, KW, dil, N, pre) in shapes:
+                    if ks > 1 and (Cin * KW + 15) // 16 < ks:
+                        continue                           # fewer K chunks than waves: the planner never splits that far
+                    e1 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, 1, pre)
+                    assert 0 <= e1 < 2e-5, (cfg, ks, M, Cin, KW, dil, N, pre, e1)
+        os.environ.pop("RVC_FORCE_CFG")
+        for streams in (3, 20):                            # folded streams; 20 streams reach the workgroup-tiled kernels on the wide layers
+            for (M, Cin, KW, dil, N, pre) in shapes + [(128, 128, 7, 3, 2520, 1), (768, 256, 1, 1, 111, 0)]:
+                e2 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, streams, pre)
+                assert 0 <= e2 < 2e-5, (streams, M, Cin, KW, dil, N, pre, e2)
+    finally:
+        os.environ.pop("RVC_FORCE_CFG", None)
+        L.rvc_destroy(h)
