@@ -118,6 +118,15 @@ class Job:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def all_ok(self, ok):
+        """True only if every rank reports success (one tiny all-reduce): ranks then skip a failed leg TOGETHER instead of parting ways
+        in front of the next barrier."""
+        if self.world == 1:
+            return bool(ok)
+        t = self.torch.tensor([1.0 if ok else 0.0], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
     def gather(self, values):
         """every rank's list of floats (equal lengths) -> list of per-rank arrays, on every rank"""
         t = self.torch.tensor(list(values), dtype=self.torch.float64, device=self.dev)
@@ -225,7 +234,13 @@ def run_config(job, z, g, S, with_index, steps, warmup, graph, index_vecs, want_
     bcast_ms = None
     if with_index:
         b0 = time.perf_counter()
-        rdist.load_shared_index(eng, index_vecs if job.rank == 0 else None, 100000, 768, job.rank, job.world)
+        err = None
+        try:
+            rdist.load_shared_index(eng, index_vecs if job.rank == 0 else None, 100000, 768, job.rank, job.world)
+        except Exception as ex:                   # e.g. librccl missing / communicator bootstrap refused on this node
+            err = str(ex)
+        if not job.all_ok(err is None):
+            raise RuntimeError("index broadcast failed on at least one rank" + (": " + err if err else ""))
         bcast_ms = round((time.perf_counter() - b0) * 1e3, 2)
         eng.set_index_rate(0.75)
     eng.set_use_graph(graph)
@@ -428,22 +443,32 @@ def main(argv=None):
     # ---- sub-configurations: every rank takes part (the timed regions are bracketed by barriers)
     sub = {}
     if not args.only_headline and full and S == 1 and not args.index:
-        try:
-            rec, e2, _, d2 = run_config(job, z, g, 1, True, args.steps, args.warmup, graph, index_vecs)
-            sub["index100k"] = rec
-            del e2, d2
+        # Each leg raises only where every rank raises together (index broadcast: agreed through Job.all_ok; anything else is deterministic
+        # per configuration), so skipping a failed leg cannot strand a rank in a collective.
+        def leg(name, fn):
+            try:
+                sub[name] = fn()
+            except Exception as ex:
+                print("bench: sub-configuration %s failed: %s" % (name, ex), file=sys.stderr)
+                sub[name] = {"error": str(ex)}
             job.torch.cuda.empty_cache()
+
+        def index100k():
+            rec, e2, _, d2 = run_config(job, z, g, 1, True, args.steps, args.warmup, graph, index_vecs)
+            del e2, d2
+            return rec
+
+        def streams64():
             k64 = max(10, min(args.steps, 20))
-            rec, e3, _, d3 = run_config(job, z, g, 64, job.world > 1, k64, 3, graph, index_vecs)
+            want_index = job.world > 1 and "error" not in (sub.get("index100k") or {})      # configs[4] shares the index over RCCL
+            rec, e3, _, d3 = run_config(job, z, g, 64, want_index, k64, 3, graph, index_vecs)
+            del e3, d3
             if rec:
                 rec["steps"] = k64
                 rec["config"] = "BASELINE configs[%d]" % (4 if job.world > 1 else 3)
-            sub["streams64"] = rec
-            del e3, d3
-        except Exception as ex:
-            if job.world > 1:
-                raise                                        # a rank that left a collective would hang the others: fail loudly
-            print("bench: sub-configuration leg failed: %s" % ex, file=sys.stderr)
+            return rec
+        leg("index100k", index100k)
+        leg("streams64", streams64)
 
     if job.rank == 0:
         out = {
