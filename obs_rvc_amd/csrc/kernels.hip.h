@@ -560,29 +560,6 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
     const float *resb = p.res ? p.res + (long long)b * p.res_bs : nullptr;
     float *yb = p.y + (long long)b * p.y_bs;
 
-    // 2. epilogue operands, requested up front
-    Epi2 pre_w[(KS > 1 || !PF) ? 1 : MF][(KS > 1 || !PF) ? 1 : NF][4];
-    Epi2 pre_r[PE];
-    if (PF && live && !p.glu) {
-        if (KS > 1) {
-#pragma unroll
-            for (int q = 0; q < PE; q++) {
-                const int e = threadIdx.x + q * WAVES * 64;
-                const int l = e & 63, r = (e >> 6) & 3, f = e >> 8, mf = f / NF, nf = f - mf * NF;
-                pre_r[q] = (e < TE) ? epi2_prefetch(p, ph, resb, yb, tm * 16 * MF + mf * 16 + (l >> 4) * 4 + r, tn * 16 * NF + nf * 16 + (l & 15)) : Epi2{0.f, 0.f, 0.f, -1};
-            }
-        } else {
-#pragma unroll
-            for (int nf = 0; nf < ((KS > 1 || !PF) ? 1 : NF); nf++) {
-                const ColOut col = col_locate(p, ph, tn * 16 * NF + nf * 16 + li);
-#pragma unroll
-                for (int mf = 0; mf < ((KS > 1 || !PF) ? 1 : MF); mf++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        pre_w[mf][nf][r] = epi2_from_col(p, ph, resb, yb, col, tm * 16 * MF + mf * 16 + kq * 4 + r);
-            }
-        }
-    }
     RVC_KP(9);
     // gathered-activation addressing: wave-uniform base + unsigned 32-bit BYTE offset per lane
     const char *xb = reinterpret_cast<const char *>(p.x + (long long)b * p.x_bs + ph.x_off) - (LIN ? 0 : p.koff_bias);
@@ -650,11 +627,35 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
             }                                                                                          \
     }
 #define RVC_LOAD_STAGE(S, C) { RVC_LOAD_A(S, C) RVC_LOAD_B(S, C) }
-    // 3. first D stages: weights (and, without a table, the activations) leave now
+    // 2. first D stages: weights (and, without a table, the activations) leave first
     if (live) {
 #pragma unroll
         for (int s = 0; s < D; s++)
             if (s < nc) { RVC_LOAD_A(s, s) if (LIN) RVC_LOAD_B(s, s) }
+    }
+    // 3b. epilogue operands: requested now, BEHIND the first weight / activation loads (their address arithmetic alone is 0.8 us at a
+    //     4-element share per thread; in front of the main loads it delayed every launch by that much)
+    Epi2 pre_w[(KS > 1 || !PF) ? 1 : MF][(KS > 1 || !PF) ? 1 : NF][4];
+    Epi2 pre_r[PE];
+    if (PF && live && !p.glu) {
+        if (KS > 1) {
+#pragma unroll
+            for (int q = 0; q < PE; q++) {
+                const int e = threadIdx.x + q * WAVES * 64;
+                const int l = e & 63, r = (e >> 6) & 3, f = e >> 8, mf = f / NF, nf = f - mf * NF;
+                pre_r[q] = (e < TE) ? epi2_prefetch(p, ph, resb, yb, tm * 16 * MF + mf * 16 + (l >> 4) * 4 + r, tn * 16 * NF + nf * 16 + (l & 15)) : Epi2{0.f, 0.f, 0.f, -1};
+            }
+        } else {
+#pragma unroll
+            for (int nf = 0; nf < ((KS > 1 || !PF) ? 1 : NF); nf++) {
+                const ColOut col = col_locate(p, ph, tn * 16 * NF + nf * 16 + li);
+#pragma unroll
+                for (int mf = 0; mf < ((KS > 1 || !PF) ? 1 : MF); mf++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        pre_w[mf][nf][r] = epi2_from_col(p, ph, resb, yb, col, tm * 16 * MF + mf * 16 + kq * 4 + r);
+            }
+        }
     }
     RVC_KP(11);
     if (!LIN) {
