@@ -440,8 +440,8 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
             // layer with enough workgroups to fill the chip
             static const int g32 = getenv("RVC_GEMM32") ? atoi(getenv("RVC_GEMM32")) : 2;
             static const long long g32_min = getenv("RVC_GEMM32_MIN") ? atoll(getenv("RVC_GEMM32_MIN")) : 768;   // fewer workgroups balance badly over 256 CUs (measured: 336 -> slower)
-            if (g32 == 1 && lds_cfg >= 0) lds_cfg += 3;
-            else if (g32 >= 2 && wgs >= g32_min) lds_cfg = 3 + (bm == 128 ? 0 : (bm == 64 ? 1 : 2));
+            if (g32 == 1 && lds_cfg >= 0 && !p.glu) lds_cfg += 3;
+            else if (g32 >= 2 && wgs >= g32_min && !p.glu) lds_cfg = 3 + (bm == 128 ? 0 : (bm == 64 ? 1 : 2));   // (gated layers stay on the kernels that are tested with the gate)
         }
     }
     if (lds_cfg >= 0) {

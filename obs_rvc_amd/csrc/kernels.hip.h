@@ -1080,18 +1080,6 @@ __global__ __launch_bounds__(256) void igemm32_kernel(IgemmP p)
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) cols[nt] = col_locate(p, ph, tn * BN + (wn * NT + nt) * 32 + c32);
     const int row0 = (tm * WM + wm) * MT * 32 + ks * 4;          // + mt * 32 + (reg & 3) + 8 * (reg >> 2)
-    if (p.glu) {
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-                for (int g = 0; g < 4; g++)
-#pragma unroll
-                    for (int r = 0; r < 2; r++)
-                        glu_from_col(p, ph, yb, cols[nt], row0 + mt * 32 + g * 8 + r, acc[mt][nt][g * 4 + r], acc[mt][nt][g * 4 + r + 2]);
-        return;
-    }
     RVC_ACT_DISPATCH(
         _Pragma("unroll") for (int mt = 0; mt < MT; mt++)
             _Pragma("unroll") for (int nt = 0; nt < NT; nt++)
