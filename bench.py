@@ -210,7 +210,11 @@ def roofline_of(eng, step, S, reps=5):
             "kernel": "rvc::igemm2_kernel / igemm32_kernel / igemm_lds_kernel (all instantiations)", "launches_per_step": n_l // reps,
             "avg_launch_us": round(tot_ms * 1e3 / max(n_l, 1), 3), "flops_per_step": tot_fl / reps,
             "sum_kernel_ms": round(tot_ms / reps, 4),
-            "note": "achieved = flops / SUM of per-launch durations; the ContentVec and f0 branches overlap on disjoint CU sets, so the sum exceeds the step's wall time -- frac_by_wall in the enclosing record uses the step's wall clock"}
+            "note": ("achieved = flops / SUM of per-launch durations; the ContentVec and f0 branches overlap on disjoint CU sets, so the sum "
+                     "exceeds the step's wall time -- frac_by_wall in the enclosing record uses the step's wall clock") if S <= 4 else
+                    ("achieved = flops / SUM of per-launch durations, measured with the two front branches issued one after the other "
+                     "(above 4 streams they share the CUs, and a co-scheduled short kernel's event duration is the long kernel's, not its "
+                     "own); the timed steps run the branches concurrently -- frac_by_wall in the enclosing record uses their wall clock")}
     if k_n:
         ach = k_by / (k_ms * 1e-3) / 1e9
         roof["retrieval_scan"] = {"bound": "hbm", "kernel": "rvc::knn_dot_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -451,6 +451,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
         p.m_fast = p.fold_n ? p.ntm : 0;
         dim3 grid(p.ntm * p.ntn, B * p.nphase);
         const size_t lds = (size_t)nchunks * 64 + (size_t)2 * 16 * (bn + 4) * 4;
+        g_last_wgs = (int)(grid.x * grid.y); g_last_waves = 4;
         const double flops = 2.0 * p.M * (double)p.N * ksum * B;
         pl.igemm_flops += flops; pl.n_igemm++;
         Plan *plp = &pl;
@@ -1809,7 +1810,12 @@ static void issue_ops(rvc_engine *e, Plan &pl, bool capturing)
     // fork/join through events; under stream capture the auxiliary streams become parallel branches of the hipGraph
     const std::vector<int> &ord = capturing ? pl.ops.order_graph : pl.ops.order_eager;
     const size_t n = pl.ops.v.size();
-    static const bool serial = getenv("RVC_SERIAL_BRANCHES") != nullptr;   // tuning aid: every op on the main stream (true per-kernel times)
+    // Every op on the main stream: as a tuning aid (environment), and for the per-launch profile when the branches share the CUs
+    // (more than 4 streams, no partition).  There a short f0 kernel that is co-scheduled with a 3 ms ContentVec GEMM is stretched to
+    // the GEMM's length by the workgroup dispatcher (19 us alone, 3158 us measured); its HIP-event duration then says nothing about
+    // the kernel.  With a CU partition the branches own disjoint CUs and are profiled as they run.
+    static const bool serial_env = getenv("RVC_SERIAL_BRANCHES") != nullptr;
+    const bool serial = serial_env || (pl.profile && !capturing && !e->partitioned);
     for (size_t k = 0; k < n; k++) {
         const size_t i = (k < ord.size() && !serial) ? (size_t)ord[k] : k;      // ops queued after the reordered prefix keep their position
         const int sid = serial ? 0 : pl.ops.sid[i];
@@ -2403,6 +2409,7 @@ double rvc_debug_conv_bench(rvc_engine *e, int M, int Cin, int KW, int dil, int 
         std::vector<float> hx((size_t)Cin * x.ld, 0.25f);
         for (int b = 0; b < Bb; b++) HIPCHK(hipMemcpy(x.p + (long long)b * x.bs - x.halo, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
         ConvOpts o; if (pre_act) { o.pre_act = ACT_LRELU; o.pre_slope = 0.1f; }
+        if (const char *a = getenv("RVC_BENCH_ACT")) o.act = atoi(a);     // epilogue activation (ACT_* value)
         add_conv1d(pl, cw, x, y, 1, pad, dil, o);
         HIPCHK(hipDeviceSynchronize());
         for (int i = 0; i < 3; i++) for (auto &op : pl.ops.v) op(e->stream);
@@ -2437,7 +2444,8 @@ int rvc_debug_conv_probe(rvc_engine *e, int M, int Cin, int KW, int dil, int N, 
         unsigned long long *d_probe; const size_t pbytes = (size_t)1 << 24;
         HIPCHK(hipMalloc(&d_probe, pbytes)); HIPCHK(hipMemset(d_probe, 0, pbytes));
         g_kprobe = d_probe;
-        add_conv1d(pl, cw, x, y, 1, pad, dil);
+        ConvOpts o; if (const char *a = getenv("RVC_BENCH_ACT")) o.act = atoi(a);
+        add_conv1d(pl, cw, x, y, 1, pad, dil, o);
         g_kprobe = nullptr;
         HIPCHK(hipDeviceSynchronize());
         for (int i = 0; i < 5; i++) for (auto &op : pl.ops.v) op(e->stream);

@@ -453,14 +453,19 @@ __device__ __forceinline__ Epi2 epi2_prefetch(const IgemmP &p, const PhaseD &ph,
     if (p.accumulate) e.yold = yb[e.yo];
     return e;
 }
+// the epilogue's arithmetic, in ONE place (every path must round the same way: eager/graph and tile choice are bit-identical)
+template <int ACT> __device__ __forceinline__ float epi2_value(float acc, float bias, float res, float yold, float slope, float scale)
+{
+    float v = act_t<ACT>(acc + bias, slope);
+    v += res;
+    v *= scale;
+    v += yold;
+    return v;
+}
 template <int ACT> __device__ __forceinline__ void epi2_finish(const IgemmP &p, float *yb, float acc, const Epi2 &e)
 {
     if (e.yo < 0) return;
-    float v = act_t<ACT>(acc + e.bias, p.slope);
-    v += e.res;
-    v *= p.scale;
-    v += e.yold;
-    yb[e.yo] = v;
+    yb[e.yo] = epi2_value<ACT>(acc, e.bias, e.res, e.yold, p.slope, p.scale);
 }
 // Column part of the output address (everything that depends on n only: stream, row, column, validity), computed once per MFMA
 // column instead of once per element -- with folded streams it holds an integer division.
@@ -490,11 +495,31 @@ __device__ __forceinline__ Epi2 epi2_from_col(const IgemmP &p, const PhaseD &ph,
     if (p.accumulate) e.yold = yb[e.yo];
     return e;
 }
+__device__ __forceinline__ Epi2 epi2_plain(float bias, int yo) { Epi2 e = {bias, 0.f, 0.f, yo}; return e; }
+// the same with the bias already in hand (batched epilogues: biases are loaded once per row, before any store)
+__device__ __forceinline__ Epi2 epi2_aux(const IgemmP &p, const PhaseD &ph, const float *resb, const float *yb, const ColOut &c, int m, float bias)
+{
+    Epi2 e = {bias, 0.f, 0.f, -1};
+    if (m >= p.M || c.yo < 0) return e;
+    const int ch = m + ph.y_c0;
+    e.yo = c.yo + ch * p.y_cs;
+    if (resb) e.res = resb[c.ro + (p.res_nogroup ? m : ch) * p.res_cs];
+    if (p.accumulate) e.yold = yb[e.yo];
+    return e;
+}
 // fused WaveNet gate on a located column (see glu_store)
 __device__ __forceinline__ void glu_from_col(const IgemmP &p, const PhaseD &ph, float *yb, const ColOut &c, int m1, float a1, float a2)
 {
     if (m1 >= p.M || c.yo < 0) return;
     const float ta = a1 + p.bias[ph.bias_off + m1], sa = a2 + p.bias[ph.bias_off + m1 + 2];
+    const int ch = (m1 >> 4) * 8 + ((m1 & 15) >> 2) * 2 + (m1 & 1) + ph.y_c0;
+    yb[c.yo + ch * p.y_cs] = tanhf(ta) * (1.0f / (1.0f + expf(-sa)));
+}
+
+__device__ __forceinline__ void glu_from_col_b(const IgemmP &p, const PhaseD &ph, float *yb, const ColOut &c, int m1, float a1, float a2, float b1, float b2)
+{
+    if (m1 >= p.M || c.yo < 0) return;
+    const float ta = a1 + b1, sa = a2 + b2;
     const int ch = (m1 >> 4) * 8 + ((m1 & 15) >> 2) * 2 + (m1 & 1) + ph.y_c0;
     yb[c.yo + ch * p.y_cs] = tanhf(ta) * (1.0f / (1.0f + expf(-sa)));
 }
@@ -788,6 +813,14 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
     }
     // D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
     if (p.glu) {
+        float gb[MF][4];                 // the gate's biases: rows kq * 4 + {0, 1} (tanh half) and + {2, 3} (sigmoid half)
+#pragma unroll
+        for (int mf = 0; mf < MF; mf++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = tm * 16 * MF + mf * 16 + kq * 4 + r;
+                gb[mf][r] = m < p.M ? p.bias[ph.bias_off + m] : 0.f;
+            }
 #pragma unroll
         for (int nf = 0; nf < NF; nf++) {
             const ColOut col = col_locate(p, ph, tn * 16 * NF + nf * 16 + li);
@@ -795,7 +828,7 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
             for (int mf = 0; mf < MF; mf++)
 #pragma unroll
                 for (int r = 0; r < 2; r++)
-                    glu_from_col(p, ph, yb, col, tm * 16 * MF + mf * 16 + kq * 4 + r, acc[0][mf][nf][r], acc[0][mf][nf][r + 2]);
+                    glu_from_col_b(p, ph, yb, col, tm * 16 * MF + mf * 16 + kq * 4 + r, acc[0][mf][nf][r], acc[0][mf][nf][r + 2], gb[mf][r], gb[mf][r + 2]);
         }
         return;
     }
@@ -807,16 +840,34 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
                         epi2_finish<A_>(p, yb, acc[0][mf][nf][r], pre_w[PF ? mf : 0][PF ? nf : 0][r]);
         )
     } else {
+        // operands in store-free batches (a load cannot be hoisted above an earlier, possibly aliasing store: element-by-element
+        // "load, store" costs one memory round trip per element -- see igemm32_kernel)
         ColOut cols[NF];
 #pragma unroll
         for (int nf = 0; nf < NF; nf++) cols[nf] = col_locate(p, ph, tn * 16 * NF + nf * 16 + li);
+        const bool has_aux = resb != nullptr || p.accumulate;
         RVC_ACT_DISPATCH(
-            _Pragma("unroll") for (int mf = 0; mf < MF; mf++)
-                _Pragma("unroll") for (int nf = 0; nf < NF; nf++)
-                    _Pragma("unroll") for (int r = 0; r < 4; r++) {
-                        const Epi2 e_ = epi2_from_col(p, ph, resb, yb, cols[nf], tm * 16 * MF + mf * 16 + kq * 4 + r);
-                        epi2_finish<A_>(p, yb, acc[0][mf][nf][r], e_);
+            _Pragma("unroll") for (int mf = 0; mf < MF; mf++) {
+                float bias_r[4];
+                _Pragma("unroll") for (int r = 0; r < 4; r++) {
+                    const int m = tm * 16 * MF + mf * 16 + kq * 4 + r;
+                    bias_r[r] = (p.bias && m < p.M) ? p.bias[ph.bias_off + m] : 0.f;
+                }
+                _Pragma("unroll") for (int nf = 0; nf < NF; nf++) {
+                    if (!has_aux) {
+                        _Pragma("unroll") for (int r = 0; r < 4; r++) {
+                            const int m = tm * 16 * MF + mf * 16 + kq * 4 + r;
+                            const Epi2 e1 = epi2_plain(bias_r[r], (m < p.M && cols[nf].yo >= 0) ? cols[nf].yo + (m + ph.y_c0) * p.y_cs : -1);
+                            epi2_finish<A_>(p, yb, acc[0][mf][nf][r], e1);
+                        }
+                    } else {
+                        Epi2 e_[4];
+                        _Pragma("unroll") for (int r = 0; r < 4; r++)
+                            e_[r] = epi2_aux(p, ph, resb, yb, cols[nf], tm * 16 * MF + mf * 16 + kq * 4 + r, bias_r[r]);
+                        _Pragma("unroll") for (int r = 0; r < 4; r++) epi2_finish<A_>(p, yb, acc[0][mf][nf][r], e_[r]);
                     }
+                }
+            }
         )
     }
     RVC_KP(6);
@@ -828,7 +879,7 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
 // and read back as MFMA B fragments by all waves; weight fragments stream global -> registers in fragment order.
 // Each activation element is fetched once per workgroup instead of once per wave.
 template <int WM, int WN, int MF, int NF, bool PRE>
-__global__ __launch_bounds__(256) void igemm_lds_kernel(IgemmP p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void igemm_lds_kernel(IgemmP p)
 {
     constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
     constexpr int RS = BN + 4;                 // LDS row stride: the 4 k-rows read by one MFMA operand fall on disjoint bank groups
@@ -930,23 +981,47 @@ __global__ __launch_bounds__(256) void igemm_lds_kernel(IgemmP p)
     ColOut cols[NF];
 #pragma unroll
     for (int nf = 0; nf < NF; nf++) cols[nf] = col_locate(p, ph, tn * BN + (wn * NF + nf) * 16 + li);
+    // operands in store-free batches (see igemm32_kernel's epilogue): the four biases of a 16-row fragment, then per 16x16 block
     if (p.glu) {
 #pragma unroll
-        for (int mf = 0; mf < MF; mf++)
+        for (int mf = 0; mf < MF; mf++) {
+            float gb[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = ((tm * WM + wm) * MF + mf) * 16 + kq * 4 + r;
+                gb[r] = m < p.M ? p.bias[ph.bias_off + m] : 0.f;
+            }
 #pragma unroll
             for (int nf = 0; nf < NF; nf++)
 #pragma unroll
                 for (int r = 0; r < 2; r++)
-                    glu_from_col(p, ph, yb, cols[nf], ((tm * WM + wm) * MF + mf) * 16 + kq * 4 + r, acc[mf][nf][r], acc[mf][nf][r + 2]);
+                    glu_from_col_b(p, ph, yb, cols[nf], ((tm * WM + wm) * MF + mf) * 16 + kq * 4 + r, acc[mf][nf][r], acc[mf][nf][r + 2], gb[r], gb[r + 2]);
+        }
         return;
     }
+    const bool has_aux = resb != nullptr || p.accumulate;
     RVC_ACT_DISPATCH(
-        _Pragma("unroll") for (int mf = 0; mf < MF; mf++)
-            _Pragma("unroll") for (int nf = 0; nf < NF; nf++)
-                _Pragma("unroll") for (int r = 0; r < 4; r++) {
-                    const Epi2 e_ = epi2_from_col(p, ph, resb, yb, cols[nf], ((tm * WM + wm) * MF + mf) * 16 + kq * 4 + r);
-                    epi2_finish<A_>(p, yb, acc[mf][nf][r], e_);
+        _Pragma("unroll") for (int mf = 0; mf < MF; mf++) {
+            float bias_r[4];
+            _Pragma("unroll") for (int r = 0; r < 4; r++) {
+                const int m = ((tm * WM + wm) * MF + mf) * 16 + kq * 4 + r;
+                bias_r[r] = (p.bias && m < p.M) ? p.bias[ph.bias_off + m] : 0.f;
+            }
+            _Pragma("unroll") for (int nf = 0; nf < NF; nf++) {
+                if (!has_aux) {
+                    _Pragma("unroll") for (int r = 0; r < 4; r++) {
+                        const int m = ((tm * WM + wm) * MF + mf) * 16 + kq * 4 + r;
+                        const Epi2 e1 = epi2_plain(bias_r[r], (m < p.M && cols[nf].yo >= 0) ? cols[nf].yo + (m + ph.y_c0) * p.y_cs : -1);
+                        epi2_finish<A_>(p, yb, acc[mf][nf][r], e1);
+                    }
+                } else {
+                    Epi2 e_[4];
+                    _Pragma("unroll") for (int r = 0; r < 4; r++)
+                        e_[r] = epi2_aux(p, ph, resb, yb, cols[nf], ((tm * WM + wm) * MF + mf) * 16 + kq * 4 + r, bias_r[r]);
+                    _Pragma("unroll") for (int r = 0; r < 4; r++) epi2_finish<A_>(p, yb, acc[mf][nf][r], e_[r]);
                 }
+            }
+        }
     )
 }
 
@@ -965,7 +1040,7 @@ __global__ __launch_bounds__(256) void igemm_lds_kernel(IgemmP p)
 // the column part of the address (stream, row, validity) is computed once per 32-column block.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int WM, int WN, int MT, int NT, bool PRE>
-__global__ __launch_bounds__(256) void igemm32_kernel(IgemmP p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void igemm32_kernel(IgemmP p)
 {
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
@@ -974,6 +1049,7 @@ __global__ __launch_bounds__(256) void igemm32_kernel(IgemmP p)
     constexpr int EPT = 16 / KR;                   // staged elements per thread per K step
     static_assert(BN <= 256 && 256 % BN == 0, "BN must divide 256");
     extern __shared__ __attribute__((aligned(16))) int s_mem[];
+    RVC_KP(0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int tn = p.m_fast ? (int)blockIdx.x / p.ntm : (int)blockIdx.x % p.ntn, tm = p.m_fast ? (int)blockIdx.x % p.ntm : (int)blockIdx.x / p.ntn;
@@ -1020,6 +1096,7 @@ __global__ __launch_bounds__(256) void igemm32_kernel(IgemmP p)
             for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
     const float pre_slope = p.pre_slope;
     __syncthreads();
+    RVC_KP(1);
     const int *kof = s_mem;
     float sb[EPT];
     f32x4 a_cur[MT][2], a_nxt[MT][2];
@@ -1035,6 +1112,7 @@ __global__ __launch_bounds__(256) void igemm32_kernel(IgemmP p)
         bt[(kr0 + i * KR) * RS + n_s] = PRE ? fmaxf(v, v * pre_slope) : v;
     }
     __syncthreads();
+    RVC_KP(2);
     // B operand of MFMA (u, j) for column block nt: row k = (2u + ks) * 4 + j of the staged tile
     const float *br = bt + wn * NT * 32 + c32 + ks * 4 * RS;
     for (int c = 0; c < nchunks; c++) {
@@ -1074,20 +1152,62 @@ __global__ __launch_bounds__(256) void igemm32_kernel(IgemmP p)
             for (int u = 0; u < 2; u++) a_cur[mt][u] = a_nxt[mt][u];
         __syncthreads();
     }
+    RVC_KP(3);
     const float *resb = p.res ? p.res + (long long)b * p.res_bs : nullptr;
     float *yb = p.y + (long long)b * p.y_bs;
     ColOut cols[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) cols[nt] = col_locate(p, ph, tn * BN + (wn * NT + nt) * 32 + c32);
     const int row0 = (tm * WM + wm) * MT * 32 + ks * 4;          // + mt * 32 + (reg & 3) + 8 * (reg >> 2)
-    RVC_ACT_DISPATCH(
-        _Pragma("unroll") for (int mt = 0; mt < MT; mt++)
-            _Pragma("unroll") for (int nt = 0; nt < NT; nt++)
-                _Pragma("unroll") for (int r = 0; r < 16; r++) {
-                    const Epi2 e_ = epi2_from_col(p, ph, resb, yb, cols[nt], row0 + mt * 32 + (r & 3) + 8 * (r >> 2));
-                    epi2_finish<A_>(p, yb, acc[mt][nt][r], e_);
+    // Epilogue operands are loaded in batches that contain no store: a load may not be moved above an earlier store (the pointers
+    // may alias), so "load bias, store, load bias, store, ..." is one memory round trip per element -- 64 of them per lane, measured
+    // 68 us of a 300 us wave lifetime on the ContentVec convolutions.  Batched: one round trip for the 16 biases of a 32-row block,
+    // one per 32x32 block for the residual / accumulate operands (none for most layers).  The batches are kept this small on
+    // purpose: a whole-tile batch took the kernel from 164 to 268 registers (3 -> 1 waves per SIMD, 1.5x slower overall).
+    const bool has_aux = resb != nullptr || p.accumulate;
+    const bool full_m = row0 - ks * 4 + MT * 32 <= p.M;          // every row of this wave's tile exists (wave-uniform)
+    if (!has_aux && full_m) {
+        // The common case, kept small on purpose: straight-line code per element is what the 64-element unrolled epilogue costs
+        // in instruction-cache footprint (the general version below is ~10x larger; with every workgroup of the chip walking
+        // through it at a different point the epilogue took 43 us per wave, most of it instruction fetch).  One predicate per
+        // 32-column block, 16 stores at scalar row offsets from one per-lane base address.
+        const float slope = p.slope, scale = p.scale;
+        const long long cs = p.y_cs;
+        RVC_ACT_DISPATCH(
+            _Pragma("unroll") for (int mt = 0; mt < MT; mt++) {
+                float bias_r[16];
+                _Pragma("unroll") for (int r = 0; r < 16; r++)
+                    bias_r[r] = p.bias ? p.bias[ph.bias_off + row0 + mt * 32 + (r & 3) + 8 * (r >> 2)] : 0.f;
+                _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {
+                    if (cols[nt].yo >= 0) {
+                        float *yc = yb + cols[nt].yo + (long long)(row0 + mt * 32 + ph.y_c0) * cs;
+                        _Pragma("unroll") for (int r = 0; r < 16; r++)
+                            yc[((r & 3) + 8 * (r >> 2)) * cs] = epi2_value<A_>(acc[mt][nt][r], bias_r[r], 0.f, 0.f, slope, scale);
+                    }
                 }
+            }
+        )
+        RVC_KP(6);
+        return;
+    }
+    RVC_ACT_DISPATCH(
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) {
+            float bias_r[16];
+            _Pragma("unroll") for (int r = 0; r < 16; r++) {
+                const int m = row0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+                bias_r[r] = (p.bias && m < p.M) ? p.bias[ph.bias_off + m] : 0.f;
+            }
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {
+                _Pragma("unroll") for (int h = 0; h < 16; h += 8) {
+                    Epi2 e_[8];
+                    _Pragma("unroll") for (int r = 0; r < 8; r++)
+                        e_[r] = epi2_aux(p, ph, resb, yb, cols[nt], row0 + mt * 32 + ((h + r) & 3) + 8 * ((h + r) >> 2), bias_r[h + r]);
+                    _Pragma("unroll") for (int r = 0; r < 8; r++) epi2_finish<A_>(p, yb, acc[mt][nt][h + r], e_[r]);
+                }
+            }
+        }
     )
+    RVC_KP(6);
 }
 
 // second stage of a split-K launch: fixed-order (deterministic) sum of the partials + epilogue

@@ -47,3 +47,16 @@ for ph in (0, 8, 9, 10, 11, 1, 2, 3, 4, 5, 6):
         dur = "%.2f" % float(np.median((t[both, ph] - t[both, prev]) / 100.0))
     print("  %d   %7.2f  %7.2f  %7.2f    %s" % (ph, r.min(), np.median(r), r.max(), dur))
     prev = ph
+# share of the summed wave lifetime spent before each stamp (what a wave is doing while it holds its slot)
+done = t[:, 6] > 0
+if done.any():
+    life = (t[done, 6] - t[done, 0]).sum()
+    prev = 0
+    parts = []
+    for ph in (8, 9, 10, 11, 1, 2, 3, 4, 5, 6):
+        ok = done & (t[:, ph] > 0) & (t[:, prev] > 0)
+        if not (t[done, ph] > 0).all():
+            continue
+        parts.append("->%d %.1f%%" % (ph, 100.0 * (t[ok, ph] - t[ok, prev]).sum() / life))
+        prev = ph
+    print("share of the waves' lifetime: " + "  ".join(parts) + "   (mean lifetime %.2f us)" % (life / done.sum() / 100.0))
