@@ -1256,6 +1256,21 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
             const float *w0 = m.conv0_raw, *gg = m.gn_g, *bb = m.gn_b; const int kt = m.conv_k[0], st = m.conv_s[0];
             const float *ain = x.p; const long long abs_ = x.bs;
             const int nt = (To + 255) / 256;
+            // many streams: 16 channels per workgroup share one register copy of the input samples (1 stream keeps one channel per
+            // workgroup: 512 workgroups are what fills the chip there)
+            int cpw = B >= 16 ? 16 : (B >= 4 ? 4 : 1);
+            while (cpw > 1 && m.conv_dim % cpw) cpw >>= 1;
+            if (kt == 10 && To <= 8 * 1024 && cpw > 1 && !getenv("RVC_NO_CONV0_MULTI")) {
+                dim3 gridm(m.conv_dim / cpw, B);
+                const int nt1k = (To + 1023) / 1024;
+                pl.ops.push_back([=](hipStream_t s) {
+                    if (nt1k <= 4) hipLaunchKernelGGL((conv0_gn_gelu_multi_kernel<4, 10>), gridm, dim3(1024), 0, s, ain, abs_, w0, st, gg, bb, y.p, To, y.ld, y.bs, cpw);
+                    else hipLaunchKernelGGL((conv0_gn_gelu_multi_kernel<8, 10>), gridm, dim3(1024), 0, s, ain, abs_, w0, st, gg, bb, y.p, To, y.ld, y.bs, cpw);
+                });
+                add_tap(pl, "cv.conv0", y);
+                x = y; T = To;
+                continue;
+            }
             pl.ops.push_back([=](hipStream_t s) {
                 if (nt <= 8) hipLaunchKernelGGL((conv0_gn_gelu_kernel<8>), grid, dim3(256), 0, s, ain, abs_, w0, kt, st, gg, bb, y.p, To, y.ld, y.bs);
                 else if (nt <= 16) hipLaunchKernelGGL((conv0_gn_gelu_kernel<16>), grid, dim3(256), 0, s, ain, abs_, w0, kt, st, gg, bb, y.p, To, y.ld, y.bs);
@@ -2412,6 +2427,44 @@ double rvc_debug_conv_bench(rvc_engine *e, int M, int Cin, int KW, int dil, int 
         if (const char *a = getenv("RVC_BENCH_ACT")) o.act = atoi(a);     // epilogue activation (ACT_* value)
         add_conv1d(pl, cw, x, y, 1, pad, dil, o);
         HIPCHK(hipDeviceSynchronize());
+        if (const char *ev = getenv("RVC_BENCH_EVICT")) {
+            // instruction-cache experiment: the target launch timed by its own dispatch events, (a) back to back with itself,
+            // (b) after launches of other kernel instantiations on small, L2-resident data.  Returns (b); prints both.
+            struct Ev { ConvW w; int M, Cin, KW, N; };
+            const int shapes[6][4] = {{64, 64, 11, 5040}, {32, 32, 7, 10080}, {128, 128, 3, 2520}, {256, 256, 11, 252}, {512, 512, 3, 111}, {16, 16, 3, 4096}};
+            Plan pe; pe.B = 1;
+            std::vector<ConvW> ews;
+            const int nev = std::min(6, std::max(1, atoi(ev)));
+            for (int k = 0; k < nev; k++) {
+                const int eM = shapes[k][0], eC = shapes[k][1], eK = shapes[k][2], eN = shapes[k][3];
+                std::vector<float> ww((size_t)eM * eC * eK, 0.01f), bb(eM, 0.f);
+                ews.push_back(prep_conv(ww.data(), bb.data(), eM, eC, eK, 1));
+                T1 ex = make_t1(pe.arena, 1, eC, eN, 8), ey = make_t1(pe.arena, 1, eM, eN, 0);
+                ConvOpts eo; eo.act = k % 3 == 0 ? ACT_LRELU : (k % 3 == 1 ? ACT_NONE : ACT_GELU);
+                add_conv1d(pe, ews.back(), ex, ey, 1, (eK - 1) / 2, 1, eo);
+            }
+            HIPCHK(hipDeviceSynchronize());
+            double t_same = 0, t_cold = 0;
+            for (int mode = 0; mode < 2; mode++) {
+                double tot = 0; int cnt = 0;
+                for (int i = 0; i < iters + 3; i++) {
+                    if (mode == 1) for (auto &op : pe.ops.v) op(e->stream);
+                    pl.profile = true; pl.prof_used = 0;
+                    for (auto &op : pl.ops.v) op(e->stream);
+                    pl.profile = false;
+                    HIPCHK(hipStreamSynchronize(e->stream));
+                    float t = 0.f;
+                    for (size_t q = 0; q < pl.prof_used; q++) { float tq; HIPCHK(hipEventElapsedTime(&tq, pl.prof[q].a, pl.prof[q].b)); t += tq; }
+                    if (i >= 3) { tot += t; cnt++; }
+                }
+                (mode == 0 ? t_same : t_cold) = tot / cnt * 1e3;
+            }
+            printf("target launch: %.2f us back to back with itself, %.2f us after %d other kernels\n", t_same, t_cold, nev);
+            for (auto &w : ews) free_conv(w);
+            free_conv(cw);
+            us = t_cold;
+            return RVC_OK;
+        }
         for (int i = 0; i < 3; i++) for (auto &op : pl.ops.v) op(e->stream);
         hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
         HIPCHK(hipEventRecord(a, e->stream));

@@ -846,6 +846,37 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
 #pragma unroll
         for (int nf = 0; nf < NF; nf++) cols[nf] = col_locate(p, ph, tn * 16 * NF + nf * 16 + li);
         const bool has_aux = resb != nullptr || p.accumulate;
+        if (!p.accumulate && (tm + 1) * 16 * MF <= p.M) {
+            // common case (every row of the tile exists, plain store): small straight-line code, one predicate per 16-column block,
+            // the residual loaded for a whole 16-row fragment before its stores (see igemm32_kernel's epilogue)
+            const float slope = p.slope, scale = p.scale;
+            const long long cs = p.y_cs, rcs = p.res_cs;
+            RVC_ACT_DISPATCH(
+                _Pragma("unroll") for (int mf = 0; mf < MF; mf++) {
+                    const int m0 = tm * 16 * MF + mf * 16 + kq * 4;
+                    float bias_r[4];
+                    _Pragma("unroll") for (int r = 0; r < 4; r++) bias_r[r] = p.bias ? p.bias[ph.bias_off + m0 + r] : 0.f;
+                    float rr[NF][4];
+                    _Pragma("unroll") for (int nf = 0; nf < NF; nf++)
+                        _Pragma("unroll") for (int r = 0; r < 4; r++) rr[nf][r] = 0.f;
+                    if (resb) {
+                        _Pragma("unroll") for (int nf = 0; nf < NF; nf++)
+                            if (cols[nf].yo >= 0) {
+                                const float *rp = resb + cols[nf].ro + (long long)(p.res_nogroup ? m0 : m0 + ph.y_c0) * rcs;
+                                _Pragma("unroll") for (int r = 0; r < 4; r++) rr[nf][r] = rp[r * rcs];
+                            }
+                    }
+                    _Pragma("unroll") for (int nf = 0; nf < NF; nf++)
+                        if (cols[nf].yo >= 0) {
+                            float *yc = yb + cols[nf].yo + (long long)(m0 + ph.y_c0) * cs;
+                            _Pragma("unroll") for (int r = 0; r < 4; r++)
+                                yc[r * cs] = epi2_value<A_>(acc[0][mf][nf][r], bias_r[r], rr[nf][r], 0.f, slope, scale);
+                        }
+                }
+            )
+            RVC_KP(6);
+            return;
+        }
         RVC_ACT_DISPATCH(
             _Pragma("unroll") for (int mf = 0; mf < MF; mf++) {
                 float bias_r[4];
@@ -1000,6 +1031,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         return;
     }
     const bool has_aux = resb != nullptr || p.accumulate;
+    if (!p.accumulate && (tm * WM + wm + 1) * MF * 16 <= p.M) {
+        // common case: small straight-line code (see igemm32_kernel's epilogue)
+        const float slope = p.slope, scale = p.scale;
+        const long long cs = p.y_cs, rcs = p.res_cs;
+        RVC_ACT_DISPATCH(
+            _Pragma("unroll") for (int mf = 0; mf < MF; mf++) {
+                const int m0 = ((tm * WM + wm) * MF + mf) * 16 + kq * 4;
+                float bias_r[4];
+                _Pragma("unroll") for (int r = 0; r < 4; r++) bias_r[r] = p.bias ? p.bias[ph.bias_off + m0 + r] : 0.f;
+                float rr[NF][4];
+                _Pragma("unroll") for (int nf = 0; nf < NF; nf++)
+                    _Pragma("unroll") for (int r = 0; r < 4; r++) rr[nf][r] = 0.f;
+                if (resb) {
+                    _Pragma("unroll") for (int nf = 0; nf < NF; nf++)
+                        if (cols[nf].yo >= 0) {
+                            const float *rp = resb + cols[nf].ro + (long long)(p.res_nogroup ? m0 : m0 + ph.y_c0) * rcs;
+                            _Pragma("unroll") for (int r = 0; r < 4; r++) rr[nf][r] = rp[r * rcs];
+                        }
+                }
+                _Pragma("unroll") for (int nf = 0; nf < NF; nf++)
+                    if (cols[nf].yo >= 0) {
+                        float *yc = yb + cols[nf].yo + (long long)(m0 + ph.y_c0) * cs;
+                        _Pragma("unroll") for (int r = 0; r < 4; r++)
+                            yc[r * cs] = epi2_value<A_>(acc[mf][nf][r], bias_r[r], rr[nf][r], 0.f, slope, scale);
+                    }
+            }
+        )
+        return;
+    }
     RVC_ACT_DISPATCH(
         _Pragma("unroll") for (int mf = 0; mf < MF; mf++) {
             float bias_r[4];
@@ -1166,23 +1226,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // purpose: a whole-tile batch took the kernel from 164 to 268 registers (3 -> 1 waves per SIMD, 1.5x slower overall).
     const bool has_aux = resb != nullptr || p.accumulate;
     const bool full_m = row0 - ks * 4 + MT * 32 <= p.M;          // every row of this wave's tile exists (wave-uniform)
-    if (!has_aux && full_m) {
+    if (!p.accumulate && full_m) {
         // The common case, kept small on purpose: straight-line code per element is what the 64-element unrolled epilogue costs
         // in instruction-cache footprint (the general version below is ~10x larger; with every workgroup of the chip walking
         // through it at a different point the epilogue took 43 us per wave, most of it instruction fetch).  One predicate per
-        // 32-column block, 16 stores at scalar row offsets from one per-lane base address.
+        // 32-column block, the block's residual operands (if any) in one batch, 16 stores at scalar row offsets from one
+        // per-lane base address.
         const float slope = p.slope, scale = p.scale;
-        const long long cs = p.y_cs;
+        const long long cs = p.y_cs, rcs = p.res_cs;
         RVC_ACT_DISPATCH(
             _Pragma("unroll") for (int mt = 0; mt < MT; mt++) {
+                const int m0 = row0 + mt * 32;
                 float bias_r[16];
                 _Pragma("unroll") for (int r = 0; r < 16; r++)
-                    bias_r[r] = p.bias ? p.bias[ph.bias_off + row0 + mt * 32 + (r & 3) + 8 * (r >> 2)] : 0.f;
+                    bias_r[r] = p.bias ? p.bias[ph.bias_off + m0 + (r & 3) + 8 * (r >> 2)] : 0.f;
                 _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {
                     if (cols[nt].yo >= 0) {
-                        float *yc = yb + cols[nt].yo + (long long)(row0 + mt * 32 + ph.y_c0) * cs;
+                        float rr[16];
+                        _Pragma("unroll") for (int r = 0; r < 16; r++) rr[r] = 0.f;
+                        if (resb) {
+                            const float *rp = resb + cols[nt].ro + (long long)(p.res_nogroup ? m0 : m0 + ph.y_c0) * rcs;
+                            _Pragma("unroll") for (int r = 0; r < 16; r++) rr[r] = rp[((r & 3) + 8 * (r >> 2)) * rcs];
+                        }
+                        float *yc = yb + cols[nt].yo + (long long)(m0 + ph.y_c0) * cs;
                         _Pragma("unroll") for (int r = 0; r < 16; r++)
-                            yc[((r & 3) + 8 * (r >> 2)) * cs] = epi2_value<A_>(acc[mt][nt][r], bias_r[r], 0.f, 0.f, slope, scale);
+                            yc[((r & 3) + 8 * (r >> 2)) * cs] = epi2_value<A_>(acc[mt][nt][r], bias_r[r], rr[r], 0.f, slope, scale);
                     }
                 }
             }
@@ -1553,6 +1621,58 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float *audio, 
     }
 }
 
+
+// The same for `cpw` consecutive channels per workgroup (many streams): a thread's NT x KT input samples are loaded ONCE into
+// registers (the stride-5 gathers are what the one-channel form spends its time on: 280 strided loads per thread and channel, 87 %
+// of the wave cycles waiting) and reused for every channel; the k weights of a channel are wave-uniform.  1024 threads per workgroup
+// keep the register copy at NT = ceil(T / 1024) samples per thread.  Same f32 chain per output as the one-channel kernel; the
+// statistics are summed in a different grouping (1024 partial sums instead of 256), as every block-size choice does.
+template <int NT, int KT>
+__global__ __launch_bounds__(1024) void conv0_gn_gelu_multi_kernel(const float *audio, long long audio_bs, const float *w, int stride, const float *g,
+                                                                   const float *bta, float *y, int T, int y_cs, long long y_bs, int cpw)
+{
+    __shared__ float red[16];
+    const int b = blockIdx.y;
+    const float *xin = audio + (long long)b * audio_bs;
+    float xr[NT][KT];
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+        const int t = threadIdx.x + i * 1024;
+        const float *xp = xin + (long long)(t < T ? t : 0) * stride;
+#pragma unroll
+        for (int k = 0; k < KT; k++) xr[i][k] = xp[k];
+    }
+    for (int cc = 0; cc < cpw; cc++) {
+        const int c = blockIdx.x * cpw + cc;
+        float wk[KT];
+#pragma unroll
+        for (int k = 0; k < KT; k++) wk[k] = w[c * KT + k];
+        float v[NT];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            float a = 0.f;
+            if ((int)threadIdx.x + i * 1024 < T) {
+#pragma unroll
+                for (int k = 0; k < KT; k++) a = fmaf(wk[k], xr[i][k], a);
+                s += a;
+            }
+            v[i] = a;
+        }
+        const float mean = block_sum(s, red) / (float)T;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT; i++) { if ((int)threadIdx.x + i * 1024 < T) { const float d = v[i] - mean; q += d * d; } }
+        const float var = block_sum(q, red) / (float)T;
+        const float inv = 1.0f / sqrtf(var + 1e-5f), gg = g[c], bb = bta[c];
+        float *r = y + (long long)b * y_bs + (long long)c * y_cs;
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const int t = threadIdx.x + i * 1024;
+            if (t < T) r[t] = apply_act((v[i] - mean) * inv * gg + bb, ACT_GELU, 0.f);
+        }
+    }
+}
 
 // GroupNorm with one group per channel (= per-channel normalisation over time) + GELU, in place.
 __global__ __launch_bounds__(256) void groupnorm_gelu_kernel(float *x, const float *g, const float *bta, int T, int cs, long long bs)

@@ -54,6 +54,30 @@ def test_64_full_size_streams_throughput_mode():
     assert np.allclose(cache5, o5.pitch_cache(), rtol=1e-5, atol=1e-3)       # per-stream state (stream 5's pitch cache) after two chunks
 
 
+def test_many_stream_first_layer_matches_the_one_channel_kernel(monkeypatch):
+    # throughput mode takes other kernels than one stream does (16 channels of the first ContentVec layer per workgroup with the input
+    # samples held in registers, streams folded into N, the 32x32x2 GEMM).  The first layer against the one-channel-per-workgroup kernel
+    # on the same 16 streams
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("full")
+    S = 16
+    xin = np.stack([voice_signal(g.input_buffer_16k_size, seed=500 + s) for s in range(S)])
+    taps = {}
+    for mode in ("multi", "single"):
+        if mode == "single":
+            monkeypatch.setenv("RVC_NO_CONV0_MULTI", "1")
+        eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"])
+        eng.set_streams(S); eng.set_noise_seed(5, 0); eng.enable_taps(True)
+        y = eng.infer_batch(xin, g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+        taps[mode] = (eng.tap("cv.conv0"), y)
+        eng.close()
+    a, b = taps["multi"][0], taps["single"][0]
+    assert a.shape == b.shape and a.size > 0 and not np.array_equal(a, np.zeros_like(a))
+    # same f32 chain per output sample; only the GroupNorm statistics are summed in another grouping (1024 partial sums instead of 256)
+    assert np.abs(a - b).max() <= 2e-5 * max(1.0, float(np.abs(b).max()))
+    assert rms(taps["multi"][1] - taps["single"][1]) < 1e-4
+
+
 def test_index_broadcast_through_rccl_one_rank():
     # rvc_rccl_unique_id + rvc_index_broadcast with a ONE-rank communicator: librccl is loaded (dlopen), ncclCommInitRank,
     # two ncclBroadcast calls (header, matrix) and ncclCommDestroy really run; the engine then retrieves exactly as after rvc_load_index
