@@ -2436,12 +2436,13 @@ double rvc_debug_conv_bench(rvc_engine *e, int M, int Cin, int KW, int dil, int 
             std::vector<ConvW> ews;
             const int nev = std::min(6, std::max(1, atoi(ev)));
             for (int k = 0; k < nev; k++) {
-                const int eM = shapes[k][0], eC = shapes[k][1], eK = shapes[k][2], eN = shapes[k][3];
+                const bool same = getenv("RVC_BENCH_EVICT_SAME") != nullptr;     // same shape = same kernel code, other buffers: data effects only
+                const int eM = same ? M : shapes[k][0], eC = same ? Cin : shapes[k][1], eK = same ? KW : shapes[k][2], eN = same ? N : shapes[k][3];
                 std::vector<float> ww((size_t)eM * eC * eK, 0.01f), bb(eM, 0.f);
                 ews.push_back(prep_conv(ww.data(), bb.data(), eM, eC, eK, 1));
                 T1 ex = make_t1(pe.arena, 1, eC, eN, 8), ey = make_t1(pe.arena, 1, eM, eN, 0);
-                ConvOpts eo; eo.act = k % 3 == 0 ? ACT_LRELU : (k % 3 == 1 ? ACT_NONE : ACT_GELU);
-                add_conv1d(pe, ews.back(), ex, ey, 1, (eK - 1) / 2, 1, eo);
+                ConvOpts eo; eo.act = same ? o.act : (k % 3 == 0 ? ACT_LRELU : (k % 3 == 1 ? ACT_NONE : ACT_GELU));
+                add_conv1d(pe, ews.back(), ex, ey, 1, (eK - 1) / 2 * (same ? dil : 1), same ? dil : 1, eo);
             }
             HIPCHK(hipDeviceSynchronize());
             double t_same = 0, t_cold = 0;
