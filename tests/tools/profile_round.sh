@@ -1,15 +1,28 @@
 #!/bin/bash
-# Round profiles: rocprofv3 kernel stats of the three single-GPU configurations + the FETCH_SIZE / WRITE_SIZE passes (separate runs,
-# --kernel-trace only, as gpurun requires).  usage: profile_round.sh <tag>   -> gpurun_out/<tag>/...
-tag=${1:-r02}; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; mkdir -p $out
+# Round profiles: rocprofv3 kernel stats of the three single-GPU configurations, the FETCH_SIZE / WRITE_SIZE passes and the SQ / TCC
+# passes (separate runs, --kernel-trace only, as gpurun requires).  Raw traces stay in /tmp on the GPU box (hundreds of MB); the
+# summaries the repository keeps are written to gpurun_out/<tag>/ under their profiles/ names.
+# usage: profile_round.sh <tag> [round]      e.g. profile_round.sh r02d r02
+tag=${1:-r02}; rnd=${2:-r02}; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; raw=/tmp/prof_$tag; mkdir -p $out $raw
 cd /tmp; export TMPDIR=/tmp
-prof() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d $out/ks_$name -- python $R/bench.py --only-headline --no-cpu "$@" > $out/bench_$name.json 2> $out/bench_$name.err; }
+prof() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d $raw/ks_$name -- python $R/bench.py --only-headline --no-cpu "$@" > $out/bench_$name.json 2> $out/bench_$name.err
+         cp $raw/ks_$name/*/*kernel_stats.csv $out/${rnd}_kernel_stats_bench_$name.csv; }
 prof 1stream --steps 100
 prof index100k --steps 100 --index
 prof 64streams --steps 15 --warmup 3 --streams 64
-pmc() { name=$1; ctr=$2; shift 2; rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/pmc_${name}_$ctr -- python $R/bench.py --only-headline --no-cpu "$@" > /dev/null 2>&1; }
+pmc() { name=$1; ctr=$2; shift 2; rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $raw/pmc_${name}_$ctr -- python $R/bench.py --only-headline --no-cpu "$@" > /dev/null 2>&1; }
 pmc index100k FETCH_SIZE --steps 40 --index
 pmc index100k WRITE_SIZE --steps 40 --index
 pmc 64streams FETCH_SIZE --steps 6 --warmup 2 --streams 64
 pmc 64streams WRITE_SIZE --steps 6 --warmup 2 --streams 64
-ls $out
+python $R/tests/tools/pmc_traffic.py $raw/pmc_index100k_FETCH_SIZE/*/*counter_collection.csv $raw/pmc_index100k_WRITE_SIZE/*/*counter_collection.csv $out/${rnd}_pmc_traffic.json "bench.py --only-headline --index (1 stream + 100k x 768 index):" > /dev/null
+python $R/tests/tools/pmc_traffic.py $raw/pmc_64streams_FETCH_SIZE/*/*counter_collection.csv $raw/pmc_64streams_WRITE_SIZE/*/*counter_collection.csv $out/${rnd}_pmc_traffic_64streams.json "bench.py --only-headline --streams 64:" > /dev/null
+# SQ / TCC counters per kernel instantiation (two passes each: 8 SQ counters, then TCC + GRBM) -> tests/tools/pmc_summary.py
+SQ="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA"
+pmcs() { name=$1; shift; rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $raw/pmcs_${name}_a -- python $R/bench.py --only-headline --no-cpu "$@" > /dev/null 2>&1
+         rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $raw/pmcs_${name}_b -- python $R/bench.py --only-headline --no-cpu "$@" > /dev/null 2>&1; }
+pmcs 1stream --steps 40
+pmcs 64streams --steps 6 --warmup 2 --streams 64
+python $R/tests/tools/pmc_summary.py $out/${rnd}_pmc_igemm_summary.json "bench_1stream=$(ls $raw/pmcs_1stream_a/*/*counter_collection.csv),$(ls $raw/pmcs_1stream_b/*/*counter_collection.csv)" \
+    "bench_64streams=$(ls $raw/pmcs_64streams_a/*/*counter_collection.csv),$(ls $raw/pmcs_64streams_b/*/*counter_collection.csv)" > $out/pmc_summary.txt
+ls -la $out
