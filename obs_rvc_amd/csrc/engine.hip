@@ -428,7 +428,8 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     // throughput mode (many streams): workgroup-tiled kernel with the activation tile shared through LDS
     int lds_cfg = -1;
     if (!getenv("RVC_NO_LDS_GEMM") && nchunks >= 2 && (size_t)nchunks * 64 + 2 * 16 * 260 * 4 <= 60 * 1024) {
-        const int bm = p.M >= 96 ? 128 : (p.M >= 48 ? 64 : (p.M > 16 ? 32 : 0));
+        int bm = p.M >= 96 ? 128 : (p.M >= 48 ? 64 : (p.M > 16 ? 32 : 0));
+        if (const char *f = getenv("RVC_G32_BM")) { const int v = atoi(f); if (v == 32 || v == 64 || v == 128) bm = v; }   // tuning aid
         const int bn = bm == 128 ? 128 : 256;
         if (bm) {
             const long long wgs = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * B * p.nphase;
@@ -444,8 +445,11 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
             else if (g32 >= 2 && wgs >= g32_min && !p.glu) lds_cfg = 3 + (bm == 128 ? 0 : (bm == 64 ? 1 : 2));   // (gated layers stay on the kernels that are tested with the gate)
         }
     }
+    // 48-row panels (ContentVec's grouped positional convolution: 16 groups of 48 channels, K = 6144 each): three 16-row fragments
+    // exactly, instead of a 64-row tile with a quarter of its MFMAs on padding
+    if (lds_cfg == 1 && p.M == 48 && !getenv("RVC_NO_BM48")) lds_cfg = 6;
     if (lds_cfg >= 0) {
-        const int bm = lds_cfg % 3 == 0 ? 128 : (lds_cfg % 3 == 1 ? 64 : 32), bn = lds_cfg % 3 == 0 ? 128 : 256;
+        const int bm = lds_cfg == 6 ? 48 : (lds_cfg % 3 == 0 ? 128 : (lds_cfg % 3 == 1 ? 64 : 32)), bn = (lds_cfg != 6 && lds_cfg % 3 == 0) ? 128 : 256;
         p.ksplit = 1; p.chunks_per_split = nchunks;
         p.ntm = (p.M + bm - 1) / bm; p.ntn = (p.N + bn - 1) / bn;
         p.m_fast = p.fold_n ? p.ntm : 0;
@@ -456,7 +460,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
         pl.igemm_flops += flops; pl.n_igemm++;
         Plan *plp = &pl;
         const int lc = lds_cfg;
-        { char d[160]; snprintf(d, sizeof d, "%s M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%u", lds_cfg >= 3 ? "g32" : "lds", p.M, p.N, p.K, B, p.nphase, bm, bn, grid.x, grid.y); pl.descs.push_back(d); }
+        { char d[160]; snprintf(d, sizeof d, "%s M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%u", (lds_cfg >= 3 && lds_cfg != 6) ? "g32" : "lds", p.M, p.N, p.K, B, p.nphase, bm, bn, grid.x, grid.y); pl.descs.push_back(d); }
         const int desc_id = (int)pl.descs.size() - 1;
         pl.ops.push_back([=](hipStream_t s) {
             ProfEvent *pe = nullptr;
@@ -468,7 +472,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
 #define RVC_LG1(K) { if (ea) hipExtLaunchKernelGGL((K), grid, dim3(256), (uint32_t)lds, s, ea, eb, 0, p); else hipLaunchKernelGGL((K), grid, dim3(256), lds, s, p); }
 #define RVC_LG(WM, WN, MF, NF) { if (pre) RVC_LG1((igemm_lds_kernel<WM, WN, MF, NF, true>)) else RVC_LG1((igemm_lds_kernel<WM, WN, MF, NF, false>)) }
 #define RVC_LG32(WM, WN, MT, NT) { if (pre) RVC_LG1((igemm32_kernel<WM, WN, MT, NT, true>)) else RVC_LG1((igemm32_kernel<WM, WN, MT, NT, false>)) }
-            if (lc == 0) RVC_LG(2, 2, 4, 4) else if (lc == 1) RVC_LG(1, 4, 4, 4) else if (lc == 2) RVC_LG(1, 4, 2, 4)
+            if (lc == 0) RVC_LG(2, 2, 4, 4) else if (lc == 1) RVC_LG(1, 4, 4, 4) else if (lc == 2) RVC_LG(1, 4, 2, 4) else if (lc == 6) RVC_LG(1, 4, 3, 4)
             else if (lc == 3) RVC_LG32(2, 2, 2, 2) else if (lc == 4) RVC_LG32(1, 4, 2, 2) else RVC_LG32(1, 4, 1, 2)
 #undef RVC_LG32
 #undef RVC_LG

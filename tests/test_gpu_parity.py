@@ -512,7 +512,8 @@ def test_every_tile_configuration_computes_the_same_convolution():
                     assert 0 <= e1 < 2e-5, (cfg, ks, M, Cin, KW, dil, N, pre, e1)
         os.environ.pop("RVC_FORCE_CFG")
         for streams in (3, 20):                            # folded streams; 20 streams reach the workgroup-tiled kernels on the wide layers
-            for (M, Cin, KW, dil, N, pre) in shapes + [(128, 128, 7, 3, 2520, 1), (768, 256, 1, 1, 111, 0)]:
+            # (+ a 48-row panel wide enough for the 48 x 256 workgroup tile, a 32-row and a 64-row panel for the narrow 32x32x2 tiles)
+            for (M, Cin, KW, dil, N, pre) in shapes + [(128, 128, 7, 3, 2520, 1), (768, 256, 1, 1, 111, 0), (48, 48, 15, 1, 5000, 0), (32, 32, 11, 1, 10080, 1), (64, 64, 7, 1, 5040, 0)]:
                 e2 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, streams, pre)
                 assert 0 <= e2 < 2e-5, (streams, M, Cin, KW, dil, N, pre, e2)
     finally:
