@@ -448,8 +448,17 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     // 48-row panels (ContentVec's grouped positional convolution: 16 groups of 48 channels, K = 6144 each): three 16-row fragments
     // exactly, instead of a 64-row tile with a quarter of its MFMAs on padding
     if (lds_cfg == 1 && p.M == 48 && !getenv("RVC_NO_BM48")) lds_cfg = 6;
+    // mid-size panels (M = 768 at 64 streams: 336 tiles of 128 x 128 balance badly over 256 CUs, and the register-direct 2 x 4 tile runs
+    // at two waves per SIMD): 128 x 64 tiles of the 32x32x2 kernel, four waves stacked in M over one 64-column activation tile
+    // (768 x 3072 projection at 64 streams: 361 -> 342 us; small, but the same kernel)
+    static const long long g32_narrow_min = getenv("RVC_G32_NARROW") ? atoll(getenv("RVC_G32_NARROW")) : 500;     // 0 = off
+    if (lds_cfg < 0 && g32_narrow_min > 0 && !getenv("RVC_NO_LDS_GEMM") && !p.glu && nchunks >= 2 && p.M >= 96 && (size_t)nchunks * 64 + 2 * 16 * 68 * 4 <= 60 * 1024) {
+        const long long wgs = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * B * p.nphase;
+        if (wgs >= g32_narrow_min) lds_cfg = 7;
+    }
     if (lds_cfg >= 0) {
-        const int bm = lds_cfg == 6 ? 48 : (lds_cfg % 3 == 0 ? 128 : (lds_cfg % 3 == 1 ? 64 : 32)), bn = (lds_cfg != 6 && lds_cfg % 3 == 0) ? 128 : 256;
+        const int bm = lds_cfg == 7 ? 128 : (lds_cfg == 6 ? 48 : (lds_cfg % 3 == 0 ? 128 : (lds_cfg % 3 == 1 ? 64 : 32)));
+        const int bn = lds_cfg == 7 ? 64 : ((lds_cfg != 6 && lds_cfg % 3 == 0) ? 128 : 256);
         p.ksplit = 1; p.chunks_per_split = nchunks;
         p.ntm = (p.M + bm - 1) / bm; p.ntn = (p.N + bn - 1) / bn;
         p.m_fast = p.fold_n ? p.ntm : 0;
@@ -472,7 +481,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
 #define RVC_LG1(K) { if (ea) hipExtLaunchKernelGGL((K), grid, dim3(256), (uint32_t)lds, s, ea, eb, 0, p); else hipLaunchKernelGGL((K), grid, dim3(256), lds, s, p); }
 #define RVC_LG(WM, WN, MF, NF) { if (pre) RVC_LG1((igemm_lds_kernel<WM, WN, MF, NF, true>)) else RVC_LG1((igemm_lds_kernel<WM, WN, MF, NF, false>)) }
 #define RVC_LG32(WM, WN, MT, NT) { if (pre) RVC_LG1((igemm32_kernel<WM, WN, MT, NT, true>)) else RVC_LG1((igemm32_kernel<WM, WN, MT, NT, false>)) }
-            if (lc == 0) RVC_LG(2, 2, 4, 4) else if (lc == 1) RVC_LG(1, 4, 4, 4) else if (lc == 2) RVC_LG(1, 4, 2, 4) else if (lc == 6) RVC_LG(1, 4, 3, 4)
+            if (lc == 0) RVC_LG(2, 2, 4, 4) else if (lc == 1) RVC_LG(1, 4, 4, 4) else if (lc == 2) RVC_LG(1, 4, 2, 4) else if (lc == 6) RVC_LG(1, 4, 3, 4) else if (lc == 7) RVC_LG32(4, 1, 1, 2)
             else if (lc == 3) RVC_LG32(2, 2, 2, 2) else if (lc == 4) RVC_LG32(1, 4, 2, 2) else RVC_LG32(1, 4, 1, 2)
 #undef RVC_LG32
 #undef RVC_LG
