@@ -2753,14 +2753,37 @@ __global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p)
     float ld[KNN_K]; int li_[KNN_K];
 #pragma unroll
     for (int k = 0; k < KNN_K; k++) { ld[k] = INFINITY; li_[k] = 0x7fffffff; }
-    for (int i = tid; i < p.n; i += 1024) {
-        const float d = a[i];
+    // sorted insert with static indices only (a `while (q > 0 && d < ld[q - 1])` walk indexes the arrays dynamically, which puts them
+    // in scratch memory): slot q takes its left neighbour if d belongs further left, d itself if it belongs here
+    auto keep = [&](float d, int i) {
         if (d < ld[KNN_K - 1]) {
-            int q = KNN_K - 1;
-            while (q > 0 && d < ld[q - 1]) { ld[q] = ld[q - 1]; li_[q] = li_[q - 1]; q--; }
-            ld[q] = d; li_[q] = i;
+#pragma unroll
+            for (int q = KNN_K - 1; q >= 1; q--) {
+                const bool left = d < ld[q - 1], here = !left && d < ld[q];
+                ld[q] = left ? ld[q - 1] : (here ? d : ld[q]);
+                li_[q] = left ? li_[q - 1] : (here ? i : li_[q]);
+            }
+            if (d < ld[0]) { ld[0] = d; li_[0] = i; }
+        }
+    };
+    // the scan of the n approximate distances: 16-byte loads, four of them in flight per thread (one load per iteration and a
+    // data-dependent branch behind it made this pass ~100 dependent round trips: 80 us for 100 k vectors, more than the scan that
+    // produced the distances).  Only the VALUE of the 4th smallest is used below, so the visiting order does not matter.
+    const int n4 = ((p.n & 3) == 0 && (reinterpret_cast<size_t>(a) & 15) == 0) ? p.n >> 2 : 0;
+    for (int i4 = tid; i4 < n4; i4 += 4 * 1024) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int g = i4 + u * 1024; v[u] = *reinterpret_cast<const f32x4 *>(a + 4 * (g < n4 ? g : i4)); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int g = i4 + u * 1024;
+            if (g < n4) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) keep(v[u][e], 4 * g + e);
+            }
         }
     }
+    for (int i = 4 * n4 + tid; i < p.n; i += 1024) keep(a[i], i);
     int pos = 0;
     for (int k = 0; k < KNN_K; k++) {
         float md = pos < KNN_K ? ld[pos] : INFINITY; int mi = pos < KNN_K ? li_[pos] : 0x7fffffff;
@@ -2796,7 +2819,21 @@ __global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p)
     const float margin = 2e-3f * (fabsf(a4 + s_xn) + s_xn + 1e-3f);
     const float thr = a4 + margin;
     __syncthreads();
-    for (int i = tid; i < p.n; i += 1024) {
+    for (int i4 = tid; i4 < n4; i4 += 4 * 1024) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int g = i4 + u * 1024; v[u] = *reinterpret_cast<const f32x4 *>(a + 4 * (g < n4 ? g : i4)); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int g = i4 + u * 1024;
+            if (g < n4) {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (v[u][e] <= thr) { int c = atomicAdd(&cnt, 1); if (c < KNN_CAND) cand_i[c] = 4 * g + e; }
+            }
+        }
+    }
+    for (int i = 4 * n4 + tid; i < p.n; i += 1024) {
         if (a[i] <= thr) { int c = atomicAdd(&cnt, 1); if (c < KNN_CAND) cand_i[c] = i; }
     }
     __syncthreads();
