@@ -255,6 +255,10 @@ struct ConvOpts {
     int m_off = 0, m_cnt = -1;   // output-row sub-range of the weight panel
     bool no_bias = false;
     bool glu = false;            // GLU-packed weight rows, gate fused into the epilogue (ModelSY flows)
+    // LayerNorm folded into its neighbours (IgemmP::ln_*): this layer consumes a not-yet-normalised tensor (weights pre-scaled, wsum
+    // per output row, optional (mean, rstd) output) / this layer's residual is LayerNorm(stored tensor) with published statistics
+    const float *ln_wsum = nullptr; float *ln_stats_out = nullptr; int ln_rows = 0;
+    const float *ln_stats_in = nullptr, *ln_g = nullptr, *ln_b = nullptr;
 };
 
 struct ProfEvent { hipEvent_t a, b; double flops; double bytes; int desc = -1; };   // bytes > 0: HBM-bound retrieval scan (flops = 0)
@@ -331,6 +335,22 @@ static const int kMF[5] = {1, 1, 1, 2, 2}, kNF[5] = {1, 2, 4, 2, 4};
 // lean kernel (igemm2): 2-D tile grid, LDS = offset table (none for LIN layers) + the KS partial tiles
 static void launch_igemm2(int cfg, int ks, bool pre, bool lin, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr)
 {
+    if (p.ln_wsum) {           // LayerNorm-consumer instantiations (checked at plan time: lin, ks > 1)
+#define RVC_LNB(MF, NF, D)                                                                                             \
+        switch (ks) {                                                                                                  \
+        case 4: launch_k(igemm2_kernel<MF, NF, D, 4, false, true, true>, p, grid, dim3(256), lds, s, ea, eb); return;  \
+        case 8: launch_k(igemm2_kernel<MF, NF, D, 8, false, true, true>, p, grid, dim3(512), lds, s, ea, eb); return;  \
+        default: launch_k(igemm2_kernel<MF, NF, (D > 8 ? 8 : D), 16, false, true, true>, p, grid, dim3(1024), lds, s, ea, eb); return; \
+        }
+        switch (cfg) {
+        case 0: RVC_LNB(1, 1, 12)
+        case 1: RVC_LNB(1, 2, 8)
+        case 2: RVC_LNB(1, 4, 5)
+        case 3: RVC_LNB(2, 2, 6)
+        default: RVC_LNB(2, 4, 4)
+        }
+#undef RVC_LNB
+    }
 #define RVC_KS2(MF, NF, D, PRE, LIN)                                                                                   \
         switch (ks) {                                                                                                  \
         case 1: launch_k(igemm2_kernel<MF, NF, D, 1, PRE, LIN>, p, grid, dim3(256), lds, s, ea, eb); return;           \
@@ -427,7 +447,8 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     }
     // throughput mode (many streams): workgroup-tiled kernel with the activation tile shared through LDS
     int lds_cfg = -1;
-    if (!getenv("RVC_NO_LDS_GEMM") && nchunks >= 2 && (size_t)nchunks * 64 + 2 * 16 * 260 * 4 <= 60 * 1024) {
+    const bool ln_fold = p.ln_wsum || p.ln_stats_in;      // folded LayerNorm lives in the register-direct kernel's K-split epilogue
+    if (!ln_fold && !getenv("RVC_NO_LDS_GEMM") && nchunks >= 2 && (size_t)nchunks * 64 + 2 * 16 * 260 * 4 <= 60 * 1024) {
         int bm = p.M >= 96 ? 128 : (p.M >= 48 ? 64 : (p.M > 16 ? 32 : 0));
         if (const char *f = getenv("RVC_G32_BM")) { const int v = atoi(f); if (v == 32 || v == 64 || v == 128) bm = v; }   // tuning aid
         const int bn = bm == 128 ? 128 : 256;
@@ -452,7 +473,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     // at two waves per SIMD): 128 x 64 tiles of the 32x32x2 kernel, four waves stacked in M over one 64-column activation tile
     // (768 x 3072 projection at 64 streams: 361 -> 342 us; small, but the same kernel)
     static const long long g32_narrow_min = getenv("RVC_G32_NARROW") ? atoll(getenv("RVC_G32_NARROW")) : 500;     // 0 = off
-    if (lds_cfg < 0 && g32_narrow_min > 0 && !getenv("RVC_NO_LDS_GEMM") && !p.glu && nchunks >= 2 && p.M >= 96 && (size_t)nchunks * 64 + 2 * 16 * 68 * 4 <= 60 * 1024) {
+    if (lds_cfg < 0 && !ln_fold && g32_narrow_min > 0 && !getenv("RVC_NO_LDS_GEMM") && !p.glu && nchunks >= 2 && p.M >= 96 && (size_t)nchunks * 64 + 2 * 16 * 68 * 4 <= 60 * 1024) {
         const long long wgs = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * B * p.nphase;
         if (wgs >= g32_narrow_min) lds_cfg = 7;
     }
@@ -499,6 +520,15 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     if (const char *f = getenv("RVC_FORCE_CFG")) {   // tuning aid: "cfg,ks[,mfast]"
         int fc = 0, fk = 1; if (sscanf(f, "%d,%d", &fc, &fk) >= 1) { cfg = fc; wg_ks = fk; }
     }
+    if (p.ln_wsum || p.ln_stats_in) {
+        // folded LayerNorm: one stream, in-workgroup K split (the statistics / the normalised residual live in that epilogue)
+        if (lds_cfg >= 0 || B != 1 || p.fold_n || p.nphase != 1) throw std::logic_error("folded LayerNorm outside its supported launch shape");
+        if (wg_ks == 1) {
+            wg_ks = 4;
+            while (cfg > 0 && (nchunks / wg_ks < 4 || wg_ks * kMF[cfg] * kNF[cfg] > 32)) cfg = cfg == 4 ? 3 : (cfg == 3 ? 1 : 0);
+        }
+        if (p.ln_wsum && (p.lin_cs4 == 0 || pre || nchunks / wg_ks < 1)) throw std::logic_error("LayerNorm consumer must be a table-free 1x1 layer");
+    }
     int ksplit = 1;
     if ((size_t)nchunks * 64 > 60 * 1024 && p.glu) throw ShapeError("gated conv too long for the fused epilogue");
     if ((size_t)nchunks * 64 > 60 * 1024) {     // koff slice would not fit in LDS: grid-level split (two-stage, rare)
@@ -533,7 +563,8 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
         grid = dim3(gx, (unsigned)slow_n, (unsigned)(B * p.nphase));
         if (grid.y > 65535 || grid.z > 65535) throw ShapeError("implicit GEMM grid too large");
         p.nbatch = B;
-        lds2 = (lin ? 0 : (size_t)nchunks * 64) + (wg_ks > 1 ? (size_t)wg_ks * kMF[cfg] * kNF[cfg] * 1024 : 0);
+        lds2 = (lin ? 0 : (size_t)nchunks * 64) + (wg_ks > 1 ? (size_t)wg_ks * kMF[cfg] * kNF[cfg] * 1024 : 0) + (p.ln_wsum ? (size_t)wg_ks * kNF[cfg] * 16 * 2 * 4 : 0);
+        if (p.ln_wsum && !lin) throw std::logic_error("LayerNorm consumer did not get the table-free kernel");
     }
     g_last_wgs = (int)(grid.x * grid.y * grid.z); g_last_waves = wg_ks > 1 ? wg_ks : 4;
     const double flops = 2.0 * p.M * (double)p.N * ksum * B;
@@ -568,6 +599,9 @@ static void fill_epilogue(IgemmP &p, const ConvW &cw, const ConvOpts &o)
     p.pre_act = o.pre_act; p.pre_slope = o.pre_act == ACT_LRELU ? o.pre_slope : 1.0f;
     p.part = nullptr;
     p.glu = o.glu ? 1 : 0;
+    p.ln_wsum = o.ln_wsum; p.ln_stats_out = o.ln_stats_out; p.ln_stats_in = o.ln_stats_in; p.ln_g = o.ln_g; p.ln_bt = o.ln_b;
+    p.ln_eps = 1e-5f; p.ln_inv_rows = o.ln_rows > 0 ? 1.0f / (float)o.ln_rows : 0.f;
+    if (o.ln_stats_in && !(o.res && o.ln_g && o.ln_b)) throw std::logic_error("normalised residual without residual / scale / shift");
     if (o.glu && (p.bias == nullptr || o.res || o.accumulate || o.act != ACT_NONE)) throw std::runtime_error("glu epilogue takes bias only");
 }
 
@@ -795,7 +829,26 @@ struct ModelCV {
     ConvW conv[7], proj, pos, final_proj;
     float *gn_g, *gn_b, *ln0_g, *ln0_b, *encln_g, *encln_b;
     float *conv0_raw = nullptr;     // [conv_dim][conv_k0] row-major copy of the first conv (fused conv + GroupNorm + GELU kernel)
-    struct Layer { ConvW qkv, o, ff1, ff2; float *ln1_g, *ln1_b, *ln2_g, *ln2_b; };
+    // qkv_f / ff1_f: the same projections with the PRECEDING LayerNorm folded in (W' = W diag(g), b' = b + W beta, wsum = row sums of W'):
+    // one-stream plans feed them the not-yet-normalised tensor and drop the LayerNorm launches (build_contentvec)
+    struct Layer { ConvW qkv, o, ff1, ff2, qkv_f, ff1_f; float *qkv_wsum = nullptr, *ff1_wsum = nullptr; float *ln1_g, *ln1_b, *ln2_g, *ln2_b; };
+    bool has_folded = false;
+    static ConvW fold_ln(const float *w, const float *bias, int M, int K, const float *g, const float *beta, float **wsum_dev)
+    {
+        std::vector<float> wf((size_t)M * K), bf(M), ws(M);
+        for (int m = 0; m < M; m++) {
+            double sb = bias ? bias[m] : 0.0, sw = 0.0;
+            for (int k = 0; k < K; k++) {
+                const float v = w[(size_t)m * K + k] * g[k];
+                wf[(size_t)m * K + k] = v;
+                sb += (double)w[(size_t)m * K + k] * beta[k];
+                sw += v;
+            }
+            bf[m] = (float)sb; ws[m] = (float)sw;
+        }
+        *wsum_dev = upload_f(ws);
+        return prep_conv(wf.data(), bf.data(), M, K, 1, 1);
+    }
     std::vector<Layer> layers;
     std::vector<float *> owned;
     size_t weight_bytes = 0;
@@ -830,6 +883,11 @@ struct ModelCV {
             L.ff2 = prep_conv(b.w(fmt("cv.l%d.ff2.w", l)), b.w(fmt("cv.l%d.ff2.b", l)), E, ffn, 1, 1);
             L.ln1_g = own(fmt("cv.l%d.ln1.g", l)); L.ln1_b = own(fmt("cv.l%d.ln1.b", l));
             L.ln2_g = own(fmt("cv.l%d.ln2.g", l)); L.ln2_b = own(fmt("cv.l%d.ln2.b", l));
+            if (E >= 256 && E % 64 == 0 && ffn % 64 == 0 && !getenv("RVC_NO_LN_FUSE")) {
+                has_folded = true;
+                L.ff1_f = fold_ln(b.w(fmt("cv.l%d.ff1.w", l)), b.w(fmt("cv.l%d.ff1.b", l)), ffn, E, b.w(fmt("cv.l%d.ln1.g", l)), b.w(fmt("cv.l%d.ln1.b", l)), &L.ff1_wsum);
+                if (l > 0) L.qkv_f = fold_ln(w.data(), bb.data(), 3 * E, E, b.w(fmt("cv.l%d.ln2.g", l - 1)), b.w(fmt("cv.l%d.ln2.b", l - 1)), &L.qkv_wsum);
+            }
             layers.push_back(L);
         }
         if (out_dim != E) final_proj = prep_conv(b.w("cv.final_proj.w"), b.w("cv.final_proj.b"), out_dim, E, 1, 1);
@@ -839,7 +897,11 @@ struct ModelCV {
     {
         for (auto &c : conv) free_conv(c);
         free_conv(proj); free_conv(pos); free_conv(final_proj);
-        for (auto &L : layers) { free_conv(L.qkv); free_conv(L.o); free_conv(L.ff1); free_conv(L.ff2); }
+        for (auto &L : layers) {
+            free_conv(L.qkv); free_conv(L.o); free_conv(L.ff1); free_conv(L.ff2); free_conv(L.qkv_f); free_conv(L.ff1_f);
+            if (L.qkv_wsum) (void)hipFree(L.qkv_wsum);
+            if (L.ff1_wsum) (void)hipFree(L.ff1_wsum);
+        }
         for (float *p : owned) (void)hipFree(p);
     }
     int out_frames(size_t L) const
@@ -1318,8 +1380,17 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
     const size_t attn_lds = ((size_t)((hd * Tp + 3) & ~3) + 16 * Tp + 16 * hd) * sizeof(float);
     if (attn_lds > 160 * 1024) throw ShapeError("ContentVec attention: window too long for the LDS-resident kernel (T <= ~490 at head size 64)");
     HIPCHK(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    // One stream: the 2 LayerNorm launches of a layer are folded into the GEMMs around them (h2 then holds the NOT yet normalised sum;
+    // `raw` says so, with the pending LayerNorm's scale / shift and the buffer its column statistics are published in)
+    const bool fuse_ln = B == 1 && m.has_folded && !pl.with_taps && !getenv("RVC_NO_LN_FUSE");
+    bool raw = false; const float *raw_g = nullptr, *raw_b = nullptr; float *raw_st = nullptr;
     for (int l = 0; l < m.run_layers; l++) {
         ModelCV::Layer &Ly = m.layers[l];
+        if (fuse_ln) {
+            float *st_a = A.floats((size_t)2 * T + 16);
+            if (raw) { ConvOpts o; o.ln_wsum = Ly.qkv_wsum; o.ln_stats_out = st_a; o.ln_rows = E; add_conv1d(pl, Ly.qkv_f, h2, qkv, 1, 0, 1, o); raw_st = st_a; }
+            else add_conv1d(pl, Ly.qkv, h2, qkv, 1, 0, 1);
+        } else
         add_conv1d(pl, Ly.qkv, h2, qkv, 1, 0, 1);
         AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = E; ap.T = T; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;
         ap.scale = 1.0f / sqrtf((float)hd); ap.rel_k = nullptr; ap.rel_v = nullptr; ap.window = 0;
@@ -1334,11 +1405,24 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
         } else {
             pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(attention_kernel, ag, dim3(256), attn_lds, s, ap); });
         }
+        if (fuse_ln) {
+            float *st_1 = A.floats((size_t)2 * T + 16);
+            {   // attention output projection + residual; the residual is LayerNorm2 of the previous layer when that one is still pending
+                ConvOpts o; o.res = h2.p; o.res_cs = h2.ld; o.res_bs = h2.bs;
+                if (raw) { o.ln_stats_in = raw_st; o.ln_g = raw_g; o.ln_b = raw_b; }
+                add_conv1d(pl, Ly.o, att, h2, 1, 0, 1, o);
+            }
+            { ConvOpts o; o.act = ACT_GELU; o.ln_wsum = Ly.ff1_wsum; o.ln_stats_out = st_1; o.ln_rows = E; add_conv1d(pl, Ly.ff1_f, h2, ff, 1, 0, 1, o); }     // LayerNorm1 folded
+            { ConvOpts o; o.res = h2.p; o.res_cs = h2.ld; o.res_bs = h2.bs; o.ln_stats_in = st_1; o.ln_g = Ly.ln1_g; o.ln_b = Ly.ln1_b; add_conv1d(pl, Ly.ff2, ff, h2, 1, 0, 1, o); }
+            if (l + 1 < m.run_layers) { raw = true; raw_g = Ly.ln2_g; raw_b = Ly.ln2_b; }
+            else { add_layernorm(pl, h2, Ly.ln2_g, Ly.ln2_b); raw = false; }
+        } else {
         { ConvOpts o; o.res = h2.p; o.res_cs = h2.ld; o.res_bs = h2.bs; add_conv1d(pl, Ly.o, att, h2, 1, 0, 1, o); }
         add_layernorm(pl, h2, Ly.ln1_g, Ly.ln1_b);
         { ConvOpts o; o.act = ACT_GELU; add_conv1d(pl, Ly.ff1, h2, ff, 1, 0, 1, o); }
         { ConvOpts o; o.res = h2.p; o.res_cs = h2.ld; o.res_bs = h2.bs; add_conv1d(pl, Ly.ff2, ff, h2, 1, 0, 1, o); }
         add_layernorm(pl, h2, Ly.ln2_g, Ly.ln2_b);
+        }
         if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "cv.l%d", l); add_tap(pl, nm, h2); } else if (l % 4 == 3) add_stamp(pl, "cv.l4");
     }
     T1 out = h2;

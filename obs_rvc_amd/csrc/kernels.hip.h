@@ -73,6 +73,15 @@ struct IgemmP {
     int fold_n;              // > 0: the streams of the launch are folded into the N axis: position n = stream (n / fold_n), local position
                              // (n % fold_n); N = streams * fold_n and the launch has one batch (tiles may straddle streams, nothing is padded per stream)
     int lin_cs4;             // igemm2 LIN layers (1x1 conv on a 1-D tensor): input channel stride in BYTES, k-th operand row = k * lin_cs4
+    // LayerNorm folded into its neighbours (one stream, ContentVec's post-LN layers):
+    //  * consumer of a not-yet-normalised tensor y (igemm2 LNB instantiations): the weights carry the LayerNorm scale, the bias its
+    //    shift; the kernel sums y and y^2 per column from the operand stream it reads anyway and finishes
+    //    out = rstd[n] * (acc - mean[n] * ln_wsum[m]) + bias[m];  the tm == 0 workgroups also publish (mean, rstd) per column
+    //  * a later layer whose RESIDUAL is LayerNorm(y): res = (y - mean[n]) * rstd[n] * ln_g[row] + ln_bt[row], from the published stats
+    const float *ln_wsum;    // [M] sum_k W'[m][k]
+    float *ln_stats_out;     // [N][2]
+    const float *ln_stats_in, *ln_g, *ln_bt;
+    float ln_eps, ln_inv_rows;
 };
 
 __device__ __forceinline__ void epilogue_store(const IgemmP &p, const PhaseD &ph, int b, int m, int n, float acc)
@@ -440,6 +449,7 @@ __device__ __forceinline__ Epi2 epi2_prefetch(const IgemmP &p, const PhaseD &ph,
 {
     Epi2 e = {0.f, 0.f, 0.f, -1};
     if (m >= p.M || n >= p.N) return e;
+    const int n_launch = n;
     int bb = 0;
     if (p.fold_n) { bb = n / p.fold_n; n -= bb * p.fold_n; }
     int nh = 0, nw = n;
@@ -449,7 +459,12 @@ __device__ __forceinline__ Epi2 epi2_prefetch(const IgemmP &p, const PhaseD &ph,
     const int ch = m + ph.y_c0;
     e.yo = bb * (int)p.y_bs + ch * p.y_cs + oh * p.y_rs + ow;
     if (p.bias) e.bias = p.bias[ph.bias_off + m];
-    if (resb) e.res = resb[bb * (int)p.res_bs + (p.res_nogroup ? m : ch) * p.res_cs + oh * p.res_rs + ow];
+    if (resb) {
+        const int rrow = p.res_nogroup ? m : ch;
+        e.res = resb[bb * (int)p.res_bs + rrow * p.res_cs + oh * p.res_rs + ow];
+        if (p.ln_stats_in)       // the residual is LayerNorm(stored tensor): normalise on the fly
+            e.res = (e.res - p.ln_stats_in[2 * n_launch]) * p.ln_stats_in[2 * n_launch + 1] * p.ln_g[rrow] + p.ln_bt[rrow];
+    }
     if (p.accumulate) e.yold = yb[e.yo];
     return e;
 }
@@ -534,9 +549,11 @@ __device__ __forceinline__ void glu_from_col_b(const IgemmP &p, const PhaseD &ph
     default: { constexpr int A_ = ACT_NONE; STMT } break;                        \
     }
 
-template <int MF, int NF, int D, int KS, bool PRE, bool LIN>
-__global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p)
+template <int MF, int NF, int D, int KS, bool PRE, bool LIN, bool LNB = false>
+__global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) __attribute__((amdgpu_waves_per_eu(LNB ? 2 : 1)))      // (LNB: 264 registers otherwise -- one wave per SIMD)
+void igemm2_kernel(IgemmP p)
 {
+    static_assert(!LNB || (LIN && !PRE && KS > 1), "LayerNorm-consumer instantiations: table-free 1x1 layers with the in-workgroup K split");
     constexpr int WAVES = KS > 1 ? KS : 4;
     constexpr int NACC = (MF * NF == 1) ? 2 : 1;   // a lone fragment alternates two accumulators (MFMA dependency)
     constexpr int TE = MF * NF * 256;
@@ -624,6 +641,9 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
 
     f32x4 a_st[D][MF];
     float b_st[D][NF][4];
+    float ln_s[LNB ? NF : 1], ln_ss[LNB ? NF : 1];     // LNB: column sums of the operand values this lane feeds to the matrix core
+#pragma unroll
+    for (int nf = 0; nf < (LNB ? NF : 1); nf++) { ln_s[nf] = 0.f; ln_ss[nf] = 0.f; }
     int4 ko_nx = make_int4(0, 0, 0, 0);
 #define RVC_LOAD_A(S, C)                                                                               \
     {                                                                                                  \
@@ -647,6 +667,7 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
         _Pragma("unroll") for (int j = 0; j < 4; j++)                                                  \
             _Pragma("unroll") for (int nf = 0; nf < NF; nf++) {                                        \
                 const float bv_ = PRE ? fmaxf(b_st[S][nf][j], b_st[S][nf][j] * pre_slope) : b_st[S][nf][j]; \
+                if (LNB) { ln_s[LNB ? nf : 0] += bv_; ln_ss[LNB ? nf : 0] = fmaf(bv_, bv_, ln_ss[LNB ? nf : 0]); } \
                 _Pragma("unroll") for (int mf = 0; mf < MF; mf++)                                      \
                     acc[j % NACC][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[S][mf][j], bv_, acc[j % NACC][mf][nf], 0, 0, 0); \
             }                                                                                          \
@@ -662,6 +683,7 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
     //     4-element share per thread; in front of the main loads it delayed every launch by that much)
     Epi2 pre_w[(KS > 1 || !PF) ? 1 : MF][(KS > 1 || !PF) ? 1 : NF][4];
     Epi2 pre_r[PE];
+    float pre_ws[LNB ? PE : 1];
     if (PF && live && !p.glu) {
         if (KS > 1) {
 #pragma unroll
@@ -669,6 +691,7 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
                 const int e = threadIdx.x + q * WAVES * 64;
                 const int l = e & 63, r = (e >> 6) & 3, f = e >> 8, mf = f / NF, nf = f - mf * NF;
                 pre_r[q] = (e < TE) ? epi2_prefetch(p, ph, resb, yb, tm * 16 * MF + mf * 16 + (l >> 4) * 4 + r, tn * 16 * NF + nf * 16 + (l & 15)) : Epi2{0.f, 0.f, 0.f, -1};
+                if (LNB) { const int m_ = tm * 16 * MF + mf * 16 + (l >> 4) * 4 + r; pre_ws[LNB ? q : 0] = (e < TE && m_ < p.M) ? p.ln_wsum[ph.bias_off + m_] : 0.f; }
             }
         } else {
 #pragma unroll
@@ -717,6 +740,7 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
         _Pragma("unroll") for (int j = 0; j < 4; j++)                                                  \
             _Pragma("unroll") for (int nf = 0; nf < NF; nf++) {                                        \
                 const float bv_ = PRE ? fmaxf(b_st[S][nf][j], b_st[S][nf][j] * pre_slope) : b_st[S][nf][j]; \
+                if (LNB) { ln_s[LNB ? nf : 0] += bv_; ln_ss[LNB ? nf : 0] = fmaf(bv_, bv_, ln_ss[LNB ? nf : 0]); } \
                 _Pragma("unroll") for (int mf = 0; mf < MF; mf++)                                      \
                     acc[j % NACC][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_old_[mf][j], bv_, acc[j % NACC][mf][nf], 0, 0, 0); \
                 b_st[S][nf][j] = *reinterpret_cast<const float *>(xb + (xo[nf] + kov_[j]));            \
@@ -777,6 +801,16 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
             for (int nf = 0; nf < NF; nf++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) red[wave * TE + ((mf * NF + nf) * 4 + r) * 64 + lane] = acc[0][mf][nf][r];
+        float *lst = red + KS * TE;                 // LNB: [KS][NF * 16][2] column sums of this wave's K slice
+        if (LNB) {
+#pragma unroll
+            for (int nf = 0; nf < NF; nf++) {
+                float s_ = ln_s[LNB ? nf : 0], q_ = ln_ss[LNB ? nf : 0];
+                s_ += __shfl_xor(s_, 16, 64); q_ += __shfl_xor(q_, 16, 64);
+                s_ += __shfl_xor(s_, 32, 64); q_ += __shfl_xor(q_, 32, 64);
+                if (kq == 0) { lst[(wave * NF * 16 + nf * 16 + li) * 2] = s_; lst[(wave * NF * 16 + nf * 16 + li) * 2 + 1] = q_; }
+            }
+        }
         RVC_KP(4);
         __syncthreads();
         RVC_KP(5);
@@ -794,6 +828,23 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
             }
             return;
         }
+        // LNB: statistics of this lane's NF columns, summed over the waves' K slices in a fixed order
+        float ln_mean[LNB ? NF : 1], ln_rstd[LNB ? NF : 1];
+        if (LNB) {
+#pragma unroll
+            for (int nf = 0; nf < NF; nf++) {
+                const int cl = nf * 16 + li;
+                float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+                for (int w = 0; w < KS; w++) { s_ += lst[(w * NF * 16 + cl) * 2]; q_ += lst[(w * NF * 16 + cl) * 2 + 1]; }
+                const float mean = s_ * p.ln_inv_rows;
+                const float var = fmaxf(q_ * p.ln_inv_rows - mean * mean, 0.f);
+                const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+                ln_mean[LNB ? nf : 0] = mean; ln_rstd[LNB ? nf : 0] = rstd;
+                const int n_ = tn * 16 * NF + cl;
+                if (p.ln_stats_out && tm == 0 && threadIdx.x < 16 && n_ < p.N) { p.ln_stats_out[2 * n_] = mean; p.ln_stats_out[2 * n_ + 1] = rstd; }
+            }
+        }
         float vsum[PE];
 #pragma unroll
         for (int q = 0; q < PE; q++) {
@@ -802,6 +853,10 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm2_kernel(IgemmP p
             if (e < TE) {
 #pragma unroll
                 for (int w = 0; w < KS; w++) v += red[w * TE + e];
+            }
+            if (LNB && e < TE) {          // the folded LayerNorm: see IgemmP::ln_wsum (an element's column is (nf, lane & 15))
+                const int nf = (e >> 8) % NF;
+                v = ln_rstd[LNB ? nf : 0] * (v - ln_mean[LNB ? nf : 0] * pre_ws[LNB ? q : 0]);
             }
             vsum[q] = v;
         }

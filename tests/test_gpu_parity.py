@@ -214,6 +214,36 @@ def test_retrieval_hits_bit_exact(preset):
         assert rms(ye - yo) < PCM_TOL
 
 
+def test_folded_layernorm_one_stream_full_size(monkeypatch):
+    # One-stream plans of the full-size ContentVec fold the two LayerNorm launches of a layer into the GEMMs around them (column
+    # statistics from the operand stream of the consuming projection, normalised residual computed in the epilogue).  Plans with taps
+    # keep the explicit LayerNorm, so the stage tests above never see the folded path: here it runs (a) against the explicit path of
+    # the same library, (b) against the oracle end to end, with retrieval hits bit-exact.
+    from obs_rvc_amd.rvc import RvcInfer
+    z, ora, eng = _pair("full")                      # no taps -> folded
+    x = voice_signal(g.input_buffer_16k_size, seed=3)
+    h_fold = eng.hubert(x)
+    monkeypatch.setenv("RVC_NO_LN_FUSE", "1")
+    ref = RvcInfer(z["data"]); ref.load_contentvec(2); ref.load_f0(); ref.load_model(z["model"]); ref.set_noise_seed(1234, 0)
+    h_expl = ref.hubert(x)
+    monkeypatch.delenv("RVC_NO_LN_FUSE")
+    assert h_fold.shape == h_expl.shape and not np.array_equal(h_fold, h_expl)        # two different code paths did run
+    assert np.abs(h_fold - h_expl).max() < 1e-5 * np.abs(h_expl).max()
+    assert rel_rms(h_fold, ora.hubert(x)) < 1e-4
+    index = W.make_index(100000, 768, seed=7)
+    for e in (ora, eng, ref):
+        e.load_index(index); e.set_index_rate(0.75)
+    for _ in range(2):
+        yo = ora.infer(x, 2560, 12, 200, 21)
+        ye = eng.infer(x, 2560, 12, 200, 21)
+        yr = ref.infer(x, 2560, 12, 200, 21)
+        io, do = ora.knn(); ie, de = eng.knn(); ir, dr = ref.knn()
+        assert np.array_equal(ie, io) and np.array_equal(ir, io)
+        assert np.allclose(de, do, rtol=1e-4)
+        assert rms(ye - yo) < PCM_TOL and rms(ye - yr) < 1e-5
+    ref.close()
+
+
 def test_retrieval_scan_exact_on_identical_queries():
     # feed the GPU's own queries to the oracle's search: indices AND distances must be bit-identical
     # (same sequential-fmaf distance, same (distance, index) ordering)
