@@ -993,7 +993,10 @@ struct ModelSY {
     int up_rate[8], up_kernel[8], rb_k[8], rb_d[8];
     ConvW phone, proj;
     float *pitch_emb = nullptr;
-    struct Layer { ConvW qkv, o, ff1, ff2; float *rel_k, *rel_v, *ln1_g, *ln1_b, *ln2_g, *ln2_b; };
+    // qkv_f: the projection with the previous layer's second LayerNorm folded in (ModelCV::fold_ln); proj_f likewise for the last layer.
+    // (The first LayerNorm of a layer feeds a 3-tap convolution with zero padding: padded positions are zero AFTER the norm, so it stays.)
+    struct Layer { ConvW qkv, o, ff1, ff2, qkv_f; float *qkv_wsum = nullptr; float *rel_k, *rel_v, *ln1_g, *ln1_b, *ln2_g, *ln2_b; };
+    ConvW proj_f; float *proj_wsum = nullptr; bool has_folded = false;
     std::vector<Layer> layers;
     struct Flow { ConvW pre, post; std::vector<ConvW> in, rs; bool flipped = false; };
     std::vector<Flow> flows;
@@ -1032,9 +1035,15 @@ struct ModelSY {
             L.rel_k = own(fmt("sy.enc.l%d.rel_k", l)); L.rel_v = own(fmt("sy.enc.l%d.rel_v", l));
             L.ln1_g = own(fmt("sy.enc.l%d.ln1.g", l)); L.ln1_b = own(fmt("sy.enc.l%d.ln1.b", l));
             L.ln2_g = own(fmt("sy.enc.l%d.ln2.g", l)); L.ln2_b = own(fmt("sy.enc.l%d.ln2.b", l));
+            if (H >= 128 && H % 16 == 0 && !getenv("RVC_NO_LN_FUSE")) {
+                has_folded = true;
+                if (l > 0) L.qkv_f = ModelCV::fold_ln(w.data(), bb.data(), 3 * H, H, b.w(fmt("sy.enc.l%d.ln2.g", l - 1)), b.w(fmt("sy.enc.l%d.ln2.b", l - 1)), &L.qkv_wsum);
+            }
             layers.push_back(L);
         }
         proj = prep_conv(b.w("sy.enc.proj.w"), b.w("sy.enc.proj.b"), 2 * inter, H, 1, 1);
+        if (has_folded)
+            proj_f = ModelCV::fold_ln(b.w("sy.enc.proj.w"), b.w("sy.enc.proj.b"), 2 * inter, H, b.w(fmt("sy.enc.l%d.ln2.g", enc_layers - 1)), b.w(fmt("sy.enc.l%d.ln2.b", enc_layers - 1)), &proj_wsum);
         const int half = inter / 2;
         for (int i = 0; i < flow_n; i++) {
             Flow F;
@@ -1133,7 +1142,8 @@ struct ModelSY {
     ~ModelSY()
     {
         free_conv(phone); free_conv(proj); free_conv(dec_pre); free_conv(dec_post);
-        for (auto &L : layers) { free_conv(L.qkv); free_conv(L.o); free_conv(L.ff1); free_conv(L.ff2); }
+        for (auto &L : layers) { free_conv(L.qkv); free_conv(L.o); free_conv(L.ff1); free_conv(L.ff2); free_conv(L.qkv_f); if (L.qkv_wsum) (void)hipFree(L.qkv_wsum); }
+        free_conv(proj_f); if (proj_wsum) (void)hipFree(proj_wsum);
         for (auto &F : flows) { free_conv(F.pre); free_conv(F.post); for (auto &c : F.in) free_conv(c); for (auto &c : F.rs) free_conv(c); }
         for (auto &c : ups) free_conv(c);
         for (auto &c : ncs) free_conv(c);
@@ -1610,9 +1620,13 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
     const int kc = H / m.heads, Tp = R | 1;
     const size_t attn_lds = ((size_t)((kc * Tp + 3) & ~3) + 16 * Tp + 16 * kc) * sizeof(float);
     if (attn_lds > 160 * 1024) throw ShapeError("synth attention: return_length too long for the LDS-resident kernel");
+    // one stream: the second LayerNorm of every encoder layer is folded into the next projection (see build_contentvec)
+    const bool fuse_ln = B == 1 && m.has_folded && !pl.with_taps && !getenv("RVC_NO_LN_FUSE");
+    bool raw = false; const float *raw_g = nullptr, *raw_b = nullptr; float *raw_st = nullptr;
     for (int l = 0; l < m.enc_layers; l++) {
         ModelSY::Layer &Ly = m.layers[l];
-        add_conv1d(pl, Ly.qkv, x, qkv, 1, 0, 1);
+        if (raw) { raw_st = A.floats((size_t)2 * R + 16); ConvOpts o; o.ln_wsum = Ly.qkv_wsum; o.ln_stats_out = raw_st; o.ln_rows = H; add_conv1d(pl, Ly.qkv_f, x, qkv, 1, 0, 1, o); }
+        else add_conv1d(pl, Ly.qkv, x, qkv, 1, 0, 1);
         AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = H; ap.T = R; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;
         ap.scale = 1.0f / sqrtf((float)kc); ap.rel_k = Ly.rel_k; ap.rel_v = Ly.rel_v; ap.window = m.window;
         const size_t small_lds = ((size_t)2 * kc * Tp + 2 * (2 * m.window + 1) * kc + 4 * kc + 4 * 64) * sizeof(float);
@@ -1623,15 +1637,21 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
             dim3 ag(m.heads * ((R + 15) / 16), B);
             pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(attention_kernel, ag, dim3(256), attn_lds, s, ap); });
         }
-        { ConvOpts o; o.res = x.p; o.res_cs = x.ld; o.res_bs = x.bs; add_conv1d(pl, Ly.o, att, x, 1, 0, 1, o); }
+        {
+            ConvOpts o; o.res = x.p; o.res_cs = x.ld; o.res_bs = x.bs;
+            if (raw) { o.ln_stats_in = raw_st; o.ln_g = raw_g; o.ln_b = raw_b; }
+            add_conv1d(pl, Ly.o, att, x, 1, 0, 1, o);
+        }
         add_layernorm(pl, x, Ly.ln1_g, Ly.ln1_b);
         { ConvOpts o; o.act = ACT_RELU; add_conv1d(pl, Ly.ff1, x, ff, 1, m.enc_k / 2, 1, o); }
         { ConvOpts o; o.res = x.p; o.res_cs = x.ld; o.res_bs = x.bs; add_conv1d(pl, Ly.ff2, ff, x, 1, m.enc_k / 2, 1, o); }
-        add_layernorm(pl, x, Ly.ln2_g, Ly.ln2_b);
+        if (fuse_ln) { raw = true; raw_g = Ly.ln2_g; raw_b = Ly.ln2_b; }
+        else add_layernorm(pl, x, Ly.ln2_g, Ly.ln2_b);
     }
     add_tap(pl, "sy.enc", x);
     T1 stats = make_t1(A, B, 2 * I, R, 0);
-    add_conv1d(pl, m.proj, x, stats, 1, 0, 1);
+    if (raw) { ConvOpts o; o.ln_wsum = m.proj_wsum; o.ln_rows = H; add_conv1d(pl, m.proj_f, x, stats, 1, 0, 1, o); }
+    else add_conv1d(pl, m.proj, x, stats, 1, 0, 1);
     add_tap(pl, "sy.stats", stats);
     T1 z = make_t1(A, B, I, R, HALO), zf = make_t1(A, B, I, R, HALO);
     {
