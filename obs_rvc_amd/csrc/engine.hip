@@ -1602,7 +1602,27 @@ static T1 build_nsf_source(rvc_engine *e, Plan &pl, int B, float *d_pitchf)
     return src;
 }
 
-static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T1 &src, float *d_pitchf, int *d_pitch, int src_join_sid)
+// The decoder adds a strided convolution of the harmonic source to the output of every upsampling stage.  Those convolutions depend on
+// the source only: they are queued right behind it on the side stream (next to the text encoder and the flow) and the upsampling
+// convolution takes their result as its residual -- 4 launches off the serial chain; the sum has the same operands as before.
+static std::vector<T1> build_noise_convs(rvc_engine *e, Plan &pl, int B, const T1 &src)
+{
+    ModelSY &m = *e->sy;
+    std::vector<T1> nz;
+    int c = m.up_init, Tc = (int)pl.R;
+    for (int i = 0; i < m.n_ups; i++) {
+        const int co = c / 2, Tn = Tc * m.up_rate[i];
+        T1 t = make_t1(pl.arena, B, co, Tn, 0);
+        int sf = 1; for (int q = i + 1; q < m.n_ups; q++) sf *= m.up_rate[q];
+        if (i + 1 < m.n_ups) add_conv1d(pl, m.ncs[i], src, t, sf, sf / 2, 1); else add_conv1d(pl, m.ncs[i], src, t, 1, 0, 1);
+        nz.push_back(t);
+        c = co; Tc = Tn;
+    }
+    return nz;
+}
+
+static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T1 &src, float *d_pitchf, int *d_pitch, int src_join_sid,
+                        const std::vector<T1> *nz = nullptr)
 {
     ModelSY &m = *e->sy;
     Arena &A = pl.arena;
@@ -1698,9 +1718,15 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         const int co = c / 2, K = m.up_kernel[i], S = m.up_rate[i], Tn = Tc * S;
         if ((K - S) % 2 != 0) throw ShapeError("upsample kernel/stride parity not supported");
         T1 u = make_t1(A, B, co, Tn, DH);
+        if (nz) {
+            const T1 &r = (*nz)[i];
+            ConvOpts o; o.pre_act = ACT_LRELU; o.pre_slope = 0.1f; o.res = r.p; o.res_cs = r.ld; o.res_bs = r.bs;
+            add_convT1d(pl, m.ups[i], xd, u, (K - S) / 2, o);
+        } else {
         { ConvOpts o; o.pre_act = ACT_LRELU; o.pre_slope = 0.1f; add_convT1d(pl, m.ups[i], xd, u, (K - S) / 2, o); }
         int sf = 1; for (int q = i + 1; q < m.n_ups; q++) sf *= m.up_rate[q];
         { ConvOpts o; o.accumulate = true; if (i + 1 < m.n_ups) add_conv1d(pl, m.ncs[i], src, u, sf, sf / 2, 1, o); else add_conv1d(pl, m.ncs[i], src, u, 1, 0, 1, o); }
+        }
         if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "sy.up%d", i); add_tap(pl, nm, u); } else add_stamp(pl, "sy.up");
         // the n_rb ResBlock chains of a stage are independent until their average
         T1 xs = make_t1(A, B, co, Tn, DH);
@@ -1925,8 +1951,11 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         // the NSF harmonic source is first needed by the decoder: it runs on a side stream next to the text encoder and the flow
         pl.ops.fork(2); pl.ops.cur = 2;
         src0 = build_nsf_source(e, pl, B, d_pitchf0);
+        std::vector<T1> nz;
+        const bool side_nz = !getenv("RVC_NO_SIDE_NOISE_CONVS");
+        if (side_nz) nz = build_noise_convs(e, pl, B, src0);
         pl.ops.cur = 0;
-        build_synth(e, pl, B, phone, src0, d_pitchf, d_pitch, 2);
+        build_synth(e, pl, B, phone, src0, d_pitchf, d_pitch, 2, side_nz ? &nz : nullptr);
         StreamState *st = e->d_state;
         pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(advance_chunk_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, B); });
     }
