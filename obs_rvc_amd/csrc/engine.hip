@@ -833,6 +833,7 @@ struct ModelCV {
     // one-stream plans feed them the not-yet-normalised tensor and drop the LayerNorm launches (build_contentvec)
     struct Layer { ConvW qkv, o, ff1, ff2, qkv_f, ff1_f; float *qkv_wsum = nullptr, *ff1_wsum = nullptr; float *ln1_g, *ln1_b, *ln2_g, *ln2_b; };
     bool has_folded = false;
+    ConvW proj_f; float *proj_wsum = nullptr;      // feature projection with the LayerNorm over the conv features folded in
     static ConvW fold_ln(const float *w, const float *bias, int M, int K, const float *g, const float *beta, float **wsum_dev)
     {
         std::vector<float> wf((size_t)M * K), bf(M), ws(M);
@@ -887,16 +888,19 @@ struct ModelCV {
                 has_folded = true;
                 L.ff1_f = fold_ln(b.w(fmt("cv.l%d.ff1.w", l)), b.w(fmt("cv.l%d.ff1.b", l)), ffn, E, b.w(fmt("cv.l%d.ln1.g", l)), b.w(fmt("cv.l%d.ln1.b", l)), &L.ff1_wsum);
                 if (l > 0) L.qkv_f = fold_ln(w.data(), bb.data(), 3 * E, E, b.w(fmt("cv.l%d.ln2.g", l - 1)), b.w(fmt("cv.l%d.ln2.b", l - 1)), &L.qkv_wsum);
+                else L.qkv_f = fold_ln(w.data(), bb.data(), 3 * E, E, b.w("cv.enc_ln.g"), b.w("cv.enc_ln.b"), &L.qkv_wsum);      // layer 0: the encoder's input LayerNorm
             }
             layers.push_back(L);
         }
         if (out_dim != E) final_proj = prep_conv(b.w("cv.final_proj.w"), b.w("cv.final_proj.b"), out_dim, E, 1, 1);
+        if (has_folded && conv_dim % 64 == 0) proj_f = fold_ln(b.w("cv.proj.w"), b.w("cv.proj.b"), embed, conv_dim, b.w("cv.ln0.g"), b.w("cv.ln0.b"), &proj_wsum);
         weight_bytes = b.bytes();
     }
     ~ModelCV()
     {
         for (auto &c : conv) free_conv(c);
-        free_conv(proj); free_conv(pos); free_conv(final_proj);
+        free_conv(proj); free_conv(pos); free_conv(final_proj); free_conv(proj_f);
+        if (proj_wsum) (void)hipFree(proj_wsum);
         for (auto &L : layers) {
             free_conv(L.qkv); free_conv(L.o); free_conv(L.ff1); free_conv(L.ff2); free_conv(L.qkv_f); free_conv(L.ff1_f);
             if (L.qkv_wsum) (void)hipFree(L.qkv_wsum);
@@ -1376,14 +1380,18 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
         x = y; T = To;
     }
     add_tap(pl, "cv.feat", x);
-    add_layernorm(pl, x, m.ln0_g, m.ln0_b);
+    const bool fuse_ln = B == 1 && m.has_folded && !pl.with_taps && !getenv("RVC_NO_LN_FUSE");
     const int E = m.embed;
     T1 h = make_t1(A, B, E, T, m.pos_k / 2);
+    if (fuse_ln && m.proj_wsum) { ConvOpts o; o.ln_wsum = m.proj_wsum; o.ln_rows = m.conv_dim; add_conv1d(pl, m.proj_f, x, h, 1, 0, 1, o); }
+    else {
+    add_layernorm(pl, x, m.ln0_g, m.ln0_b);
     add_conv1d(pl, m.proj, x, h, 1, 0, 1);
+    }
     add_tap(pl, "cv.proj", h);
     T1 h2 = make_t1(A, B, E, T, 0);
     { ConvOpts o; o.act = ACT_GELU; o.res = h.p; o.res_cs = h.ld; o.res_bs = h.bs; add_conv1d(pl, m.pos, h, h2, 1, m.pos_k / 2, 1, o); }
-    add_layernorm(pl, h2, m.encln_g, m.encln_b);
+    if (!fuse_ln) add_layernorm(pl, h2, m.encln_g, m.encln_b);      // (folded: layer 0 consumes the not yet normalised sum, see below)
     add_tap(pl, "cv.pos", h2);
     T1 qkv = make_t1(A, B, 3 * E, T, 0), att = make_t1(A, B, E, T, 0), ff = make_t1(A, B, m.ffn, T, 0);
     const int hd = E / m.heads, Tp = T | 1;
@@ -1392,8 +1400,7 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
     HIPCHK(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // One stream: the 2 LayerNorm launches of a layer are folded into the GEMMs around them (h2 then holds the NOT yet normalised sum;
     // `raw` says so, with the pending LayerNorm's scale / shift and the buffer its column statistics are published in)
-    const bool fuse_ln = B == 1 && m.has_folded && !pl.with_taps && !getenv("RVC_NO_LN_FUSE");
-    bool raw = false; const float *raw_g = nullptr, *raw_b = nullptr; float *raw_st = nullptr;
+    bool raw = fuse_ln; const float *raw_g = m.encln_g, *raw_b = m.encln_b; float *raw_st = nullptr;
     for (int l = 0; l < m.run_layers; l++) {
         ModelCV::Layer &Ly = m.layers[l];
         if (fuse_ln) {
