@@ -2634,6 +2634,88 @@ double rvc_debug_conv_bench(rvc_engine *e, int M, int Cin, int KW, int dil, int 
     return us;
 }
 
+// test aid for the folded LayerNorm (IgemmP::ln_*): two launches on deterministic data against a double-precision host evaluation --
+//   (1) y1 = W1 . LN(x) + b1 through the folded weights on the RAW x, publishing the column statistics;
+//   (2) y2 = W2 . z + b2 + LN(x), the residual normalised on the fly from the statistics launch (1) published (needs M2 = K rows).
+// Tile shape / K split are whatever the planner (or RVC_FORCE_CFG) picks; the planner forces an in-workgroup K split.  Returns the
+// largest |gpu - host| / rms(host) over both outputs and the published (mean, rstd); negative on failure.
+double rvc_debug_ln_fold_check(rvc_engine *e, int M, int K, int N)
+{
+    double worst = -1.0;
+    (void)guarded(e, [&]() {
+        if (K % 16 != 0) throw ShapeError("K must be a multiple of 16");
+        auto rnd = [](size_t i, unsigned salt) { return (float)((((i + 1) * 2654435761u) ^ (salt * 40503u) ^ (i >> 5)) % 2001) / 1000.0f - 1.0f; };
+        std::vector<float> w1((size_t)M * K), b1(M), w2((size_t)K * M), b2(K), g(K), beta(K), hx((size_t)K * N), hz((size_t)M * N);
+        for (size_t i = 0; i < w1.size(); i++) w1[i] = 0.5f * rnd(i, 1);
+        for (size_t i = 0; i < w2.size(); i++) w2[i] = 0.5f * rnd(i, 2);
+        for (int m = 0; m < M; m++) b1[m] = 0.1f * rnd(m, 3);
+        for (int k = 0; k < K; k++) { b2[k] = 0.1f * rnd(k, 4); g[k] = 1.0f + 0.3f * rnd(k, 5); beta[k] = 0.2f * rnd(k, 6); }
+        for (size_t i = 0; i < hx.size(); i++) hx[i] = 2.0f * rnd(i, 7) + 0.3f;          // a mean that is not zero
+        for (size_t i = 0; i < hz.size(); i++) hz[i] = rnd(i, 8);
+        float *wsum = nullptr;
+        ConvW c1 = ModelCV::fold_ln(w1.data(), b1.data(), M, K, g.data(), beta.data(), &wsum);
+        ConvW c2 = prep_conv(w2.data(), b2.data(), K, M, 1, 1);
+        float *dg = upload_f(g), *dbeta = upload_f(beta);
+        Plan pl; pl.B = 1;
+        T1 x = make_t1(pl.arena, 1, K, N, 0), y1 = make_t1(pl.arena, 1, M, N, 0), z = make_t1(pl.arena, 1, M, N, 0), y2 = make_t1(pl.arena, 1, K, N, 0);
+        float *st = pl.arena.floats((size_t)2 * N + 16);
+        for (int k = 0; k < K; k++) HIPCHK(hipMemcpy(x.p + (long long)k * x.ld, &hx[(size_t)k * N], (size_t)N * 4, hipMemcpyHostToDevice));
+        for (int m = 0; m < M; m++) HIPCHK(hipMemcpy(z.p + (long long)m * z.ld, &hz[(size_t)m * N], (size_t)N * 4, hipMemcpyHostToDevice));
+        { ConvOpts o; o.ln_wsum = wsum; o.ln_stats_out = st; o.ln_rows = K; add_conv1d(pl, c1, x, y1, 1, 0, 1, o); }
+        { ConvOpts o; o.res = x.p; o.res_cs = x.ld; o.res_bs = x.bs; o.ln_stats_in = st; o.ln_g = dg; o.ln_b = dbeta; add_conv1d(pl, c2, z, y2, 1, 0, 1, o); }
+        HIPCHK(hipDeviceSynchronize());
+        for (auto &op : pl.ops.v) op(e->stream);
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipGetLastError());
+        // host: LayerNorm over the K rows of every column (two-pass, double), then the two layers
+        std::vector<double> ln((size_t)K * N), mean(N), rstd(N);
+        for (int n = 0; n < N; n++) {
+            double s = 0; for (int k = 0; k < K; k++) s += hx[(size_t)k * N + n];
+            const double mu = s / K; double q = 0;
+            for (int k = 0; k < K; k++) { const double d = hx[(size_t)k * N + n] - mu; q += d * d; }
+            mean[n] = mu; rstd[n] = 1.0 / std::sqrt(q / K + 1e-5);
+            for (int k = 0; k < K; k++) ln[(size_t)k * N + n] = (hx[(size_t)k * N + n] - mu) * rstd[n] * g[k] + beta[k];
+        }
+        double err = 0.0;
+        std::vector<float> row(N), hst((size_t)2 * N);
+        {
+            double ss = 0; std::vector<double> ref((size_t)M * N);
+            for (int m = 0; m < M; m++) for (int n = 0; n < N; n++) {
+                double a = b1[m]; for (int k = 0; k < K; k++) a += (double)w1[(size_t)m * K + k] * ln[(size_t)k * N + n];
+                ref[(size_t)m * N + n] = a; ss += a * a;
+            }
+            const double rms1 = std::sqrt(ss / ((double)M * N)) + 1e-12;
+            for (int m = 0; m < M; m++) {
+                HIPCHK(hipMemcpy(row.data(), y1.p + (long long)m * y1.ld, (size_t)N * 4, hipMemcpyDeviceToHost));
+                for (int n = 0; n < N; n++) err = std::max(err, std::fabs((double)row[n] - ref[(size_t)m * N + n]) / rms1);
+            }
+        }
+        {
+            double ss = 0; std::vector<double> ref((size_t)K * N);
+            for (int k = 0; k < K; k++) for (int n = 0; n < N; n++) {
+                double a = b2[k]; for (int m = 0; m < M; m++) a += (double)w2[(size_t)k * M + m] * hz[(size_t)m * N + n];
+                a += ln[(size_t)k * N + n];
+                ref[(size_t)k * N + n] = a; ss += a * a;
+            }
+            const double rms2 = std::sqrt(ss / ((double)K * N)) + 1e-12;
+            for (int k = 0; k < K; k++) {
+                HIPCHK(hipMemcpy(row.data(), y2.p + (long long)k * y2.ld, (size_t)N * 4, hipMemcpyDeviceToHost));
+                for (int n = 0; n < N; n++) err = std::max(err, std::fabs((double)row[n] - ref[(size_t)k * N + n]) / rms2);
+            }
+        }
+        HIPCHK(hipMemcpy(hst.data(), st, (size_t)2 * N * 4, hipMemcpyDeviceToHost));
+        for (int n = 0; n < N; n++) {
+            err = std::max(err, std::fabs((double)hst[2 * n] - mean[n]) / (std::fabs(mean[n]) + 1.0));
+            err = std::max(err, std::fabs((double)hst[2 * n + 1] - rstd[n]) / rstd[n]);
+        }
+        worst = err;
+        free_conv(c1); free_conv(c2);
+        (void)hipFree(wsum); (void)hipFree(dg); (void)hipFree(dbeta);
+        return RVC_OK;
+    });
+    return worst;
+}
+
 // tuning build only (-DRVC_KPROBE): one launch of a Conv1d with per-wave phase stamps (device wall clock, 10 ns ticks):
 // out[wave][16]; returns the number of waves (workgroups * waves per workgroup), *event_us = the dispatch's own begin..end time
 int rvc_debug_conv_probe(rvc_engine *e, int M, int Cin, int KW, int dil, int N, unsigned long long *out, size_t cap_waves, double *event_us, int *waves_per_wg)

@@ -214,6 +214,34 @@ def test_retrieval_hits_bit_exact(preset):
         assert rms(ye - yo) < PCM_TOL
 
 
+def test_folded_layernorm_every_tile_and_split():
+    # the folded LayerNorm lives in the K-split epilogue of the table-free 1x1 GEMM: the models only ever reach two of its 15 instantiations
+    # (5 tile shapes x K split 4 / 8 / 16).  All of them, on small layers, against a double-precision host LayerNorm + GEMM: the consumer
+    # on the raw tensor (folded weights, statistics from the operand stream, published), then a layer whose residual is the normalised tensor
+    import ctypes as C
+    from obs_rvc_amd import _native
+    L = _native.lib()
+    L.rvc_debug_ln_fold_check.restype = C.c_double
+    L.rvc_debug_ln_fold_check.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    h = C.c_void_p()
+    assert L.rvc_create(b"/tmp", 0, C.byref(h)) == 0
+    try:
+        for (M, K, N) in ((96, 256, 37), (64, 512, 111), (144, 768, 21)):
+            e0 = L.rvc_debug_ln_fold_check(h, M, K, N)                  # the planner's own choice
+            assert 0 <= e0 < 2e-5, (M, K, N, e0)
+            for cfg in range(5):
+                for ks in (4, 8, 16):
+                    if (K // 16) // ks < 1:
+                        continue
+                    os.environ["RVC_FORCE_CFG"] = "%d,%d" % (cfg, ks)
+                    e1 = L.rvc_debug_ln_fold_check(h, M, K, N)
+                    assert 0 <= e1 < 2e-5, (cfg, ks, M, K, N, e1)
+            os.environ.pop("RVC_FORCE_CFG", None)
+    finally:
+        os.environ.pop("RVC_FORCE_CFG", None)
+        L.rvc_destroy(h)
+
+
 def test_folded_layernorm_one_stream_full_size(monkeypatch):
     # One-stream plans of the full-size ContentVec fold the two LayerNorm launches of a layer into the GEMMs around them (column
     # statistics from the operand stream of the consuming projection, normalised residual computed in the epilogue).  Plans with taps
