@@ -2874,6 +2874,19 @@ __global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p)
     const float margin = 2e-3f * (fabsf(a4 + s_xn) + s_xn + 1e-3f);
     const float thr = a4 + margin;
     __syncthreads();
+    // The candidates are among the per-thread top-4 lists unless some thread holds MORE than four values within the margin (its list is
+    // then truncated: its 4th entry is still <= thr).  Common case: collect from the lists, no second pass over the n distances.
+    if (ld[KNN_K - 1] <= thr) atomicOr(&cnt, 0x40000000);
+    __syncthreads();
+    const bool truncated = (cnt & 0x40000000) != 0;
+    __syncthreads();
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    if (!truncated) {
+#pragma unroll
+        for (int k = 0; k < KNN_K; k++)
+            if (ld[k] <= thr) { int c = atomicAdd(&cnt, 1); if (c < KNN_CAND) cand_i[c] = li_[k]; }
+    } else {
     for (int i4 = tid; i4 < n4; i4 += 4 * 1024) {
         f32x4 v[4];
 #pragma unroll
@@ -2890,6 +2903,7 @@ __global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p)
     }
     for (int i = 4 * n4 + tid; i < p.n; i += 1024) {
         if (a[i] <= thr) { int c = atomicAdd(&cnt, 1); if (c < KNN_CAND) cand_i[c] = i; }
+    }
     }
     __syncthreads();
     const int ncand = cnt;
