@@ -2637,8 +2637,9 @@ double rvc_debug_conv_bench(rvc_engine *e, int M, int Cin, int KW, int dil, int 
 //   (1) y1 = W1 . LN(x) + b1 through the folded weights on the RAW x, publishing the column statistics;
 //   (2) y2 = W2 . z + b2 + LN(x), the residual normalised on the fly from the statistics launch (1) published (needs M2 = K rows).
 // Tile shape / K split are whatever the planner (or RVC_FORCE_CFG) picks; the planner forces an in-workgroup K split.  Returns the
-// largest |gpu - host| / rms(host) over both outputs and the published (mean, rstd); negative on failure.
-double rvc_debug_ln_fold_check(rvc_engine *e, int M, int K, int N)
+// largest |gpu - host| / rms(host) over both outputs and the published (mean, rstd); negative on failure.  `offset` = mean of the
+// tensor being normalised (spread ~1.15): large values probe the cancellation in the one-pass statistics.
+double rvc_debug_ln_fold_check(rvc_engine *e, int M, int K, int N, float offset)
 {
     double worst = -1.0;
     (void)guarded(e, [&]() {
@@ -2649,7 +2650,7 @@ double rvc_debug_ln_fold_check(rvc_engine *e, int M, int K, int N)
         for (size_t i = 0; i < w2.size(); i++) w2[i] = 0.5f * rnd(i, 2);
         for (int m = 0; m < M; m++) b1[m] = 0.1f * rnd(m, 3);
         for (int k = 0; k < K; k++) { b2[k] = 0.1f * rnd(k, 4); g[k] = 1.0f + 0.3f * rnd(k, 5); beta[k] = 0.2f * rnd(k, 6); }
-        for (size_t i = 0; i < hx.size(); i++) hx[i] = 2.0f * rnd(i, 7) + 0.3f;          // a mean that is not zero
+        for (size_t i = 0; i < hx.size(); i++) hx[i] = 2.0f * rnd(i, 7) + offset;        // column mean = offset, spread ~1.15
         for (size_t i = 0; i < hz.size(); i++) hz[i] = rnd(i, 8);
         float *wsum = nullptr;
         ConvW c1 = ModelCV::fold_ln(w1.data(), b1.data(), M, K, g.data(), beta.data(), &wsum);

@@ -641,9 +641,15 @@ void igemm2_kernel(IgemmP p)
 
     f32x4 a_st[D][MF];
     float b_st[D][NF][4];
-    float ln_s[LNB ? NF : 1], ln_ss[LNB ? NF : 1];     // LNB: column sums of the operand values this lane feeds to the matrix core
+    // LNB: column sums of the operand values this lane feeds to the matrix core, taken relative to the column's FIRST element (every
+    // lane and wave of a column loads the same one): the one-pass variance E[d^2] - E[d]^2 then cancels against a shift of the order
+    // of the spread, not of the mean (a column with |mean| >> std would otherwise lose its variance to rounding)
+    float ln_s[LNB ? NF : 1], ln_ss[LNB ? NF : 1], ln_c[LNB ? NF : 1];
 #pragma unroll
-    for (int nf = 0; nf < (LNB ? NF : 1); nf++) { ln_s[nf] = 0.f; ln_ss[nf] = 0.f; }
+    for (int nf = 0; nf < (LNB ? NF : 1); nf++) {
+        ln_s[nf] = 0.f; ln_ss[nf] = 0.f;
+        ln_c[nf] = LNB ? *reinterpret_cast<const float *>(xb + (xo[LNB ? nf : 0] - (unsigned)((c0 * 16 + kq * 4) * p.lin_cs4))) : 0.f;
+    }
     int4 ko_nx = make_int4(0, 0, 0, 0);
 #define RVC_LOAD_A(S, C)                                                                               \
     {                                                                                                  \
@@ -667,7 +673,7 @@ void igemm2_kernel(IgemmP p)
         _Pragma("unroll") for (int j = 0; j < 4; j++)                                                  \
             _Pragma("unroll") for (int nf = 0; nf < NF; nf++) {                                        \
                 const float bv_ = PRE ? fmaxf(b_st[S][nf][j], b_st[S][nf][j] * pre_slope) : b_st[S][nf][j]; \
-                if (LNB) { ln_s[LNB ? nf : 0] += bv_; ln_ss[LNB ? nf : 0] = fmaf(bv_, bv_, ln_ss[LNB ? nf : 0]); } \
+                if (LNB) { const float d_ = bv_ - ln_c[LNB ? nf : 0]; ln_s[LNB ? nf : 0] += d_; ln_ss[LNB ? nf : 0] = fmaf(d_, d_, ln_ss[LNB ? nf : 0]); } \
                 _Pragma("unroll") for (int mf = 0; mf < MF; mf++)                                      \
                     acc[j % NACC][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[S][mf][j], bv_, acc[j % NACC][mf][nf], 0, 0, 0); \
             }                                                                                          \
@@ -740,7 +746,7 @@ void igemm2_kernel(IgemmP p)
         _Pragma("unroll") for (int j = 0; j < 4; j++)                                                  \
             _Pragma("unroll") for (int nf = 0; nf < NF; nf++) {                                        \
                 const float bv_ = PRE ? fmaxf(b_st[S][nf][j], b_st[S][nf][j] * pre_slope) : b_st[S][nf][j]; \
-                if (LNB) { ln_s[LNB ? nf : 0] += bv_; ln_ss[LNB ? nf : 0] = fmaf(bv_, bv_, ln_ss[LNB ? nf : 0]); } \
+                if (LNB) { const float d_ = bv_ - ln_c[LNB ? nf : 0]; ln_s[LNB ? nf : 0] += d_; ln_ss[LNB ? nf : 0] = fmaf(d_, d_, ln_ss[LNB ? nf : 0]); } \
                 _Pragma("unroll") for (int mf = 0; mf < MF; mf++)                                      \
                     acc[j % NACC][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_old_[mf][j], bv_, acc[j % NACC][mf][nf], 0, 0, 0); \
                 b_st[S][nf][j] = *reinterpret_cast<const float *>(xb + (xo[nf] + kov_[j]));            \
@@ -837,8 +843,9 @@ void igemm2_kernel(IgemmP p)
                 float s_ = 0.f, q_ = 0.f;
 #pragma unroll
                 for (int w = 0; w < KS; w++) { s_ += lst[(w * NF * 16 + cl) * 2]; q_ += lst[(w * NF * 16 + cl) * 2 + 1]; }
-                const float mean = s_ * p.ln_inv_rows;
-                const float var = fmaxf(q_ * p.ln_inv_rows - mean * mean, 0.f);
+                const float msh = s_ * p.ln_inv_rows;                       // mean of (y - first element)
+                const float var = fmaxf(q_ * p.ln_inv_rows - msh * msh, 0.f);
+                const float mean = ln_c[LNB ? nf : 0] + msh;
                 const float rstd = 1.0f / sqrtf(var + p.ln_eps);
                 ln_mean[LNB ? nf : 0] = mean; ln_rstd[LNB ? nf : 0] = rstd;
                 const int n_ = tn * 16 * NF + cl;

@@ -222,19 +222,23 @@ def test_folded_layernorm_every_tile_and_split():
     from obs_rvc_amd import _native
     L = _native.lib()
     L.rvc_debug_ln_fold_check.restype = C.c_double
-    L.rvc_debug_ln_fold_check.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.rvc_debug_ln_fold_check.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]
     h = C.c_void_p()
     assert L.rvc_create(b"/tmp", 0, C.byref(h)) == 0
     try:
         for (M, K, N) in ((96, 256, 37), (64, 512, 111), (144, 768, 21)):
-            e0 = L.rvc_debug_ln_fold_check(h, M, K, N)                  # the planner's own choice
+            e0 = L.rvc_debug_ln_fold_check(h, M, K, N, 0.3)             # the planner's own choice
             assert 0 <= e0 < 2e-5, (M, K, N, e0)
+            # a tensor whose mean is 100x its spread: the statistics are taken relative to the column's first element, so the variance
+            # survives; what remains is the cancellation acc - mean * wsum of the folded form (~1e-7 * mean / spread)
+            e9 = L.rvc_debug_ln_fold_check(h, M, K, N, 100.0)
+            assert 0 <= e9 < 2e-3, (M, K, N, e9)
             for cfg in range(5):
                 for ks in (4, 8, 16):
                     if (K // 16) // ks < 1:
                         continue
                     os.environ["RVC_FORCE_CFG"] = "%d,%d" % (cfg, ks)
-                    e1 = L.rvc_debug_ln_fold_check(h, M, K, N)
+                    e1 = L.rvc_debug_ln_fold_check(h, M, K, N, 0.3)
                     assert 0 <= e1 < 2e-5, (cfg, ks, M, K, N, e1)
             os.environ.pop("RVC_FORCE_CFG", None)
     finally:
