@@ -1345,9 +1345,10 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
             const float *w0 = m.conv0_raw, *gg = m.gn_g, *bb = m.gn_b; const int kt = m.conv_k[0], st = m.conv_s[0];
             const float *ain = x.p; const long long abs_ = x.bs;
             const int nt = (To + 255) / 256;
-            // many streams: 16 channels per workgroup share one register copy of the input samples (1 stream keeps one channel per
-            // workgroup: 512 workgroups are what fills the chip there)
-            int cpw = B >= 16 ? 16 : (B >= 4 ? 4 : 1);
+            // 16 channels per workgroup share one register copy of the input samples at many streams; one stream: 2 (256 workgroups of
+            // 1024 threads, half the strided gathers: 42.8 -> ~15 us, 25-30 us off the ContentVec branch; 4 and 8 measured the same / worse)
+            int cpw = B >= 16 ? 16 : (B >= 4 ? 4 : 2);
+            if (const char *f = getenv("RVC_CONV0_CPW")) cpw = std::max(1, atoi(f));      // tuning aid
             while (cpw > 1 && m.conv_dim % cpw) cpw >>= 1;
             if (kt == 10 && To <= 8 * 1024 && cpw > 1 && !getenv("RVC_NO_CONV0_MULTI")) {
                 dim3 gridm(m.conv_dim / cpw, B);
