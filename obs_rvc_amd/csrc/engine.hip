@@ -771,7 +771,9 @@ static void add_layernorm(Plan &pl, const T1 &x, const float *g, const float *b)
     // many streams: 16-column strips held in registers (float4 rows; needs 16-byte aligned rows, which every plan tensor has: ld and
     // halo are multiples of 4).  Reading the padding columns behind T is safe (inside the row), they are never written.
     if (x.B >= 16 && x.ld % 4 == 0 && x.halo % 4 == 0 && ((x.T + 3) / 4 * 4 <= x.ld - x.halo) && !getenv("RVC_NO_LN_STRIP")) {
-        dim3 sg((x.T + 15) / 16, x.B);
+        // grid x = stream, y = strip: workgroup (b, strip) runs on XCD (strip * B + b) % 8 = b % 8 when B is a multiple of 8, so the two
+        // 64-byte halves of every 128-byte line (adjacent strips of one stream) are fetched by the same XCD's L2, once
+        dim3 sg(x.B, (x.T + 15) / 16);
         const int nr = (x.C + 63) / 64;
         pl.ops.push_back([=](hipStream_t s) {
             if (nr <= 4) hipLaunchKernelGGL((layernorm_strip_kernel<4>), sg, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);

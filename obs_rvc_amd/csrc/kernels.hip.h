@@ -1591,7 +1591,7 @@ __global__ __launch_bounds__(256) void layernorm_strip_kernel(const float *x, fl
 {
     __shared__ float red[64][17];
     __shared__ float s_stat[2][16];
-    const int t0 = blockIdx.x * 16, b = blockIdx.y, tid = threadIdx.x, quad = tid & 3, rg = tid >> 2;
+    const int t0 = blockIdx.y * 16, b = blockIdx.x, tid = threadIdx.x, quad = tid & 3, rg = tid >> 2;      // (grid: x = stream, y = strip)
     const float *xb = x + (long long)b * x_bs + t0 + quad * 4;
     f32x4 v[NR];
 #pragma unroll
