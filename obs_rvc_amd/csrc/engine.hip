@@ -1183,7 +1183,7 @@ struct rvc_engine {
     // constants for the mel front end
     float *d_window = nullptr, *d_twiddle = nullptr, *d_basis = nullptr; int *d_band = nullptr;
     // retrieval index
-    float *d_index = nullptr, *d_indexT = nullptr, *d_indexF = nullptr, *d_ynorm = nullptr; size_t index_n = 0, index_dim = 0; bool index_owned = true;
+    float *d_index = nullptr, *d_indexT = nullptr, *d_indexF = nullptr, *d_ynorm = nullptr, *d_nhn = nullptr; size_t index_n = 0, index_dim = 0; bool index_owned = true;
     float index_rate = 0.f;
     // streams
     int n_streams = 1;
@@ -1889,9 +1889,31 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
             // provably sufficient candidate set; the exhaustive exact scan below only runs for streams whose candidate set overflowed.
             const bool fast = C % 16 == 0 && !getenv("RVC_KNN_EXHAUSTIVE");
             int *d_overflow = (int *)pl.arena.alloc((size_t)B * sizeof(int));
+            // many streams: all queries against the index as ONE implicit GEMM (queries = weight operand in fragment order, transposed
+            // index = activation operand, -|y|^2 / 2 as a per-column residual, scale -2): one pass over the index instead of one per 16
+            // queries (64 streams x 11 queries: 44 passes, 3.5 ms -> one ~1 ms MFMA-bound launch).  Same approximate distances up to
+            // fp32 summation order; the exact re-rank behind it is unchanged.
+            const int Q = B * nq, Qpad = (Q + 127) / 128 * 128;
+            const bool gemm_scan = fast && Q >= 128 && e->d_indexT && e->d_nhn && !getenv("RVC_KNN_NO_GEMM");
             if (fast) {
-                float *d_approx = pl.arena.floats((size_t)B * nq * e->index_n);
-                for (int q0 = 0; q0 < nq; q0 += 16) {
+                float *d_approx = pl.arena.floats((size_t)(gemm_scan ? Qpad : Q) * e->index_n);
+                if (gemm_scan) {
+                    float *d_qf = pl.arena.floats((size_t)Qpad * C);
+                    const int n_idx = (int)e->index_n;
+                    {
+                        dim3 grid(Qpad / 16, C / 16); int *ovf = d_overflow; const int nb = B;
+                        pl.ops.push_back([=](hipStream_t s) {
+                            HIPCHK(hipMemsetAsync(ovf, 0, (size_t)nb * sizeof(int), s));
+                            hipLaunchKernelGGL(knn_pack_queries_kernel, grid, dim3(64), 0, s, d_q, Q, C, d_qf);
+                        });
+                    }
+                    ConvW qw; qw.w = d_qf; qw.bias = nullptr; qw.M = Qpad; qw.K = C; qw.Kp = C; qw.Cin = C; qw.Cout = Qpad; qw.KW = 1; qw.groups = 1; qw.nphase = 1; qw.owns = false;
+                    T1 xi; xi.p = e->d_indexT; xi.B = 1; xi.C = C; xi.T = n_idx; xi.ld = n_idx; xi.halo = 0; xi.bs = (long long)C * n_idx;
+                    T1 ya; ya.p = d_approx; ya.B = 1; ya.C = Qpad; ya.T = n_idx; ya.ld = n_idx; ya.halo = 0; ya.bs = (long long)Qpad * n_idx;
+                    ConvOpts o; o.no_bias = true; o.res = e->d_nhn; o.res_cs = 0; o.res_bs = 0; o.scale = -2.0f;
+                    add_conv1d(pl, qw, xi, ya, 1, 0, 1, o);
+                }
+                for (int q0 = 0; q0 < nq && !gemm_scan; q0 += 16) {
                     KnnDotP dp{}; dp.indexF = e->d_indexF; dp.ynorm = e->d_ynorm; dp.n = (int)e->index_n; dp.dim = C;
                     dp.q = d_q; dp.q_bs = (long long)nq * C; dp.nq = nq; dp.q0 = q0; dp.approx = d_approx; dp.approx_bs = (long long)nq * e->index_n;
                     dp.overflow = d_overflow;
@@ -2159,6 +2181,7 @@ void rvc_destroy(rvc_engine *e)
     if (e->d_index && e->index_owned) (void)hipFree(e->d_index);
     if (e->d_indexT) (void)hipFree(e->d_indexT);
     if (e->d_ynorm) (void)hipFree(e->d_ynorm);
+    if (e->d_nhn) (void)hipFree(e->d_nhn);
     if (e->d_indexF) (void)hipFree(e->d_indexF);
     if (e->d_state) (void)hipFree(e->d_state);
     if (e->d_cp) (void)hipFree(e->d_cp);
@@ -2431,8 +2454,10 @@ static void build_index_transpose(rvc_engine *e)
         HIPCHK(hipMemcpy(e->d_indexF, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     if (e->d_ynorm) (void)hipFree(e->d_ynorm);
+    if (e->d_nhn) (void)hipFree(e->d_nhn);
     HIPCHK(hipMalloc(&e->d_ynorm, e->index_n * sizeof(float)));
-    hipLaunchKernelGGL(knn_norms_kernel, dim3((unsigned)((e->index_n + 255) / 256)), dim3(256), 0, 0, e->d_index, (int)e->index_n, (int)e->index_dim, e->d_ynorm);
+    HIPCHK(hipMalloc(&e->d_nhn, e->index_n * sizeof(float)));
+    hipLaunchKernelGGL(knn_norms_kernel, dim3((unsigned)((e->index_n + 255) / 256)), dim3(256), 0, 0, e->d_index, (int)e->index_n, (int)e->index_dim, e->d_ynorm, e->d_nhn);
     HIPCHK(hipDeviceSynchronize());
 }
 

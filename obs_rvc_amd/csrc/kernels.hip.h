@@ -2765,8 +2765,8 @@ __global__ __launch_bounds__(256) void knn_dot_kernel(KnnDotP p)
     }
 }
 
-// |y_i|^2 for every index vector (load time)
-__global__ void knn_norms_kernel(const float *index, int n, int dim, float *ynorm)
+// |y_i|^2 for every index vector (load time); nhn = -|y_i|^2 / 2 is the per-column "residual" of the many-stream distance GEMM
+__global__ void knn_norms_kernel(const float *index, int n, int dim, float *ynorm, float *nhn)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -2774,6 +2774,18 @@ __global__ void knn_norms_kernel(const float *index, int n, int dim, float *ynor
     float s = 0.f;
     for (int d = 0; d < dim; d++) s = fmaf(r[d], r[d], s);
     ynorm[i] = s;
+    nhn[i] = -0.5f * s;
+}
+
+// Many streams: the queries of all streams as the WEIGHT operand of one implicit GEMM against the transposed index (approx[q][i] =
+// |y_i|^2 - 2 x_q . y_i for every stream's queries in ONE pass over the index instead of one pass per 16 queries): [Q][dim] ->
+// MFMA-fragment order [tile of 16 queries][chunk of 16 dims][lane][4], rows past Q zero.  grid = (Qpad / 16, dim / 16), 64 threads.
+__global__ __launch_bounds__(64) void knn_pack_queries_kernel(const float *q, int Q, int dim, float *qf)
+{
+    const int t = blockIdx.x, c = blockIdx.y, l = threadIdx.x, v = t * 16 + (l & 15);
+    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+    if (v < Q) x = *reinterpret_cast<const f32x4 *>(q + (long long)v * dim + c * 16 + (l >> 4) * 4);
+    *reinterpret_cast<f32x4 *>(qf + (((long long)t * gridDim.y + c) * 64 + l) * 4) = x;
 }
 
 // Stage B (knn_select_blend_kernel): one workgroup per (unique query, stream).

@@ -78,6 +78,35 @@ def test_many_stream_first_layer_matches_the_one_channel_kernel(monkeypatch):
     assert rms(taps["multi"][1] - taps["single"][1]) < 1e-4
 
 
+def test_many_stream_retrieval_scan_as_one_gemm(monkeypatch):
+    # from 12 streams on, the approximate distances of ALL streams' queries come from one implicit GEMM over the transposed index
+    # (queries as the weight operand) instead of one pass over the index per 16 queries.  The exact re-rank behind it is the same
+    # kernel, so hits, distances and audio must be IDENTICAL to the per-16-queries scan, and stream 0 must match the oracle's search
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("full")
+    S = 16
+    index = W.make_index(100000, 768, seed=7)
+    xin = np.stack([voice_signal(g.input_buffer_16k_size, seed=700 + s) for s in range(S)])
+    res = {}
+    for mode in ("gemm", "scan"):
+        if mode == "scan":
+            monkeypatch.setenv("RVC_KNN_NO_GEMM", "1")
+        eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"])
+        eng.set_streams(S); eng.set_noise_seed(9, 0); eng.load_index(index); eng.set_index_rate(0.75)
+        y = eng.infer_batch(xin, g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+        idx, dist = eng.knn(rows_cap=S * 64)
+        res[mode] = (y, idx.copy(), dist.copy())
+        eng.close()
+    assert res["gemm"][1].shape == res["scan"][1].shape and res["gemm"][1].size >= 21 * 4
+    assert np.array_equal(res["gemm"][1], res["scan"][1]) and np.array_equal(res["gemm"][2], res["scan"][2])
+    assert np.array_equal(res["gemm"][0], res["scan"][0])
+    o = _oracle(z, 9, 0); o.load_index(index); o.set_index_rate(0.75)
+    yo = o.infer(xin[0], g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+    io, do = o.knn()
+    assert np.array_equal(res["gemm"][1][:io.shape[0]], io)
+    assert rms(res["gemm"][0][0] - yo) < PCM_TOL
+
+
 def test_index_broadcast_through_rccl_one_rank():
     # rvc_rccl_unique_id + rvc_index_broadcast with a ONE-rank communicator: librccl is loaded (dlopen), ncclCommInitRank,
     # two ncclBroadcast calls (header, matrix) and ncclCommDestroy really run; the engine then retrieves exactly as after rvc_load_index
