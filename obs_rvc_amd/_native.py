@@ -27,7 +27,19 @@ SYMBOLS = [
 ]
 
 
-SOURCES = ("engine.hip", "kernels.hip.h", "resample.hip.h", "session.hip.h", "rccl_bcast.hip.h", "blob.h", "rvc_rpc.cpp")
+SOURCES = ("engine.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "igemm2_inst.hip", "igemm_tiled_inst.hip", "version.cpp",
+           "resample.hip.h", "session.hip.h", "rccl_bcast.hip.h", "blob.h", "rvc_rpc.cpp")
+
+# translation units of the library: (source, extra flags, files whose contents decide whether the object is stale).  The implicit-GEMM
+# template instantiations are the bulk of the compile time; as separate units they build in parallel (5 min -> about 1.5 min on 8 cores)
+# and are not rebuilt when only the engine changes.
+_IGEMM_DEPS = ("igemm.hip.h", "igemm_launch.h")
+_ENGINE_DEPS = ("engine.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "resample.hip.h", "session.hip.h", "rccl_bcast.hip.h", "blob.h")
+UNITS = [("engine.hip", [], _ENGINE_DEPS)] + \
+        [("igemm2_inst.hip", ["-DRVC_IGEMM2_CFG=%d" % c], ("igemm2_inst.hip",) + _IGEMM_DEPS) for c in range(5)] + \
+        [("igemm_tiled_inst.hip", ["-DRVC_TILED_PART=%d" % c], ("igemm_tiled_inst.hip",) + _IGEMM_DEPS) for c in range(4)]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+OBJ_CACHE = os.environ.get("RVC_OBJ_CACHE", "/tmp/rvc_obj_cache")
 
 
 def source_hash() -> str:
@@ -54,18 +66,64 @@ def binary_hash(path: str = None) -> str:
     return blob[i + 15:i + 31].decode("ascii", "replace") if i >= 0 else ""
 
 
+def _unit_key(src, flags, deps, extra_flags):
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS + list(flags) + list(extra_flags)).encode())
+    for n in tuple(deps) + ("../../include/rvc_mi355x.h",):
+        with open(os.path.join(CSRC, n), "rb") as fh:
+            h.update(n.encode() + b"\0" + fh.read())
+    return "%s-%s" % (os.path.splitext(src)[0], h.hexdigest()[:20])
+
+
+def compile_units(extra_flags=(), verbose=False, extra_units=()):
+    """Compile every translation unit whose object is not in the cache (content-addressed: sources + flags), in parallel.
+    -> list of object paths"""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_CACHE, exist_ok=True)
+    jobs, objs = [], []
+    for src, flags, deps in list(UNITS) + list(extra_units):
+        obj = os.path.join(OBJ_CACHE, _unit_key(src, flags, tuple(deps), extra_flags) + ".o")
+        objs.append(obj)
+        if not os.path.exists(obj):
+            jobs.append((["hipcc"] + HIPCC_FLAGS + list(flags) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj + ".tmp.o"], obj))
+
+    def run(job):
+        cmd, obj = job
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        os.replace(obj + ".tmp.o", obj)
+    if jobs:
+        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+            list(ex.map(run, jobs))
+    return objs
+
+
+def link_library(objs, out, want_hash, verbose=False):
+    ver = os.path.join(OBJ_CACHE, "version-%s.o" % want_hash)
+    cmd = ["hipcc", "-O2", "-fPIC", "-c", '-DRVC_SRC_HASH="%s"' % want_hash, os.path.join(CSRC, "version.cpp"), "-o", ver]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + [ver, "-o", out, "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950: the engine library and the rvc-rpc protocol-compatible executable.  A library is reused only
-    if the source hash compiled into it equals the hash of the sources on disk (never by modification time)."""
+    """hipcc --offload-arch=gfx950: the engine library (one object per translation unit, built in parallel, linked into
+    csrc/librvc_mi355x.so) and the rvc-rpc protocol-compatible executable.  A library is reused only if the source hash compiled
+    into it equals the hash of the sources on disk (never by modification time)."""
     want = source_hash()
     have = binary_hash()
     if force or have != want:
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", '-DRVC_SRC_HASH="%s"' % want,
-               os.path.join(CSRC, "engine.hip"), "-o", SO_PATH, "-ldl"]
         if verbose:
             print("source hash %s, binary %s -> rebuilding" % (want, have or "(none)"))
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        if force:
+            import shutil
+            shutil.rmtree(OBJ_CACHE, ignore_errors=True)
+        link_library(compile_units(verbose=verbose), SO_PATH, want, verbose)
     elif verbose:
         print("librvc_mi355x.so carries source hash %s = sources on disk: up to date" % have)
     rpc_src = os.path.join(CSRC, "rvc_rpc.cpp")

@@ -7,6 +7,7 @@
 #include "../../include/rvc_mi355x.h"
 #include "blob.h"
 #include "kernels.hip.h"
+#include "igemm_launch.h"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -321,64 +322,7 @@ struct Plan {
     }
 };
 
-// Profile mode times a kernel with the start / stop events of hipExtLaunchKernelGGL: they carry the dispatch's own begin / end
-// timestamps (what rocprofv3 --kernel-trace reports), not the time between two event-record packets around it.
-template <typename K> static void launch_k(K kern, const IgemmP &p, dim3 grid, dim3 block, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
-{
-    if (ea) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, s, ea, eb, 0, p);
-    else hipLaunchKernelGGL(kern, grid, block, lds, s, p);
-}
-
-// tile configurations: index -> (MF, NF); every tile exists with KS in {1, 4, 8, 16}
-static const int kMF[5] = {1, 1, 1, 2, 2}, kNF[5] = {1, 2, 4, 2, 4};
-
-// lean kernel (igemm2): 2-D tile grid, LDS = offset table (none for LIN layers) + the KS partial tiles
-static void launch_igemm2(int cfg, int ks, bool pre, bool lin, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr)
-{
-    if (p.ln_wsum) {           // LayerNorm-consumer instantiations (checked at plan time: lin, ks > 1)
-#define RVC_LNB(MF, NF, D)                                                                                             \
-        switch (ks) {                                                                                                  \
-        case 4: launch_k(igemm2_kernel<MF, NF, D, 4, false, true, true>, p, grid, dim3(256), lds, s, ea, eb); return;  \
-        case 8: launch_k(igemm2_kernel<MF, NF, D, 8, false, true, true>, p, grid, dim3(512), lds, s, ea, eb); return;  \
-        default: launch_k(igemm2_kernel<MF, NF, (D > 8 ? 8 : D), 16, false, true, true>, p, grid, dim3(1024), lds, s, ea, eb); return; \
-        }
-        switch (cfg) {
-        case 0: RVC_LNB(1, 1, 12)
-        case 1: RVC_LNB(1, 2, 8)
-        case 2: RVC_LNB(1, 4, 5)
-        case 3: RVC_LNB(2, 2, 6)
-        default: RVC_LNB(2, 4, 4)
-        }
-#undef RVC_LNB
-    }
-#define RVC_KS2(MF, NF, D, PRE, LIN)                                                                                   \
-        switch (ks) {                                                                                                  \
-        case 1: launch_k(igemm2_kernel<MF, NF, D, 1, PRE, LIN>, p, grid, dim3(256), lds, s, ea, eb); return;           \
-        case 4: launch_k(igemm2_kernel<MF, NF, D, 4, PRE, LIN>, p, grid, dim3(256), lds, s, ea, eb); return;           \
-        case 8: launch_k(igemm2_kernel<MF, NF, D, 8, PRE, LIN>, p, grid, dim3(512), lds, s, ea, eb); return;           \
-        default: launch_k(igemm2_kernel<MF, NF, (D > 8 ? 8 : D), 16, PRE, LIN>, p, grid, dim3(1024), lds, s, ea, eb); return; \
-        }
-#define RVC_CASE2(C, MF, NF, D)                                                                                        \
-    case C:                                                                                                            \
-        if (lin) { RVC_KS2(MF, NF, D, false, true) } else if (pre) { RVC_KS2(MF, NF, D, true, false) } else { RVC_KS2(MF, NF, D, false, false) }
-    switch (cfg) {
-        RVC_CASE2(0, 1, 1, 12)
-        RVC_CASE2(1, 1, 2, 8)
-        RVC_CASE2(2, 1, 4, 5)
-        RVC_CASE2(3, 2, 2, 6)
-        RVC_CASE2(4, 2, 4, 4)
-    }
-#undef RVC_CASE2
-#undef RVC_KS2
-}
-
-// the first-generation kernel remains for the two-stage grid-level split-K (offset table too long for LDS): 16x16 tiles only
-static void launch_igemm(bool pre, const IgemmP &p, dim3 grid, hipStream_t s)
-{
-    const size_t lds = (size_t)p.chunks_per_split * 16 * sizeof(int);
-    if (pre) hipLaunchKernelGGL((igemm_kernel<1, 1, 12, 1, true>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((igemm_kernel<1, 1, 12, 1, false>), grid, dim3(256), lds, s, p);
-}
+// (launch_igemm2 / launch_igemm_v1 / launch_igemm_tiled: igemm_launch.h -- the template instantiations are separate translation units)
 
 static unsigned long long *g_kprobe = nullptr;   // tuning build (-DRVC_KPROBE): destination of the per-wave phase stamps
 static int g_last_waves = 0, g_last_wgs = 0;
@@ -502,14 +446,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
                 pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
             }
             hipEvent_t ea = pe ? pe->a : nullptr, eb = pe ? pe->b : nullptr;
-#define RVC_LG1(K) { if (ea) hipExtLaunchKernelGGL((K), grid, dim3(256), (uint32_t)lds, s, ea, eb, 0, p); else hipLaunchKernelGGL((K), grid, dim3(256), lds, s, p); }
-#define RVC_LG(WM, WN, MF, NF) { if (pre) RVC_LG1((igemm_lds_kernel<WM, WN, MF, NF, true>)) else RVC_LG1((igemm_lds_kernel<WM, WN, MF, NF, false>)) }
-#define RVC_LG32(WM, WN, MT, NT) { if (pre) RVC_LG1((igemm32_kernel<WM, WN, MT, NT, true>)) else RVC_LG1((igemm32_kernel<WM, WN, MT, NT, false>)) }
-            if (lc == 0) RVC_LG(2, 2, 4, 4) else if (lc == 1) RVC_LG(1, 4, 4, 4) else if (lc == 2) RVC_LG(1, 4, 2, 4) else if (lc == 6) RVC_LG(1, 4, 3, 4) else if (lc == 7) RVC_LG32(4, 1, 1, 2)
-            else if (lc == 3) RVC_LG32(2, 2, 2, 2) else if (lc == 4) RVC_LG32(1, 4, 2, 2) else RVC_LG32(1, 4, 1, 2)
-#undef RVC_LG32
-#undef RVC_LG
-#undef RVC_LG1
+            launch_igemm_tiled(lc, pre, p, grid, lds, s, ea, eb);
         });
         return;
     }
@@ -587,7 +524,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
             if (ksplit > 1) HIPCHK(hipEventRecord(pe->a, s));
         }
         if (lean) launch_igemm2(cfg, wg_ks, pre, lin, p, grid, lds2, s, pe ? pe->a : nullptr, pe ? pe->b : nullptr);
-        else launch_igemm(pre, p, grid, s);
+        else launch_igemm_v1(pre, p, grid, s);
         if (ksplit > 1) hipLaunchKernelGGL(splitk_epilogue_kernel, egrid, dim3(256), 0, s, p);
         if (pe && ksplit > 1) HIPCHK(hipEventRecord(pe->b, s));
     });
@@ -2128,11 +2065,7 @@ static std::string native_path(const std::string &p)
 // ---------------------------------------------------------------------------------------
 extern "C" {
 
-#ifndef RVC_SRC_HASH
-#define RVC_SRC_HASH "unhashed"
-#endif
-// "... rvc-mi355x-src:<sha256[:16] of the sources this binary was compiled from>" (obs_rvc_amd/_native.py source_hash / binary_hash)
-const char *rvc_version(void) { return "rvc-mi355x 0.2 (gfx950) rvc-mi355x-src:" RVC_SRC_HASH; }
+// rvc_version(): version.cpp
 
 rvc_status rvc_create(const char *data_path, int device, rvc_engine **out)
 {
@@ -2910,3 +2843,38 @@ rvc_status rvc_get_tap(rvc_engine *e, const char *name, float *out, size_t cap, 
 #include "resample.hip.h"
 #include "session.hip.h"
 #include "rccl_bcast.hip.h"
+
+// single-translation-unit build (tuning tools: `hipcc -DRVC_UNITY engine.hip`): pull the instantiation units in
+#ifdef RVC_UNITY
+#define RVC_IGEMM2_CFG 0
+#include "igemm2_inst.hip"
+#undef RVC_IGEMM2_CFG
+#undef RVC_FN
+#undef RVC_MF
+#undef RVC_NF
+#undef RVC_D
+#define RVC_IGEMM2_CFG 1
+#include "igemm2_inst.hip"
+#undef RVC_IGEMM2_CFG
+#undef RVC_FN
+#undef RVC_MF
+#undef RVC_NF
+#undef RVC_D
+#define RVC_IGEMM2_CFG 2
+#include "igemm2_inst.hip"
+#undef RVC_IGEMM2_CFG
+#undef RVC_FN
+#undef RVC_MF
+#undef RVC_NF
+#undef RVC_D
+#define RVC_IGEMM2_CFG 3
+#include "igemm2_inst.hip"
+#undef RVC_IGEMM2_CFG
+#undef RVC_FN
+#undef RVC_MF
+#undef RVC_NF
+#undef RVC_D
+#define RVC_IGEMM2_CFG 4
+#include "igemm2_inst.hip"
+#include "igemm_tiled_inst.hip"
+#endif

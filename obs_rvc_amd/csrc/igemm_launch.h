@@ -1,0 +1,35 @@
+// igemm_launch.h -- host-side entry points of the implicit-GEMM kernel family.  The template instantiations are compiled in their
+// own translation units (igemm2_inst.hip once per tile configuration, igemm_tiled_inst.hip) so that the library builds in parallel.
+#pragma once
+#include "igemm.hip.h"
+
+namespace rvc {
+
+// tile configurations of the register-direct kernel: index -> (MF, NF); every tile exists with KS in {1, 4, 8, 16}
+static const int kMF[5] = {1, 1, 1, 2, 2}, kNF[5] = {1, 2, 4, 2, 4};
+
+// lean kernel (igemm2): 2-D tile grid, LDS = offset table (none for LIN layers) + the KS partial tiles.  ea / eb: optional start /
+// stop events of hipExtLaunchKernelGGL (the dispatch's own begin / end timestamps: what rocprofv3 --kernel-trace reports).
+void launch_igemm2(int cfg, int ks, bool pre, bool lin, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
+void launch_igemm2_cfg0(int ks, bool pre, bool lin, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+void launch_igemm2_cfg1(int ks, bool pre, bool lin, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+void launch_igemm2_cfg2(int ks, bool pre, bool lin, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+void launch_igemm2_cfg3(int ks, bool pre, bool lin, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+void launch_igemm2_cfg4(int ks, bool pre, bool lin, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+// the first-generation kernel remains for the two-stage grid-level split-K (offset table too long for LDS): 16x16 tiles only
+void launch_igemm_v1(bool pre, const IgemmP &p, dim3 grid, hipStream_t s);
+// workgroup-tiled throughput kernels: lc 0-2 / 6 = igemm_lds_kernel (128x128, 64x256, 32x256, 48x256), 3-5 / 7 = igemm32_kernel
+void launch_igemm_tiled(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
+
+void launch_igemm_tiled_p0(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+void launch_igemm_tiled_p1(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+void launch_igemm_tiled_p2(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+void launch_igemm_tiled_p3(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+
+template <typename K> static inline void launch_k(K kern, const IgemmP &p, dim3 grid, dim3 block, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
+{
+    if (ea) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, s, ea, eb, 0, p);
+    else hipLaunchKernelGGL(kern, grid, block, lds, s, p);
+}
+
+}  // namespace rvc
