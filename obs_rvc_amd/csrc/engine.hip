@@ -8,6 +8,7 @@
 #include "blob.h"
 #include "kernels.hip.h"
 #include "igemm_launch.h"
+#include "synth_front.h"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -311,6 +312,8 @@ struct Plan {
     unsigned long long *d_stamps = nullptr; std::vector<std::string> stamp_names;
     // chunk pipelining (rvc_set_pipeline): plans alternate between two slots; ev_done marks the end of this plan's previous chunk
     int slot = 0; hipEvent_t ev_done = nullptr; bool ev_done_valid = false;
+    unsigned long long *front_stamps = nullptr;
+    unsigned *front_epoch = nullptr;      // tag base of the persistent synthesizer front end (synth_front.h): advanced at the end of every chunk
     // graph
     hipGraphExec_t graph_exec = nullptr;
     ~Plan()
@@ -1579,77 +1582,137 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
     const int R = (int)pl.R, H = m.hidden, I = m.inter, F = m.filter, half = I / 2;
     const int HALO = 4;
     if (m.enc_k / 2 > HALO || m.wn_k / 2 > HALO) throw ShapeError("synth kernel sizes exceed the halo");
-    T1 x = make_t1(A, B, H, R, HALO);
-    add_conv1d(pl, m.phone, phone, x, 1, 0, 1);
-    {
-        dim3 grid((H * R + 255) / 256, B); float *emb = m.pitch_emb; float sq = sqrtf((float)H);
-        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(embed_pitch_kernel, grid, dim3(256), 0, s, x.p, x.ld, x.bs, emb, d_pitch, H, R, sq); });
-    }
-    add_tap(pl, "sy.emb", x);
-    T1 qkv = make_t1(A, B, 3 * H, R, 0), att = make_t1(A, B, H, R, 0), ff = make_t1(A, B, F, R, HALO);
-    const int kc = H / m.heads, Tp = R | 1;
-    const size_t attn_lds = ((size_t)((kc * Tp + 3) & ~3) + 16 * Tp + 16 * kc) * sizeof(float);
-    if (attn_lds > 160 * 1024) throw ShapeError("synth attention: return_length too long for the LDS-resident kernel");
-    // one stream: the second LayerNorm of every encoder layer is folded into the next projection (see build_contentvec)
-    const bool fuse_ln = B == 1 && m.has_folded && !pl.with_taps && !getenv("RVC_NO_LN_FUSE");
-    bool raw = false; const float *raw_g = nullptr, *raw_b = nullptr; float *raw_st = nullptr;
-    for (int l = 0; l < m.enc_layers; l++) {
-        ModelSY::Layer &Ly = m.layers[l];
-        if (raw) { raw_st = A.floats((size_t)2 * R + 16); ConvOpts o; o.ln_wsum = Ly.qkv_wsum; o.ln_stats_out = raw_st; o.ln_rows = H; add_conv1d(pl, Ly.qkv_f, x, qkv, 1, 0, 1, o); }
-        else add_conv1d(pl, Ly.qkv, x, qkv, 1, 0, 1);
-        AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = H; ap.T = R; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;
-        ap.scale = 1.0f / sqrtf((float)kc); ap.rel_k = Ly.rel_k; ap.rel_v = Ly.rel_v; ap.window = m.window;
-        const size_t small_lds = ((size_t)2 * kc * Tp + 2 * (2 * m.window + 1) * kc + 4 * kc + 4 * 64) * sizeof(float);
-        if (R <= 64 && small_lds <= 160 * 1024 && !getenv("RVC_NO_SMALL_ATTN")) {
-            dim3 ag(m.heads * ((R + 3) / 4), B);
-            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(relpos_attention_small_kernel, ag, dim3(256), small_lds, s, ap); });
-        } else {
-            dim3 ag(m.heads * ((R + 15) / 16), B);
-            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(attention_kernel, ag, dim3(256), attn_lds, s, ap); });
-        }
-        {
-            ConvOpts o; o.res = x.p; o.res_cs = x.ld; o.res_bs = x.bs;
-            if (raw) { o.ln_stats_in = raw_st; o.ln_g = raw_g; o.ln_b = raw_b; }
-            add_conv1d(pl, Ly.o, att, x, 1, 0, 1, o);
-        }
-        add_layernorm(pl, x, Ly.ln1_g, Ly.ln1_b);
-        { ConvOpts o; o.act = ACT_RELU; add_conv1d(pl, Ly.ff1, x, ff, 1, m.enc_k / 2, 1, o); }
-        { ConvOpts o; o.res = x.p; o.res_cs = x.ld; o.res_bs = x.bs; add_conv1d(pl, Ly.ff2, ff, x, 1, m.enc_k / 2, 1, o); }
-        if (fuse_ln) { raw = true; raw_g = Ly.ln2_g; raw_b = Ly.ln2_b; }
-        else add_layernorm(pl, x, Ly.ln2_g, Ly.ln2_b);
-    }
-    add_tap(pl, "sy.enc", x);
-    T1 stats = make_t1(A, B, 2 * I, R, 0);
-    if (raw) { ConvOpts o; o.ln_wsum = m.proj_wsum; o.ln_rows = H; add_conv1d(pl, m.proj_f, x, stats, 1, 0, 1, o); }
-    else add_conv1d(pl, m.proj, x, stats, 1, 0, 1);
-    add_tap(pl, "sy.stats", stats);
     T1 z = make_t1(A, B, I, R, HALO), zf = make_t1(A, B, I, R, HALO);
-    {
-        dim3 grid(((I * R + 3) / 4 + 255) / 256, B); StreamState *st = e->d_state; CallParams *cp = e->d_cp;
-        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(prior_sample_kernel, grid, dim3(256), 0, s, stats.p, stats.ld, stats.bs, z.p, z.ld, z.bs, I, R, st, cp); });
-    }
-    add_tap(pl, "sy.zp", z);
-    // hh (WaveNet state, rows 0..H) and skip (rows H..2H) share one tensor: the res_skip conv updates both in one launch
-    T1 hs = make_t1(A, B, 2 * H, R, HALO), acts = make_t1(A, B, H, R, 0);
-    T1 hh = hs.rows(0, H), skip = hs.rows(H, H);
-    for (int fi = m.flow_n - 1; fi >= 0; fi--) {
-        ModelSY::Flow &Fw = m.flows[fi];
-        const T1 x0 = Fw.flipped ? z.rows(half, half) : z.rows(0, half), x1 = Fw.flipped ? z.rows(0, half) : z.rows(half, half);
-        add_conv1d(pl, Fw.pre, x0, hs, 1, 0, 1);                       // hh = pre(x0), skip = 0
-        for (int j = 0; j < m.wn_layers; j++) {
-            { ConvOpts o; o.glu = true; add_conv1d(pl, Fw.in[j], hh, acts, 1, (m.wn_k - 1) / 2, 1, o); }   // acts = tanh(.) * sigmoid(.)
-            ConvOpts o; o.accumulate = true;
-            if (j < m.wn_layers - 1) add_conv1d(pl, Fw.rs[j], acts, hs, 1, 0, 1, o);     // hh += res, skip += skip part
-            else add_conv1d(pl, Fw.rs[j], acts, skip, 1, 0, 1, o);
+    // One stream: text encoder + prior sample + flows as ONE persistent launch (synth_front.hip: ~70 layers on a 21-column window hand
+    // their outputs from workgroup to workgroup as tagged granules instead of crossing ~70 kernel boundaries).
+    bool front_done = false;
+    // Opt-in (RVC_SYNTH_FRONT=1): with the per-step costs measured so far it equals the per-layer launches, it does
+    // not beat them yet.
+    if (B == 1 && !pl.with_taps && getenv("RVC_SYNTH_FRONT") && !getenv("RVC_NO_SYNTH_FRONT")) {
+        SynFrontP P{};
+        auto sw = [](const ConvW &cw, int M) { SfW w; w.w = cw.w; w.b = cw.bias; w.M = M; w.nchunks = cw.Kp / 16; return w; };
+        P.T = R; P.C = m.phone_dim; P.H = H; P.F = F; P.I = I; P.heads = m.heads; P.window = m.window; P.n_layers = m.enc_layers; P.n_flows = m.flow_n;
+        P.wn_layers = m.wn_layers; P.enc_k = m.enc_k; P.wn_k = m.wn_k;
+        const bool fits = m.enc_layers <= SF_MAX_LAYERS && m.flow_n <= SF_MAX_FLOWS && m.wn_layers <= 4 && phone.C == m.phone_dim;
+        if (fits) {
+            P.phone = phone.p; P.phone_ld = phone.ld; P.pitch = d_pitch; P.pitch_emb = m.pitch_emb;
+            P.phone_w = sw(m.phone, H); P.proj = sw(m.proj, 2 * I);
+            for (int l = 0; l < m.enc_layers; l++) {
+                ModelSY::Layer &Ly = m.layers[l];
+                SfLayer &D = P.layer[l];
+                D.qkv = sw(Ly.qkv, 3 * H); D.o = sw(Ly.o, H); D.ff1 = sw(Ly.ff1, F); D.ff2 = sw(Ly.ff2, H);
+                D.rel_k = Ly.rel_k; D.rel_v = Ly.rel_v; D.ln1_g = Ly.ln1_g; D.ln1_b = Ly.ln1_b; D.ln2_g = Ly.ln2_g; D.ln2_b = Ly.ln2_b;
+            }
+            for (int i = 0; i < m.flow_n; i++) {
+                ModelSY::Flow &Fw = m.flows[i];
+                SfFlow &D = P.flow[i];
+                D.pre = sw(Fw.pre, H);                         // (rows H..2H of the panel are the zero rows that clear the skip accumulator: not needed here)
+                D.post = sw(Fw.post, half); D.flipped = Fw.flipped ? 1 : 0;
+                for (int j = 0; j < m.wn_layers; j++) { D.in[j] = sw(Fw.in[j], 2 * H); D.rs[j] = sw(Fw.rs[j], j < m.wn_layers - 1 ? 2 * H : H); }
+            }
+            P.z_out = z.p; P.z_ld = z.ld; P.st = e->d_state; P.cp = e->d_cp; P.status = &e->d_state[0].status;
+            if (synth_front_supported(P)) {
+                P.gran = (unsigned long long *)A.alloc(synth_front_ws_granules(P) * sizeof(unsigned long long));
+                pl.front_epoch = (unsigned *)A.alloc(256);
+                P.epoch = pl.front_epoch;
+                if (getenv("RVC_FRONT_STAMPS")) { pl.front_stamps = (unsigned long long *)A.alloc(512 * 8); P.stamps = pl.front_stamps; }
+                // algorithmic flops of the layers inside the launch (2 M N K per layer at N = return_length), for the per-launch profile
+                double fl = 0;
+                auto add = [&](const SfW &w) { fl += 2.0 * w.M * (double)R * w.nchunks * 16.0; };
+                add(P.phone_w); add(P.proj);
+                for (int l = 0; l < m.enc_layers; l++) { add(P.layer[l].qkv); add(P.layer[l].o); add(P.layer[l].ff1); add(P.layer[l].ff2); }
+                for (int i = 0; i < m.flow_n; i++) { add(P.flow[i].pre); add(P.flow[i].post); for (int j = 0; j < m.wn_layers; j++) { add(P.flow[i].in[j]); add(P.flow[i].rs[j]); } }
+                pl.igemm_flops += fl; pl.n_igemm++;
+                { char d[160]; snprintf(d, sizeof d, "synth_front persistent: %d steps, %d workgroups, T=%d", synth_front_steps(P), synth_front_grid(P), R); pl.descs.push_back(d); }
+                const int desc_id = (int)pl.descs.size() - 1;
+                Plan *plp = &pl;
+                pl.ops.push_back([=](hipStream_t s) {
+                    ProfEvent *pe = nullptr;
+                    if (plp->profile) {
+                        if (plp->prof_used == plp->prof.size()) { ProfEvent ev; HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b)); ev.flops = 0; ev.bytes = 0; plp->prof.push_back(ev); }
+                        pe = &plp->prof[plp->prof_used++]; pe->flops = fl; pe->bytes = 0; pe->desc = desc_id;
+                        HIPCHK(hipEventRecord(pe->a, s));
+                    }
+                    launch_synth_front(P, s);
+                    if (pe) HIPCHK(hipEventRecord(pe->b, s));
+                });
+                add_stamp(pl, "sy.flow");
+                front_done = true;
+            }
         }
-        { ConvOpts o; o.scale = -1.f; o.accumulate = true; add_conv1d(pl, Fw.post, skip, x1, 1, 0, 1, o); }
-        add_stamp(pl, "sy.flow");
     }
-    if (m.flow_n & 1) {
-        // odd number of flips: materialise the last one
-        T1 zi = z, zo = zf; dim3 grid((I * R + 255) / 256, B);
-        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(flip_channels_kernel, grid, dim3(256), 0, s, zi.p, zo.p, I, R, zi.ld, zi.bs); });
-        std::swap(z, zf);
+    if (!front_done) {
+        T1 x = make_t1(A, B, H, R, HALO);
+        add_conv1d(pl, m.phone, phone, x, 1, 0, 1);
+        {
+            dim3 grid((H * R + 255) / 256, B); float *emb = m.pitch_emb; float sq = sqrtf((float)H);
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(embed_pitch_kernel, grid, dim3(256), 0, s, x.p, x.ld, x.bs, emb, d_pitch, H, R, sq); });
+        }
+        add_tap(pl, "sy.emb", x);
+        T1 qkv = make_t1(A, B, 3 * H, R, 0), att = make_t1(A, B, H, R, 0), ff = make_t1(A, B, F, R, HALO);
+        const int kc = H / m.heads, Tp = R | 1;
+        const size_t attn_lds = ((size_t)((kc * Tp + 3) & ~3) + 16 * Tp + 16 * kc) * sizeof(float);
+        if (attn_lds > 160 * 1024) throw ShapeError("synth attention: return_length too long for the LDS-resident kernel");
+        // one stream: the second LayerNorm of every encoder layer is folded into the next projection (see build_contentvec)
+        const bool fuse_ln = B == 1 && m.has_folded && !pl.with_taps && !getenv("RVC_NO_LN_FUSE");
+        bool raw = false; const float *raw_g = nullptr, *raw_b = nullptr; float *raw_st = nullptr;
+        for (int l = 0; l < m.enc_layers; l++) {
+            ModelSY::Layer &Ly = m.layers[l];
+            if (raw) { raw_st = A.floats((size_t)2 * R + 16); ConvOpts o; o.ln_wsum = Ly.qkv_wsum; o.ln_stats_out = raw_st; o.ln_rows = H; add_conv1d(pl, Ly.qkv_f, x, qkv, 1, 0, 1, o); }
+            else add_conv1d(pl, Ly.qkv, x, qkv, 1, 0, 1);
+            AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = H; ap.T = R; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;
+            ap.scale = 1.0f / sqrtf((float)kc); ap.rel_k = Ly.rel_k; ap.rel_v = Ly.rel_v; ap.window = m.window;
+            const size_t small_lds = ((size_t)2 * kc * Tp + 2 * (2 * m.window + 1) * kc + 4 * kc + 4 * 64) * sizeof(float);
+            if (R <= 64 && small_lds <= 160 * 1024 && !getenv("RVC_NO_SMALL_ATTN")) {
+                dim3 ag(m.heads * ((R + 3) / 4), B);
+                pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(relpos_attention_small_kernel, ag, dim3(256), small_lds, s, ap); });
+            } else {
+                dim3 ag(m.heads * ((R + 15) / 16), B);
+                pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(attention_kernel, ag, dim3(256), attn_lds, s, ap); });
+            }
+            {
+                ConvOpts o; o.res = x.p; o.res_cs = x.ld; o.res_bs = x.bs;
+                if (raw) { o.ln_stats_in = raw_st; o.ln_g = raw_g; o.ln_b = raw_b; }
+                add_conv1d(pl, Ly.o, att, x, 1, 0, 1, o);
+            }
+            add_layernorm(pl, x, Ly.ln1_g, Ly.ln1_b);
+            { ConvOpts o; o.act = ACT_RELU; add_conv1d(pl, Ly.ff1, x, ff, 1, m.enc_k / 2, 1, o); }
+            { ConvOpts o; o.res = x.p; o.res_cs = x.ld; o.res_bs = x.bs; add_conv1d(pl, Ly.ff2, ff, x, 1, m.enc_k / 2, 1, o); }
+            if (fuse_ln) { raw = true; raw_g = Ly.ln2_g; raw_b = Ly.ln2_b; }
+            else add_layernorm(pl, x, Ly.ln2_g, Ly.ln2_b);
+        }
+        add_tap(pl, "sy.enc", x);
+        T1 stats = make_t1(A, B, 2 * I, R, 0);
+        if (raw) { ConvOpts o; o.ln_wsum = m.proj_wsum; o.ln_rows = H; add_conv1d(pl, m.proj_f, x, stats, 1, 0, 1, o); }
+        else add_conv1d(pl, m.proj, x, stats, 1, 0, 1);
+        add_tap(pl, "sy.stats", stats);
+        {
+            dim3 grid(((I * R + 3) / 4 + 255) / 256, B); StreamState *st = e->d_state; CallParams *cp = e->d_cp;
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(prior_sample_kernel, grid, dim3(256), 0, s, stats.p, stats.ld, stats.bs, z.p, z.ld, z.bs, I, R, st, cp); });
+        }
+        add_tap(pl, "sy.zp", z);
+        // hh (WaveNet state, rows 0..H) and skip (rows H..2H) share one tensor: the res_skip conv updates both in one launch
+        T1 hs = make_t1(A, B, 2 * H, R, HALO), acts = make_t1(A, B, H, R, 0);
+        T1 hh = hs.rows(0, H), skip = hs.rows(H, H);
+        for (int fi = m.flow_n - 1; fi >= 0; fi--) {
+            ModelSY::Flow &Fw = m.flows[fi];
+            const T1 x0 = Fw.flipped ? z.rows(half, half) : z.rows(0, half), x1 = Fw.flipped ? z.rows(0, half) : z.rows(half, half);
+            add_conv1d(pl, Fw.pre, x0, hs, 1, 0, 1);                       // hh = pre(x0), skip = 0
+            for (int j = 0; j < m.wn_layers; j++) {
+                { ConvOpts o; o.glu = true; add_conv1d(pl, Fw.in[j], hh, acts, 1, (m.wn_k - 1) / 2, 1, o); }   // acts = tanh(.) * sigmoid(.)
+                ConvOpts o; o.accumulate = true;
+                if (j < m.wn_layers - 1) add_conv1d(pl, Fw.rs[j], acts, hs, 1, 0, 1, o);     // hh += res, skip += skip part
+                else add_conv1d(pl, Fw.rs[j], acts, skip, 1, 0, 1, o);
+            }
+            { ConvOpts o; o.scale = -1.f; o.accumulate = true; add_conv1d(pl, Fw.post, skip, x1, 1, 0, 1, o); }
+            add_stamp(pl, "sy.flow");
+        }
+        if (m.flow_n & 1) {
+            // odd number of flips: materialise the last one
+            T1 zi = z, zo = zf; dim3 grid((I * R + 255) / 256, B);
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(flip_channels_kernel, grid, dim3(256), 0, s, zi.p, zo.p, I, R, zi.ld, zi.bs); });
+            std::swap(z, zf);
+        }
     }
     add_tap(pl, "sy.z", z);
     const int upp = m.upp();
@@ -1929,7 +1992,8 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         pl.ops.cur = 0;
         build_synth(e, pl, B, phone, src0, d_pitchf, d_pitch, 2, side_nz ? &nz : nullptr);
         StreamState *st = e->d_state;
-        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(advance_chunk_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, B); });
+        unsigned *fep = pl.front_epoch;
+        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(advance_chunk_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, B, fep); });
     }
     HIPCHK(hipDeviceSynchronize());
     // bounded plan cache (each geometry owns its activation arena and graph): evict the oldest
@@ -2034,7 +2098,7 @@ static rvc_status check_status(rvc_engine *e)
             int zero = 0;
             for (int c = b; c < e->n_streams; c++)
                 if (e->h_status[c] != 0) HIPCHK(hipMemcpy((char *)(e->d_state + c) + offsetof(StreamState, status), &zero, sizeof(int), hipMemcpyHostToDevice));
-            if (code == 7) { e->err = "GRU hand-off timed out (multi-CU recurrence)"; return RVC_BACKEND; }
+            if (code == 7) { e->err = "a cross-workgroup hand-off timed out (GRU recurrence / persistent synthesizer front end)"; return RVC_BACKEND; }
             e->err = "to_local_average_cents: index out of bounds (argmax bin >= 348), the reference panics here";
             return RVC_PANIC;
         }
@@ -2786,6 +2850,31 @@ rvc_status rvc_profile_last_knn(rvc_engine *e, int *launches, double *kernel_ms,
         if (bytes) *bytes = by;
         return RVC_OK;
     });
+}
+
+// test aid: launches (ops) of the last call's plan and whether its synthesizer front end is the persistent kernel (synth_front.h)
+int rvc_debug_last_plan(rvc_engine *e, int *n_ops, int *persistent_front)
+{
+    if (!e || !e->last_plan) return 0;
+    int n = 0;
+    for (size_t i = 0; i < e->last_plan->ops.v.size(); i++) if (e->last_plan->ops.kind[i] == 0) n++;
+    if (n_ops) *n_ops = n;
+    if (persistent_front) *persistent_front = e->last_plan->front_epoch ? 1 : 0;
+    return 1;
+}
+
+// tuning aid (RVC_FRONT_STAMPS=1): step start times of the persistent synthesizer front end in the last call, us since its first step
+int rvc_debug_front_stamps(rvc_engine *e, double *out, int cap)
+{
+    if (!e || !e->last_plan || !e->last_plan->front_stamps) return 0;
+    unsigned long long h[512];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, e->last_plan->front_stamps, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    int n = 0;
+    for (int i = 1; i < 128 && h[i]; i++) { if (n < cap) out[n] = (double)(h[i] - h[1]) / 100.0; n++; }
+    // sub-step stamps of step i (1-based) at out[128 + i * 4 + k], us since the step's start (0 where the step has none)
+    for (int i = 1; i < 96 && 128 + i * 4 + 3 < cap; i++)
+        for (int k = 0; k < 4; k++) out[128 + i * 4 + k] = (h[128 + i * 4 + k] && h[i]) ? (double)((long long)(h[128 + i * 4 + k] - h[i])) / 100.0 : 0.0;
+    return n;
 }
 
 // tuning aid: one line per profiled launch of the last call: "<us> <gflop> <description>"

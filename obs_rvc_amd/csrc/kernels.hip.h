@@ -2,6 +2,7 @@
 // templates, which live in igemm.hip.h).  Layout convention and the GEMM formulation: see igemm.hip.h.
 #pragma once
 #include "igemm.hip.h"
+#include "state.hip.h"
 
 namespace rvc {
 
@@ -883,19 +884,7 @@ __global__ __launch_bounds__(256) void gru_multi_kernel(GruMultiP p)
 // ------------------------------------------------------------------------------------
 // per-stream state + per-call parameters
 // ------------------------------------------------------------------------------------
-struct CallParams {
-    float uppower;          // 2^(pitch_shift / 12) with truncating division (rvc.rs:121)
-    uint32_t seed;
-    uint32_t chunk_base;    // chunk counter of stream 0 is chunk[b] (kept per stream on device)
-    int pad_;
-};
-struct StreamState {        // one per stream
-    float cache_pitchf[1024];   // rvc.rs:42
-    uint32_t chunk;
-    uint32_t stream_id;
-    int status;             // 0 ok, 6 = the reference would have panicked (rmvpe.rs:124 out-of-bounds)
-    int pad_;
-};
+// (CallParams / StreamState: state.hip.h)
 
 // RMVPE decode (rmvpe.rs:118-133, 243-248) + pitch shift (rvc.rs:121-122) + pitch cache update and
 // slice (rvc.rs:167-179) + get_f0_post (f0/mod.rs:7-12).  One workgroup per stream.
@@ -1026,25 +1015,7 @@ __global__ void embed_pitch_kernel(float *x, int cs, long long bs, const float *
 }
 
 // Philox4x32-10, the same counter layout as oracle/rvc_oracle.c (ora_philox_normal)
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
-{
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-        uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-}
-__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
-__device__ __forceinline__ void philox_normal4(uint32_t seed, uint32_t stream, uint32_t chunk, uint32_t purpose, uint32_t blk, float z[4])
-{
-    uint32_t c[4] = {blk, 0u, chunk, purpose};
-    philox4x32_10(c, seed, stream);
-    float r0 = sqrtf(-2.0f * logf(u01(c[0]))), a0 = 6.28318530717958647692f * u01(c[1]);
-    float r1 = sqrtf(-2.0f * logf(u01(c[2]))), a1 = 6.28318530717958647692f * u01(c[3]);
-    z[0] = r0 * cosf(a0); z[1] = r0 * sinf(a0); z[2] = r1 * cosf(a1); z[3] = r1 * sinf(a1);
-}
+// (philox4x32_10 / u01 / philox_normal4: state.hip.h)
 
 // z_p = m + exp(logs) * eps * 0.66666 ; stats [B][2I][ld] -> z [B][I][ld]; eps index = c*T + t
 __global__ void prior_sample_kernel(const float *stats, int s_cs, long long s_bs, float *z, int z_cs, long long z_bs, int I, int T,
@@ -1196,10 +1167,13 @@ __global__ __launch_bounds__(1024) void nsf_source_kernel(SrcP p)
 }
 
 // bump the per-stream chunk counters after a call
-__global__ void advance_chunk_kernel(StreamState *st, int B)
+// end of a chunk: the streams' chunk counters, and the tag base of the persistent synthesizer front end (synth_front.h: 64 >= its
+// steps per launch; the base restarts before it could wrap into tag 0)
+__global__ void advance_chunk_kernel(StreamState *st, int B, unsigned *front_epoch)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) st[b].chunk += 1;
+    if (b == 0 && front_epoch) { const unsigned v = *front_epoch; *front_epoch = v > 0xFFFF0000u ? 0u : v + 64u; }
 }
 
 // ------------------------------------------------------------------------------------

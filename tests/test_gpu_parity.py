@@ -581,3 +581,39 @@ def test_every_tile_configuration_computes_the_same_convolution():
     finally:
         os.environ.pop("RVC_FORCE_CFG", None)
         L.rvc_destroy(h)
+
+
+def test_persistent_synth_front_matches_layer_launches():
+    """One stream: text encoder + prior + flows run as ONE persistent launch (csrc/synth_front.hip, tagged-granule hand-offs between
+    workgroups; opt-in through RVC_SYNTH_FRONT=1).  Same chunks through that path and through the per-layer launches: the audio must agree to fp32
+    summation order, both must agree with the oracle, and the persistent path must really be the one that ran."""
+    import ctypes as C
+    from oracle import oracle as O
+    from obs_rvc_amd import _native
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("full")
+    audio = voice_signal(g.sample_frame_16k * 18, seed=5)
+    rings = list(chunk_stream(audio, g.input_buffer_16k_size, g.sample_frame_16k))[-4:]
+    ora = O.OracleRvcInfer(z["data"]); ora.load_contentvec(2); ora.load_f0(1); ora.load_model(z["model"]); ora.set_noise_seed(77, 3)
+    ref = [ora.infer(r, g.sample_frame_16k, 12, g.skip_head, g.model_return_length) for r in rings]
+    outs, info = {}, {}
+    for mode in ("persistent", "layers"):
+        if mode == "layers":
+            os.environ.pop("RVC_SYNTH_FRONT", None)
+        else:
+            os.environ["RVC_SYNTH_FRONT"] = "1"
+        try:
+            eng = RvcInfer(z["data"]); eng.load_contentvec(RvcModelVersion.V2); eng.load_f0(); eng.load_model(z["model"]); eng.set_noise_seed(77, 3)
+            outs[mode] = [eng.infer(r, g.sample_frame_16k, 12, g.skip_head, g.model_return_length) for r in rings]
+            n_ops, pers = C.c_int(0), C.c_int(0)
+            assert _native.lib().rvc_debug_last_plan(eng._h, C.byref(n_ops), C.byref(pers)) == 1
+            info[mode] = (n_ops.value, pers.value)
+            eng.close()
+        finally:
+            os.environ.pop("RVC_SYNTH_FRONT", None)
+    assert info["persistent"][1] == 1 and info["layers"][1] == 0, info
+    assert info["persistent"][0] <= info["layers"][0] - 60, info          # ~70 layer launches became one
+    for i in range(len(rings)):
+        assert rms(outs["persistent"][i] - ref[i]) < PCM_TOL, (i, rms(outs["persistent"][i] - ref[i]))
+        assert rms(outs["layers"][i] - ref[i]) < PCM_TOL
+        assert rms(outs["persistent"][i] - outs["layers"][i]) < 2e-5 * max(rms(ref[i]), 1e-3) + 1e-6, (i, rms(outs["persistent"][i] - outs["layers"][i]))
