@@ -11,8 +11,12 @@ rank runs the same per-GPU work (weak scaling, no per-chunk collective).  The sa
   index100k  BASELINE configs[2]: + 100k x 768 flat-L2 retrieval (k = 4, rate 0.75); with N > 1 the index reaches every rank through
              the engine's own RCCL broadcast (rvc_index_broadcast)
   streams64  BASELINE configs[3] (N = 1) / configs[4] (N > 1: 64 streams per GPU, stream s of the job on rank s mod N, shared index
-             broadcast over RCCL): throughput mode, every stage batched over the streams
-and the host-buffer boundary of the reference (`latency_ms_host_buffer`: rvc_infer with H2D + D2H inside the call).
+             broadcast over RCCL; also emitted as the top-level key `config4`): throughput mode, every stage batched over the streams
+  streams64_index100k (N = 1)  one rank's work of configs[4] on one GPU: 64 streams + the 100k x 768 index
+  streams{2,4,8,16,32}         where the chip saturates (ms / step, frames / s)
+  v1_256     the literal reading of configs[1] ("ContentVec-256"): v1 models, 256-d features from layer 9 (enums.rs:10-23)
+and the host-buffer boundary of the reference (`latency_ms_host_buffer`: rvc_infer with H2D + D2H inside the call = SURVEY 8d's
+latency definition).  `latency_ms` of the headline comes from a soak of >= 1000 synchronised chunks inside the run (p50 / p99 / p99.9).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--index] [--only-headline] [--no-cpu] [--dry-launch]
 
@@ -61,19 +65,29 @@ def parse_args(argv=None):
 
 # ------------------------------------------------------------------------------------------------------------ launcher
 def spawn_ranks(args, argv):
-    """`bench.py --gpus N` without a torchrun environment: one child process per GPU, rank r on device r."""
+    """`bench.py --gpus N` without a torchrun environment: one child process per GPU, rank r on device r.  Every rank's stdout and
+    stderr go to files (gpurun_out/bench_ranks/rank<r>.{out,err}); rank 0's stdout is replayed here (its last line is the JSON line);
+    if a rank fails the run fails with that rank's last lines."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs = []
+    logdir = os.environ.get("RVC_BENCH_LOGDIR") or os.path.join(ROOT, "gpurun_out", "bench_ranks")
+    os.makedirs(logdir, exist_ok=True)
+    procs, files = [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), RVC_BENCH_CHILD="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out = procs[0].communicate()[0].decode()
+        fo = open(os.path.join(logdir, "rank%d.out" % r), "wb"); fe = open(os.path.join(logdir, "rank%d.err" % r), "wb")
+        files += [fo, fe]
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=fo, stderr=fe))
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out)
+    for f in files:
+        f.close()
+    sys.stdout.write(open(os.path.join(logdir, "rank0.out"), "rb").read().decode(errors="replace"))
     sys.stdout.flush()
     if any(rcs):
+        for r, rc in enumerate(rcs):
+            if rc:
+                tail = open(os.path.join(logdir, "rank%d.err" % r), "rb").read().decode(errors="replace").splitlines()[-25:]
+                print("bench.py: rank %d exited with %d; its last lines (%s):\n  %s" % (r, rc, os.path.join(logdir, "rank%d.err" % r), "\n  ".join(tail)), file=sys.stderr)
         raise SystemExit("bench.py: rank exit codes %s" % rcs)
 
 
@@ -195,18 +209,11 @@ def roofline_of(eng, step, S, reps=5):
         k_n += kn; k_ms += kms; k_by += kby
     eng.set_profile(False)
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-    # HBM traffic per launch: PMC counters cannot be collected inside this process -- the figure comes from a committed
-    # `rocprofv3 --pmc FETCH_SIZE` pass of the same command (gfx950 x2 correction applied, see the file's "source" note)
-    tname = "r02_pmc_traffic.json" if S == 1 else "r02_pmc_traffic_%dstreams.json" % S
-    traffic = {}
-    try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", tname)))
-    except Exception:
-        tname = None
+    # HBM traffic per launch: PMC counters cannot be collected inside this process -> null here; the `rocprofv3 --pmc` passes of this
+    # command (gfx950 corrections applied) are committed under profiles/ (r03_pmc_traffic*.json) and summarised in DESIGN.md section 7
     roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 5),
-            "traffic": traffic.get("igemm_all_instantiations", {}).get("hbm_read_bytes_per_launch"),
-            "traffic_source": ("static: profiles/%s (separate rocprofv3 --pmc pass, not measured in this run)" % tname) if tname else None,
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": None,
+            "traffic_note": "not measured in this run (PMC needs its own rocprofv3 pass): profiles/r03_pmc_traffic*.json",
             "kernel": "rvc::igemm2_kernel / igemm32_kernel / igemm_lds_kernel (all instantiations)", "launches_per_step": n_l // reps,
             "avg_launch_us": round(tot_ms * 1e3 / max(n_l, 1), 3), "flops_per_step": tot_fl / reps,
             "sum_kernel_ms": round(tot_ms / reps, 4),
@@ -219,23 +226,24 @@ def roofline_of(eng, step, S, reps=5):
         ach = k_by / (k_ms * 1e-3) / 1e9
         roof["retrieval_scan"] = {"bound": "hbm", "kernel": "rvc::knn_dot_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": k_by / k_n, "avg_launch_us": round(k_ms * 1e3 / k_n, 2),
-                                  "traffic": (traffic.get("knn_dot_kernel", {}).get("hbm_read_bytes_per_launch") if S == 1 else None),
-                                  "traffic_source": ("static: profiles/%s" % tname) if (tname and S == 1) else None}
+                                  "traffic": None}
     return roof
 
 
-def run_config(job, z, g, S, with_index, steps, warmup, graph, index_vecs, want_roofline=True):
-    """One configuration on every rank: S streams per GPU, retrieval on/off.  -> record (rank 0) / None"""
+def run_config(job, z, g, S, with_index, steps, warmup, graph, index_vecs, want_roofline=True, version=2, soak=0):
+    """One configuration on every rank: S streams per GPU, retrieval on/off.  soak > 0: that many more synchronised chunks after the
+    timed region for the latency distribution (p99.9 needs >= 1000 samples).  -> record (rank 0) / None"""
     from obs_rvc_amd import dist as rdist
     from obs_rvc_amd.rvc import RvcInfer
     torch = job.torch
     eng = RvcInfer(z["data"], device=job.local_rank)
-    eng.load_contentvec(2); eng.load_f0(1); eng.load_model(z["model"])
+    eng.load_contentvec(version); eng.load_f0(1); eng.load_model(z["model"])
     eng.set_streams(S)
     # stream s of this rank is stream (s * world + rank) of the job: round-robin sharding (SURVEY.md section 8e)
     stream_ids = [s * job.world + job.rank for s in range(S)]
     eng.set_noise_seed(1234, job.rank * S)
     bcast_ms = None
+    bcast_info = None
     if with_index:
         b0 = time.perf_counter()
         err = None
@@ -246,6 +254,7 @@ def run_config(job, z, g, S, with_index, steps, warmup, graph, index_vecs, want_
         if not job.all_ok(err is None):
             raise RuntimeError("index broadcast failed on at least one rank" + (": " + err if err else ""))
         bcast_ms = round((time.perf_counter() - b0) * 1e3, 2)
+        bcast_info = eng.index_broadcast_info() if job.world > 1 else None
         eng.set_index_rate(0.75)
     eng.set_use_graph(graph)
     n_rings = 8 if S <= 8 else 4
@@ -253,22 +262,32 @@ def run_config(job, z, g, S, with_index, steps, warmup, graph, index_vecs, want_
     d_rings = torch.from_numpy(rings).cuda()
     d_out = torch.empty((S, g.model_return_size), dtype=torch.float32, device="cuda")
     elapsed, lat, step = timed_leg(job, eng, d_rings, d_out, g, steps, warmup)
+    soak_lat = []
+    for i in range(soak):                        # latency distribution: more synchronised chunks behind the timed region
+        t1 = time.perf_counter(); step(i); soak_lat.append(time.perf_counter() - t1)
     lat_all = job.gather(lat)
+    soak_all = job.gather(soak_lat) if soak else []
     per_rank = [FRAMES_PER_CHUNK * steps * S / float(np.sum(l)) for l in lat_all]
     rec = None
     roof = roofline_of(eng, step, S) if (job.rank == 0 and want_roofline) else None
     if job.rank == 0:
-        allat = np.concatenate(lat_all)
+        allat = np.concatenate(lat_all + soak_all)
         value = FRAMES_PER_CHUNK * steps * S * job.world / elapsed
         ms = elapsed / steps * 1e3
         rec = {"frames_per_s": round(value, 2), "ms_per_step": round(ms, 4), "streams_per_gpu": S, "streams_total": S * job.world, "n_gpus": job.world,
                "retrieval": "100k x768 flat-L2 k=4 rate 0.75" if with_index else "off",
-               "latency_ms": {"p50": pct(allat, 50), "p99": pct(allat, 99), "max": round(float(allat.max()) * 1e3, 4)},
+               "latency_ms": {"p50": pct(allat, 50), "p99": pct(allat, 99), "p99.9": pct(allat, 99.9), "max": round(float(allat.max()) * 1e3, 4),
+                              "samples": int(allat.size)},
                "rtf": round(float(np.percentile(allat, 99)) / 0.160, 5),
                "per_rank_frames_per_s": [round(v, 1) for v in per_rank]}
         if with_index:
-            rec["index_broadcast"] = {"via": "rvc_index_broadcast (ncclBroadcast, librccl over xGMI)", "rccl_ranks": job.world, "bytes": 100000 * 768 * 4,
-                                      "ms_incl_comm_init": bcast_ms}
+            if bcast_info:      # what the communicator itself reports (ncclCommCount) and where the load step's time went
+                rec["index_broadcast"] = {"via": "rvc_index_broadcast (ncclBroadcast, librccl over xGMI)", "rccl_ranks": bcast_info["ranks"], "bytes": 100000 * 768 * 4,
+                                          "ms_comm_init": bcast_info["ms_comm_init"], "ms_broadcast": bcast_info["ms_broadcast"],
+                                          "ms_device_repack": bcast_info["ms_repack"], "ms_total_host": bcast_ms}
+            else:
+                rec["index_broadcast"] = {"via": "rvc_load_index (one rank: plain upload, no communicator)", "rccl_ranks": 0, "bytes": 100000 * 768 * 4,
+                                          "ms_total_host": bcast_ms}
         if roof:
             roof["frac_by_wall"] = round(roof["flops_per_step"] / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 5)
             rec["roofline"] = roof
@@ -322,19 +341,21 @@ def chain_leg(eng, S, g):
     F, n_ch = ses.sample_frame_size, 34 if S == 1 else 12
     x48 = np.stack([np.interp(np.arange(F * n_ch) / 48000.0, np.arange(chunk * n_ch) / 16000.0, voice_signal(chunk * n_ch, seed=99 + s)).astype(np.float32)
                     for s in range(S)])
-    ts, panics = [], 0
+    ts, panics, ok = [], 0, []
     for i in range(n_ch):
         xin = x48[:, i * F:(i + 1) * F] if S > 1 else x48[0, i * F:(i + 1) * F]
         h0 = time.perf_counter()
+        good = True
         try:
             ses.process_one_frame(np.ascontiguousarray(xin))
         except RvcInferError as ex:
             if "Panic" not in str(ex):
                 raise
-            panics += 1            # reported after the chunk has run: its time is still a valid sample
-        ts.append(time.perf_counter() - h0)
+            panics += 1; good = False          # counted, and kept out of the median
+        ts.append(time.perf_counter() - h0); ok.append(good)
     del ses
-    return {"ms_per_chunk": round(float(np.median(ts[n_ch // 5:])) * 1e3, 4), "chunks": n_ch, "panic_chunks": panics}
+    kept = [t for t, gd in list(zip(ts, ok))[n_ch // 5:] if gd]
+    return {"ms_per_chunk": round(float(np.median(kept)) * 1e3, 4) if kept else None, "chunks": n_ch, "chunks_in_median": len(kept), "panic_chunks": panics}
 
 
 def cpu_baseline_leg(z, rings, g, with_index, index_vecs):
@@ -392,8 +413,14 @@ def dry_launch(args):
         print(json.dumps({"metric": "dry launch (no GPU work)", "dry_launch": True, "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup,
                           "streams_total": total, "streams_covered": streams == list(range(total)),
                           "per_rank_streams": [[int(v) for v in o[1:]] for o in owned],
-                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "latency_samples": int(sum(len(l) for l in lat_all))}))
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "latency_samples": int(sum(len(l) for l in lat_all)),
+                          # the real run's shape with more than one rank: BASELINE configs[4] as a top-level key
+                          "config4": ({"dry_launch": True, "streams_per_gpu": S, "streams_total": total, "n_gpus": job.world,
+                                       "per_rank_streams": [len(o) - 1 for o in owned]} if job.world > 1 else None)}))
     job.close()
+    if os.environ.get("RVC_BENCH_FAIL_RANK") == str(job.rank):        # test aid: a rank that dies after the collectives
+        print("bench: simulated failure of rank %d (RVC_BENCH_FAIL_RANK)" % job.rank, file=sys.stderr)
+        sys.exit(3)
 
 
 # ------------------------------------------------------------------------------------------------------------ main
@@ -409,8 +436,10 @@ def main(argv=None):
         print("bench: --gpus %d but WORLD_SIZE=%d: running the %d ranks that exist" % (args.gpus, job.world, job.world), file=sys.stderr)
     from common import BASELINE_160MS as g, zoo
     from obs_rvc_amd import weights as W
-    if job.rank == 0:
+    if job.rank == 0:                      # one rank writes the model zoo, the others read it
         z = zoo(args.preset)
+        if not args.only_headline and args.preset == "full" and args.streams == 1 and not args.index:
+            zoo(args.preset, 1)
     job.barrier()
     z = zoo(args.preset)
     graph = bool(args.graph and not args.no_graph)
@@ -419,7 +448,8 @@ def main(argv=None):
 
     # ---- headline: BASELINE configs[1] (or what --streams / --index ask for) on every rank
     S = args.streams
-    head, eng, rings, d_rings = run_config(job, z, g, S, args.index and full, args.steps, args.warmup, graph, index_vecs)
+    soak_n = int(os.environ.get("RVC_BENCH_SOAK", "1000")) if (S == 1 and full and not args.only_headline) else 0
+    head, eng, rings, d_rings = run_config(job, z, g, S, args.index and full, args.steps, args.warmup, graph, index_vecs, soak=soak_n)
     extra = {}
     if job.rank == 0 and not args.only_headline:
         skip = os.environ.get("RVC_BENCH_SKIP", "").split(",")     # debugging aid: leg names to leave out
@@ -471,8 +501,39 @@ def main(argv=None):
                 rec["steps"] = k64
                 rec["config"] = "BASELINE configs[%d]" % (4 if job.world > 1 else 3)
             return rec
+        def sweep(S2):
+            def fn():
+                k = max(10, min(args.steps, 30))
+                rec, e4, _, d4 = run_config(job, z, g, S2, False, k, 3, graph, index_vecs, want_roofline=False)
+                del e4, d4
+                if rec:
+                    rec["steps"] = k
+                return rec
+            return fn
+
+        def streams64_index100k():
+            k64 = max(10, min(args.steps, 20))
+            rec, e5, _, d5 = run_config(job, z, g, 64, True, k64, 3, graph, index_vecs, want_roofline=False)
+            del e5, d5
+            if rec:
+                rec["steps"] = k64
+                rec["config"] = "one rank of BASELINE configs[4] on one GPU: 64 streams + the 100k x 768 index"
+            return rec
+
+        def v1_256():
+            z1 = zoo(args.preset, 1)
+            rec, e6, _, d6 = run_config(job, z1, g, 1, False, args.steps, args.warmup, graph, index_vecs, version=1)
+            del e6, d6
+            if rec:
+                rec["config"] = "BASELINE configs[1] read literally: ContentVec-256 (v1: layer 9 + final_proj, enums.rs:10-23) + RMVPE + v1 NSF-HiFiGAN 48k"
+            return rec
         leg("index100k", index100k)
         leg("streams64", streams64)
+        if job.world == 1:
+            leg("streams64_index100k", streams64_index100k)
+        for S2 in (2, 4, 8, 16, 32):
+            leg("streams%d" % S2, sweep(S2))
+        leg("v1_256", v1_256)
 
     if job.rank == 0:
         out = {
@@ -484,7 +545,11 @@ def main(argv=None):
                        "streams_per_gpu": S, "streams_total": S * job.world, "chunk_ms": 160, "input_samples_16k": g.input_buffer_16k_size,
                        "output_samples": g.model_return_size, "hip_graph": graph,
                        "timed_api": "rvc_infer_device: inputs resident in HBM when the timed region starts, one synchronisation per chunk; the host-buffer boundary (H2D + D2H inside the call) is latency_ms_host_buffer"},
-            "latency_ms": head["latency_ms"], "rtf": head["rtf"], "rccl_ranks": job.world, "per_rank_frames_per_s": head["per_rank_frames_per_s"],
+            "latency_ms": head["latency_ms"], "rtf": head["rtf"],
+            # ranks the engine's RCCL communicator reported (ncclCommCount) in the index broadcast of this run; 0 = no communicator was needed
+            "rccl_ranks": (((sub.get("streams64") or {}).get("index_broadcast") or (sub.get("index100k") or {}).get("index_broadcast") or head.get("index_broadcast") or {}).get("rccl_ranks", 0)),
+            "per_rank_frames_per_s": head["per_rank_frames_per_s"],
+            "value_contract": "value / ms_per_step / latency_ms: rvc_infer_device, inputs resident in HBM when the timed region starts (the bench contract); the reference's host-buffer boundary (SURVEY 8d: request bytes available -> reply bytes complete, H2D + D2H inside the call) is latency_ms_host_buffer, measured in the same run",
             "latency_ms_host_buffer": extra.get("latency_ms_host_buffer"),
             "host_buffer_api_ms_per_chunk": (extra.get("latency_ms_host_buffer") or {}).get("p50"),
             "plugin_chain": extra.get("plugin_chain"),
@@ -494,6 +559,8 @@ def main(argv=None):
         }
         if args.index and head.get("index_broadcast"):
             out["index_broadcast"] = head["index_broadcast"]
+        if job.world > 1 and sub.get("streams64"):
+            out["config4"] = sub["streams64"]        # BASELINE configs[4]: 64 streams per GPU x N GPUs, index broadcast over RCCL
         # librccl prints a version banner through C stdio when its first communicator is created: push it out now so that the
         # JSON line below is the LAST line on stdout
         try:

@@ -54,11 +54,17 @@ extern "C" {
     pub fn rvc_rccl_unique_id(id128: *mut c_void) -> c_int;
     pub fn rvc_index_broadcast(e: *mut RvcEngine, unique_id128: *const c_void, rank: c_int, world: c_int,
                                vectors: *const c_float, n: usize, dim: usize) -> c_int;
+    pub fn rvc_rccl_available() -> c_int;
+    pub fn rvc_index_broadcast_info(e: *mut RvcEngine, ms: *mut f64, ranks: *mut c_int) -> c_int;
 
     // ---- many streams per GPU
     pub fn rvc_set_streams(e: *mut RvcEngine, n_streams: c_int) -> c_int;
     pub fn rvc_infer_batch(e: *mut RvcEngine, input: *const c_float, n: usize, sample_frame_16k_size: usize, pitch_shift: i32,
                            skip_head: u32, return_length: u32, out: *mut c_float, cap_per_stream: usize, out_len: *mut usize) -> c_int;
+    pub fn rvc_infer_batch_v(e: *mut RvcEngine, input: *const c_float, n: usize, sample_frame_16k_size: usize, pitch_shift: *const i32,
+                             skip_head: u32, return_length: u32, out: *mut c_float, cap_per_stream: usize, out_len: *mut usize) -> c_int;
+    pub fn rvc_infer_device_v(e: *mut RvcEngine, d_input: *const c_void, n: usize, sample_frame_16k_size: usize, pitch_shift: *const i32,
+                              skip_head: u32, return_length: u32, d_out: *mut c_void, cap_per_stream: usize, out_len: *mut usize, sync: c_int) -> c_int;
     pub fn rvc_infer_device(e: *mut RvcEngine, d_input: *const c_void, n: usize, sample_frame_16k_size: usize, pitch_shift: i32,
                             skip_head: u32, return_length: u32, d_out: *mut c_void, cap_per_stream: usize, out_len: *mut usize,
                             sync: c_int) -> c_int;
@@ -84,6 +90,7 @@ extern "C" {
     pub fn rvc_session_destroy(s: *mut RvcSession);
     pub fn rvc_session_frame_size(s: *mut RvcSession) -> usize;
     pub fn rvc_session_set_params(s: *mut RvcSession, pitch_shift: i32, rms_mix_rate: c_double);
+    pub fn rvc_session_set_params_stream(s: *mut RvcSession, stream: c_int, pitch_shift: i32, rms_mix_rate: f64) -> c_int;
     pub fn rvc_session_geometry(s: *mut RvcSession, out: *mut i32);
     pub fn rvc_session_process(s: *mut RvcSession, input_sample: *const c_float, n: usize, output: *mut c_float, cap: usize,
                                sola_offset: *mut usize) -> c_int;

@@ -50,6 +50,12 @@ typedef enum {
 
 typedef struct rvc_engine rvc_engine;
 
+/* Process environment: when the library is loaded it plants GPU_MAX_HW_QUEUES=16 unless the variable is already set (the HIP runtime
+ * maps a process's streams onto 4 hardware queues by default; the engine runs 4 streams per chunk, and a second engine or an RCCL
+ * communicator in the same process would share queues with them: +5-20 % per-chunk latency).  The runtime reads
+ * the variable when IT initialises, so load this library before the first HIP call or set the variable yourself; set
+ * RVC_NO_RUNTIME_DEFAULTS=1 to have the library leave the environment alone. */
+
 /* RvcInfer::new.  device = HIP device ordinal (-1: current / LOCAL_RANK default 0). */
 rvc_status rvc_create(const char *data_path, int device, rvc_engine **out);
 void rvc_destroy(rvc_engine *e);
@@ -89,6 +95,14 @@ void rvc_reset_state(rvc_engine *e);     /* zero the 1024-entry pitch cache and 
 #define RVC_RCCL_UNIQUE_ID_BYTES 128
 rvc_status rvc_rccl_unique_id(void *id128);
 rvc_status rvc_index_broadcast(rvc_engine *e, const void *unique_id128, int rank, int world, const float *vectors, size_t n, size_t dim);
+/* RVC_OK when librccl can be loaded in this process (creates no communicator).  Hosts agree on it across ranks BEFORE calling
+ * rvc_index_broadcast, so that a rank without the library cannot leave the others waiting in the communicator set-up.  Inside
+ * rvc_index_broadcast every local check precedes the first collective, and the ranks agree on the header (one all-reduce) before the
+ * payload broadcast: they fail together. */
+rvc_status rvc_rccl_available(void);
+/* the engine's last rvc_index_broadcast: ms[0] communicator set-up, ms[1] header + agreement + payload broadcast, ms[2] device-side
+ * repack of the index (MFMA-fragment order + norms; the matrix never returns to the host); *ranks = ncclCommCount */
+rvc_status rvc_index_broadcast_info(rvc_engine *e, double ms[3], int *ranks);
 
 /* ---- many concurrent streams on one GPU (BASELINE configs 4-5) ---- */
 /* The engine then holds n_streams independent stream states (pitch cache, noise counters) that share weights. */
@@ -100,6 +114,12 @@ rvc_status rvc_infer_batch(rvc_engine *e, const float *input, size_t n, size_t s
  * unless sync != 0).  Used by the throughput bench so that the timed region starts with inputs in HBM. */
 rvc_status rvc_infer_device(rvc_engine *e, const void *d_input, size_t n, size_t sample_frame_16k_size, int32_t pitch_shift,
                             uint32_t skip_head, uint32_t return_length, void *d_out, size_t cap_per_stream, size_t *out_len, int sync);
+/* the same with one pitch shift PER STREAM (pitch_shift[n_streams]): every stream of a batch is a caller of its own with its own
+ * settings, as every stream is its own process in the reference (obs-rvc/src/lib.rs:701-707) */
+rvc_status rvc_infer_batch_v(rvc_engine *e, const float *input, size_t n, size_t sample_frame_16k_size, const int32_t *pitch_shift,
+                             uint32_t skip_head, uint32_t return_length, float *out, size_t cap_per_stream, size_t *out_len);
+rvc_status rvc_infer_device_v(rvc_engine *e, const void *d_input, size_t n, size_t sample_frame_16k_size, const int32_t *pitch_shift,
+                              uint32_t skip_head, uint32_t return_length, void *d_out, size_t cap_per_stream, size_t *out_len, int sync);
 rvc_status rvc_synchronize(rvc_engine *e);
 void rvc_set_use_graph(rvc_engine *e, int on);    /* replay the per-chunk launch sequence from a hipGraph */
 /* Offline throughput mode (no counterpart in the reference, whose protocol is one request at a time): with on != 0, consecutive
@@ -142,7 +162,9 @@ rvc_status rvc_session_create(rvc_engine *e, size_t sample_rate, double sample_l
                               size_t model_output_sample_rate, int32_t pitch_shift, double rms_mix_rate, int skip_inference, rvc_session **out);
 void rvc_session_destroy(rvc_session *s);
 size_t rvc_session_frame_size(rvc_session *s);                 /* sample_frame_size: samples per process call, in and out */
-void rvc_session_set_params(rvc_session *s, int32_t pitch_shift, double rms_mix_rate);
+void rvc_session_set_params(rvc_session *s, int32_t pitch_shift, double rms_mix_rate);      /* every stream */
+/* one stream's pitch shift and RMS mix rate (the plugin's per-instance settings, obs-rvc/src/lib.rs:174-185); the others keep theirs */
+rvc_status rvc_session_set_params_stream(rvc_session *s, int stream, int32_t pitch_shift, double rms_mix_rate);
 void rvc_session_geometry(rvc_session *s, int32_t out[10]);   /* the derived sizes of lib.rs:200-227 (see session.hip.h) */
 rvc_status rvc_session_process(rvc_session *s, const float *input_sample, size_t n, float *output, size_t cap, size_t *sola_offset);
 

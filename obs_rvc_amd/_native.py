@@ -17,13 +17,13 @@ SYMBOLS = [
     "rvc_create", "rvc_destroy", "rvc_load_contentvec", "rvc_load_model", "rvc_load_f0", "rvc_unload_model",
     "rvc_hubert", "rvc_extract_feature", "rvc_pitch", "rvc_infer", "rvc_last_error_message",
     "rvc_load_index", "rvc_load_index_device", "rvc_set_index_rate", "rvc_get_knn", "rvc_set_noise_seed", "rvc_reset_state",
-    "rvc_set_streams", "rvc_infer_batch", "rvc_infer_device", "rvc_synchronize", "rvc_set_use_graph", "rvc_set_pipeline",
+    "rvc_set_streams", "rvc_infer_batch", "rvc_infer_device", "rvc_infer_batch_v", "rvc_infer_device_v", "rvc_synchronize", "rvc_set_use_graph", "rvc_set_pipeline",
     "rvc_last_gpu_ms", "rvc_profile_last", "rvc_set_profile", "rvc_enable_taps", "rvc_get_tap", "rvc_get_pitch_cache",
     "rvc_index_device_ptr", "rvc_device", "rvc_version", "rvc_envelop_mixing", "rvc_sola_step", "rvc_profile_last_knn",
     "rvc_resampler_create", "rvc_resampler_destroy", "rvc_resampler_input_frames_next", "rvc_resampler_output_frames_max",
     "rvc_resampler_reset", "rvc_resampler_process", "rvc_resampler_process_device",
-    "rvc_rccl_unique_id", "rvc_index_broadcast",
-    "rvc_session_create", "rvc_session_destroy", "rvc_session_process", "rvc_session_frame_size", "rvc_session_set_params", "rvc_session_geometry",
+    "rvc_rccl_unique_id", "rvc_index_broadcast", "rvc_rccl_available", "rvc_index_broadcast_info",
+    "rvc_session_create", "rvc_session_destroy", "rvc_session_process", "rvc_session_frame_size", "rvc_session_set_params", "rvc_session_set_params_stream", "rvc_session_geometry",
 ]
 
 
@@ -143,7 +143,10 @@ def lib():
         return _LIB
     if not os.path.exists(SO_PATH):
         raise RuntimeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % SO_PATH)
-    L = C.CDLL(os.environ.get("RVC_LIB_OVERRIDE") or SO_PATH)     # override: A/B timing of an older build (tuning aid)
+    # RVC_LIB_OVERRIDE (A/B timing of an older build) is honoured only together with RVC_TUNING=1: outside the tuning tools nothing but the
+    # in-tree library is ever loaded
+    override = os.environ.get("RVC_LIB_OVERRIDE") if os.environ.get("RVC_TUNING") == "1" else None
+    L = C.CDLL(override or SO_PATH)
     vp, fp, sz, i32, u32 = C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_int32, C.c_uint32
     L.rvc_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     L.rvc_destroy.argtypes = [vp]
@@ -171,6 +174,8 @@ def lib():
     L.rvc_set_streams.argtypes = [vp, C.c_int]
     L.rvc_infer_batch.argtypes = [vp, fp, sz, sz, i32, u32, u32, fp, sz, C.POINTER(sz)]
     L.rvc_infer_device.argtypes = [vp, vp, sz, sz, i32, u32, u32, vp, sz, C.POINTER(sz), C.c_int]
+    L.rvc_infer_batch_v.argtypes = [vp, fp, sz, sz, C.POINTER(i32), u32, u32, fp, sz, C.POINTER(sz)]
+    L.rvc_infer_device_v.argtypes = [vp, vp, sz, sz, C.POINTER(i32), u32, u32, vp, sz, C.POINTER(sz), C.c_int]
     L.rvc_synchronize.argtypes = [vp]
     L.rvc_set_use_graph.argtypes = [vp, C.c_int]
     L.rvc_set_use_graph.restype = None
@@ -204,9 +209,10 @@ def lib():
     L.rvc_resampler_reset.restype = None
     L.rvc_resampler_process.argtypes = [vp, fp, sz, fp, sz, C.POINTER(sz)]
     L.rvc_resampler_process_device.argtypes = [vp, vp, vp, C.c_int]
-    if hasattr(L, "rvc_rccl_unique_id") or not os.environ.get("RVC_LIB_OVERRIDE"):
+    if hasattr(L, "rvc_rccl_unique_id") or not override:
         L.rvc_rccl_unique_id.argtypes = [vp]
         L.rvc_index_broadcast.argtypes = [vp, vp, C.c_int, C.c_int, fp, sz, sz]
+        L.rvc_index_broadcast_info.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.rvc_session_create.argtypes = [vp, sz, C.c_double, C.c_double, C.c_double, sz, i32, C.c_double, C.c_int, C.POINTER(vp)]
     L.rvc_session_destroy.argtypes = [vp]
     L.rvc_session_destroy.restype = None
@@ -215,6 +221,7 @@ def lib():
     L.rvc_session_frame_size.restype = sz
     L.rvc_session_set_params.argtypes = [vp, i32, C.c_double]
     L.rvc_session_set_params.restype = None
+    L.rvc_session_set_params_stream.argtypes = [vp, C.c_int, i32, C.c_double]
     L.rvc_session_geometry.argtypes = [vp, C.POINTER(i32)]
     L.rvc_session_geometry.restype = None
     _LIB = L

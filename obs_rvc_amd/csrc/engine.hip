@@ -25,8 +25,15 @@
 // streams concurrently per chunk; a second engine in the process, or the streams an RCCL communicator leaves behind, then share
 // queues with them and the per-chunk latency rises by 5-20 % (measured: 2.38 -> 2.84 ms for an engine created after a communicator;
 // flat 2.38 ms with 16 queues).  The variable is read when the runtime initialises, so a default is planted when this library is
-// loaded -- it does not override a value the host has set, and a host that has already initialised HIP should set it itself.
-__attribute__((constructor)) static void rvc_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// loaded -- it does not override a value the host has set, and a host that has already initialised HIP should set it itself
+// (the variable then has no effect: rvc_create says so once on stderr).  A host that wants its environment left alone sets
+// RVC_NO_RUNTIME_DEFAULTS=1 (documented in include/rvc_mi355x.h and INTEGRATION.md).
+static bool g_planted_queues = false;
+__attribute__((constructor)) static void rvc_runtime_defaults()
+{
+    if (getenv("RVC_NO_RUNTIME_DEFAULTS")) return;
+    if (!getenv("GPU_MAX_HW_QUEUES")) { setenv("GPU_MAX_HW_QUEUES", "16", 0); g_planted_queues = true; }
+}
 
 namespace rvc {
 
@@ -257,6 +264,7 @@ struct ConvOpts {
     int m_off = 0, m_cnt = -1;   // output-row sub-range of the weight panel
     bool no_bias = false;
     bool glu = false;            // GLU-packed weight rows, gate fused into the epilogue (ModelSY flows)
+    bool final_out = false;      // the chunk's last convolution: writes the caller's device buffer when the call provides one (Plan::cur_out)
     // LayerNorm folded into its neighbours (IgemmP::ln_*): this layer consumes a not-yet-normalised tensor (weights pre-scaled, wsum
     // per output row, optional (mean, rstd) output) / this layer's residual is LayerNorm(stored tensor) with published statistics
     const float *ln_wsum = nullptr; float *ln_stats_out = nullptr; int ln_rows = 0;
@@ -312,6 +320,10 @@ struct Plan {
     unsigned long long *d_stamps = nullptr; std::vector<std::string> stamp_names;
     // chunk pipelining (rvc_set_pipeline): plans alternate between two slots; ev_done marks the end of this plan's previous chunk
     int slot = 0; hipEvent_t ev_done = nullptr; bool ev_done_valid = false;
+    // per-call pointers (eager launches): the kernels that read the input / write the audio take them at launch time, so a device-resident
+    // caller needs no staging copy in front of the chunk and no copy behind it (a captured graph bakes pointers: it keeps d_in / audio)
+    const float *cur_in = nullptr; float *cur_out = nullptr; long long cur_out_bs = 0;
+    bool in_direct_ok = true, out_direct_ok = false;
     unsigned long long *front_stamps = nullptr;
     unsigned *front_epoch = nullptr;      // tag base of the persistent synthesizer front end (synth_front.h): advanced at the end of every chunk
     // graph
@@ -331,7 +343,7 @@ static unsigned long long *g_kprobe = nullptr;   // tuning build (-DRVC_KPROBE):
 static int g_last_waves = 0, g_last_wgs = 0;
 
 // generic: the caller fills geometry (N, NW, strides, koff, phases); this picks the tile + split-K and queues the op
-static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases)
+static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases, bool final_out = false)
 {
     p.probe = g_kprobe;
     // many streams: fold them into the N axis (one launch-wide column index instead of a grid dimension), so that tiles are cut from
@@ -449,7 +461,8 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
                 pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
             }
             hipEvent_t ea = pe ? pe->a : nullptr, eb = pe ? pe->b : nullptr;
-            launch_igemm_tiled(lc, pre, p, grid, lds, s, ea, eb);
+            if (final_out && plp->cur_out) { IgemmP q = p; q.y = plp->cur_out; q.y_bs = plp->cur_out_bs; launch_igemm_tiled(lc, pre, q, grid, lds, s, ea, eb); }
+            else launch_igemm_tiled(lc, pre, p, grid, lds, s, ea, eb);
         });
         return;
     }
@@ -526,7 +539,8 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
             pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
             if (ksplit > 1) HIPCHK(hipEventRecord(pe->a, s));
         }
-        if (lean) launch_igemm2(cfg, wg_ks, pre, lin, p, grid, lds2, s, pe ? pe->a : nullptr, pe ? pe->b : nullptr);
+        if (lean && final_out && plp->cur_out) { IgemmP q = p; q.y = plp->cur_out; q.y_bs = plp->cur_out_bs; launch_igemm2(cfg, wg_ks, pre, lin, q, grid, lds2, s, pe ? pe->a : nullptr, pe ? pe->b : nullptr); }
+        else if (lean) launch_igemm2(cfg, wg_ks, pre, lin, p, grid, lds2, s, pe ? pe->a : nullptr, pe ? pe->b : nullptr);
         else launch_igemm_v1(pre, p, grid, s);
         if (ksplit > 1) hipLaunchKernelGGL(splitk_epilogue_kernel, egrid, dim3(256), 0, s, p);
         if (pe && ksplit > 1) HIPCHK(hipEventRecord(pe->b, s));
@@ -578,7 +592,7 @@ static void add_conv1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int 
         ph[g].bias_off = g * cw.M;
         ph[g].koff_off = 0;
     }
-    queue_igemm(pl, p, x.B, koff, ph);
+    queue_igemm(pl, p, x.B, koff, ph, o.final_out);
 }
 
 // Several stride-1 convs of the same Cin/Cout but different kernel size / dilation as ONE launch (phase j = conv j): the
@@ -1125,6 +1139,8 @@ struct rvc_engine {
     // retrieval index
     float *d_index = nullptr, *d_indexT = nullptr, *d_indexF = nullptr, *d_ynorm = nullptr, *d_nhn = nullptr; size_t index_n = 0, index_dim = 0; bool index_owned = true;
     float index_rate = 0.f;
+    float index_prep_ms = 0.f;                                  // device-side repack + norms of the last index load
+    double bcast_ms[3] = {0, 0, 0}; int bcast_ranks = 0;         // last rvc_index_broadcast: communicator set-up, broadcast, repack (ms); ranks the communicator reports
     // streams
     int n_streams = 1;
     StreamState *d_state = nullptr;
@@ -1138,7 +1154,8 @@ struct rvc_engine {
     // offline throughput mode: consecutive unsynchronised infer_device calls overlap chunk i+1's two front branches with chunk i's
     // synthesizer (two plan slots; the branch streams are ordered by events instead of forking from the main stream)
     bool pipeline = false, pipe_now = false; int pipe_slot = 0; hipEvent_t ev_in = nullptr; const void *pipe_input = nullptr; size_t pipe_input_bytes = 0;
-    float pushed_uppower = -1.f; uint32_t pushed_seed = 0; bool pushed_valid = false;
+    std::vector<float> pushed_up; uint32_t pushed_seed = 0; bool pushed_valid = false;      // what the device holds: per-stream multipliers, seed
+    float *h_up = nullptr; unsigned up_slot = 0;        // pinned ring of 8 blocks of 4096 per-stream multipliers (async strided copies read them later)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
     size_t last_knn_rows = 0;
@@ -1203,6 +1220,7 @@ static void reset_state(rvc_engine *e)
     std::vector<StreamState> st(e->n_streams);
     for (int b = 0; b < e->n_streams; b++) { memset(&st[b], 0, sizeof(StreamState)); st[b].stream_id = e->stream_id0 + (uint32_t)b; }
     HIPCHK(hipMemcpy(e->d_state, st.data(), sizeof(StreamState) * e->n_streams, hipMemcpyHostToDevice));
+    e->pushed_valid = false;       // (the per-stream multipliers live in StreamState)
 }
 
 // CU partition for the two concurrent branches of a chunk at low stream counts: the f0 branch (RMVPE: ~140 short weight-streaming
@@ -1298,24 +1316,29 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
             if (kt == 10 && To <= 8 * 1024 && cpw > 1 && !getenv("RVC_NO_CONV0_MULTI")) {
                 dim3 gridm(m.conv_dim / cpw, B);
                 const int nt1k = (To + 1023) / 1024;
+                Plan *plp = &pl;
                 pl.ops.push_back([=](hipStream_t s) {
-                    if (nt1k <= 4) hipLaunchKernelGGL((conv0_gn_gelu_multi_kernel<4, 10>), gridm, dim3(1024), 0, s, ain, abs_, w0, st, gg, bb, y.p, To, y.ld, y.bs, cpw);
-                    else hipLaunchKernelGGL((conv0_gn_gelu_multi_kernel<8, 10>), gridm, dim3(1024), 0, s, ain, abs_, w0, st, gg, bb, y.p, To, y.ld, y.bs, cpw);
+                    const float *in_ = plp->cur_in ? plp->cur_in : ain;      // a device-resident caller's buffer is read in place
+                    if (nt1k <= 4) hipLaunchKernelGGL((conv0_gn_gelu_multi_kernel<4, 10>), gridm, dim3(1024), 0, s, in_, abs_, w0, st, gg, bb, y.p, To, y.ld, y.bs, cpw);
+                    else hipLaunchKernelGGL((conv0_gn_gelu_multi_kernel<8, 10>), gridm, dim3(1024), 0, s, in_, abs_, w0, st, gg, bb, y.p, To, y.ld, y.bs, cpw);
                 });
                 add_tap(pl, "cv.conv0", y);
                 x = y; T = To;
                 continue;
             }
+            Plan *plp = &pl;
             pl.ops.push_back([=](hipStream_t s) {
-                if (nt <= 8) hipLaunchKernelGGL((conv0_gn_gelu_kernel<8>), grid, dim3(256), 0, s, ain, abs_, w0, kt, st, gg, bb, y.p, To, y.ld, y.bs);
-                else if (nt <= 16) hipLaunchKernelGGL((conv0_gn_gelu_kernel<16>), grid, dim3(256), 0, s, ain, abs_, w0, kt, st, gg, bb, y.p, To, y.ld, y.bs);
-                else hipLaunchKernelGGL((conv0_gn_gelu_kernel<32>), grid, dim3(256), 0, s, ain, abs_, w0, kt, st, gg, bb, y.p, To, y.ld, y.bs);
+                const float *in_ = plp->cur_in ? plp->cur_in : ain;
+                if (nt <= 8) hipLaunchKernelGGL((conv0_gn_gelu_kernel<8>), grid, dim3(256), 0, s, in_, abs_, w0, kt, st, gg, bb, y.p, To, y.ld, y.bs);
+                else if (nt <= 16) hipLaunchKernelGGL((conv0_gn_gelu_kernel<16>), grid, dim3(256), 0, s, in_, abs_, w0, kt, st, gg, bb, y.p, To, y.ld, y.bs);
+                else hipLaunchKernelGGL((conv0_gn_gelu_kernel<32>), grid, dim3(256), 0, s, in_, abs_, w0, kt, st, gg, bb, y.p, To, y.ld, y.bs);
             });
             add_tap(pl, "cv.conv0", y);
             x = y; T = To;
             continue;
         }
         ConvOpts o; o.act = i == 0 ? ACT_NONE : ACT_GELU;
+        if (i == 0) pl.in_direct_ok = false;      // (the generic convolution bakes its input pointer: this plan keeps the staging copy)
         add_conv1d(pl, m.conv[i], x, y, m.conv_s[i], 0, 1, o);
         if (i == 0) {
             dim3 grid(m.conv_dim, B);
@@ -1430,7 +1453,8 @@ static T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k,
         mp.window = e->d_window; mp.twiddle = e->d_twiddle; mp.basis = e->d_basis; mp.band = e->d_band;
         mp.mel = d_mel; mp.img = img.p; mp.img_bs = img.bs; mp.img_ld = img.ld; mp.bn_scale = m.bn_scale; mp.bn_shift = m.bn_shift;
         dim3 grid(Tm, B);
-        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(mel_frontend_kernel, grid, dim3(256), 0, s, mp); });
+        Plan *plp = &pl;
+        pl.ops.push_back([=](hipStream_t s) { MelP m2 = mp; if (plp->cur_in) m2.audio = plp->cur_in; hipLaunchKernelGGL(mel_frontend_kernel, grid, dim3(256), 0, s, m2); });
         add_stamp(pl, "rm.mel0");
         if (pl.with_taps) { T1 t; t.p = d_mel; t.B = B; t.C = 128; t.T = Tm; t.ld = Tm; t.halo = 0; t.bs = 128LL * Tm; add_tap(pl, "rm.mel", t); }
     }
@@ -1794,8 +1818,9 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         xd = xs; c = co; Tc = Tn;
     }
     pl.audio = make_t1(A, B, 1, Tc, 0);
-    { ConvOpts o; o.pre_act = ACT_LRELU; o.pre_slope = 0.01f; o.act = ACT_TANH; o.no_bias = true; add_conv1d(pl, m.dec_post, xd, pl.audio, 1, 3, 1, o); }
+    { ConvOpts o; o.pre_act = ACT_LRELU; o.pre_slope = 0.01f; o.act = ACT_TANH; o.no_bias = true; o.final_out = true; add_conv1d(pl, m.dec_post, xd, pl.audio, 1, 3, 1, o); }
     pl.N = (size_t)Tc;
+    pl.out_direct_ok = pl.audio.ld == Tc && !pl.with_taps;     // (the split-K fallback writes through a second kernel: ksplit > 1 never happens for this 7-tap layer)
     if (pl.audio.ld != Tc) {
         // make the output rows contiguous [B][N] for the device-pointer API
         T1 a2; a2.p = A.floats((size_t)B * Tc); a2.B = B; a2.C = 1; a2.T = Tc; a2.ld = Tc; a2.halo = 0; a2.bs = Tc;
@@ -1807,6 +1832,7 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
 }
 
 // ------------------------------- plan -------------------------------------------------
+static void ensure_index_transposed(rvc_engine *e);
 static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32_t skip_head, uint32_t R, int slot = 0)
 {
     const int B = e->n_streams;
@@ -1894,7 +1920,11 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
             // queries (64 streams x 11 queries: 44 passes, 3.5 ms -> one ~1 ms MFMA-bound launch).  Same approximate distances up to
             // fp32 summation order; the exact re-rank behind it is unchanged.
             const int Q = B * nq, Qpad = (Q + 127) / 128 * 128;
-            const bool gemm_scan = fast && Q >= 128 && e->d_indexT && e->d_nhn && !getenv("RVC_KNN_NO_GEMM");
+            // (the GEMM path addresses its operands with 32-bit byte / element offsets: the knn_dot loop, whose strides are 64-bit, takes
+            // indexes beyond that range)
+            const bool gemm_fits = (size_t)C * e->index_n * sizeof(float) < ((size_t)1 << 31) && (size_t)Qpad * e->index_n < ((size_t)1 << 31);
+            const bool gemm_scan = fast && Q >= 128 && gemm_fits && e->d_nhn && !getenv("RVC_KNN_NO_GEMM");
+            if (gemm_scan || !fast) ensure_index_transposed(e);
             if (fast) {
                 float *d_approx = pl.arena.floats((size_t)(gemm_scan ? Qpad : Q) * e->index_n);
                 if (gemm_scan) {
@@ -1944,6 +1974,7 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
             for (int q0 = 0; q0 < nq; q0 += KNN_MAXQ) {
                 const int qn = std::min(KNN_MAXQ, nq - q0);
                 KnnP kp{}; kp.indexT = e->d_indexT; kp.index = e->d_index; kp.n = (int)e->index_n; kp.dim = C; kp.nblk = nblk;
+                kp.v_stride = e->d_indexT ? 1 : C; kp.d_stride = e->d_indexT ? (long long)e->index_n : 1;
                 // query sub-range: pointers offset so that [B][nq] strides stay those of the full arrays
                 kp.q = d_q + (size_t)q0 * C; kp.nq = qn; kp.cand_d = cand_d + (size_t)q0 * nblk * KNN_K; kp.cand_i = cand_i + (size_t)q0 * nblk * KNN_K;
                 kp.overflow = fast ? d_overflow : nullptr;
@@ -1992,8 +2023,8 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         pl.ops.cur = 0;
         build_synth(e, pl, B, phone, src0, d_pitchf, d_pitch, 2, side_nz ? &nz : nullptr);
         StreamState *st = e->d_state;
-        unsigned *fep = pl.front_epoch;
-        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(advance_chunk_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, B, fep); });
+        unsigned *fep = pl.front_epoch; int *hst = e->h_status;      // (pinned host memory, mapped: the kernel writes the status words where the host reads them)
+        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(advance_chunk_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, B, fep, hst); });
     }
     HIPCHK(hipDeviceSynchronize());
     // bounded plan cache (each geometry owns its activation arena and graph): evict the oldest
@@ -2056,21 +2087,30 @@ static void run_plan(rvc_engine *e, Plan &pl)
 
 static float uppower(int32_t pitch_shift) { return ldexpf(1.0f, pitch_shift / 12); }   // rvc.rs:121, truncating division (Q1)
 
-static void push_call_params(rvc_engine *e, int32_t pitch_shift)
+// Per-call parameters: the seed (CallParams) and one pitch-shift multiplier PER STREAM (StreamState::uppower: every stream of a batch
+// is its own caller with its own settings, obs-rvc/src/lib.rs:701-707).  shifts == nullptr: `pitch_shift` for every stream.
+static void push_call_params(rvc_engine *e, int32_t pitch_shift, const int32_t *shifts = nullptr)
 {
-    const float up = uppower(pitch_shift);
-    // The device block already holds these values (every write to it is ordered on the main stream, and the last one wrote exactly this):
-    // nothing to copy -- a 16-byte H2D copy is a 4-5 us blit kernel in front of both branches of every chunk otherwise.
-    if (e->pushed_valid && e->pushed_uppower == up && e->pushed_seed == e->seed) return;
-    if (e->pipeline) HIPCHK(hipDeviceSynchronize());   // the f0 branch of the next chunk may already be running: drain before the block changes
-    e->pushed_uppower = up; e->pushed_seed = e->seed; e->pushed_valid = true;
+    const int B = e->n_streams;
+    // The device already holds these values (every write to them is ordered on the main stream, and the last one wrote exactly this):
+    // nothing to copy -- a small H2D copy is a 4-5 us blit kernel in front of both branches of every chunk otherwise.
+    bool same = e->pushed_valid && e->pushed_seed == e->seed && (int)e->pushed_up.size() == B;
+    for (int b = 0; b < B && same; b++) same = e->pushed_up[b] == uppower(shifts ? shifts[b] : pitch_shift);
+    if (same) return;
+    if (e->pipeline) HIPCHK(hipDeviceSynchronize());   // the f0 branch of the next chunk may already be running: drain before the values change
     // every call writes its own pinned block: an unsynchronised call's copy may still be pending when the next call arrives
-    // (64 blocks: far more calls than the stream can hold unfinished copies for would have to be queued to wrap around)
-    CallParams *h = e->h_cp + (e->cp_slot++ & 63u);
-    h->uppower = up;
-    h->seed = e->seed;
-    h->chunk_base = 0;
-    HIPCHK(hipMemcpyAsync(e->d_cp, h, sizeof(CallParams), hipMemcpyHostToDevice, e->stream));
+    if (!e->pushed_valid || e->pushed_seed != e->seed) {
+        CallParams *h = e->h_cp + (e->cp_slot++ & 63u);
+        h->uppower = uppower(shifts ? shifts[0] : pitch_shift);
+        h->seed = e->seed;
+        h->chunk_base = 0;
+        HIPCHK(hipMemcpyAsync(e->d_cp, h, sizeof(CallParams), hipMemcpyHostToDevice, e->stream));
+    }
+    float *hu = e->h_up + (size_t)(e->up_slot++ & 7u) * 4096;
+    e->pushed_up.resize(B);
+    for (int b = 0; b < B; b++) hu[b] = e->pushed_up[b] = uppower(shifts ? shifts[b] : pitch_shift);
+    HIPCHK(hipMemcpy2DAsync((char *)e->d_state + offsetof(StreamState, uppower), sizeof(StreamState), hu, sizeof(float), sizeof(float), (size_t)B, hipMemcpyHostToDevice, e->stream));
+    e->pushed_seed = e->seed; e->pushed_valid = true;
     if (e->pipeline) {
         // pipelined calls do not fork the front branches from the main stream: order them behind the parameter copy explicitly
         HIPCHK(hipEventRecord(e->ev_cp, e->stream));
@@ -2153,6 +2193,8 @@ rvc_status rvc_create(const char *data_path, int device, rvc_engine **out)
         HIPCHK(hipHostMalloc((void **)&e->h_cp, 64 * sizeof(CallParams)));
         HIPCHK(hipEventCreateWithFlags(&e->ev_cp, hipEventDisableTiming));
         HIPCHK(hipHostMalloc((void **)&e->h_status, 4096 * sizeof(int)));
+        memset(e->h_status, 0, 4096 * sizeof(int));
+        HIPCHK(hipHostMalloc((void **)&e->h_up, (size_t)8 * 4096 * sizeof(float)));
         init_constants(e);
         alloc_state(e);
     } catch (const std::exception &x) {
@@ -2184,6 +2226,7 @@ void rvc_destroy(rvc_engine *e)
     if (e->d_cp) (void)hipFree(e->d_cp);
     if (e->h_cp) (void)hipHostFree(e->h_cp);
     if (e->h_status) (void)hipHostFree(e->h_status);
+    if (e->h_up) (void)hipHostFree(e->h_up);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -2303,7 +2346,8 @@ rvc_status rvc_pitch(rvc_engine *e, const float *input, size_t n, int32_t pitch_
 }
 
 static rvc_status infer_common(rvc_engine *e, const void *input, bool input_on_device, size_t n, size_t frame16k, int32_t pitch_shift,
-                               uint32_t skip_head, uint32_t return_length, void *out, bool out_on_device, size_t cap, size_t *out_len, bool sync)
+                               uint32_t skip_head, uint32_t return_length, void *out, bool out_on_device, size_t cap, size_t *out_len, bool sync,
+                               const int32_t *shifts = nullptr)
 {
     if (!e->sy) return RVC_MODEL_NOT_LOADED;             // rvc.rs:141-143
     if (!e->cv) return RVC_CONTENTVEC_NOT_LOADED;        // rvc.rs:85-88 (via extract_feature at rvc.rs:151)
@@ -2313,7 +2357,15 @@ static rvc_status infer_common(rvc_engine *e, const void *input, bool input_on_d
     if (out_len) *out_len = pl->N;
     if (cap < pl->N) return RVC_SHAPE;
     const int B = pl->B;
-    push_call_params(e, pitch_shift);
+    push_call_params(e, pitch_shift, shifts);
+    // Device-resident callers: the first kernels read the caller's buffer and the last one writes the caller's buffer (eager launches
+    // take the pointers at launch time) -- no staging copy in front of the chunk, no copy behind it.  A captured graph bakes its
+    // pointers and keeps both copies; pipelined calls keep the input copy (it decouples the caller's buffer from the chunk in flight).
+    static const bool no_direct = getenv("RVC_NO_DIRECT_IO") != nullptr;
+    const bool direct_in = input_on_device && !pipe && !e->use_graph && pl->in_direct_ok && !no_direct;
+    const bool direct_out = out_on_device && !e->use_graph && pl->out_direct_ok && !no_direct;
+    pl->cur_in = direct_in ? (const float *)input : nullptr;
+    pl->cur_out = direct_out ? (float *)out : nullptr; pl->cur_out_bs = (long long)cap;
     if (pipe) {
         // chunk pipelining: the two front branches of this chunk start as soon as THEIR previous work and this plan slot's previous
         // chunk are done -- not after the previous chunk's synthesizer on the main stream
@@ -2322,20 +2374,21 @@ static rvc_status infer_common(rvc_engine *e, const void *input, bool input_on_d
         HIPCHK(hipMemcpyAsync(pl->d_in, input, (size_t)B * n * sizeof(float), hipMemcpyDeviceToDevice, cvs));
         HIPCHK(hipEventRecord(e->ev_in, cvs));
         HIPCHK(hipStreamWaitEvent(rms, e->ev_in, 0));
-    } else {
+    } else if (!direct_in) {
         HIPCHK(hipMemcpyAsync(pl->d_in, input, (size_t)B * n * sizeof(float), input_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
     }
     e->pipe_now = pipe;
     run_plan(e, *pl);
     e->pipe_now = false;
-    HIPCHK(hipMemcpy2DAsync(out, cap * sizeof(float), pl->audio.p, pl->N * sizeof(float), pl->N * sizeof(float), B,
-                            out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream));
+    if (!direct_out)
+        HIPCHK(hipMemcpy2DAsync(out, cap * sizeof(float), pl->audio.p, pl->N * sizeof(float), pl->N * sizeof(float), B,
+                                out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream));
     if (!pl->ev_done) HIPCHK(hipEventCreateWithFlags(&pl->ev_done, hipEventDisableTiming));
     HIPCHK(hipEventRecord(pl->ev_done, e->stream));
     pl->ev_done_valid = true;
     e->last_knn_rows = pl->with_index ? return_length : 0;
+    e->status_queued = true;        // the chunk's last kernel writes the status words into the host-mapped block (advance_chunk_kernel)
     if (!sync) return RVC_OK;
-    queue_status(e);
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1));
     return check_status(e);
@@ -2361,6 +2414,25 @@ rvc_status rvc_infer_device(rvc_engine *e, const void *d_input, size_t n, size_t
                             uint32_t return_length, void *d_out, size_t cap_per_stream, size_t *out_len, int sync)
 {
     return guarded(e, [&]() { return infer_common(e, d_input, true, n, sample_frame_16k_size, pitch_shift, skip_head, return_length, d_out, true, cap_per_stream, out_len, sync != 0); });
+}
+
+// many streams, every stream with its own pitch shift (each stream of a batch is a caller of its own: obs-rvc/src/lib.rs:701-707)
+rvc_status rvc_infer_batch_v(rvc_engine *e, const float *input, size_t n, size_t sample_frame_16k_size, const int32_t *pitch_shift, uint32_t skip_head,
+                             uint32_t return_length, float *out, size_t cap_per_stream, size_t *out_len)
+{
+    return guarded(e, [&]() {
+        if (!pitch_shift) throw ShapeError("infer_batch_v: pitch_shift[n_streams] is required");
+        return infer_common(e, input, false, n, sample_frame_16k_size, 0, skip_head, return_length, out, false, cap_per_stream, out_len, true, pitch_shift);
+    });
+}
+
+rvc_status rvc_infer_device_v(rvc_engine *e, const void *d_input, size_t n, size_t sample_frame_16k_size, const int32_t *pitch_shift, uint32_t skip_head,
+                              uint32_t return_length, void *d_out, size_t cap_per_stream, size_t *out_len, int sync)
+{
+    return guarded(e, [&]() {
+        if (!pitch_shift) throw ShapeError("infer_device_v: pitch_shift[n_streams] is required");
+        return infer_common(e, d_input, true, n, sample_frame_16k_size, 0, skip_head, return_length, d_out, true, cap_per_stream, out_len, sync != 0, pitch_shift);
+    });
 }
 
 rvc_status rvc_synchronize(rvc_engine *e)
@@ -2426,37 +2498,55 @@ void rvc_get_pitch_cache(rvc_engine *e, int stream, float *out1024)
     });
 }
 
-static void build_index_transpose(rvc_engine *e)
+}  // extern "C"
+
+namespace rvc {
+
+// Everything the retrieval kernels need besides the row-major matrix, built ON THE DEVICE from the copy that is already in HBM
+// (uploaded once, or delivered by the RCCL broadcast): the MFMA-fragment-order copy for the one-pass approximate scan and the vector
+// norms.  No host round trip (round 2 copied the 307 MB matrix back to the host, repacked it in a single-threaded loop and uploaded two
+// more copies: seconds per rank behind a 2 ms broadcast).  The transposed copy is NOT built here: see ensure_index_transposed.
+static void build_index_aux(rvc_engine *e)
 {
-    // [n][dim] -> [dim][n] on the host once at load (load path, not the per-chunk path)
-    std::vector<float> h(e->index_n * e->index_dim), t(e->index_n * e->index_dim);
-    HIPCHK(hipMemcpy(h.data(), e->d_index, h.size() * sizeof(float), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < e->index_n; i++) for (size_t d = 0; d < e->index_dim; d++) t[d * e->index_n + i] = h[i * e->index_dim + d];
-    if (e->d_indexT) (void)hipFree(e->d_indexT);
-    HIPCHK(hipMalloc(&e->d_indexT, t.size() * sizeof(float)));
-    HIPCHK(hipMemcpy(e->d_indexT, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
-    // MFMA-fragment-major copy for the one-pass approximate-distance kernel: [tile of 16 vectors][chunk of 16 dims][lane][4]
+    if (e->d_indexT) { (void)hipFree(e->d_indexT); e->d_indexT = nullptr; }
     if (e->d_indexF) { (void)hipFree(e->d_indexF); e->d_indexF = nullptr; }
-    if (e->index_dim % 16 == 0) {
-        const size_t nt = (e->index_n + 15) / 16, nc = e->index_dim / 16;
-        std::vector<float> f(nt * nc * 256, 0.f);
-        for (size_t tl = 0; tl < nt; tl++)
-            for (size_t c = 0; c < nc; c++)
-                for (size_t l = 0; l < 64; l++) {
-                    const size_t v = tl * 16 + (l & 15);
-                    if (v >= e->index_n) continue;
-                    memcpy(&f[((tl * nc + c) * 64 + l) * 4], &h[v * e->index_dim + c * 16 + (l >> 4) * 4], 16);
-                }
-        HIPCHK(hipMalloc(&e->d_indexF, f.size() * sizeof(float)));
-        HIPCHK(hipMemcpy(e->d_indexF, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
     if (e->d_ynorm) (void)hipFree(e->d_ynorm);
     if (e->d_nhn) (void)hipFree(e->d_nhn);
+    e->d_ynorm = e->d_nhn = nullptr;
+    hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    HIPCHK(hipEventRecord(a, e->stream));
+    if (e->index_dim % 16 == 0) {
+        const long long nt = ((long long)e->index_n + 15) / 16, nc = (long long)e->index_dim / 16, total4 = nt * nc * 64;
+        HIPCHK(hipMalloc(&e->d_indexF, (size_t)total4 * 4 * sizeof(float)));
+        hipLaunchKernelGGL(knn_pack_index_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, e->stream, e->d_index, (long long)e->index_n, (int)e->index_dim, e->d_indexF, total4);
+    }
     HIPCHK(hipMalloc(&e->d_ynorm, e->index_n * sizeof(float)));
     HIPCHK(hipMalloc(&e->d_nhn, e->index_n * sizeof(float)));
-    hipLaunchKernelGGL(knn_norms_kernel, dim3((unsigned)((e->index_n + 255) / 256)), dim3(256), 0, 0, e->d_index, (int)e->index_n, (int)e->index_dim, e->d_ynorm, e->d_nhn);
-    HIPCHK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(knn_norms_kernel, dim3((unsigned)((e->index_n + 255) / 256)), dim3(256), 0, e->stream, e->d_index, (int)e->index_n, (int)e->index_dim, e->d_ynorm, e->d_nhn);
+    HIPCHK(hipEventRecord(b, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipGetLastError());
+    float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, a, b));
+    e->index_prep_ms = ms;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
 }
+
+// [dim][n] copy of the index, built by a device transpose the first time a plan needs it: the many-stream distance GEMM (the index is
+// its activation operand) and the forced / non-MFMA exhaustive scan.  A single stream never builds it (HBM then holds the index twice:
+// row-major for the exact re-rank and the blend, fragment order for the scan); its degenerate-data fallback walks the row-major copy.
+static void ensure_index_transposed(rvc_engine *e)
+{
+    if (e->d_indexT || !e->d_index) return;
+    HIPCHK(hipMalloc(&e->d_indexT, e->index_n * e->index_dim * sizeof(float)));
+    dim3 grid((unsigned)((e->index_n + 31) / 32), (unsigned)((e->index_dim + 31) / 32));
+    hipLaunchKernelGGL(knn_transpose_kernel, grid, dim3(256), 0, e->stream, e->d_index, (long long)e->index_n, (int)e->index_dim, e->d_indexT);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipGetLastError());
+}
+
+}  // namespace rvc
+
+extern "C" {
 
 rvc_status rvc_load_index(rvc_engine *e, const float *vectors, size_t n, size_t dim)
 {
@@ -2468,7 +2558,7 @@ rvc_status rvc_load_index(rvc_engine *e, const float *vectors, size_t n, size_t 
         e->index_owned = true;
         HIPCHK(hipMemcpy(e->d_index, vectors, n * dim * sizeof(float), hipMemcpyHostToDevice));
         e->index_n = n; e->index_dim = dim;
-        build_index_transpose(e);
+        build_index_aux(e);
         e->plans.clear(); e->last_plan = nullptr;
         return RVC_OK;
     });
@@ -2484,7 +2574,7 @@ rvc_status rvc_load_index_device(rvc_engine *e, const void *d_vectors, size_t n,
         e->index_owned = true;
         HIPCHK(hipMemcpy(e->d_index, d_vectors, n * dim * sizeof(float), hipMemcpyDeviceToDevice));
         e->index_n = n; e->index_dim = dim;
-        build_index_transpose(e);
+        build_index_aux(e);
         e->plans.clear(); e->last_plan = nullptr;
         return RVC_OK;
     });
@@ -2541,7 +2631,7 @@ rvc_status rvc_envelop_mixing(rvc_engine *e, const float *input, float *output, 
         HIPCHK(hipMemcpyAsync(d_out, output, output_len * 4, hipMemcpyHostToDevice, e->stream));
         hipLaunchKernelGGL(post_rms_kernel, dim3(nf), dim3(256), 0, e->stream, d_in, n, frame, hop, d_r, 0LL, 0LL);
         hipLaunchKernelGGL(post_rms_kernel, dim3(nf), dim3(256), 0, e->stream, d_out, n, frame, hop, d_r + nf, 0LL, 0LL);
-        hipLaunchKernelGGL(post_mix_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, d_out, n, d_r, nf, d_r + nf, nf, (float)(1.0 - mix_rate), 0LL, 0LL);
+        hipLaunchKernelGGL(post_mix_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, d_out, n, d_r, nf, d_r + nf, nf, (float)(1.0 - mix_rate), 0LL, 0LL, (const float *)nullptr);
         HIPCHK(hipMemcpyAsync(output, d_out, output_len * 4, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_r);

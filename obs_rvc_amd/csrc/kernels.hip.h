@@ -907,7 +907,7 @@ __global__ __launch_bounds__(1024) void pitch_post_kernel(PitchP p)
     __shared__ int idxs[1024];
     const int b = blockIdx.x, t = threadIdx.x;
     StreamState *st = p.st + b;
-    const float up = p.cp->uppower;
+    const float up = st->uppower;        // per stream: every stream of a batch is its own caller with its own pitch shift (obs-rvc/src/lib.rs:701-707)
     // Row scan split over bin groups: thread (tt = t % TT, grp = t / TT) scans bins [grp*BPG, ...) of time step tt (loads
     // coalesced along time), then group 0 combines.  Same result as the sequential scan of the zero-padded row (368 wide,
     // "first strictly greater wins", padded[0] = 0): start = first index of the maximum if it is > 0, else 0.
@@ -1169,10 +1169,12 @@ __global__ __launch_bounds__(1024) void nsf_source_kernel(SrcP p)
 // bump the per-stream chunk counters after a call
 // end of a chunk: the streams' chunk counters, and the tag base of the persistent synthesizer front end (synth_front.h: 64 >= its
 // steps per launch; the base restarts before it could wrap into tag 0)
-__global__ void advance_chunk_kernel(StreamState *st, int B, unsigned *front_epoch)
+// ...and the streams' status words, written straight into host-mapped memory (the host reads them after the call's one
+// synchronisation: no copy kernel behind the chunk)
+__global__ void advance_chunk_kernel(StreamState *st, int B, unsigned *front_epoch, int *host_status)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) st[b].chunk += 1;
+    if (b < B) { st[b].chunk += 1; if (host_status) host_status[b] = st[b].status; }
     if (b == 0 && front_epoch) { const unsigned v = *front_epoch; *front_epoch = v > 0xFFFF0000u ? 0u : v + 64u; }
 }
 
@@ -1186,8 +1188,9 @@ __global__ void advance_chunk_kernel(StreamState *st, int B, unsigned *front_epo
 #define KNN_K 4
 #define KNN_MAXQ 16
 struct KnnP {
-    const float *indexT;     // [dim][n]
+    const float *indexT;     // [dim][n] (or nullptr: the scan walks the row-major index, v_stride = dim, d_stride = 1)
     const float *index;      // [n][dim]
+    long long v_stride, d_stride;   // element (vector i, dimension d) of the scanned copy = base[i * v_stride + d * d_stride]
     int n, dim;
     const float *q;          // unique queries, stream stride q_bs
     long long q_bs, cand_bs;
@@ -1212,12 +1215,14 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(KnnP p)
     if (i < p.n) {
         // HBM-streaming loop: 8 independent coalesced loads in flight per thread, then the FMAs in ascending-d order
         // (the distance stays a sequential fmaf chain over d, bit-identical to the reference definition)
-        const float *col = p.indexT + i;
+        // (transposed copy: coalesced across the threads; without one -- a single stream, where this scan only runs for degenerate
+        // data -- every thread streams its own row of the row-major index: same arithmetic, same order, bit-identical distances)
+        const float *col = (p.indexT ? p.indexT : p.index) + (long long)i * p.v_stride;
         int d = 0;
         for (; d + 8 <= p.dim; d += 8) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(col + (long long)(d + u) * p.n);
+            for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(col + (long long)(d + u) * p.d_stride);
 #pragma unroll
             for (int u = 0; u < 8; u++) {
 #pragma unroll
@@ -1225,7 +1230,7 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(KnnP p)
             }
         }
         for (; d < p.dim; d++) {
-            float v = col[(long long)d * p.n];
+            float v = col[(long long)d * p.d_stride];
 #pragma unroll
             for (int j = 0; j < KNN_MAXQ; j++) if (j < p.nq) { float df = smem[j * p.dim + d] - v; acc[j] = fmaf(df, df, acc[j]); }
         }
@@ -1414,6 +1419,34 @@ __global__ void knn_norms_kernel(const float *index, int n, int dim, float *ynor
     for (int d = 0; d < dim; d++) s = fmaf(r[d], r[d], s);
     ynorm[i] = s;
     nhn[i] = -0.5f * s;
+}
+
+// Load-time repack of the index on the device (the matrix arrives in HBM by upload or by the RCCL broadcast and never goes back to
+// the host): [n][dim] -> MFMA-fragment order [tile of 16 vectors][chunk of 16 dims][lane][4] for knn_dot_kernel (vectors past n zero).
+// One thread per float4 of the output; reads are 16-byte pieces of 16 neighbouring rows.
+__global__ __launch_bounds__(256) void knn_pack_index_kernel(const float *index, long long n, int dim, float *indexF, long long total4)
+{
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total4) return;
+    const int nc = dim / 16;
+    const int l = (int)(o & 63);
+    const long long tc = o >> 6, tl = tc / nc;
+    const int c = (int)(tc - tl * nc);
+    const long long v = tl * 16 + (l & 15);
+    f32x4 val = {0.f, 0.f, 0.f, 0.f};
+    if (v < n) val = *reinterpret_cast<const f32x4 *>(index + v * dim + c * 16 + (l >> 4) * 4);
+    *reinterpret_cast<f32x4 *>(indexF + o * 4) = val;
+}
+// [n][dim] -> [dim][n] through a 32 x 33 LDS tile (only plans that need the transposed copy build it: the many-stream distance GEMM
+// and the forced exhaustive scan)
+__global__ __launch_bounds__(256) void knn_transpose_kernel(const float *index, long long n, int dim, float *indexT)
+{
+    __shared__ float tile[32][33];
+    const long long v0 = (long long)blockIdx.x * 32; const int d0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) { const long long v = v0 + r; const int d = d0 + tx; tile[r][tx] = (v < n && d < dim) ? index[v * dim + d] : 0.f; }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) { const int d = d0 + r; const long long v = v0 + tx; if (d < dim && v < n) indexT[(long long)d * n + v] = tile[tx][r]; }
 }
 
 // Many streams: the queries of all streams as the WEIGHT operand of one implicit GEMM against the transposed index (approx[q][i] =
@@ -1661,8 +1694,10 @@ __device__ __forceinline__ float lerp_align_corners_at(const float *in, int n_in
     return in[fl] * (1.0f - fr) + in[ce] * fr;
 }
 // rt_utils.rs:119-132
-__global__ void post_mix_kernel(float *out, int n, const float *r1, int n1, const float *r2, int n2, float mix_power, long long out_bs, long long r_bs)
+// mix_power_v: per-stream exponent (or nullptr: mix_power for every stream); an exponent of 0 leaves the stream untouched (powf(x, 0) = 1)
+__global__ void post_mix_kernel(float *out, int n, const float *r1, int n1, const float *r2, int n2, float mix_power, long long out_bs, long long r_bs, const float *mix_power_v)
 {
+    if (mix_power_v) mix_power = mix_power_v[blockIdx.y];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     out += blockIdx.y * out_bs; r1 += blockIdx.y * r_bs; r2 += blockIdx.y * r_bs;

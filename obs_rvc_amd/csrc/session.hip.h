@@ -39,7 +39,9 @@ struct rvc_session {
     int sample_rate = 0, zc = 0, sample_frame_size = 0, sample_frame_16k = 0, crossfade_frame_size = 0, sola_buffer_frame_size = 0,
         sola_search_frame_size = 0, extra_frame_size = 0, input_buffer_size = 0, input_buffer_16k_size = 0, model_return_length = 0,
         model_return_size = 0, skip_head = 0, model_rate = 0, up_out = 0;
-    int32_t pitch_shift = 0; double rms_mix_rate = 1.0; bool skip_inference = false;
+    bool skip_inference = false;
+    // per-stream settings (every stream is a caller of its own, obs-rvc/src/lib.rs:701-707, 174-185): pitch shift and RMS mix rate
+    std::vector<int32_t> pitch_shift; std::vector<double> rms_mix_rate; float *d_mixpow = nullptr; bool mix_dirty = true;
     rvc_resampler *down = nullptr, *up = nullptr;
     float *d_in[2] = {nullptr, nullptr}, *d_in16[2] = {nullptr, nullptr};
     int par = 0, par16 = 0;
@@ -58,7 +60,7 @@ void rvc_session_destroy(rvc_session *s)
     (void)hipStreamSynchronize(s->e->stream);
     rvc_resampler_destroy(s->down); rvc_resampler_destroy(s->up);
     for (float *p : {s->d_in[0], s->d_in[1], s->d_in16[0], s->d_in16[1], s->d_chunk, s->d_down, s->d_model, s->d_up, s->d_rms, s->d_sola, s->d_frame, s->d_cor}) (void)hipFree(p);
-    (void)hipFree(s->d_off);
+    (void)hipFree(s->d_off); (void)hipFree(s->d_mixpow);
     delete s;
 }
 
@@ -76,7 +78,7 @@ rvc_status rvc_session_create(rvc_engine *e, size_t sample_rate, double sample_l
         // and every device buffer allocated so far are released
         std::unique_ptr<rvc_session, void (*)(rvc_session *)> sp(new rvc_session(), rvc_session_destroy);
         rvc_session *s = sp.get();
-        s->e = e; s->B = e->n_streams; s->h_off.resize(s->B); s->sample_rate = (int)sample_rate; s->pitch_shift = pitch_shift; s->rms_mix_rate = rms_mix_rate; s->skip_inference = skip_inference != 0;
+        s->e = e; s->B = e->n_streams; s->h_off.resize(s->B); s->sample_rate = (int)sample_rate; s->pitch_shift.assign(s->B, pitch_shift); s->rms_mix_rate.assign(s->B, rms_mix_rate); s->skip_inference = skip_inference != 0;
         const int zc = s->zc = (int)sample_rate / 100;                                                             // lib.rs:200
         const int sft = (int)llround(sample_length * (double)sample_rate / zc);                                     // lib.rs:202
         s->sample_frame_size = sft * zc; s->sample_frame_16k = sft * 160;                                           // lib.rs:203-205
@@ -111,6 +113,7 @@ rvc_status rvc_session_create(rvc_engine *e, size_t sample_rate, double sample_l
         dev(&s->d_rms, (size_t)2 * s->n_rms); dev(&s->d_sola, s->sola_buffer_frame_size); dev(&s->d_frame, s->sample_frame_size);
         dev(&s->d_cor, (size_t)s->sola_search_frame_size + 1);
         HIPCHK(hipMalloc(&s->d_off, 4 * NB));
+        HIPCHK(hipMalloc(&s->d_mixpow, 4 * NB));
         HIPCHK(hipStreamSynchronize(e->stream));
         *out = sp.release();
         return RVC_OK;
@@ -118,7 +121,19 @@ rvc_status rvc_session_create(rvc_engine *e, size_t sample_rate, double sample_l
 }
 
 size_t rvc_session_frame_size(rvc_session *s) { return s ? (size_t)s->sample_frame_size : 0; }
-void rvc_session_set_params(rvc_session *s, int32_t pitch_shift, double rms_mix_rate) { if (s) { s->pitch_shift = pitch_shift; s->rms_mix_rate = rms_mix_rate; } }
+void rvc_session_set_params(rvc_session *s, int32_t pitch_shift, double rms_mix_rate)
+{
+    if (!s) return;
+    s->pitch_shift.assign(s->B, pitch_shift); s->rms_mix_rate.assign(s->B, rms_mix_rate); s->mix_dirty = true;
+}
+// one stream's settings (the other streams keep theirs)
+rvc_status rvc_session_set_params_stream(rvc_session *s, int stream, int32_t pitch_shift, double rms_mix_rate)
+{
+    if (!s) return RVC_BACKEND;
+    if (stream < 0 || stream >= s->B) { s->e->err = "session: stream out of range"; return RVC_SHAPE; }
+    s->pitch_shift[stream] = pitch_shift; s->rms_mix_rate[stream] = rms_mix_rate; s->mix_dirty = true;
+    return RVC_OK;
+}
 
 // geometry as the plugin derives it (tests): 0 sample_frame_size, 1 sample_frame_16k, 2 input_buffer_size, 3 input_buffer_16k_size,
 // 4 model_return_length, 5 model_return_size, 6 skip_head, 7 sola_buffer_frame_size, 8 sola_search_frame_size, 9 extra_frame_size
@@ -161,8 +176,8 @@ rvc_status rvc_session_process(rvc_session *s, const float *input_sample, size_t
                                     (size_t)s->input_buffer_16k_size * 4, (size_t)s->model_return_size * 4, B, hipMemcpyDeviceToDevice, st));
         } else {
             size_t got = 0;
-            rvc_status rc = infer_common(e, ring16, true, (size_t)s->input_buffer_16k_size, (size_t)s->sample_frame_16k, s->pitch_shift, (uint32_t)s->skip_head,
-                                         (uint32_t)s->model_return_length, s->d_model, true, (size_t)s->model_return_size, &got, false);
+            rvc_status rc = infer_common(e, ring16, true, (size_t)s->input_buffer_16k_size, (size_t)s->sample_frame_16k, 0, (uint32_t)s->skip_head,
+                                         (uint32_t)s->model_return_length, s->d_model, true, (size_t)s->model_return_size, &got, false, s->pitch_shift.data());
             if (rc != RVC_OK) return rc;
             if (got != (size_t)s->model_return_size) throw ShapeError("session: the loaded synthesizer's output rate does not match model_output_sample_rate");
         }
@@ -170,11 +185,19 @@ rvc_status rvc_session_process(rvc_session *s, const float *input_sample, size_t
         resampler_launch(s->up, s->d_model, s->d_up, s->model_return_size, s->up_out);
         // lib.rs:758-765
         const long long up_bs = s->up_out;
-        if (s->rms_mix_rate < 1.0) {
+        bool any_mix = false;
+        for (int b = 0; b < B; b++) any_mix = any_mix || s->rms_mix_rate[b] < 1.0;
+        if (any_mix) {
+            if (s->mix_dirty) {      // exponent 1 - rate per stream; a stream at rate >= 1 gets 0: powf(x, 0) = 1 leaves it untouched (lib.rs:758)
+                std::vector<float> mp(B);
+                for (int b = 0; b < B; b++) mp[b] = s->rms_mix_rate[b] < 1.0 ? (float)(1.0 - s->rms_mix_rate[b]) : 0.f;
+                HIPCHK(hipMemcpy(s->d_mixpow, mp.data(), 4 * (size_t)B, hipMemcpyHostToDevice));
+                s->mix_dirty = false;
+            }
             const int nn = s->up_out, frame = 4 * s->zc, hop = s->zc, nf = s->n_rms;
             hipLaunchKernelGGL(post_rms_kernel, dim3(nf, B), dim3(256), 0, st, ring + s->extra_frame_size, nn, frame, hop, s->d_rms, (long long)s->input_buffer_size, 2LL * nf);
             hipLaunchKernelGGL(post_rms_kernel, dim3(nf, B), dim3(256), 0, st, s->d_up, nn, frame, hop, s->d_rms + nf, up_bs, 2LL * nf);
-            hipLaunchKernelGGL(post_mix_kernel, dim3((nn + 255) / 256, B), dim3(256), 0, st, s->d_up, nn, s->d_rms, nf, s->d_rms + nf, nf, (float)(1.0 - s->rms_mix_rate), up_bs, 2LL * nf);
+            hipLaunchKernelGGL(post_mix_kernel, dim3((nn + 255) / 256, B), dim3(256), 0, st, s->d_up, nn, s->d_rms, nf, s->d_rms + nf, nf, 0.f, up_bs, 2LL * nf, s->d_mixpow);
         }
         // lib.rs:768-794
         const long long cor_bs = s->sola_search_frame_size + 1;
@@ -184,7 +207,6 @@ rvc_status rvc_session_process(rvc_session *s, const float *input_sample, size_t
                            s->sample_frame_size, s->d_frame, s->d_off, s->d_cor, up_bs, (long long)s->sola_buffer_frame_size, (long long)s->sample_frame_size, cor_bs);
         HIPCHK(hipMemcpy2DAsync(output, cap * 4, s->d_frame, (size_t)s->sample_frame_size * 4, (size_t)s->sample_frame_size * 4, B, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(s->h_off.data(), s->d_off, 4 * (size_t)B, hipMemcpyDeviceToHost, st));
-        if (!s->skip_inference) queue_status(e);
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
         if (sola_offset) for (int b = 0; b < B; b++) sola_offset[b] = (size_t)s->h_off[b];

@@ -10,7 +10,7 @@ namespace rvc {
 // per-stream state + per-call parameters
 // ------------------------------------------------------------------------------------
 struct CallParams {
-    float uppower;          // 2^(pitch_shift / 12) with truncating division (rvc.rs:121)
+    float uppower;          // (round 2: one multiplier per call; now per stream, StreamState::uppower -- kept for layout)
     uint32_t seed;
     uint32_t chunk_base;    // chunk counter of stream 0 is chunk[b] (kept per stream on device)
     int pad_;
@@ -19,8 +19,8 @@ struct StreamState {        // one per stream
     float cache_pitchf[1024];   // rvc.rs:42
     uint32_t chunk;
     uint32_t stream_id;
-    int status;             // 0 ok, 6 = the reference would have panicked (rmvpe.rs:124 out-of-bounds)
-    int pad_;
+    int status;             // 0 ok, 6 = the reference would have panicked (rmvpe.rs:124 out-of-bounds), 7 = a hand-off timed out
+    float uppower;          // this stream's 2^(pitch_shift / 12), truncating division (rvc.rs:121): every stream is its own caller
 };
 
 // Philox4x32-10, the same counter layout as oracle/rvc_oracle.c (ora_philox_normal)

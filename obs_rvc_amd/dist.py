@@ -36,20 +36,47 @@ def broadcast_index(vecs: Optional[np.ndarray], n: int, dim: int, rank: int, wor
     return t
 
 
+def _all_agree(ok: bool, world: int) -> bool:
+    """True only if every rank reports success (one tiny all-reduce on the default process group)."""
+    if world == 1:
+        return bool(ok)
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
+
+
 def exchange_unique_id(eng, rank: int, world: int) -> bytes:
-    """Rank 0 asks the engine (librccl) for a unique id; every rank returns the same 128 bytes."""
-    box = [eng.rccl_unique_id() if rank == 0 else None]
+    """Rank 0 asks the engine (librccl) for a unique id; every rank returns the same 128 bytes.  A failure on rank 0 still travels
+    through the object broadcast (as None), so that every rank raises in step instead of waiting for an id that never comes."""
+    box = [None]
+    err = None
+    if rank == 0:
+        try:
+            box[0] = eng.rccl_unique_id()
+        except Exception as ex:                       # librccl refused: tell the others
+            err = ex
     if world > 1:
         import torch.distributed as dist
         dist.broadcast_object_list(box, src=0)
+    if box[0] is None:
+        raise RuntimeError("rank 0 could not create an RCCL unique id" + (": %s" % err if err else ""))
     return box[0]
 
 
 def load_shared_index(eng, vecs: Optional[np.ndarray], n: int, dim: int, rank: int, world: int) -> None:
-    """Every rank ends up with the same HBM-resident index: rank 0 uploads it once and the engine broadcasts it over RCCL / xGMI
-    (with world == 1 the call still goes through RCCL, a one-rank communicator)."""
-    uid = exchange_unique_id(eng, rank, world)
-    eng.index_broadcast(uid, rank, world, vecs if rank == 0 else None)
+    """Every rank ends up with the same HBM-resident index.  One rank: a plain upload (no RCCL, no librccl needed).  More: rank 0
+    uploads it once and the engine broadcasts it over RCCL / xGMI (rvc_index_broadcast); the ranks first agree that all of them can
+    load librccl, so that none waits in the communicator set-up for a peer that never joins."""
+    if world == 1:
+        eng.load_index(vecs)
+    else:
+        if not _all_agree(eng.rccl_available(), world):
+            raise RuntimeError("librccl is not loadable on every rank")
+        uid = exchange_unique_id(eng, rank, world)
+        eng.index_broadcast(uid, rank, world, vecs if rank == 0 else None)
     p, nbytes = eng.index_device_ptr()
     if nbytes != n * dim * 4:
-        raise RuntimeError("index broadcast delivered %d bytes, expected %d" % (nbytes, n * dim * 4))
+        raise RuntimeError("index load delivered %d bytes, expected %d" % (nbytes, n * dim * 4))

@@ -126,6 +126,17 @@ class RvcInfer:
         else:
             self._chk(self._L.rvc_index_broadcast(self._h, unique_id, int(rank), int(world), None, 0, 0))
 
+    def rccl_available(self) -> bool:
+        """rvc_rccl_available: can this process load librccl?  (no communicator is created)"""
+        return int(self._L.rvc_rccl_available()) == 0
+
+    def index_broadcast_info(self):
+        """rvc_index_broadcast_info -> {ms_comm_init, ms_broadcast, ms_repack, ranks} of this engine's last broadcast"""
+        ms = (C.c_double * 3)()
+        ranks = C.c_int(0)
+        self._chk(self._L.rvc_index_broadcast_info(self._h, ms, C.byref(ranks)))
+        return {"ms_comm_init": round(ms[0], 3), "ms_broadcast": round(ms[1], 3), "ms_repack": round(ms[2], 3), "ranks": int(ranks.value)}
+
     def set_index_rate(self, rate: float):
         self._L.rvc_set_index_rate(self._h, float(rate))
 
@@ -146,15 +157,22 @@ class RvcInfer:
         self._chk(self._L.rvc_set_streams(self._h, int(n)))
         self.n_streams = int(n)
 
-    def infer_batch(self, inputs, sample_frame_16k_size: int, pitch_shift: int, skip_head: int, return_length: int):
-        """inputs (n_streams, n) -> (n_streams, N)."""
+    def infer_batch(self, inputs, sample_frame_16k_size: int, pitch_shift, skip_head: int, return_length: int):
+        """inputs (n_streams, n) -> (n_streams, N).  pitch_shift: one int for every stream, or a sequence of n_streams ints (every
+        stream of a batch is a caller of its own: rvc_infer_batch_v)."""
         x, xp = _f32(inputs)
         assert x.ndim == 2 and x.shape[0] == self.n_streams
         n = C.c_size_t()
         cap = int(return_length) * 1024 + 16
         out = np.empty((self.n_streams, cap), np.float32)
-        self._chk(self._L.rvc_infer_batch(self._h, xp, x.shape[1], int(sample_frame_16k_size), int(pitch_shift), int(skip_head),
-                                          int(return_length), out.ctypes.data_as(_FP), cap, C.byref(n)))
+        if np.ndim(pitch_shift) == 0:
+            self._chk(self._L.rvc_infer_batch(self._h, xp, x.shape[1], int(sample_frame_16k_size), int(pitch_shift), int(skip_head),
+                                              int(return_length), out.ctypes.data_as(_FP), cap, C.byref(n)))
+        else:
+            sh = np.ascontiguousarray(pitch_shift, dtype=np.int32)
+            assert sh.shape == (self.n_streams,)
+            self._chk(self._L.rvc_infer_batch_v(self._h, xp, x.shape[1], int(sample_frame_16k_size), sh.ctypes.data_as(C.POINTER(C.c_int32)), int(skip_head),
+                                                int(return_length), out.ctypes.data_as(_FP), cap, C.byref(n)))
         return out[:, : n.value].copy()
 
     def infer_device(self, d_in_ptr: int, n: int, sample_frame_16k_size: int, pitch_shift: int, skip_head: int, return_length: int,

@@ -99,8 +99,12 @@ class NativeStreamingSession:
         if h and getattr(self._engine, "_h", None):
             self._L.rvc_session_destroy(h)
 
-    def set_params(self, pitch_shift: int, rms_mix_rate: float) -> None:
-        self._L.rvc_session_set_params(self._h, pitch_shift, rms_mix_rate)
+    def set_params(self, pitch_shift: int, rms_mix_rate: float, stream: int = None) -> None:
+        """Settings of every stream, or (stream given) of one stream only (rvc_session_set_params_stream)."""
+        if stream is None:
+            self._L.rvc_session_set_params(self._h, pitch_shift, rms_mix_rate)
+        elif int(self._L.rvc_session_set_params_stream(self._h, int(stream), int(pitch_shift), float(rms_mix_rate))) != 0:
+            raise ValueError("stream out of range")
 
     def process_one_frame(self, input_sample: np.ndarray) -> np.ndarray:
         """One chunk of one stream (shape (sample_frame_size,)) or of every stream of the engine ((streams, sample_frame_size))."""

@@ -158,3 +158,46 @@ def test_rust_ffi_matches_header():
                 "pub fn pitch(&mut self, input: ArrayView1<f32>, pitch_shift: i32, sample_frame_16k_size: usize) -> Result<Array1<f32>, RvcInferError>",
                 "pub fn infer("):
         assert sig in shim, sig
+
+
+def _rust_pub_fns(text):
+    """{name: (normalised argument list, normalised return type)} of the `pub fn`s of a Rust source"""
+    import re
+    out = {}
+    for m in re.finditer(r"pub fn (\w+)\s*\((.*?)\)\s*(?:->\s*(.*?))?\s*\{", text, flags=re.S):
+        norm = lambda t: re.sub(r"\s+", " ", (t or "").replace("ndarray::", "")).strip().rstrip(",").strip()
+        args = [norm(a) for a in re.split(r",(?![^<>]*>)", m.group(2)) if norm(a)]
+        out.setdefault(m.group(1), (args, norm(m.group(3))))
+    return out
+
+
+def test_rust_shim_signatures_match_the_reference():
+    # bindings/rust/rvc/src/rvc.rs must keep the reference's public surface (rvc/src/rvc.rs:30-220): same method names, argument names
+    # and types, return types -- modulo ort::Error -> BackendError (the one type of the API that named ONNX Runtime).  The reference
+    # file is read where it lies (build container only); nothing of it is copied into the repo.
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref_path = "/root/reference/rvc/src/rvc.rs"
+    if not os.path.exists(ref_path):
+        pytest.skip("reference sources not present on this machine")
+    ref = _rust_pub_fns(open(ref_path).read())
+    shim = _rust_pub_fns(open(os.path.join(root, "bindings", "rust", "rvc", "src", "rvc.rs")).read())
+    nine = ["new", "load_contentvec", "load_model", "load_f0", "unload_model", "hubert", "extract_feature", "pitch", "infer"]
+    assert [n for n in nine if n in ref] == nine, sorted(ref)
+    for name in nine:
+        assert name in shim, name
+        rargs, rret = ref[name]
+        sargs, sret = shim[name]
+        assert sargs == rargs, (name, sargs, rargs)
+        assert sret == rret.replace("ort::Error", "BackendError"), (name, sret, rret)
+
+
+def test_rust_build_scripts_carry_the_library_path():
+    # the library crate must not rely on rustc-link-arg (it does not reach dependent binaries) nor on a relative default path
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    b = open(os.path.join(root, "bindings", "rust", "rvc", "build.rs")).read()
+    code = "\n".join(ln for ln in b.splitlines() if not ln.lstrip().startswith("//"))
+    assert "RVC_MI355X_LIB_DIR" in code and "cargo:libdir=" in code and "rustc-link-arg" not in code and "CARGO_MANIFEST_DIR" not in code
+    assert 'links = "rvc_mi355x"' in open(os.path.join(root, "bindings", "rust", "rvc", "Cargo.toml")).read()
+    r = open(os.path.join(root, "bindings", "rust", "rvc-rpc", "build.rs")).read()
+    assert "DEP_RVC_MI355X_LIBDIR" in r and "cargo:rustc-link-arg-bins=-Wl,-rpath," in r
+    assert '+build = "build.rs"' in open(os.path.join(root, "bindings", "rust", "rvc-rpc", "main.rs.patch")).read()

@@ -62,6 +62,26 @@ def test_bench_launcher_spawns_ranks_dry():
     j = _last_json(r.stdout.decode())
     assert j["dry_launch"] is True and j["n_gpus"] == 2 and j["streams_total"] == 128 and j["streams_covered"] is True
     assert j["per_rank_streams"][0][:3] == [0, 2, 4] and j["per_rank_streams"][1][:3] == [1, 3, 5] and j["latency_samples"] == 8
+    # more than one rank: BASELINE configs[4] is also a top-level key of the line (the driver's parser cannot miss it)
+    assert j["config4"]["n_gpus"] == 2 and j["config4"]["streams_total"] == 128 and j["config4"]["per_rank_streams"] == [64, 64]
+
+
+def test_bench_launcher_keeps_rank_logs_and_reports_the_failing_rank(tmp_path):
+    # every rank's stdout / stderr go to files; a rank that fails takes the run down with ITS last lines (round 2 sent the children's
+    # output to /dev/null: a failing rank 5 of 8 would have been a bare exit code)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["RVC_BENCH_LOGDIR"] = str(tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "2"], env=env, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    for rk in (0, 1):
+        assert (tmp_path / ("rank%d.out" % rk)).exists() and (tmp_path / ("rank%d.err" % rk)).exists()
+    assert _last_json((tmp_path / "rank0.out").read_text())["n_gpus"] == 2
+    env["RVC_BENCH_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "2"], env=env, capture_output=True, timeout=300)
+    assert r.returncode != 0
+    err = r.stderr.decode()
+    assert "rank 1 exited with 3" in err and "simulated failure of rank 1" in err and "rank exit codes [0, 3]" in err, err
+    assert _last_json(r.stdout.decode())["n_gpus"] == 2          # rank 0's line is still replayed
 
 
 def test_bench_under_torchrun_dry():

@@ -54,6 +54,27 @@ def test_64_full_size_streams_throughput_mode():
     assert np.allclose(cache5, o5.pitch_cache(), rtol=1e-5, atol=1e-3)       # per-stream state (stream 5's pitch cache) after two chunks
 
 
+def test_every_stream_has_its_own_pitch_shift():
+    # every stream of a batch is a caller of its own (one process per stream in the reference, obs-rvc/src/lib.rs:701-707): five streams
+    # with the shifts {12, 0, -12, 7, 13} (Q1: truncating division by 12) through rvc_infer_batch_v against five oracles, three chunks,
+    # the shifts changing between chunks; then one shift for all through the scalar entry point on the same engine
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("tiny")
+    S = 5
+    shifts = [np.array([12, 0, -12, 7, 13], np.int32), np.array([12, 0, -12, 7, 13], np.int32), np.array([-24, 24, 5, 12, 0], np.int32)]
+    eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"]); eng.set_streams(S); eng.set_noise_seed(21, 40)
+    oras = [_oracle(z, 21, 40 + s) for s in range(S)]
+    for c in range(4):
+        xin = np.stack([voice_signal(g.input_buffer_16k_size, seed=500 + 10 * c + s) for s in range(S)])
+        sh = shifts[c] if c < 3 else np.full(S, 7, np.int32)
+        ye = eng.infer_batch(xin, g.sample_frame_16k, sh if c < 3 else 7, g.skip_head, g.model_return_length)
+        for s in range(S):
+            yo = oras[s].infer(xin[s], g.sample_frame_16k, int(sh[s]), g.skip_head, g.model_return_length)
+            assert rms(ye[s] - yo) < PCM_TOL, (c, s, rms(ye[s] - yo))
+    for s in range(S):
+        assert np.allclose(eng.pitch_cache(s), oras[s].pitch_cache(), rtol=1e-5, atol=1e-3), s
+
+
 def test_many_stream_first_layer_matches_the_one_channel_kernel(monkeypatch):
     # throughput mode takes other kernels than one stream does (16 channels of the first ContentVec layer per workgroup with the input
     # samples held in registers, streams folded into N, the 32x32x2 GEMM).  The first layer against the one-channel-per-workgroup kernel
@@ -123,7 +144,10 @@ def test_index_broadcast_through_rccl_one_rank():
     b = RvcInfer(z["data"]); b.load_contentvec(2); b.load_f0(); b.load_model(z["model"]); b.set_noise_seed(3, 0)
     uid = b.rccl_unique_id()
     assert len(uid) == 128 and any(uid)
-    rdist.load_shared_index(b, vecs, 3000, dim, 0, 1)
+    assert b.rccl_available()
+    b.index_broadcast(uid, 0, 1, vecs)
+    info = b.index_broadcast_info()
+    assert info["ranks"] == 1 and info["ms_comm_init"] > 0 and info["ms_broadcast"] > 0 and 0 < info["ms_repack"] < 5.0, info
     b.set_index_rate(0.75)
     yb = b.infer(x, 2560, 12, 200, 21); ib, db = b.knn()
     assert np.array_equal(ia, ib) and np.array_equal(da, db) and np.array_equal(ya, yb)
@@ -136,6 +160,28 @@ def test_index_broadcast_through_rccl_one_rank():
         c.index_broadcast(c.rccl_unique_id(), 0, 1, None)          # rank 0 with nothing to send
     with pytest.raises(RvcInferError):
         c.index_broadcast(uid, 3, 2, None)                         # rank outside the world
+    # one rank through the host-side helper: a plain upload, no communicator (librccl is not needed for single-GPU use)
+    d = RvcInfer(z["data"]); d.load_contentvec(2); d.load_f0(); d.load_model(z["model"]); d.set_noise_seed(3, 0)
+    rdist.load_shared_index(d, vecs, 3000, dim, 0, 1)
+    d.set_index_rate(0.75)
+    yd = d.infer(x, 2560, 12, 200, 21); idd, ddd = d.knn()
+    assert np.array_equal(ia, idd) and np.array_equal(da, ddd) and np.array_equal(ya, yd)
+
+
+def test_index_setup_behind_the_broadcast_stays_on_the_device():
+    # BASELINE configs[4]'s load step at full size on one rank: 100k x 768 through rvc_index_broadcast.  What follows the broadcast on every
+    # rank -- the MFMA-fragment-order copy and the norms -- is built by device kernels from the matrix already in HBM: a few
+    # milliseconds (round 2: a D2H copy, a single-threaded host repack and two more uploads, seconds per rank), and no transposed copy
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("tiny")
+    vecs = W.make_index()
+    assert vecs.shape == (100000, 768)
+    e = RvcInfer(z["data"])
+    e.index_broadcast(e.rccl_unique_id(), 0, 1, vecs)
+    info = e.index_broadcast_info()
+    assert info["ranks"] == 1 and info["ms_repack"] < 5.0, info
+    p, nbytes = e.index_device_ptr()
+    assert nbytes == vecs.nbytes
 
 
 def test_bench_line_single_rank_smoke():

@@ -225,6 +225,41 @@ def test_native_session_batches_streams():
 
 
 @pytest.mark.gpu
+def test_native_session_per_stream_settings():
+    # rvc_session_set_params_stream: three streams of one batched session with their own pitch shift and RMS mix rate (one of them 1.0 =
+    # no envelope mixing) must equal three single-stream sessions with those settings; settings changed mid-stream
+    from obs_rvc_amd.rvc import RvcInfer
+    from obs_rvc_amd.streaming import NativeStreamingSession
+    z = zoo("tiny")
+
+    def engine(streams, sid0):
+        e = RvcInfer(z["data"]); e.load_contentvec(2); e.load_f0(); e.load_model(z["model"]); e.set_streams(streams); e.set_noise_seed(3, sid0)
+        return e
+    S = 3
+    params = [(12, 0.6), (0, 1.0), (-12, 0.25)]
+    eb = engine(S, 0)
+    batched = NativeStreamingSession(eb, 48000, 0.16, 0.07, 2.0, 4800, 12, 0.6)
+    for sidx, (ps, mix) in enumerate(params):
+        batched.set_params(ps, mix, stream=sidx)
+    singles = []
+    for sidx, (ps, mix) in enumerate(params):
+        e1 = engine(1, sidx)
+        singles.append((e1, NativeStreamingSession(e1, 48000, 0.16, 0.07, 2.0, 4800, ps, mix)))
+    F = batched.sample_frame_size
+    audio = [np.interp(np.arange(F * 8) / 48000.0, np.arange(2560 * 8) / 16000.0, voice_signal(2560 * 8, seed=60 + sidx)).astype(np.float32) for sidx in range(S)]
+    for c in range(8):
+        if c == 5:                                    # stream 1 changes its settings mid-stream, the others keep theirs
+            batched.set_params(7, 0.5, stream=1); singles[1][1].set_params(7, 0.5)
+        x = np.stack([a[c * F:(c + 1) * F] for a in audio])
+        yb = batched.process_one_frame(x)
+        for sidx in range(S):
+            y1 = singles[sidx][1].process_one_frame(x[sidx])
+            assert np.abs(yb[sidx] - y1).max() < 2e-5, (c, sidx, float(np.abs(yb[sidx] - y1).max()))
+            assert batched.last_sola_offsets[sidx] == singles[sidx][1].last_sola_offset
+    with pytest.raises(ValueError):
+        batched.set_params(0, 1.0, stream=3)
+
+
 def test_native_session_at_the_plugin_maximum_settings():
     # 1.5 s chunks: the 72 960-sample downsampler chunk no longer fits the LDS-resident polyphase row (global-memory row fallback);
     # native session vs the host-side state machine over a second engine (tight), and vs the all-CPU chain while the SOLA offsets
