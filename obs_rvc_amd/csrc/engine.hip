@@ -409,7 +409,9 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     }
     // throughput mode (many streams): workgroup-tiled kernel with the activation tile shared through LDS
     int lds_cfg = -1;
-    const bool ln_fold = p.ln_wsum || p.ln_stats_in;      // folded LayerNorm lives in the register-direct kernel's K-split epilogue
+    bool phase_epi = false;                               // per-phase activation / output tensor: igemm2 only
+    for (const PhaseD &q : phv) phase_epi = phase_epi || q.act_p1 != 0 || q.y_off != 0;
+    const bool ln_fold = p.ln_wsum || p.ln_stats_in || phase_epi;      // folded LayerNorm lives in the register-direct kernel's K-split epilogue
     if (!ln_fold && !getenv("RVC_NO_LDS_GEMM") && nchunks >= 2 && (size_t)nchunks * 64 + 2 * 16 * 260 * 4 <= 60 * 1024) {
         int bm = p.M >= 96 ? 128 : (p.M >= 48 ? 64 : (p.M > 16 ? 32 : 0));
         if (const char *f = getenv("RVC_G32_BM")) { const int v = atoi(f); if (v == 32 || v == 64 || v == 128) bm = v; }   // tuning aid
@@ -486,7 +488,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
         if (p.ln_wsum && (p.lin_cs4 == 0 || pre || nchunks / wg_ks < 1)) throw std::logic_error("LayerNorm consumer must be a table-free 1x1 layer");
     }
     int ksplit = 1;
-    if ((size_t)nchunks * 64 > 60 * 1024 && p.glu) throw ShapeError("gated conv too long for the fused epilogue");
+    if ((size_t)nchunks * 64 > 60 * 1024 && (p.glu || phase_epi)) throw ShapeError("fused conv too long for the in-workgroup K split");
     if ((size_t)nchunks * 64 > 60 * 1024) {     // koff slice would not fit in LDS: grid-level split (two-stage, rare)
         ksplit = (int)(((size_t)nchunks * 64 + 60 * 1024 - 1) / (60 * 1024));
         cfg = 0; wg_ks = 1;
@@ -875,7 +877,7 @@ struct ModelCV {
     }
 };
 
-struct ResBlockW { ConvW c1, c2, sc; bool has_sc = false; int ci = 0, co = 0; };
+struct ResBlockW { ConvW c1, c2, sc; bool has_sc = false; int ci = 0, co = 0; float *pair_bias = nullptr; };    // pair_bias: [c1.bias; sc.bias] for the fused c1 + shortcut launch
 struct ModelRM {
     int en_out, levels, n_blocks, inter_layers, n_mels, gru_hidden, n_out;
     float bn_scale, bn_shift;
@@ -889,7 +891,12 @@ struct ModelRM {
         ResBlockW r; r.ci = ci; r.co = co;
         r.c1 = prep_conv(b.w(pre + "c1.w"), b.w(pre + "c1.b"), co, ci, 9, 1);
         r.c2 = prep_conv(b.w(pre + "c2.w"), b.w(pre + "c2.b"), co, co, 9, 1);
-        if (ci != co) { r.has_sc = true; r.sc = prep_conv(b.w(pre + "sc.w"), b.w(pre + "sc.b"), co, ci, 1, 1); }
+        if (ci != co) {
+            r.has_sc = true; r.sc = prep_conv(b.w(pre + "sc.w"), b.w(pre + "sc.b"), co, ci, 1, 1);
+            std::vector<float> pb(b.w(pre + "c1.b"), b.w(pre + "c1.b") + co);
+            pb.insert(pb.end(), b.w(pre + "sc.b"), b.w(pre + "sc.b") + co);
+            r.pair_bias = upload_f(pb);
+        }
         return r;
     }
     explicit ModelRM(const Blob &b)
@@ -941,7 +948,7 @@ struct ModelRM {
     }
     ~ModelRM()
     {
-        auto fb = [](std::vector<std::vector<ResBlockW>> &vv) { for (auto &v : vv) for (auto &r : v) { free_conv(r.c1); free_conv(r.c2); free_conv(r.sc); } };
+        auto fb = [](std::vector<std::vector<ResBlockW>> &vv) { for (auto &v : vv) for (auto &r : v) { free_conv(r.c1); free_conv(r.c2); free_conv(r.sc); if (r.pair_bias) (void)hipFree(r.pair_bias); } };
         fb(enc); fb(inter); fb(dec);
         for (auto &u : up) free_conv(u);
         free_conv(cnn); free_conv(gru_ih); free_conv(fc);
@@ -1419,10 +1426,65 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
 }
 
 // ------------------------------- RMVPE ------------------------------------------------
+// c1 (3x3, ReLU) -> y1 and the shortcut (1x1, no activation) -> out as the two phases of ONE launch over the shared input x
+static void add_conv2d_with_shortcut(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &y1, const T2 &out)
+{
+    if (x.H != y1.H || x.W != y1.W || out.H != x.H || out.W != x.W || y1.cs != out.cs || y1.ld != out.ld || (x.B > 1 && y1.bs != out.bs)) throw ShapeError("conv2d + shortcut: layouts differ");
+    const ConvW &c1 = w.c1, &sc = w.sc;
+    IgemmP p{};
+    p.x = x.p; p.y = y1.p;
+    p.M = c1.M; p.N = x.H * x.W;
+    p.NW = x.W; p.x_hs = x.ld; p.x_ws = 1; p.y_hm = 1; p.y_ws = 1; p.OW = y1.W;
+    p.x_bs = x.bs; p.y_bs = y1.bs; p.y_cs = y1.cs; p.y_rs = y1.ld;
+    ConvOpts o; o.act = ACT_RELU;
+    fill_epilogue(p, c1, o);
+    p.bias = w.pair_bias;
+    std::vector<int> koff;
+    std::vector<PhaseD> ph(2);
+    ph[0] = PhaseD{}; ph[1] = PhaseD{};
+    // phase 0: the 3x3 convolution (one-row images: only the middle tap row can hit data, see add_conv2d)
+    if (x.H == 1 && !c1.host_w.empty() && !getenv("RVC_NO_TAP_PRUNE")) {
+        const int K3 = c1.Cin * 3, Kp3 = round16(K3);
+        std::vector<float> panel((size_t)c1.M * Kp3, 0.f);
+        for (int mo = 0; mo < c1.M; mo++)
+            for (int ci = 0; ci < c1.Cin; ci++)
+                for (int kw = 0; kw < 3; kw++) panel[(size_t)mo * Kp3 + ci * 3 + kw] = c1.host_w[(size_t)mo * c1.K + ci * 9 + 3 + kw];
+        float *dw = upload_fragments(panel, 1, c1.M, Kp3);
+        pl.owned_dev.push_back(dw);
+        p.w = dw; ph[0].nchunks = Kp3 / 16;
+        koff.assign(Kp3, 0);
+        for (int ci = 0; ci < c1.Cin; ci++) for (int kw = 0; kw < 3; kw++) koff[ci * 3 + kw] = ci * x.cs + (kw - 1);
+    } else {
+        p.w = c1.w; ph[0].nchunks = c1.Kp / 16;
+        koff.assign(c1.Kp, 0);
+        for (int ci = 0; ci < c1.Cin; ci++) for (int k = 0; k < 9; k++) koff[ci * 9 + k] = ci * x.cs + (k / 3 - 1) * x.ld + (k % 3 - 1);
+    }
+    // phase 1: the shortcut: its own weights (offset from phase 0's: both are device pointers of one flat address space), K, bias
+    // slice, output tensor and (no) activation
+    ph[1].w_off = sc.w - p.w;
+    ph[1].nchunks = sc.Kp / 16;
+    ph[1].koff_off = (int)koff.size();
+    ph[1].bias_off = c1.M;
+    ph[1].act_p1 = ACT_NONE + 1;
+    ph[1].y_off = out.p - y1.p;
+    const size_t base = koff.size();
+    koff.resize(base + sc.Kp, 0);
+    for (int ci = 0; ci < sc.Cin; ci++) koff[base + ci] = ci * x.cs;
+    p.K = std::max(ph[0].nchunks, ph[1].nchunks) * 16;
+    queue_igemm(pl, p, x.B, koff, ph);
+}
+
 static T2 res_block(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &out)
 {
     Arena &A = pl.arena;
     T2 y1 = make_t2(A, x.B, w.co, x.H, x.W);
+    // few streams: the 3x3 convolution and the 1x1 shortcut read the same input -- one launch with two phases (own K, own output tensor,
+    // own activation) instead of two dependent launches (11 blocks of RMVPE have a shortcut: 11 launches off the f0 branch)
+    if (w.has_sc && w.pair_bias && x.B <= 4 && (x.B == 1 || y1.bs == out.bs) && !getenv("RVC_NO_SC_MERGE")) {      // (one stream stride for both outputs)
+        add_conv2d_with_shortcut(pl, w, x, y1, out);
+        ConvOpts o; o.act = ACT_RELU; o.accumulate = true; add_conv2d(pl, w.c2, y1, out, o);
+        return out;
+    }
     { ConvOpts o; o.act = ACT_RELU; add_conv2d(pl, w.c1, x, y1, o); }
     if (w.has_sc) {
         add_conv2d(pl, w.sc, x, out);
@@ -1509,17 +1571,17 @@ static T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k,
         size_t lds = (size_t)4 * Hg * sizeof(float);
         float *wt = m.whhT, *bh = m.bhh;
         dim3 grid(2, B);
-        if (Hg == 256 && B <= 8 && !getenv("RVC_GRU_GENERIC")) {
+        if (Hg == 256 && B <= 8 && Tm <= 256 && !getenv("RVC_GRU_GENERIC")) {
             // few streams: spread each direction over 8 CUs with W_hh resident in LDS (granule hand-off per step)
             GruMultiP gp{}; gp.gi = gi.p; gp.gi_cs = gi.ld; gp.gi_bs = gi.bs; gp.whh = m.whh; gp.bhh = m.bhh; gp.out = gout.p; gp.o_cs = gout.ld; gp.o_bs = gout.bs;
             gp.Tm = Tm; gp.status = &e->d_state[0].status; gp.status_stride = (int)(sizeof(StreamState) / sizeof(int));
             const size_t gbytes = (size_t)B * 2 * 2 * 256 * sizeof(unsigned long long);
             gp.gran = (unsigned long long *)pl.arena.alloc(gbytes);
-            const size_t lds3 = (size_t)(96 * 260 + 256 + 96) * sizeof(float);
+            const size_t lds3 = (size_t)(256 + 96 + (size_t)Tm * 96) * sizeof(float);      // h, gate pre-activations, this slice's input gates for all steps
             const dim3 g3(8, 2, B);
             pl.ops.push_back([=](hipStream_t s) {
                 HIPCHK(hipMemsetAsync(gp.gran, 0, gbytes, s));
-                hipLaunchKernelGGL(gru_multi_kernel, g3, dim3(256), lds3, s, gp);
+                hipLaunchKernelGGL(gru_multi_kernel, g3, dim3(384), lds3, s, gp);
             });
         } else {
             pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(gru_kernel, grid, dim3(threads), lds, s, gi.p, gi.ld, gi.bs, wt, bh, gout.p, gout.ld, gout.bs, Hg, Tm); });
@@ -1943,11 +2005,20 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
                     ConvOpts o; o.no_bias = true; o.res = e->d_nhn; o.res_cs = 0; o.res_bs = 0; o.scale = -2.0f;
                     add_conv1d(pl, qw, xi, ya, 1, 0, 1, o);
                 }
+                // per-wave candidate lists of the one-pass scan (one stream / few streams: the select stage reads n / 4 entries per query)
+                const long long nwaves = ((long long)e->index_n + 15) / 16;
+                float *wl_d = nullptr; int *wl_i = nullptr;
+                if (!gemm_scan && !getenv("RVC_KNN_NO_WAVE_LISTS")) {
+                    wl_d = pl.arena.floats((size_t)B * nq * nwaves * 4);
+                    wl_i = (int *)pl.arena.alloc((size_t)B * nq * nwaves * 4 * sizeof(int));
+                }
                 for (int q0 = 0; q0 < nq && !gemm_scan; q0 += 16) {
-                    KnnDotP dp{}; dp.indexF = e->d_indexF; dp.ynorm = e->d_ynorm; dp.n = (int)e->index_n; dp.dim = C;
+                    KnnDotP dp{}; dp.indexF = e->d_indexF; dp.wl_d = wl_d; dp.wl_i = wl_i; dp.wl_bs = (long long)nq * nwaves * 4; dp.ynorm = e->d_ynorm; dp.n = (int)e->index_n; dp.dim = C;
                     dp.q = d_q; dp.q_bs = (long long)nq * C; dp.nq = nq; dp.q0 = q0; dp.approx = d_approx; dp.approx_bs = (long long)nq * e->index_n;
                     dp.overflow = d_overflow;
-                    dim3 grid((unsigned)((e->index_n + 63) / 64), B);
+                    // persistent grid (the waves walk the index tiles; measured: 256 / 512 / 768 / 1024 / one tile per wave = 100 / 79 / 86 / 73 / 74 us per 307 MB)
+                    static const unsigned knn_wgs = getenv("RVC_KNN_WGS") ? (unsigned)atoi(getenv("RVC_KNN_WGS")) : 1024u;
+                    dim3 grid(std::min((unsigned)((e->index_n + 63) / 64), std::max(knn_wgs / (unsigned)B, 64u)), B);
                     const size_t qlds = (size_t)16 * (C + 4) * sizeof(float);
                     if (qlds > 160 * 1024) throw ShapeError("feature dimension too large for the retrieval kernel");
                     Plan *plp = &pl;
@@ -1965,7 +2036,7 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
                 KnnSelP sp{}; sp.approx = d_approx; sp.approx_bs = (long long)nq * e->index_n; sp.n = (int)e->index_n; sp.dim = C; sp.nq = nq;
                 sp.index = e->d_index; sp.q = d_q; sp.q_bs = (long long)nq * C; sp.skip_head = (int)skip_head; sp.T = T; sp.R = (int)R; sp.first_raw = first_raw;
                 sp.rate = e->index_rate; sp.phone = phone.p; sp.ph_cs = phone.ld; sp.ph_bs = phone.bs; sp.out_idx = pl.d_knn_idx; sp.out_dist = pl.d_knn_dist;
-                sp.overflow = d_overflow;
+                sp.overflow = d_overflow; sp.wl_d = wl_d; sp.wl_i = wl_i; sp.wl_bs = (long long)nq * nwaves * 4;
                 dim3 sgrid(nq, B);
                 const size_t slds = (size_t)33 * (C + 4) * sizeof(float);
                 if (slds > 128 * 1024) throw ShapeError("feature dimension too large for the retrieval kernel");

@@ -44,6 +44,10 @@ struct PhaseD {
     int bias_off;      // offset into bias
     int koff_off;      // offset into the koff table
     int nchunks;       // K/16 of this phase (fused launches of convs with different kernel sizes; filled by queue_igemm)
+    // igemm2 only (register-direct kernel, launches that fuse two DIFFERENT convolutions of one input: RMVPE's 3x3 + shortcut):
+    int act_p1;        // this phase's epilogue activation + 1 (0: the launch's IgemmP::act)
+    int pad_;
+    long long y_off;   // element offset of this phase's output tensor from IgemmP::y
 };
 
 struct IgemmP {
@@ -540,8 +544,9 @@ __device__ __forceinline__ void glu_from_col_b(const IgemmP &p, const PhaseD &ph
     yb[c.yo + ch * p.y_cs] = tanhf(ta) * (1.0f / (1.0f + expf(-sa)));
 }
 
-#define RVC_ACT_DISPATCH(STMT)                                                   \
-    switch (p.act) {                                                             \
+#define RVC_ACT_DISPATCH(STMT) RVC_ACT_DISPATCH_SEL(p.act, STMT)
+#define RVC_ACT_DISPATCH_SEL(SEL, STMT)                                          \
+    switch (SEL) {                                                             \
     case ACT_RELU: { constexpr int A_ = ACT_RELU; STMT } break;                  \
     case ACT_LRELU: { constexpr int A_ = ACT_LRELU; STMT } break;                \
     case ACT_GELU: { constexpr int A_ = ACT_GELU; STMT } break;                  \
@@ -601,7 +606,8 @@ void igemm2_kernel(IgemmP p)
     const bool live = tm < p.ntm && tn < p.ntn;
     const int li = lane & 15, kq = lane >> 4;
     const float *resb = p.res ? p.res + (long long)b * p.res_bs : nullptr;
-    float *yb = p.y + (long long)b * p.y_bs;
+    float *yb = p.y + (long long)b * p.y_bs + ph.y_off;
+    const int act_sel = ph.act_p1 ? ph.act_p1 - 1 : p.act;
 
     RVC_KP(9);
     // gathered-activation addressing: wave-uniform base + unsigned 32-bit BYTE offset per lane
@@ -868,7 +874,7 @@ void igemm2_kernel(IgemmP p)
             }
             vsum[q] = v;
         }
-        RVC_ACT_DISPATCH(
+        RVC_ACT_DISPATCH_SEL(act_sel, 
             _Pragma("unroll") for (int q = 0; q < PE; q++) epi2_finish<A_>(p, yb, vsum[q], pre_r[q]);
         )
         RVC_KP(6);
@@ -896,7 +902,7 @@ void igemm2_kernel(IgemmP p)
         return;
     }
     if (PF) {
-        RVC_ACT_DISPATCH(
+        RVC_ACT_DISPATCH_SEL(act_sel, 
             _Pragma("unroll") for (int mf = 0; mf < MF; mf++)
                 _Pragma("unroll") for (int nf = 0; nf < NF; nf++)
                     _Pragma("unroll") for (int r = 0; r < 4; r++)
@@ -914,7 +920,7 @@ void igemm2_kernel(IgemmP p)
             // the residual loaded for a whole 16-row fragment before its stores (see igemm32_kernel's epilogue)
             const float slope = p.slope, scale = p.scale;
             const long long cs = p.y_cs, rcs = p.res_cs;
-            RVC_ACT_DISPATCH(
+            RVC_ACT_DISPATCH_SEL(act_sel, 
                 _Pragma("unroll") for (int mf = 0; mf < MF; mf++) {
                     const int m0 = tm * 16 * MF + mf * 16 + kq * 4;
                     float bias_r[4];
@@ -940,7 +946,7 @@ void igemm2_kernel(IgemmP p)
             RVC_KP(6);
             return;
         }
-        RVC_ACT_DISPATCH(
+        RVC_ACT_DISPATCH_SEL(act_sel, 
             _Pragma("unroll") for (int mf = 0; mf < MF; mf++) {
                 float bias_r[4];
                 _Pragma("unroll") for (int r = 0; r < 4; r++) {

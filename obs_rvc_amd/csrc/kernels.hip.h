@@ -812,24 +812,31 @@ struct GruMultiP {
     int status_stride;
     int Tm;
 };
-__global__ __launch_bounds__(256) void gru_multi_kernel(GruMultiP p)
+// Round 3: the 96 x 256 slice of W_hh lives in REGISTERS (thread (row r, quarter q) keeps its 64 weights for all steps: the matvec
+// reads only h from LDS, 16 broadcast b128 reads per thread, instead of streaming 96 KB of weights through LDS every step), the
+// slice's input gates gi[Tm][96] are copied to LDS once (they were three global loads per step on the critical path), and a step
+// has two workgroup barriers instead of three.  384 threads; 98 -> ~45 us for 2 x 32 steps.
+__global__ __launch_bounds__(384) void gru_multi_kernel(GruMultiP p)
 {
-    constexpr int H = 256, G = 8, U = H / G, ROWS = 3 * U, RS = H + 4;
+    constexpr int H = 256, G = 8, U = H / G, ROWS = 3 * U, NT = 384;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *w = smem;                    // [ROWS][RS]
-    float *hs = w + ROWS * RS;          // [H]
+    float *hs = smem;                   // [H]
     float *gh = hs + H;                 // [ROWS]
-    // (placing a group's 8 workgroups on one XCD was measured: no gain, the agent-scope hand-off goes through memory either way)
+    float *gis = gh + ROWS;             // [Tm][ROWS]: input gates of this slice (b_ih included), row = gate * U + unit
     const int g = blockIdx.x, dir = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-    const float *wsrc = p.whh + (long long)dir * 3 * H * H;
-    for (int i = tid; i < ROWS * (H / 4); i += 256) {
-        const int row = i / (H / 4), c4 = i - row * (H / 4);
-        const int gate = row / U, u = row - gate * U;
-        *reinterpret_cast<f32x4 *>(w + row * RS + c4 * 4) = *reinterpret_cast<const f32x4 *>(wsrc + (long long)(gate * H + g * U + u) * H + c4 * 4);
-    }
-    hs[tid] = 0.f;
+    const int r = tid >> 2, q = tid & 3;                 // row of the slice, quarter of the hidden vector
+    const int gate = r / U, u = r - gate * U;
+    const float *wsrc = p.whh + (long long)dir * 3 * H * H + (long long)(gate * H + g * U + u) * H + q * 64;
+    f32x4 w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = *reinterpret_cast<const f32x4 *>(wsrc + i * 4);
+    const float bias = p.bhh[dir * 3 * H + gate * H + g * U + u];
     const float *gib = p.gi + (long long)b * p.gi_bs + (long long)dir * 3 * H * p.gi_cs;
-    const float *bh = p.bhh + dir * 3 * H;
+    for (int i = tid; i < p.Tm * ROWS; i += NT) {
+        const int rr = i / p.Tm, t = i - rr * p.Tm, gg = rr / U, uu = rr - gg * U;      // coalesced along time
+        gis[t * ROWS + rr] = gib[(long long)(gg * H + g * U + uu) * p.gi_cs + t];
+    }
+    if (tid < H) hs[tid] = 0.f;
     float *ob = p.out + (long long)b * p.o_bs + (long long)dir * H * p.o_cs;
     unsigned long long *gr = p.gran + ((long long)(b * 2 + dir) * 2) * H;
     __syncthreads();
@@ -838,37 +845,39 @@ __global__ __launch_bounds__(256) void gru_multi_kernel(GruMultiP p)
         const int t = dir == 0 ? step : p.Tm - 1 - step;
         if (step > 0) {
             // gather h_{step-1}: granule `tid` of slot (step-1)&1 must carry tag == step
-            const unsigned long long *src = gr + ((step - 1) & 1) * H + tid;
-            unsigned long long x = 0;
-            unsigned spins = 0;
-            while (!dead) {
-                x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)(x >> 32) == (unsigned)step) break;
-                if (++spins > (1u << 22)) { dead = true; p.status[b * p.status_stride] = 7; }
-                __builtin_amdgcn_s_sleep(1);
+            if (tid < H) {
+                const unsigned long long *src = gr + ((step - 1) & 1) * H + tid;
+                unsigned long long x = 0;
+                unsigned spins = 0;
+                while (!dead) {
+                    x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(x >> 32) == (unsigned)step) break;
+                    if (++spins > (1u << 22)) { dead = true; p.status[b * p.status_stride] = 7; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                hs[tid] = __uint_as_float((unsigned)x);
             }
-            hs[tid] = __uint_as_float((unsigned)x);
             __syncthreads();
         }
-        // 96 rows x 256: two threads per row, 128 k each
-        if (tid < 2 * ROWS) {
-            const int row = tid >> 1, half = tid & 1;
-            const float *wr = w + row * RS + half * (H / 2);
-            const float *hr = hs + half * (H / 2);
+        // row r, columns q * 64 ..: the four quarters of a row sit in adjacent lanes
+        {
+            const float *hq = hs + q * 64;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < H / 2; k += 4) {
-                const f32x4 wv = *reinterpret_cast<const f32x4 *>(wr + k), hv = *reinterpret_cast<const f32x4 *>(hr + k);
-                a0 += wv[0] * hv[0]; a1 += wv[1] * hv[1]; a2 += wv[2] * hv[2]; a3 += wv[3] * hv[3];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const f32x4 hv = *reinterpret_cast<const f32x4 *>(hq + i * 4);
+                a0 = fmaf(w[i][0], hv[0], a0); a1 = fmaf(w[i][1], hv[1], a1); a2 = fmaf(w[i][2], hv[2], a2); a3 = fmaf(w[i][3], hv[3], a3);
             }
             float a = (a0 + a1) + (a2 + a3);
             a += __shfl_xor(a, 1, 64);
-            if (half == 0) { const int gate = row / U, u = row - gate * U; gh[row] = a + bh[gate * H + g * U + u]; }
+            a += __shfl_xor(a, 2, 64);
+            if (q == 0) gh[r] = a + bias;
         }
         __syncthreads();
         if (tid < U) {
             const int unit = g * U + tid;
-            const float ir = gib[(long long)unit * p.gi_cs + t], iz = gib[(long long)(H + unit) * p.gi_cs + t], in_ = gib[(long long)(2 * H + unit) * p.gi_cs + t];
+            const float *gi = gis + t * ROWS;
+            const float ir = gi[tid], iz = gi[U + tid], in_ = gi[2 * U + tid];
             const float rg = 1.0f / (1.0f + expf(-(ir + gh[tid])));
             const float zg = 1.0f / (1.0f + expf(-(iz + gh[U + tid])));
             const float ng = tanhf(in_ + rg * gh[2 * U + tid]);
@@ -877,7 +886,8 @@ __global__ __launch_bounds__(256) void gru_multi_kernel(GruMultiP p)
             __hip_atomic_store(gr + (step & 1) * H + unit, ((unsigned long long)(unsigned)(step + 1) << 32) | (unsigned long long)__float_as_uint(hn),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __syncthreads();
+        // (no barrier here: hs[unit] of the own slice is rewritten only after this thread's granule has been polled back, gh only
+        // after the next step's first barrier)
     }
 }
 
@@ -1354,7 +1364,17 @@ struct KnnDotP {
     const float *q; long long q_bs; int nq, q0;
     float *approx; long long approx_bs;        // approx[b][q][n]
     int *overflow;                              // [B], cleared here, raised by the select stage
+    // per-wave candidate lists: the 4 smallest approximate distances (ascending by (distance, index)) of every wave's 16 vectors,
+    // per query -- the select stage reads these n / 4 entries instead of the n approximations (the global top-4 is in their union)
+    float *wl_d; int *wl_i; long long wl_bs;   // [b][q][waves][4]
 };
+// compare-exchange of two (distance, index) pairs, ascending, ties by index (deterministic)
+__device__ __forceinline__ void knn_cx(float &d0, int &i0, float &d1, int &i1)
+{
+    const bool sw = d1 < d0 || (d1 == d0 && i1 < i0);
+    const float td = sw ? d1 : d0, ud = sw ? d0 : d1; const int ti = sw ? i1 : i0, ui = sw ? i0 : i1;
+    d0 = td; i0 = ti; d1 = ud; i1 = ui;
+}
 __global__ __launch_bounds__(256) void knn_dot_kernel(KnnDotP p)
 {
     constexpr int D = 8;
@@ -1372,10 +1392,10 @@ __global__ __launch_bounds__(256) void knn_dot_kernel(KnnDotP p)
         }
     }
     __syncthreads();
-    const int i0 = (blockIdx.x * 4 + wave) * 16;
-    if (i0 >= p.n) return;
     const int li = lane & 15, kq = lane >> 4;
     const int nc = p.dim >> 4;
+    // persistent workgroups: the 48 KB query block is staged once per workgroup, then its waves walk the index tiles
+    for (int i0 = (blockIdx.x * 4 + wave) * 16; i0 < p.n; i0 += gridDim.x * 64) {
     // one wave-wide dwordx4 load = one 1 KiB fragment, fully contiguous: the wave streams its 16 vectors as nc consecutive KiB
     const float *ar = p.indexF + (long long)(i0 >> 4) * nc * 256 + lane * 4;
     const float *br = s_q + li * QS + kq * 4;
@@ -1399,13 +1419,38 @@ __global__ __launch_bounds__(256) void knn_dot_kernel(KnnDotP p)
     }
     // D layout: row (index vector) = (lane >> 4) * 4 + r, column (query) = lane & 15
     const int qcol = p.q0 + li;
+    float vd[4]; int vi[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int v = i0 + kq * 4 + r;
+        vd[r] = v < p.n ? p.ynorm[v] - 2.0f * (acc0[r] + acc1[r]) : INFINITY;
+        vi[r] = v < p.n ? v : 0x7fffffff;
+    }
     if (qcol < p.nq) {
         float *out = p.approx + (long long)b * p.approx_bs + (long long)qcol * p.n;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int v = i0 + kq * 4 + r;
-            if (v < p.n) out[v] = p.ynorm[v] - 2.0f * (acc0[r] + acc1[r]);
+        for (int r = 0; r < 4; r++) if (vi[r] != 0x7fffffff) out[vi[r]] = vd[r];
+    }
+    if (p.wl_d) {
+        // this wave's 4 smallest of its 16 vectors, per query column: sort the lane's 4, then two bitonic merges with the lanes that
+        // hold the other rows of the column (lane ^ 16, lane ^ 32): min(a[k], b[3 - k]) keeps the 4 smallest of two sorted 4-lists
+        knn_cx(vd[0], vi[0], vd[1], vi[1]); knn_cx(vd[2], vi[2], vd[3], vi[3]); knn_cx(vd[0], vi[0], vd[2], vi[2]);
+        knn_cx(vd[1], vi[1], vd[3], vi[3]); knn_cx(vd[1], vi[1], vd[2], vi[2]);
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            float od[4]; int oi[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) { od[r] = __shfl_xor(vd[3 - r], o, 64); oi[r] = __shfl_xor(vi[3 - r], o, 64); }
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const bool t = od[r] < vd[r] || (od[r] == vd[r] && oi[r] < vi[r]); vd[r] = t ? od[r] : vd[r]; vi[r] = t ? oi[r] : vi[r]; }
+            knn_cx(vd[0], vi[0], vd[2], vi[2]); knn_cx(vd[1], vi[1], vd[3], vi[3]); knn_cx(vd[0], vi[0], vd[1], vi[1]); knn_cx(vd[2], vi[2], vd[3], vi[3]);
         }
+        if (kq == 0 && qcol < p.nq) {
+            const long long o4 = (long long)b * p.wl_bs + ((long long)qcol * ((p.n + 15) >> 4) + (i0 >> 4)) * 4;
+            *reinterpret_cast<f32x4 *>(p.wl_d + o4) = (f32x4){vd[0], vd[1], vd[2], vd[3]};
+            *reinterpret_cast<int4 *>(p.wl_i + o4) = make_int4(vi[0], vi[1], vi[2], vi[3]);
+        }
+    }
     }
 }
 
@@ -1475,6 +1520,7 @@ struct KnnSelP {
     int skip_head, T, R, first_raw; float rate;
     float *phone; int ph_cs; long long ph_bs;
     int *out_idx; float *out_dist; int *overflow;
+    const float *wl_d; const int *wl_i; long long wl_bs;      // per-wave candidate lists of knn_dot_kernel (or nullptr: scan the approximations)
 };
 __global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p)
 {
@@ -1516,6 +1562,26 @@ __global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p)
     // data-dependent branch behind it made this pass ~100 dependent round trips: 80 us for 100 k vectors, more than the scan that
     // produced the distances).  Only the VALUE of the 4th smallest is used below, so the visiting order does not matter.
     const int n4 = ((p.n & 3) == 0 && (reinterpret_cast<size_t>(a) & 15) == 0) ? p.n >> 2 : 0;
+    // One stream (knn_dot_kernel left per-wave lists): the global top-4 of the approximations is in the union of the waves' top-4
+    // lists -- n / 4 (distance, index) entries instead of n distances (round 2: this pass over 11 x 400 KB took two-thirds of the
+    // scan's own time).  min4 = the smallest 4th entry seen: a wave whose 4th entry is inside the margin may hide a 5th candidate.
+    float min4 = INFINITY;
+    if (p.wl_d) {
+        const int nw = (p.n + 15) >> 4;
+        const float *wd_ = p.wl_d + (long long)b * p.wl_bs + (long long)j * nw * 4;
+        const int *wi_ = p.wl_i + (long long)b * p.wl_bs + (long long)j * nw * 4;
+        for (int w0 = tid; w0 < nw; w0 += 4 * 1024) {
+            f32x4 dv[4]; int4 iv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int w = w0 + u * 1024 < nw ? w0 + u * 1024 : w0; dv[u] = *reinterpret_cast<const f32x4 *>(wd_ + 4 * (long long)w); iv[u] = *reinterpret_cast<const int4 *>(wi_ + 4 * (long long)w); }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (w0 + u * 1024 < nw) {
+                    keep(dv[u][0], iv[u].x); keep(dv[u][1], iv[u].y); keep(dv[u][2], iv[u].z); keep(dv[u][3], iv[u].w);
+                    min4 = fminf(min4, dv[u][3]);
+                }
+        }
+    } else {
     for (int i4 = tid; i4 < n4; i4 += 4 * 1024) {
         f32x4 v[4];
 #pragma unroll
@@ -1530,6 +1596,7 @@ __global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p)
         }
     }
     for (int i = 4 * n4 + tid; i < p.n; i += 1024) keep(a[i], i);
+    }
     int pos = 0;
     for (int k = 0; k < KNN_K; k++) {
         float md = pos < KNN_K ? ld[pos] : INFINITY; int mi = pos < KNN_K ? li_[pos] : 0x7fffffff;
@@ -1567,7 +1634,7 @@ __global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p)
     __syncthreads();
     // The candidates are among the per-thread top-4 lists unless some thread holds MORE than four values within the margin (its list is
     // then truncated: its 4th entry is still <= thr).  Common case: collect from the lists, no second pass over the n distances.
-    if (ld[KNN_K - 1] <= thr) atomicOr(&cnt, 0x40000000);
+    if (ld[KNN_K - 1] <= thr || min4 <= thr) atomicOr(&cnt, 0x40000000);       // (a truncated list -- this thread's or a wave's -- sends the stream through the full pass below)
     __syncthreads();
     const bool truncated = (cnt & 0x40000000) != 0;
     __syncthreads();
