@@ -3,13 +3,16 @@
 # passes (separate runs, --kernel-trace only, as gpurun requires).  Raw traces stay in /tmp on the GPU box (hundreds of MB); the
 # summaries the repository keeps are written to gpurun_out/<tag>/ under their profiles/ names.
 # usage: profile_round.sh <tag> [round]      e.g. profile_round.sh r02d r02
-tag=${1:-r02}; rnd=${2:-r02}; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; raw=/tmp/prof_$tag; mkdir -p $out $raw
+tag=${1:-r03}; rnd=${2:-r03}; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; raw=/tmp/prof_$tag; mkdir -p $out $raw
 cd /tmp; export TMPDIR=/tmp
 prof() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d $raw/ks_$name -- python $R/bench.py --only-headline --no-cpu "$@" > $out/bench_$name.json 2> $out/bench_$name.err
          cp $raw/ks_$name/*/*kernel_stats.csv $out/${rnd}_kernel_stats_bench_$name.csv; }
 prof 1stream --steps 100
 prof index100k --steps 100 --index
 prof 64streams --steps 15 --warmup 3 --streams 64
+# the two front branches issued one after the other: true per-kernel durations at many streams (what roofline.frac of the 64-stream line uses)
+RVC_SERIAL_BRANCHES=1 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/ks_64serial -- python $R/bench.py --only-headline --no-cpu --steps 15 --warmup 3 --streams 64 > $out/bench_64streams_serial.json 2> $out/bench_64streams_serial.err
+cp $raw/ks_64serial/*/*kernel_stats.csv $out/${rnd}_kernel_stats_bench_64streams_serial_branches.csv
 pmc() { name=$1; ctr=$2; shift 2; rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $raw/pmc_${name}_$ctr -- python $R/bench.py --only-headline --no-cpu "$@" > /dev/null 2>&1; }
 pmc index100k FETCH_SIZE --steps 40 --index
 pmc index100k WRITE_SIZE --steps 40 --index
