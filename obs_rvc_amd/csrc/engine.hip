@@ -1128,6 +1128,7 @@ struct ModelSY {
 // ---------------------------------------------------------------------------------------
 }  // namespace rvc
 
+namespace rvc { struct StreamSet; }
 using namespace rvc;
 
 struct rvc_engine {
@@ -1136,6 +1137,7 @@ struct rvc_engine {
     // aux streams: 1 = f0 branch, 2 = side work (NSF source), 3 = ContentVec branch when the CUs are partitioned.  Four streams
     // in total: the runtime multiplexes streams onto 4 hardware queues, a fifth stream would share (and serialise with) another.
     hipStream_t stream = nullptr, aux[3] = {nullptr, nullptr, nullptr};
+    struct rvc::StreamSet *sset = nullptr;             // the engine's streams are borrowed from a per-device pool (never destroyed)
     bool partition_ok = false, partitioned = false;   // CU-masked streams available / currently in use (n_streams <= 4)
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
     std::unique_ptr<ModelCV> cv;
@@ -1238,40 +1240,52 @@ static void reset_state(rvc_engine *e)
 // stream it creates -- an engine created after another one had been destroyed then ran its MAIN stream on a partition (measured:
 // 2.41 -> 2.79-3.1 ms per chunk for the second engine of a process; no effect without masks).  Masked pairs live in a per-device
 // pool for the life of the process; engines borrow a pair and hand it back.
-struct MaskedPair { int device; hipStream_t f0, cv; bool in_use; };
+// Round 3: the same holds, less visibly, for plain streams: every stream an engine creates takes the next hardware queue, and after a
+// few create / destroy cycles in one process (the bench's sub-configurations, a host that reloads engines) a new engine's main stream
+// can share a queue with its own masked f0 stream -- the two then serialise (measured in one bench process: v1 2.15 -> 2.71 ms, two
+// streams 3.35 -> 4.79 ms per chunk for engines created after several others had come and gone).  So ALL streams of an engine come
+// from a per-device pool of complete sets (main + three plain auxiliaries + the masked pair), created together -- six consecutive
+// hardware queues -- and never destroyed; an engine borrows a set and hands it back.
+struct StreamSet { int device; hipStream_t main, plain[3], f0, cv; bool masked_ok, in_use; };
 static std::mutex g_pool_mu;
-static std::vector<MaskedPair> g_pool;
+static std::vector<StreamSet *> g_pool;
 
-static bool acquire_masked_pair(int device, int ncu, int nf0, hipStream_t *f0, hipStream_t *cv)
+static StreamSet *acquire_stream_set(int device, int ncu, int nf0, bool want_masks)
 {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    for (auto &m : g_pool)
-        if (m.device == device && !m.in_use) { m.in_use = true; *f0 = m.f0; *cv = m.cv; return true; }
-    MaskedPair m{device, nullptr, nullptr, true};
-    for (int i = 0; i < 2; i++) {
-        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-        for (int c = 0; c < ncu; c++) if ((c < nf0) == (i == 0)) mask[c / 32] |= 1u << (c % 32);
-        hipStream_t *dst = i == 0 ? &m.f0 : &m.cv;
-        if (hipExtStreamCreateWithCUMask(dst, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;          // (a first stream that did get created stays allocated: it must not be destroyed either)
+    for (StreamSet *m : g_pool)
+        if (m->device == device && !m->in_use) { m->in_use = true; return m; }
+    StreamSet *m = new StreamSet{device, nullptr, {nullptr, nullptr, nullptr}, nullptr, nullptr, false, true};
+    // creation order = the order a lone engine always used: main, the masked pair, the side stream (the first bench run of this
+    // pool created all plain streams first: 2.17 -> 2.80 ms per chunk -- queue assignment follows creation order); the two plain
+    // streams that stand in for the masked pair at more than 4 streams are created when such an engine first borrows the set
+    // tuning aid: RVC_STREAM_ORDER = a permutation of "mfcs" (main, f0 masked, ContentVec masked, side), RVC_STREAM_PAD = dummy streams first
+    const char *ord = getenv("RVC_STREAM_ORDER"); if (!ord || strlen(ord) != 4) ord = "mfcs";
+    if (const char *pd = getenv("RVC_STREAM_PAD")) for (int i = 0; i < atoi(pd); i++) { hipStream_t d; HIPCHK(hipStreamCreateWithFlags(&d, hipStreamNonBlocking)); }
+    m->masked_ok = want_masks;
+    for (int k = 0; k < 4; k++) {
+        const char w = ord[k];
+        if (w == 'm') HIPCHK(hipStreamCreateWithFlags(&m->main, hipStreamNonBlocking));
+        else if (w == 's') HIPCHK(hipStreamCreateWithFlags(&m->plain[1], hipStreamNonBlocking));
+        else if (want_masks && m->masked_ok) {
+            const int i = w == 'f' ? 0 : 1;
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+            for (int c = 0; c < ncu; c++) if ((c < nf0) == (i == 0)) mask[c / 32] |= 1u << (c % 32);
+            hipStream_t *dst = i == 0 ? &m->f0 : &m->cv;
+            if (hipExtStreamCreateWithCUMask(dst, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+                (void)hipGetLastError();
+                m->masked_ok = false;        // (a first stream that did get created stays allocated: it must not be destroyed either)
+            }
         }
     }
     g_pool.push_back(m);
-    *f0 = m.f0; *cv = m.cv;
-    return true;
+    return m;
 }
-static void release_masked_pair(hipStream_t f0)
+static void release_stream_set(StreamSet *m)
 {
+    if (!m) return;
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    for (auto &m : g_pool) if (m.f0 == f0) m.in_use = false;
-}
-
-static void release_aux_streams(rvc_engine *e)
-{
-    if (e->partitioned && e->aux[0]) { release_masked_pair(e->aux[0]); e->aux[0] = nullptr; e->aux[2] = nullptr; }
-    for (int i = 0; i < 3; i++) if (e->aux[i]) { (void)hipStreamDestroy(e->aux[i]); e->aux[i] = nullptr; }
-    e->partitioned = false;
+    m->in_use = false;
 }
 
 static void configure_aux_streams(rvc_engine *e)
@@ -1279,15 +1293,17 @@ static void configure_aux_streams(rvc_engine *e)
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, e->device));
     int ncu = prop.multiProcessorCount, nf0 = ncu / 8;
     if (const char *f = getenv("RVC_F0_CUS")) { const int v = atoi(f); if (v >= 8 && v < ncu) nf0 = v; }   // tuning aid
-    bool want = e->partition_ok && ncu >= 64 && ncu <= 1024 && e->n_streams <= 4;
-    if (e->aux[0] && want == e->partitioned) return;
-    release_aux_streams(e);
-    if (want) {
-        if (acquire_masked_pair(e->device, ncu, nf0, &e->aux[0], &e->aux[2])) e->partitioned = true;
-        else { want = false; e->partition_ok = false; }
+    if (!e->sset) {
+        e->sset = acquire_stream_set(e->device, ncu, nf0, e->partition_ok && ncu >= 64 && ncu <= 1024);
+        e->stream = e->sset->main;
+        if (!e->sset->masked_ok) e->partition_ok = false;
     }
-    for (int i = 0; i < 3; i++)
-        if (!e->aux[i]) HIPCHK(hipStreamCreateWithFlags(&e->aux[i], hipStreamNonBlocking));
+    const bool want = e->partition_ok && e->sset->masked_ok && e->n_streams <= 4;
+    if (!want) for (int i = 0; i < 3; i += 2) if (!e->sset->plain[i]) HIPCHK(hipStreamCreateWithFlags(&e->sset->plain[i], hipStreamNonBlocking));
+    e->partitioned = want;
+    e->aux[0] = want ? e->sset->f0 : e->sset->plain[0];
+    e->aux[1] = e->sset->plain[1];
+    e->aux[2] = want ? e->sset->cv : e->sset->plain[2];
 }
 
 static void alloc_state(rvc_engine *e)
@@ -2254,7 +2270,6 @@ rvc_status rvc_create(const char *data_path, int device, rvc_engine **out)
     e->device = device;
     try {
         set_device(e);
-        HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         for (int i = 0; i < 3; i++) { HIPCHK(hipEventCreateWithFlags(&e->ev_fork[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming)); }
         e->partition_ok = !getenv("RVC_NO_CUMASK");
         configure_aux_streams(e);
@@ -2270,6 +2285,7 @@ rvc_status rvc_create(const char *data_path, int device, rvc_engine **out)
         alloc_state(e);
     } catch (const std::exception &x) {
         fprintf(stderr, "rvc_create: %s\n", x.what());
+        release_stream_set(e->sset);
         delete e;
         return RVC_BACKEND;
     }
@@ -2306,8 +2322,7 @@ void rvc_destroy(rvc_engine *e)
         if (e->ev_fork[i]) (void)hipEventDestroy(e->ev_fork[i]);
         if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
     }
-    release_aux_streams(e);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
+    release_stream_set(e->sset);      // (the streams stay in the per-device pool)
     delete e;
 }
 
