@@ -27,7 +27,7 @@ SYMBOLS = [
 ]
 
 
-SOURCES = ("engine.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "igemm2_inst.hip", "igemm_tiled_inst.hip", "version.cpp",
+SOURCES = ("engine.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "igemm2_inst.hip", "igemm_tiled_inst.hip", "conv_tile.hip.h", "conv_tile_inst.hip", "version.cpp",
            "synth_front.hip", "synth_front.h", "state.hip.h",
            "resample.hip.h", "session.hip.h", "rccl_bcast.hip.h", "blob.h", "rvc_rpc.cpp")
 
@@ -39,7 +39,8 @@ _ENGINE_DEPS = ("engine.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", 
                 "synth_front.h", "state.hip.h")
 UNITS = [("engine.hip", [], _ENGINE_DEPS), ("synth_front.hip", [], ("synth_front.hip", "synth_front.h", "state.hip.h"))] + \
         [("igemm2_inst.hip", ["-DRVC_IGEMM2_CFG=%d" % c], ("igemm2_inst.hip",) + _IGEMM_DEPS) for c in range(5)] + \
-        [("igemm_tiled_inst.hip", ["-DRVC_TILED_PART=%d" % c], ("igemm_tiled_inst.hip",) + _IGEMM_DEPS) for c in range(4)]
+        [("igemm_tiled_inst.hip", ["-DRVC_TILED_PART=%d" % c], ("igemm_tiled_inst.hip",) + _IGEMM_DEPS) for c in range(4)] + \
+        [("conv_tile_inst.hip", [], ("conv_tile_inst.hip", "conv_tile.hip.h") + _IGEMM_DEPS)]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 OBJ_CACHE = os.environ.get("RVC_OBJ_CACHE", "/tmp/rvc_obj_cache")
 

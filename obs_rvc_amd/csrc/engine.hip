@@ -342,6 +342,118 @@ struct Plan {
 static unsigned long long *g_kprobe = nullptr;   // tuning build (-DRVC_KPROBE): destination of the per-wave phase stamps
 static int g_last_waves = 0, g_last_wgs = 0;
 
+// One stream, stride-1 1-D convolution with a long output: conv_tile_kernel (conv_tile.hip.h) stages the input rows once per workgroup.
+// Builds the LDS-offset tables (k -> row * RS + tap column) from the layer's gather table and a work-item table that balances the
+// unequal phases of a fused launch over the CUs (workgroup b lands on CU b % ncu: tests/tools/place_probe.hip).  false = not eligible.
+static int g_ncu = 256;
+static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phv, double ksum, bool final_out)
+{
+    const int mode = getenv("RVC_CONV_TILE") ? atoi(getenv("RVC_CONV_TILE")) : 1;       // 0 = off, 2 = wherever eligible (tests); read per plan
+    if (!mode || B != 1 || p.fold_n || p.x_ld <= 0 || p.x_hs || p.x_ws != 1 || p.y_hm || p.lin_cs4 || p.glu || p.ln_wsum || p.ln_stats_in || p.ln_stats_out || p.part) return false;
+    if (p.M > 128 && mode < 2) return false;
+    const int kshares = getenv("RVC_CONV_TILE_KS") ? atoi(getenv("RVC_CONV_TILE_KS")) : 2;      // tuning aid: 1 = four waves per tile
+    const int t128 = getenv("RVC_CONV_TILE_128") ? atoi(getenv("RVC_CONV_TILE_128")) : 0;          // tuning aid: tile of the > 64-row layers (0 = 128 x 16, 3 = 64 x 32)
+    const int tc0 = p.M > 64 ? t128 : (p.M > 32 ? 1 : 2), tc = tc0 == 3 ? 3 : tc0 + (kshares == 2 ? 4 : 0);
+    const int BM = kTileBM[tc0], BN = kTileBN[tc0];
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    if (ntm > 255 || ntn > 32767 || phv.size() > 255) return false;
+    const long long nitems = (long long)ntm * ntn * (long long)phv.size();
+    if (mode < 2 && nitems < 3 * g_ncu / 2) return false;                // short outputs: the K-split kernel fills the chip better
+    // per phase: (channel, tap) of every k from the gather table (entries are ci * ld + tap * dil - pad, k = ci * KW + tap); the kernel walks K
+    // tap-major in chunks of 16 channels, so the phase's weights are repacked: chunk t * G + g, slot kk <- k = (g * 16 + kk) * KW + t
+    std::vector<PhaseD> phs(phv);
+    std::vector<float> wnew;
+    size_t lds_max = 0;
+    const int mt = (p.M + 15) / 16;
+    for (PhaseD &q : phs) {
+        const int K = q.nchunks * 16;
+        int cin = 1;
+        for (int k = 0; k < K; k++) cin = std::max(cin, (int)std::floor((double)koff[q.koff_off + k] / p.x_ld + 0.5) + 1);
+        if (cin % 16 != 0 || K % cin != 0) return false;
+        const int KW = K / cin;
+        if (KW > 255) return false;
+        const int dmin = koff[q.koff_off];
+        const int dil = KW > 1 ? koff[q.koff_off + 1] - koff[q.koff_off] : 1;
+        if (dil < 1 || dil > 255 || dmin > 0 || dmin < p.x_lo) return false;
+        for (int k = 0; k < K; k++) if (koff[q.koff_off + k] != (k / KW) * p.x_ld + dmin + (k % KW) * dil) return false;
+        const int rl = BN + (KW - 1) * dil, rt = rl | 1, cs = cin + 8;
+        q.t_tab = KW | (dil << 8); q.t_cin = cin; q.t_rs = rt; q.t_dmin = dmin;
+        if (q.nchunks < 2) return false;
+        lds_max = std::max(lds_max, (std::max<size_t>(((size_t)cin * rt + 63) / 64 * 64, (size_t)kTileWF[tc0] * 256) + (size_t)rl * cs) * 4);
+        std::vector<float> wold((size_t)mt * q.nchunks * 256);
+        HIPCHK(hipMemcpy(wold.data(), p.w + q.w_off, wold.size() * 4, hipMemcpyDeviceToHost));
+        const size_t base = wnew.size();
+        wnew.resize(base + wold.size());
+        const int G = cin / 16;
+        for (int t = 0; t < mt; t++)
+            for (int tap = 0; tap < KW; tap++)
+                for (int g = 0; g < G; g++)
+                    for (int l = 0; l < 64; l++)
+                        for (int j = 0; j < 4; j++) {
+                            const int k = (g * 16 + (l >> 4) * 4 + j) * KW + tap;          // the source's k
+                            wnew[base + (((size_t)t * q.nchunks + tap * G + g) * 64 + l) * 4 + j] =
+                                wold[(((size_t)t * q.nchunks + k / 16) * 64 + (((k % 16) / 4) << 4 | (l & 15))) * 4 + (k % 4)];
+                        }
+        q.w_off = (long long)base;
+    }
+    if (lds_max > 100 * 1024) return false;
+    p.w = pl.arena.upload(wnew);
+    // work items, longest first, dealt to the CUs by longest-processing-time; block r * ncu + j = the r-th item of CU j
+    struct It { int w, code; };
+    std::vector<It> items;
+    for (size_t f = 0; f < phs.size(); f++)
+        for (int tm = 0; tm < ntm; tm++)
+            for (int tn = 0; tn < ntn; tn++) items.push_back({phs[f].nchunks + 12, (int)f | (tm << 8) | (tn << 16)});
+    std::stable_sort(items.begin(), items.end(), [](const It &a, const It &b) { return a.w > b.w; });
+    const int nb = g_ncu;
+    std::vector<std::vector<int>> bins(nb);
+    {
+        std::vector<std::pair<long long, int>> heap;        // (load, bin): min-heap by load, then bin
+        for (int j = 0; j < nb; j++) heap.push_back({0, j});
+        auto cmp = [](const std::pair<long long, int> &a, const std::pair<long long, int> &b) { return a > b; };
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        for (const It &it : items) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            auto &top = heap.back();
+            bins[top.second].push_back(it.code); top.first += it.w;
+            std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+    }
+    if (getenv("RVC_CONV_TILE_PLAIN")) {           // tuning aid: dispatch order = longest first, no pairing
+        for (auto &bn : bins) bn.clear();
+        for (size_t i = 0; i < items.size(); i++) bins[i % nb].push_back(items[i].code);
+    }
+    size_t rounds = 0;
+    for (auto &bn : bins) rounds = std::max(rounds, bn.size());
+    std::vector<int> order(rounds * nb, -1);
+    for (int j = 0; j < nb; j++) for (size_t r = 0; r < bins[j].size(); r++) order[r * nb + j] = bins[j][r];
+    p.items = pl.arena.upload(order);
+    p.ttab = nullptr;
+    p.ph = pl.arena.upload(phs);
+    p.nphase = (int)phs.size();
+    p.ph0 = phs[0];
+    p.ntm = ntm; p.ntn = ntn; p.ksplit = 1; p.nbatch = B; p.m_fast = 0;
+    const dim3 grid((unsigned)order.size(), (unsigned)B);
+    g_last_wgs = (int)nitems; g_last_waves = 4;
+    const double flops = 2.0 * p.M * (double)p.N * ksum * B;
+    pl.igemm_flops += flops; pl.n_igemm++;
+    Plan *plp = &pl;
+    { char d[200]; snprintf(d, sizeof d, "tile M=%d N=%d K=%d B=%d nph=%d tile=%dx%d items=%lld grid=%u lds=%zu pre=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, BM, BN, nitems, grid.x, lds_max, (int)(p.pre_act != ACT_NONE), ksum); pl.descs.push_back(d); }
+    const int desc_id = (int)pl.descs.size() - 1;
+    const IgemmP pc = p;
+    pl.ops.push_back([=](hipStream_t s) {
+        ProfEvent *pe = nullptr;
+        if (plp->profile) {
+            if (plp->prof_used == plp->prof.size()) { ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; e.bytes = 0; plp->prof.push_back(e); }
+            pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
+        }
+        hipEvent_t ea = pe ? pe->a : nullptr, eb = pe ? pe->b : nullptr;
+        if (final_out && plp->cur_out) { IgemmP q = pc; q.y = plp->cur_out; q.y_bs = plp->cur_out_bs; launch_conv_tile(tc, q, grid, lds_max, s, ea, eb); }
+        else launch_conv_tile(tc, pc, grid, lds_max, s, ea, eb);
+    });
+    return true;
+}
+
 // generic: the caller fills geometry (N, NW, strides, koff, phases); this picks the tile + split-K and queues the op
 static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases, bool final_out = false)
 {
@@ -411,6 +523,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     int lds_cfg = -1;
     bool phase_epi = false;                               // per-phase activation / output tensor: igemm2 only
     for (const PhaseD &q : phv) phase_epi = phase_epi || q.act_p1 != 0 || q.y_off != 0;
+    if (queue_conv_tile(pl, p, B, koff, phv, ksum, final_out)) return;
     const bool ln_fold = p.ln_wsum || p.ln_stats_in || phase_epi;      // folded LayerNorm lives in the register-direct kernel's K-split epilogue
     if (!ln_fold && !getenv("RVC_NO_LDS_GEMM") && nchunks >= 2 && (size_t)nchunks * 64 + 2 * 16 * 260 * 4 <= 60 * 1024) {
         int bm = p.M >= 96 ? 128 : (p.M >= 48 ? 64 : (p.M > 16 ? 32 : 0));
@@ -578,6 +691,7 @@ static void add_conv1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int 
     p.M = o.m_cnt >= 0 ? o.m_cnt : cw.M; p.N = y.T; p.K = cw.Kp;
     p.NW = y.T; p.x_hs = 0; p.x_ws = stride; p.y_hm = 0; p.y_ws = 1; p.OW = y.T;
     p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.ld; p.y_rs = 0;
+    p.x_ld = x.ld; p.x_lo = -x.halo; p.x_lim = x.T - 1 + x.halo;
     fill_epilogue(p, cw, o);
     // 1x1 convolution with a whole number of 16-row chunks: operand row k sits at k * channel stride, no offset table (igemm2 LIN)
     if (KW == 1 && cw.groups == 1 && pad == 0 && cw.K == cw.Kp) p.lin_cs4 = x.ld * 4;
@@ -610,6 +724,7 @@ static void add_conv1d_multi(Plan &pl, const std::vector<const ConvW *> &cws, co
     p.M = c0.M; p.N = y.T; p.K = 0;
     p.NW = y.T; p.x_hs = 0; p.x_ws = 1; p.y_hm = 0; p.y_ws = 1; p.OW = y.T;
     p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.ld; p.y_rs = 0;
+    p.x_ld = x.ld; p.x_lo = -x.halo; p.x_lim = x.T - 1 + x.halo;
     fill_epilogue(p, c0, o);
     p.res_nogroup = res_grouped ? 0 : 1;
     std::vector<int> koff;
@@ -1292,6 +1407,7 @@ static void configure_aux_streams(rvc_engine *e)
 {
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, e->device));
     int ncu = prop.multiProcessorCount, nf0 = ncu / 8;
+    g_ncu = ncu > 0 ? ncu : 256;
     if (const char *f = getenv("RVC_F0_CUS")) { const int v = atoi(f); if (v >= 8 && v < ncu) nf0 = v; }   // tuning aid
     if (!e->sset) {
         e->sset = acquire_stream_set(e->device, ncu, nf0, e->partition_ok && ncu >= 64 && ncu <= 1024);
@@ -2822,15 +2938,32 @@ double rvc_debug_conv_bench(rvc_engine *e, int M, int Cin, int KW, int dil, int 
             us = t_cold;
             return RVC_OK;
         }
-        for (int i = 0; i < 3; i++) for (auto &op : pl.ops.v) op(e->stream);
+        // RVC_BENCH_COLD=<MB>: rotate through enough copies of the weights that every launch reads them from HBM (what a chunk does:
+        // the models together exceed the 256 MB memory-side cache)
+        std::vector<ConvW> cold_w; std::vector<Plan *> cold_p;
+        if (const char *cm = getenv("RVC_BENCH_COLD")) {
+            const size_t per = w.size() * 4, want = (size_t)atoi(cm) << 20;
+            const int ncopy = (int)std::min<size_t>(512, std::max<size_t>(2, (want + per - 1) / per));
+            for (int k = 0; k < ncopy; k++) {
+                cold_w.push_back(prep_conv(w.data(), bias.data(), M, Cin, KW, 1));
+                Plan *q = new Plan; q->B = Bb;
+                add_conv1d(*q, cold_w.back(), x, y, 1, pad, dil, o);
+                cold_p.push_back(q);
+            }
+            HIPCHK(hipDeviceSynchronize());
+        }
+        auto run_once = [&](int i) { if (cold_p.empty()) { for (auto &op : pl.ops.v) op(e->stream); } else { for (auto &op : cold_p[i % cold_p.size()]->ops.v) op(e->stream); } };
+        for (int i = 0; i < 3; i++) run_once(i);
         hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
         HIPCHK(hipEventRecord(a, e->stream));
-        for (int i = 0; i < iters; i++) for (auto &op : pl.ops.v) op(e->stream);
+        for (int i = 0; i < iters; i++) run_once(i + 3);
         HIPCHK(hipEventRecord(b, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         float ms; HIPCHK(hipEventElapsedTime(&ms, a, b));
         us = ms * 1e3 / iters;
         (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        for (Plan *q : cold_p) delete q;
+        for (auto &cwk : cold_w) free_conv(cwk);
         free_conv(cw);
         return RVC_OK;
     });
@@ -3142,4 +3275,5 @@ rvc_status rvc_get_tap(rvc_engine *e, const char *name, float *out, size_t cap, 
 #define RVC_IGEMM2_CFG 4
 #include "igemm2_inst.hip"
 #include "igemm_tiled_inst.hip"
+#include "conv_tile_inst.hip"
 #endif

@@ -48,6 +48,11 @@ struct PhaseD {
     int act_p1;        // this phase's epilogue activation + 1 (0: the launch's IgemmP::act)
     int pad_;
     long long y_off;   // element offset of this phase's output tensor from IgemmP::y
+    // conv_tile_kernel only (conv_tile.hip.h): the staged input tile of this phase
+    int t_tab;         // offset of the phase's LDS-offset table in IgemmP::ttab (ints; padded to whole 256-int pieces)
+    int t_cin;         // input rows staged
+    int t_rs;          // LDS row stride (floats) = BN + reach of the taps, padded
+    int t_dmin;        // column of the leftmost tap relative to the output column (<= 0)
 };
 
 struct IgemmP {
@@ -87,6 +92,10 @@ struct IgemmP {
     float *ln_stats_out;     // [N][2]
     const float *ln_stats_in, *ln_g, *ln_bt;
     float ln_eps, ln_inv_rows;
+    // conv_tile_kernel (conv_tile.hip.h): work-item table (phase | m-tile << 8 | n-tile << 16, or -1) indexed by blockIdx.x, LDS-offset
+    // tables, and the input row geometry (row stride, first / last readable column of a row: the halo)
+    const int *items, *ttab;
+    int x_ld, x_lo, x_lim, pad2_;
 };
 
 __device__ __forceinline__ void epilogue_store(const IgemmP &p, const PhaseD &ph, int b, int m, int n, float acc)

@@ -573,13 +573,25 @@ def test_every_tile_configuration_computes_the_same_convolution():
                     e1 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, 1, pre)
                     assert 0 <= e1 < 2e-5, (cfg, ks, M, Cin, KW, dil, N, pre, e1)
         os.environ.pop("RVC_FORCE_CFG")
+        # conv_tile_kernel (one stream, stride-1 1-D convolutions whose input channels come in 16s: input tile staged once per workgroup, K walked
+        # tap-major from repacked weights): every tile shape, with one and two K shares, forced onto short and long layers alike
+        for tile128 in ("0", "3"):
+            for ks in ("1", "2"):
+                os.environ.update(RVC_CONV_TILE="2", RVC_CONV_TILE_KS=ks, RVC_CONV_TILE_128=tile128)
+                for (M, Cin, KW, dil, N, pre) in [(40, 32, 7, 3, 300, 1), (64, 512, 3, 1, 50, 0), (33, 16, 11, 1, 130, 1), (100, 48, 5, 2, 1000, 0), (128, 128, 7, 3, 2520, 1),
+                                                  (128, 128, 11, 5, 700, 1), (32, 32, 11, 1, 10080, 1), (64, 64, 7, 1, 5040, 0), (16, 16, 1, 1, 40, 0), (256, 64, 3, 1, 97, 1)]:
+                    e3 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, 1, pre)
+                    assert 0 <= e3 < 2e-5, ("conv_tile", tile128, ks, M, Cin, KW, dil, N, pre, e3)
+        for k in ("RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_CONV_TILE_128"):
+            os.environ.pop(k, None)
         for streams in (3, 20):                            # folded streams; 20 streams reach the workgroup-tiled kernels on the wide layers
             # (+ a 48-row panel wide enough for the 48 x 256 workgroup tile, a 32-row and a 64-row panel for the narrow 32x32x2 tiles)
             for (M, Cin, KW, dil, N, pre) in shapes + [(128, 128, 7, 3, 2520, 1), (768, 256, 1, 1, 111, 0), (48, 48, 15, 1, 5000, 0), (32, 32, 11, 1, 10080, 1), (64, 64, 7, 1, 5040, 0)]:
                 e2 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, streams, pre)
                 assert 0 <= e2 < 2e-5, (streams, M, Cin, KW, dil, N, pre, e2)
     finally:
-        os.environ.pop("RVC_FORCE_CFG", None)
+        for k in ("RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_CONV_TILE_128"):
+            os.environ.pop(k, None)
         L.rvc_destroy(h)
 
 

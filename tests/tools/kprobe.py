@@ -14,8 +14,8 @@ CSRC = os.path.join(ROOT, "obs_rvc_amd", "csrc")
 SO = os.path.join(CSRC, "librvc_kprobe%s.so" % os.environ.get("KPROBE_TAG", ""))
 EXTRA = os.environ.get("KPROBE_FLAGS", "").split()
 src = os.path.join(CSRC, "engine.hip")
-if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(os.path.join(CSRC, f)) for f in ("engine.hip", "kernels.hip.h")):
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRVC_KPROBE", "-DRVC_UNITY"] + EXTRA + [src, "-o", SO])
+if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(os.path.join(CSRC, f)) for f in ("engine.hip", "kernels.hip.h", "igemm.hip.h", "conv_tile.hip.h")):
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRVC_KPROBE", "-DRVC_UNITY"] + EXTRA + [src, os.path.join(CSRC, "synth_front.hip"), "-o", SO])
 if len(sys.argv) < 6:
     raise SystemExit("built " + SO)
 M, Cin, KW, dil, N = [int(v) for v in sys.argv[1:6]]
