@@ -260,6 +260,7 @@ def test_native_session_per_stream_settings():
         batched.set_params(0, 1.0, stream=3)
 
 
+@pytest.mark.gpu
 def test_native_session_at_the_plugin_maximum_settings():
     # 1.5 s chunks: the 72 960-sample downsampler chunk no longer fits the LDS-resident polyphase row (global-memory row fallback);
     # native session vs the host-side state machine over a second engine (tight), and vs the all-CPU chain while the SOLA offsets
