@@ -64,11 +64,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_
     constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
     constexpr int DA = MF == 1 ? 8 : 6;            // weight chunks in flight per wave
     extern __shared__ __attribute__((aligned(16))) int s_mem[];
-    const int item = p.items[blockIdx.x];
+    const int item = p.items[2 * blockIdx.x];
     if (item < 0) return;
     RVC_KP(0);
     const int phase = item & 0xff, tm = (item >> 8) & 0xff, tn = item >> 16;
-    const int b = (int)blockIdx.y;
+    const int b = p.items[2 * blockIdx.x + 1];
     const PhaseD ph = p.nphase == 1 ? p.ph0 : p.ph[phase];
     const int nchunks = ph.nchunks;
     const int lane = threadIdx.x & 63;

@@ -6,26 +6,31 @@
 
 namespace rvc {
 
-void launch_conv_tile(int tc, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
+void launch_conv_tile(int tile, int kshares, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
 {
-    // tc = tile (0: 128 x 16, 1: 64 x 32, 2: 32 x 64) + 4 * (K shares - 1)
+#define RVC_CT_ALL(X) X(4, 1, 2, 1, 1) X(4, 1, 1, 2, 1) X(2, 2, 1, 2, 1) X(4, 1, 2, 1, 2) X(4, 1, 1, 2, 2) X(2, 2, 1, 2, 2) X(2, 1, 2, 2, 2) \
+                      X(4, 1, 2, 4, 1) X(4, 1, 1, 4, 1) X(2, 2, 1, 4, 1) X(4, 1, 2, 4, 2) X(4, 1, 1, 4, 2) X(2, 2, 1, 4, 2) X(4, 1, 2, 2, 1) X(4, 1, 2, 2, 2)
     static const bool big_lds = [] {        // tiles of the long-dilation phases pass 64 KB
-        for (const void *f : {(const void *)conv_tile_kernel<4, 1, 2, 1, 1>, (const void *)conv_tile_kernel<4, 1, 1, 2, 1>, (const void *)conv_tile_kernel<2, 2, 1, 2, 1>,
-                              (const void *)conv_tile_kernel<4, 1, 2, 1, 2>, (const void *)conv_tile_kernel<4, 1, 1, 2, 2>, (const void *)conv_tile_kernel<2, 2, 1, 2, 2>,
-                              (const void *)conv_tile_kernel<2, 1, 2, 2, 2>})
-            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+#define RVC_CT_ATTR(a, b, c, d, e) (void)hipFuncSetAttribute((const void *)conv_tile_kernel<a, b, c, d, e>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        RVC_CT_ALL(RVC_CT_ATTR)
+#undef RVC_CT_ATTR
         return true;
     }();
     (void)big_lds;
-    switch (tc) {
-    case 0: launch_k(conv_tile_kernel<4, 1, 2, 1, 1>, p, grid, dim3(256), lds, s, ea, eb); return;
-    case 1: launch_k(conv_tile_kernel<4, 1, 1, 2, 1>, p, grid, dim3(256), lds, s, ea, eb); return;
-    case 2: launch_k(conv_tile_kernel<2, 2, 1, 2, 1>, p, grid, dim3(256), lds, s, ea, eb); return;
-    case 3: launch_k(conv_tile_kernel<2, 1, 2, 2, 2>, p, grid, dim3(256), lds, s, ea, eb); return;        // 64 x 32: two waves stacked in M x two K shares, 2 x 2 fragments per wave
-    case 4: launch_k(conv_tile_kernel<4, 1, 2, 1, 2>, p, grid, dim3(512), lds, s, ea, eb); return;
-    case 5: launch_k(conv_tile_kernel<4, 1, 1, 2, 2>, p, grid, dim3(512), lds, s, ea, eb); return;
-    default: launch_k(conv_tile_kernel<2, 2, 1, 2, 2>, p, grid, dim3(512), lds, s, ea, eb); return;
+#define RVC_CT_GO(a, b, c, d, e) { launch_k(conv_tile_kernel<a, b, c, d, e>, p, grid, dim3(64 * a * b * e), lds, s, ea, eb); return; }
+    const int k2 = kshares == 2;
+    switch (tile) {
+    case 0: if (k2) RVC_CT_GO(4, 1, 2, 1, 2) else RVC_CT_GO(4, 1, 2, 1, 1)
+    case 1: if (k2) RVC_CT_GO(4, 1, 1, 2, 2) else RVC_CT_GO(4, 1, 1, 2, 1)
+    case 2: if (k2) RVC_CT_GO(2, 2, 1, 2, 2) else RVC_CT_GO(2, 2, 1, 2, 1)
+    case 3: RVC_CT_GO(2, 1, 2, 2, 2)
+    case 4: if (k2) RVC_CT_GO(4, 1, 2, 4, 2) else RVC_CT_GO(4, 1, 2, 4, 1)
+    case 5: if (k2) RVC_CT_GO(4, 1, 1, 4, 2) else RVC_CT_GO(4, 1, 1, 4, 1)
+    case 7: if (k2) RVC_CT_GO(4, 1, 2, 2, 2) else RVC_CT_GO(4, 1, 2, 2, 1)
+    default: if (k2) RVC_CT_GO(2, 2, 1, 4, 2) else RVC_CT_GO(2, 2, 1, 4, 1)
     }
+#undef RVC_CT_GO
+#undef RVC_CT_ALL
 }
 
 }  // namespace rvc

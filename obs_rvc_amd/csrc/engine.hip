@@ -349,16 +349,22 @@ static int g_ncu = 256;
 static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phv, double ksum, bool final_out)
 {
     const int mode = getenv("RVC_CONV_TILE") ? atoi(getenv("RVC_CONV_TILE")) : 1;       // 0 = off, 2 = wherever eligible (tests); read per plan
-    if (!mode || B != 1 || p.fold_n || p.x_ld <= 0 || p.x_hs || p.x_ws != 1 || p.y_hm || p.lin_cs4 || p.glu || p.ln_wsum || p.ln_stats_in || p.ln_stats_out || p.part) return false;
-    if (p.M > 128 && mode < 2) return false;
-    const int kshares = getenv("RVC_CONV_TILE_KS") ? atoi(getenv("RVC_CONV_TILE_KS")) : 2;      // tuning aid: 1 = four waves per tile
+    auto no = [&](int why) { if (getenv("RVC_CONV_TILE_DEBUG")) fprintf(stderr, "conv_tile: not taken (%d) M=%d N=%d B=%d\n", why, p.M, p.N, B); return false; };
+    const int multi = getenv("RVC_CONV_TILE_MULTI") ? atoi(getenv("RVC_CONV_TILE_MULTI")) : 0;   // streams from which the wide tiles take over (0 = one stream only)
+    if (!mode || p.fold_n || p.x_ld <= 0 || p.x_hs || p.x_ws != 1 || p.y_hm || p.lin_cs4 || p.glu || p.ln_wsum || p.ln_stats_in || p.ln_stats_out || p.part) return no(1);
+    if (B != 1 && !(multi > 0 && B >= multi)) return no(2);
+    if (p.M > 128 && mode < 2) return no(3);
+    const bool wide = B != 1;
+    int kshares = getenv("RVC_CONV_TILE_KS") ? atoi(getenv("RVC_CONV_TILE_KS")) : (wide ? 1 : 2);      // tuning aid: 1 = one wave per fragment set
     const int t128 = getenv("RVC_CONV_TILE_128") ? atoi(getenv("RVC_CONV_TILE_128")) : 0;          // tuning aid: tile of the > 64-row layers (0 = 128 x 16, 3 = 64 x 32)
-    const int tc0 = p.M > 64 ? t128 : (p.M > 32 ? 1 : 2), tc = tc0 == 3 ? 3 : tc0 + (kshares == 2 ? 4 : 0);
+    const int w128 = getenv("RVC_CONV_TILE_W128") ? atoi(getenv("RVC_CONV_TILE_W128")) : 4;        // tuning aid: wide tile of the > 64-row layers (4 = 128 x 64, 7 = 128 x 32)
+    const int tc0 = wide ? (p.M > 64 ? w128 : (p.M > 32 ? 5 : 6)) : (p.M > 64 ? t128 : (p.M > 32 ? 1 : 2));
+    if (tc0 == 3) kshares = 2;
     const int BM = kTileBM[tc0], BN = kTileBN[tc0];
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-    if (ntm > 255 || ntn > 32767 || phv.size() > 255) return false;
-    const long long nitems = (long long)ntm * ntn * (long long)phv.size();
-    if (mode < 2 && nitems < 3 * g_ncu / 2) return false;                // short outputs: the K-split kernel fills the chip better
+    if (ntm > 255 || ntn > 32767 || phv.size() > 255) return no(4);
+    const long long nitems = (long long)ntm * ntn * (long long)phv.size() * B;
+    if (mode < 2 && nitems < 3 * g_ncu / 2) return no(5);                // short outputs: the K-split kernel fills the chip better
     // per phase: (channel, tap) of every k from the gather table (entries are ci * ld + tap * dil - pad, k = ci * KW + tap); the kernel walks K
     // tap-major in chunks of 16 channels, so the phase's weights are repacked: chunk t * G + g, slot kk <- k = (g * 16 + kk) * KW + t
     std::vector<PhaseD> phs(phv);
@@ -369,16 +375,16 @@ static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &
         const int K = q.nchunks * 16;
         int cin = 1;
         for (int k = 0; k < K; k++) cin = std::max(cin, (int)std::floor((double)koff[q.koff_off + k] / p.x_ld + 0.5) + 1);
-        if (cin % 16 != 0 || K % cin != 0) return false;
+        if (cin % 16 != 0 || K % cin != 0) return no(6);
         const int KW = K / cin;
-        if (KW > 255) return false;
+        if (KW > 255) return no(7);
         const int dmin = koff[q.koff_off];
         const int dil = KW > 1 ? koff[q.koff_off + 1] - koff[q.koff_off] : 1;
-        if (dil < 1 || dil > 255 || dmin > 0 || dmin < p.x_lo) return false;
-        for (int k = 0; k < K; k++) if (koff[q.koff_off + k] != (k / KW) * p.x_ld + dmin + (k % KW) * dil) return false;
+        if (dil < 1 || dil > 255 || dmin > 0 || dmin < p.x_lo) return no(8);
+        for (int k = 0; k < K; k++) if (koff[q.koff_off + k] != (k / KW) * p.x_ld + dmin + (k % KW) * dil) return no(9);
         const int rl = BN + (KW - 1) * dil, rt = rl | 1, cs = cin + 8;
         q.t_tab = KW | (dil << 8); q.t_cin = cin; q.t_rs = rt; q.t_dmin = dmin;
-        if (q.nchunks < 2) return false;
+        if (q.nchunks < 2) return no(10);
         lds_max = std::max(lds_max, (std::max<size_t>(((size_t)cin * rt + 63) / 64 * 64, (size_t)kTileWF[tc0] * 256) + (size_t)rl * cs) * 4);
         std::vector<float> wold((size_t)mt * q.nchunks * 256);
         HIPCHK(hipMemcpy(wold.data(), p.w + q.w_off, wold.size() * 4, hipMemcpyDeviceToHost));
@@ -396,44 +402,46 @@ static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &
                         }
         q.w_off = (long long)base;
     }
-    if (lds_max > 100 * 1024) return false;
+    if (lds_max > (wide ? 150 : 100) * 1024) return no(11);
     p.w = pl.arena.upload(wnew);
     // work items, longest first, dealt to the CUs by longest-processing-time; block r * ncu + j = the r-th item of CU j
-    struct It { int w, code; };
+    struct It { int w, code, b; };
     std::vector<It> items;
-    for (size_t f = 0; f < phs.size(); f++)
-        for (int tm = 0; tm < ntm; tm++)
-            for (int tn = 0; tn < ntn; tn++) items.push_back({phs[f].nchunks + 12, (int)f | (tm << 8) | (tn << 16)});
+    for (int bb = 0; bb < B; bb++)
+        for (size_t f = 0; f < phs.size(); f++)
+            for (int tm = 0; tm < ntm; tm++)
+                for (int tn = 0; tn < ntn; tn++) items.push_back({phs[f].nchunks + 12, (int)f | (tm << 8) | (tn << 16), bb});
     std::stable_sort(items.begin(), items.end(), [](const It &a, const It &b) { return a.w > b.w; });
     const int nb = g_ncu;
-    std::vector<std::vector<int>> bins(nb);
+    std::vector<std::vector<int>> bins(nb);          // indices into items
     {
         std::vector<std::pair<long long, int>> heap;        // (load, bin): min-heap by load, then bin
         for (int j = 0; j < nb; j++) heap.push_back({0, j});
         auto cmp = [](const std::pair<long long, int> &a, const std::pair<long long, int> &b) { return a > b; };
         std::make_heap(heap.begin(), heap.end(), cmp);
-        for (const It &it : items) {
+        for (size_t i = 0; i < items.size(); i++) {
             std::pop_heap(heap.begin(), heap.end(), cmp);
             auto &top = heap.back();
-            bins[top.second].push_back(it.code); top.first += it.w;
+            bins[top.second].push_back((int)i); top.first += items[i].w;
             std::push_heap(heap.begin(), heap.end(), cmp);
         }
     }
     if (getenv("RVC_CONV_TILE_PLAIN")) {           // tuning aid: dispatch order = longest first, no pairing
         for (auto &bn : bins) bn.clear();
-        for (size_t i = 0; i < items.size(); i++) bins[i % nb].push_back(items[i].code);
+        for (size_t i = 0; i < items.size(); i++) bins[i % nb].push_back((int)i);
     }
     size_t rounds = 0;
     for (auto &bn : bins) rounds = std::max(rounds, bn.size());
-    std::vector<int> order(rounds * nb, -1);
-    for (int j = 0; j < nb; j++) for (size_t r = 0; r < bins[j].size(); r++) order[r * nb + j] = bins[j][r];
+    std::vector<int> order(rounds * nb * 2, -1);
+    for (int j = 0; j < nb; j++)
+        for (size_t r = 0; r < bins[j].size(); r++) { order[(r * nb + j) * 2] = items[bins[j][r]].code; order[(r * nb + j) * 2 + 1] = items[bins[j][r]].b; }
     p.items = pl.arena.upload(order);
     p.ttab = nullptr;
     p.ph = pl.arena.upload(phs);
     p.nphase = (int)phs.size();
     p.ph0 = phs[0];
     p.ntm = ntm; p.ntn = ntn; p.ksplit = 1; p.nbatch = B; p.m_fast = 0;
-    const dim3 grid((unsigned)order.size(), (unsigned)B);
+    const dim3 grid((unsigned)(order.size() / 2), 1u);
     g_last_wgs = (int)nitems; g_last_waves = 4;
     const double flops = 2.0 * p.M * (double)p.N * ksum * B;
     pl.igemm_flops += flops; pl.n_igemm++;
@@ -448,8 +456,8 @@ static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &
             pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
         }
         hipEvent_t ea = pe ? pe->a : nullptr, eb = pe ? pe->b : nullptr;
-        if (final_out && plp->cur_out) { IgemmP q = pc; q.y = plp->cur_out; q.y_bs = plp->cur_out_bs; launch_conv_tile(tc, q, grid, lds_max, s, ea, eb); }
-        else launch_conv_tile(tc, pc, grid, lds_max, s, ea, eb);
+        if (final_out && plp->cur_out) { IgemmP q = pc; q.y = plp->cur_out; q.y_bs = plp->cur_out_bs; launch_conv_tile(tc0, kshares, q, grid, lds_max, s, ea, eb); }
+        else launch_conv_tile(tc0, kshares, pc, grid, lds_max, s, ea, eb);
     });
     return true;
 }
@@ -462,6 +470,15 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     // B * N columns -- the ContentVec window (N = 111), the text encoder (N = 21) or RMVPE's deep levels (N = 4..64) no longer pad
     // every stream up to a tile.  All offsets stay below 2^31 bytes / elements for every geometry the plugin can ask for (checked).
     const int streams = B;
+    if (B > 1) {
+        // many streams, stride-1 1-D convolution: the staged-tile kernel with its wide tiles, streams as a grid dimension (tried before the fold)
+        std::vector<PhaseD> phq(phases);
+        double ks0 = 0;
+        for (PhaseD &q : phq) { if (q.nchunks == 0) q.nchunks = p.K / 16; ks0 += q.nchunks * 16.0; }
+        std::stable_sort(phq.begin(), phq.end(), [](const PhaseD &a, const PhaseD &b) { return a.nchunks > b.nchunks; });
+        IgemmP pt = p;
+        if (queue_conv_tile(pl, pt, B, koff, phq, ks0, final_out)) return;
+    }
     if (B > 1 && !getenv("RVC_NO_FOLD")) {
         const long long lim = (1LL << 29);
         if ((long long)B * p.x_bs < lim && (long long)B * p.y_bs < lim && (long long)B * (p.res ? p.res_bs : 0) < lim && (long long)B * p.N < (1LL << 30) &&

@@ -8,6 +8,9 @@ SHAPES = {  # name: (M, Cin, KW, dil, N)
     "cv_qkv": (2304, 768, 1, 1, 111), "cv_o": (768, 768, 1, 1, 111), "cv_ff1": (3072, 768, 1, 1, 111), "cv_ff2": (768, 3072, 1, 1, 111),
     "hg3_k11": (32, 32, 11, 1, 10080), "hg3_k3": (32, 32, 3, 5, 10080), "hg2_k11": (64, 64, 11, 1, 5040), "hg1_k7": (128, 128, 7, 3, 2520),
     "hg0_k11": (256, 256, 11, 1, 252), "rm_l5x64": (512, 512, 3, 1, 256), "rm_l4x64": (256, 256, 9, 1, 1024), "rm_l3x64": (128, 128, 9, 1, 4096), "cv_conv2": (512, 512, 3, 1, 1791), "enc_ff1": (768, 192, 3, 1, 21),
+    "d128_k3": (128, 128, 3, 1, 2520), "d128_k7": (128, 128, 7, 1, 2520), "d128_k11": (128, 128, 11, 1, 2520), "d128_k11d5": (128, 128, 11, 5, 2520),
+    "d64_k3": (64, 64, 3, 1, 5040), "d64_k7": (64, 64, 7, 1, 5040), "d64_k11": (64, 64, 11, 1, 5040), "d64_k11d5": (64, 64, 11, 5, 5040),
+    "d32_k3": (32, 32, 3, 1, 10080), "d32_k7": (32, 32, 7, 1, 10080), "d32_k11": (32, 32, 11, 1, 10080), "d32_k11d5": (32, 32, 11, 5, 10080),
 }
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
