@@ -757,6 +757,131 @@ __global__ __launch_bounds__(256) void relpos_attention_small_kernel(AttnP p)
     }
 }
 
+// The same attention on the matrix cores (one stream: the VALU kernel above is a latency chain of ~200 dependent LDS-read + FMA steps per lane,
+// 12.4 us per layer).  grid = (heads * ceil(T / 16), streams): a workgroup owns 16 query columns of one head.  Every product is a 16x16x4 fp32
+// MFMA (A[i = lane & 15][k = lane >> 4], B[k][j = lane & 15], D[row = (lane >> 4) * 4 + r][col = lane & 15]):
+//   scores[i][j] = sum_d q[d][i] k[d][j]            P[i][r] = sum_d q[d][i] rel_k[r][d]        scores[i][j] += P[i][j - i + W] inside the window
+//   out[c][i]    = sum_j v[c][j] S[i][j] + sum_r rel_v[r][c] Ssk[i][r]      with Ssk[i][r] = S[i][i + r - W] (zero outside [0, T))
+// Padded k (j >= T, r >= NR) multiplies a ZEROED S / Ssk entry by a finite staged value; padded rows / columns of D are not stored.
+__global__ __launch_bounds__(256) void relpos_attention_mfma_kernel(AttnP p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = 256;
+    const int kc = p.E / p.heads, T = p.T, TP = T | 1, Wd = p.window, NR = 2 * Wd + 1, NRP = (NR + 3) & ~3;
+    const int JF = (T + 15) >> 4, SW = JF * 16, RF = (NR + 15) >> 4, PW = RF * 16;
+    const int h = blockIdx.x / JF, qb = blockIdx.x - h * JF, b = blockIdx.y;
+    const int col0 = qb * 16, nq = T - col0 < 16 ? T - col0 : 16;
+    float *q = smem, *kk = q + kc * 16, *vv = kk + kc * TP, *rk = vv + kc * TP, *rv = rk + PW * kc;
+    float *Sx = rv + NRP * kc, *P = Sx + 16 * SW, *Ssk = P + 16 * PW;
+    const float *base = p.qkv + (long long)b * p.bs;
+    // staging: every global load is issued before the first LDS write (one memory round trip)
+    const int tsh = T <= 32 ? 5 : 6, tmask = (1 << tsh) - 1;
+    constexpr int KV_IT = 16, RT_IT = 12, Q_IT = 6;
+    const int kv_n = kc << tsh, rk_n = PW * kc, rv_n = NRP * kc, rt_n = NR * kc, q_n = kc * 16;
+    float kr[KV_IT], vr[KV_IT], rkr[RT_IT], rvr[RT_IT], qr[Q_IT];
+#pragma unroll
+    for (int u = 0; u < Q_IT; u++) {
+        const int idx = threadIdx.x + u * NT, d = idx >> 4, c = idx & 15;
+        qr[u] = (idx < q_n && c < nq) ? base[(long long)(h * kc + d) * p.cs + col0 + c] * p.scale : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < KV_IT; u++) {
+        const int idx = threadIdx.x + u * NT, d = idx >> tsh, t = idx & tmask;
+        const bool ok = idx < kv_n && t < T;
+        kr[u] = ok ? base[(long long)(p.E + h * kc + d) * p.cs + t] : 0.f;
+        vr[u] = ok ? base[(long long)(2 * p.E + h * kc + d) * p.cs + t] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < RT_IT; u++) {
+        const int j = threadIdx.x + u * NT;
+        rkr[u] = j < rt_n ? p.rel_k[j] : 0.f;
+        rvr[u] = j < rt_n ? p.rel_v[j] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < Q_IT; u++) { const int idx = threadIdx.x + u * NT; if (idx < q_n) q[idx] = qr[u]; }
+#pragma unroll
+    for (int u = 0; u < KV_IT; u++) {
+        const int idx = threadIdx.x + u * NT, d = idx >> tsh, t = idx & tmask;
+        if (idx < kv_n && t < TP) { kk[d * TP + t] = kr[u]; vv[d * TP + t] = vr[u]; }       // (column T of the odd padding: zero)
+    }
+#pragma unroll
+    for (int u = 0; u < RT_IT; u++) {
+        const int j = threadIdx.x + u * NT;
+        if (j < rk_n) rk[j] = rkr[u];
+        if (j < rv_n) rv[j] = rvr[u];
+    }
+    // sizes beyond the unrolled staging (no official configuration: 2 heads x 96, window 10, T <= 32)
+    for (int idx = threadIdx.x + Q_IT * NT; idx < q_n; idx += NT) { const int d = idx >> 4, c = idx & 15; q[idx] = c < nq ? base[(long long)(h * kc + d) * p.cs + col0 + c] * p.scale : 0.f; }
+    for (int idx = threadIdx.x + KV_IT * NT; idx < kv_n; idx += NT) {
+        const int d = idx >> tsh, t = idx & tmask;
+        if (t < TP) { kk[d * TP + t] = t < T ? base[(long long)(p.E + h * kc + d) * p.cs + t] : 0.f; vv[d * TP + t] = t < T ? base[(long long)(2 * p.E + h * kc + d) * p.cs + t] : 0.f; }
+    }
+    for (int j = threadIdx.x + RT_IT * NT; j < rk_n; j += NT) rk[j] = j < rt_n ? p.rel_k[j] : 0.f;
+    for (int j = threadIdx.x + RT_IT * NT; j < rv_n; j += NT) rv[j] = j < rt_n ? p.rel_v[j] : 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
+    // scores and P: items (16-column block of keys), then (16-row block of relative positions), one per wave and pass
+    for (int it = wave; it < JF + RF; it += 4) {
+        const bool is_p = it >= JF;
+        const int f = is_p ? it - JF : it;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        const float *qa = q + kq * 16 + li;
+        const float *bb = is_p ? rk + (f * 16 + li) * kc + kq : kk + kq * TP + f * 16 + li;
+        const int bst = is_p ? 4 : 4 * TP;
+        for (int ks = 0; ks + 1 < kc / 4; ks += 2) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[ks * 64], bb[ks * bst], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[(ks + 1) * 64], bb[(ks + 1) * bst], a1, 0, 0, 0);
+        }
+        if ((kc / 4) & 1) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[(kc / 4 - 1) * 64], bb[(kc / 4 - 1) * bst], a0, 0, 0, 0);
+        a0 += a1;
+        float *dst = is_p ? P + f * 16 : Sx + f * 16;
+        const int dw = is_p ? PW : SW;
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[(kq * 4 + r) * dw + li] = a0[r];
+    }
+    __syncthreads();
+    // softmax with the relative-position term: 16 lanes per query row, keys strided over the lanes
+    {
+        const int i = threadIdx.x >> 4, gi = col0 + i;
+        float *Sr = Sx + i * SW, *Kr = Ssk + i * PW;
+        const float *Pr = P + i * PW;
+        float mx = -INFINITY;
+        if (gi < T) {
+            for (int j = li; j < T; j += 16) {
+                float a = Sr[j];
+                const int r = j - gi;
+                if (r >= -Wd && r <= Wd) a += Pr[r + Wd];
+                Sr[j] = a; mx = fmaxf(mx, a);
+            }
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+        float sum = 0.f;
+        if (gi < T) for (int j = li; j < T; j += 16) { const float ex = expf(Sr[j] - mx); Sr[j] = ex; sum += ex; }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 16);
+        const float inv = 1.0f / sum;
+        for (int j = li; j < SW; j += 16) Sr[j] = (gi < T && j < T) ? Sr[j] * inv : 0.f;
+        // (the 16 lanes of a row run in lockstep inside one wave: Sr is complete before it is read back skewed)
+        for (int r = li; r < PW; r += 16) { const int j = gi + r - Wd; Kr[r] = (gi < T && r < NR && j >= 0 && j < T) ? Sr[j] : 0.f; }
+    }
+    __syncthreads();
+    // attention output of the own columns: items = 16-channel blocks of the head
+    for (int cf = wave; cf < kc / 16; cf += 4) {
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        const float *va = vv + (cf * 16 + li) * TP + kq, *sb = Sx + li * SW + kq;
+        for (int ks = 0; ks < (T + 3) / 4; ks++) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va[ks * 4], sb[ks * 4], a0, 0, 0, 0);
+        const float *ra = rv + kq * kc + cf * 16 + li, *kb = Ssk + li * PW + kq;
+        for (int ks = 0; ks < NRP / 4; ks++) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[ks * 4 * kc], kb[ks * 4], a1, 0, 0, 0);
+        a0 += a1;
+        // D: row = channel cf * 16 + kq * 4 + r, col = query li
+        if (col0 + li < T) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) p.out[(long long)b * p.o_bs + (long long)(h * kc + cf * 16 + kq * 4 + r) * p.o_cs + col0 + li] = a0[r];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // RMVPE head: bidirectional GRU recurrence (input projections come from the implicit GEMM)
 // gi: [B][2*3H][ld] (forward gates rows 0..3H, backward rows 3H..6H; biases b_ih included)
