@@ -598,6 +598,10 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
         });
         return;
     }
+    // one stream, table-free layers of the ContentVec window (N = 111) that the size rule sends to lone 16 x 16 fragments: every B fragment costs
+    // four dword gathers (9-12 clocks each on the CU's single vector-memory path) for ONE MFMA row block; two fragments along N per wave and eight
+    // K shares halve the weight loads per MFMA (isolated: 768 x 3072 18.5 -> 14.9 us, 768 x 768 6.5 -> 5.7 us; in the chain: ContentVec -22 us)
+    if (cfg == 0 && wg_ks == 4 && B == 1 && !p.fold_n && p.lin_cs4 && p.nphase == 1 && p.M >= 256 && p.N > 64 && p.N <= 128 && nchunks >= 32 && !p.ln_wsum && !getenv("RVC_NO_LIN_16x32")) { cfg = 1; wg_ks = 8; }
     if (const char *f = getenv("RVC_TUNE")) {        // tuning aid: "M,K:cfg,ks;M,K:cfg,ks;..." overrides the tile choice of matching layers
         for (const char *q = f; q && *q; ) {
             int tm = 0, tk = 0, tc = 0, tks = 1;
