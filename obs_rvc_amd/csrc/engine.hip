@@ -20,6 +20,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <thread>
 
 // The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The engine runs four
 // streams concurrently per chunk; a second engine in the process, or the streams an RCCL communicator leaves behind, then share
@@ -1104,7 +1105,15 @@ struct ModelSY {
     struct Layer { ConvW qkv, o, ff1, ff2, qkv_f; float *qkv_wsum = nullptr; float *rel_k, *rel_v, *ln1_g, *ln1_b, *ln2_g, *ln2_b; };
     ConvW proj_f; float *proj_wsum = nullptr; bool has_folded = false;
     std::vector<Layer> layers;
-    struct Flow { ConvW pre, post; std::vector<ConvW> in, rs; bool flipped = false; };
+    struct Flow {
+        ConvW pre, post; std::vector<ConvW> in, rs; bool flipped = false;
+        // one stream: the WaveNet with its 1x1 res_skip layers composed into the following in-layers (compose_flows): host copies of the
+        // layer weights in model order, and the composed panels
+        std::vector<float> h_pre_w, h_pre_b, h_post_w, h_post_b;
+        std::vector<std::vector<float>> h_in_w, h_in_b, h_rs_w, h_rs_b;
+        ConvW pre1, postc; std::vector<ConvW> inc;
+    };
+    bool composed = false;
     std::vector<Flow> flows;
     ConvW dec_pre, dec_post;
     std::vector<ConvW> ups, ncs;
@@ -1166,6 +1175,7 @@ struct ModelSY {
                     for (int q = 0; q < half; q++) w[(size_t)r * half + q] = pw[(size_t)r * half + (F.flipped ? half - 1 - q : q)];
                 }
                 F.pre = prep_conv(w.data(), bb.data(), 2 * H, half, 1, 1);
+                F.h_pre_w.assign(w.begin(), w.begin() + (size_t)H * half); F.h_pre_b.assign(bb.begin(), bb.begin() + H);
             }
             // speaker conditioning is a load-time constant (sid baked, rvc.rs:186-187): fold cond(g) into the in-layer biases
             const float *cw = b.w(fmt("sy.flow%d.cond.w", i)), *cb = b.w(fmt("sy.flow%d.cond.b", i));
@@ -1190,9 +1200,11 @@ struct ModelSY {
                         pb[r] = bias[src];
                     }
                     F.in.push_back(prep_conv(w.data(), pb.data(), 2 * H, H, wn_k, 1));
+                    F.h_in_w.emplace_back(iw, iw + (size_t)2 * H * Kin); F.h_in_b.push_back(bias);
                 }
                 int rs_c = j < wn_layers - 1 ? 2 * H : H;
                 F.rs.push_back(prep_conv(b.w(fmt("sy.flow%d.rs%d.w", i, j)), b.w(fmt("sy.flow%d.rs%d.b", i, j)), rs_c, H, 1, 1));
+                { const float *rw = b.w(fmt("sy.flow%d.rs%d.w", i, j)), *rb = b.w(fmt("sy.flow%d.rs%d.b", i, j)); F.h_rs_w.emplace_back(rw, rw + (size_t)rs_c * H); F.h_rs_b.emplace_back(rb, rb + rs_c); }
             }
             {
                 const float *pw = b.w(fmt("sy.flow%d.post.w", i)), *pb = b.w(fmt("sy.flow%d.post.b", i));
@@ -1203,6 +1215,7 @@ struct ModelSY {
                     bb[r] = pb[src];
                 }
                 F.post = prep_conv(w.data(), bb.data(), half, H, 1, 1);
+                F.h_post_w = w; F.h_post_b = bb;
             }
             flows.push_back(F);
         }
@@ -1245,12 +1258,88 @@ struct ModelSY {
         // return audio of the wrong length without any error (e.g. an import that guessed the first upsample rate)
         if (sr != 100 * upp()) throw std::runtime_error(fmt("synthesizer: sr %d", sr) + fmt(" != 100 * prod(upsample rates) = %d", 100 * upp()));
     }
+    // One stream: every flow's WaveNet runs 4 x (gated k-tap in-layer, 1x1 res_skip layer) -- ten dependent launches of a 21-column window.  The
+    // res_skip layers are linear, so they are composed into what follows them (exactly, in double, at the first one-stream plan):
+    //   x_j = h0 + sum_{i<j} (R_i a_i + r_i)                      =>  in_j(x_j) = W_j * [1 | h0 | a_0 .. a_{j-1}]   with W_j(a_i) = W_j o R_i
+    //   post(skip) = P (sum_j S_j a_j + s_j) + p                   =>  one 1x1 layer over [a_0 .. a_{n-1}]
+    // (R_i / S_i: the residual / skip rows of res_skip layer i; the constant r_i rides on a row of ones -- zero in the halo, like the zero padding
+    // the in-layer sees -- so the edges of the window stay exact.)  Six launches per flow instead of ten.
+    void compose_flows()
+    {
+        if (composed) return;
+        const int H = hidden, half = inter / 2, K5 = wn_k, nl = wn_layers;
+        auto one_flow = [&](Flow &F, std::vector<std::vector<float>> &wj, std::vector<std::vector<float>> &bj, std::vector<float> &wpc, std::vector<float> &bpc) {
+            for (int j = 0; j < nl; j++) {
+                const int Cin = 16 + H * (j + 1);
+                std::vector<double> w((size_t)2 * H * Cin * K5, 0.0);
+                const float *W5 = F.h_in_w[j].data();                 // [2H][H][K5], model row order
+                for (int o = 0; o < 2 * H; o++)
+                    for (int m = 0; m < H; m++)
+                        for (int t = 0; t < K5; t++) w[((size_t)o * Cin + 16 + m) * K5 + t] = W5[((size_t)o * H + m) * K5 + t];
+                std::vector<double> acc(H);
+                for (int i = 0; i < j; i++) {
+                    const float *R = F.h_rs_w[i].data(), *rb = F.h_rs_b[i].data();      // rows 0..H: the residual part
+                    for (int o = 0; o < 2 * H; o++)
+                        for (int t = 0; t < K5; t++) {
+                            std::fill(acc.begin(), acc.end(), 0.0);
+                            double one = 0.0;
+                            for (int m = 0; m < H; m++) {
+                                const double v = W5[((size_t)o * H + m) * K5 + t];
+                                const float *Rm = R + (size_t)m * H;
+                                for (int c = 0; c < H; c++) acc[c] += v * Rm[c];
+                                one += v * rb[m];
+                            }
+                            for (int c = 0; c < H; c++) w[((size_t)o * Cin + 16 + H * (i + 1) + c) * K5 + t] = acc[c];
+                            w[((size_t)o * Cin) * K5 + t] += one;
+                        }
+                }
+                // GLU row packing, as for the plain in-layers
+                std::vector<float> wp((size_t)2 * H * Cin * K5), pb((size_t)2 * H);
+                for (int r = 0; r < 2 * H; r++) {
+                    const int f = r >> 4, kq = (r & 15) >> 2, rr = r & 3;
+                    const int src = f * 8 + kq * 2 + (rr & 1) + (rr >= 2 ? H : 0);
+                    for (size_t q = 0; q < (size_t)Cin * K5; q++) wp[(size_t)r * Cin * K5 + q] = (float)w[(size_t)src * Cin * K5 + q];
+                    pb[r] = F.h_in_b[j][src];
+                }
+                wj.push_back(std::move(wp)); bj.push_back(std::move(pb));
+            }
+            wpc.assign((size_t)half * nl * H, 0.f); bpc.assign(half, 0.f);
+            for (int r = 0; r < half; r++) {
+                double bacc = F.h_post_b[r];
+                for (int j = 0; j < nl; j++) {
+                    const int row0 = j < nl - 1 ? H : 0;                               // skip rows of res_skip layer j
+                    const float *S = F.h_rs_w[j].data() + (size_t)row0 * H, *sb = F.h_rs_b[j].data() + row0;
+                    std::vector<double> a(H, 0.0);
+                    for (int h = 0; h < H; h++) {
+                        const double v = F.h_post_w[(size_t)r * H + h];
+                        for (int c = 0; c < H; c++) a[c] += v * S[(size_t)h * H + c];
+                        bacc += v * sb[h];
+                    }
+                    for (int c = 0; c < H; c++) wpc[(size_t)r * nl * H + (size_t)j * H + c] = (float)a[c];
+                }
+                bpc[r] = (float)bacc;
+            }
+        };
+        const size_t nf = flows.size();
+        std::vector<std::vector<std::vector<float>>> WJ(nf), BJ(nf);
+        std::vector<std::vector<float>> WP(nf), BP(nf);
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < nf; i++) th.emplace_back([&, i]() { one_flow(flows[i], WJ[i], BJ[i], WP[i], BP[i]); });
+        for (auto &t : th) t.join();
+        for (size_t i = 0; i < nf; i++) {
+            Flow &F = flows[i];
+            F.pre1 = prep_conv(F.h_pre_w.data(), F.h_pre_b.data(), H, half, 1, 1);
+            for (int j = 0; j < nl; j++) F.inc.push_back(prep_conv(WJ[i][j].data(), BJ[i][j].data(), 2 * H, 16 + H * (j + 1), K5, 1));
+            F.postc = prep_conv(WP[i].data(), BP[i].data(), half, nl * H, 1, 1);
+        }
+        composed = true;
+    }
     ~ModelSY()
     {
         free_conv(phone); free_conv(proj); free_conv(dec_pre); free_conv(dec_post);
         for (auto &L : layers) { free_conv(L.qkv); free_conv(L.o); free_conv(L.ff1); free_conv(L.ff2); free_conv(L.qkv_f); if (L.qkv_wsum) (void)hipFree(L.qkv_wsum); }
         free_conv(proj_f); if (proj_wsum) (void)hipFree(proj_wsum);
-        for (auto &F : flows) { free_conv(F.pre); free_conv(F.post); for (auto &c : F.in) free_conv(c); for (auto &c : F.rs) free_conv(c); }
+        for (auto &F : flows) { free_conv(F.pre); free_conv(F.post); for (auto &c : F.in) free_conv(c); for (auto &c : F.rs) free_conv(c); if (composed) { free_conv(F.pre1); free_conv(F.postc); for (auto &c : F.inc) free_conv(c); } }
         for (auto &c : ups) free_conv(c);
         for (auto &c : ncs) free_conv(c);
         for (auto &s : rbs) for (auto &ch : s) for (auto &pr : ch) { free_conv(pr.first); free_conv(pr.second); }
@@ -1940,9 +2029,25 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         // hh (WaveNet state, rows 0..H) and skip (rows H..2H) share one tensor: the res_skip conv updates both in one launch
         T1 hs = make_t1(A, B, 2 * H, R, HALO), acts = make_t1(A, B, H, R, 0);
         T1 hh = hs.rows(0, H), skip = hs.rows(H, H);
+        // one stream: WaveNets with their res_skip layers composed away (ModelSY::compose_flows): 6 launches per flow instead of 10
+        const bool wn_composed = B == 1 && H % 16 == 0 && !pl.with_taps && !getenv("RVC_NO_WN_COMPOSE");
+        T1 U;
+        if (wn_composed) {
+            m.compose_flows();
+            U = make_t1(A, B, 16 + H * (m.wn_layers + 1), R, HALO);        // [ones block | h0 | a_0 .. a_{n-1}]
+            std::vector<float> ones(R, 1.0f);
+            HIPCHK(hipMemcpy(U.p, ones.data(), (size_t)R * sizeof(float), hipMemcpyHostToDevice));
+        }
         for (int fi = m.flow_n - 1; fi >= 0; fi--) {
             ModelSY::Flow &Fw = m.flows[fi];
             const T1 x0 = Fw.flipped ? z.rows(half, half) : z.rows(0, half), x1 = Fw.flipped ? z.rows(0, half) : z.rows(half, half);
+            if (wn_composed) {
+                add_conv1d(pl, Fw.pre1, x0, U.rows(16, H), 1, 0, 1);
+                for (int j = 0; j < m.wn_layers; j++) { ConvOpts o; o.glu = true; add_conv1d(pl, Fw.inc[j], U.rows(0, 16 + H * (j + 1)), U.rows(16 + H * (j + 1), H), 1, (m.wn_k - 1) / 2, 1, o); }
+                { ConvOpts o; o.scale = -1.f; o.accumulate = true; add_conv1d(pl, Fw.postc, U.rows(16 + H, m.wn_layers * H), x1, 1, 0, 1, o); }
+                add_stamp(pl, "sy.flow");
+                continue;
+            }
             add_conv1d(pl, Fw.pre, x0, hs, 1, 0, 1);                       // hh = pre(x0), skip = 0
             for (int j = 0; j < m.wn_layers; j++) {
                 { ConvOpts o; o.glu = true; add_conv1d(pl, Fw.in[j], hh, acts, 1, (m.wn_k - 1) / 2, 1, o); }   // acts = tanh(.) * sigmoid(.)

@@ -624,7 +624,7 @@ def test_persistent_synth_front_matches_layer_launches():
         finally:
             os.environ.pop("RVC_SYNTH_FRONT", None)
     assert info["persistent"][1] == 1 and info["layers"][1] == 0, info
-    assert info["persistent"][0] <= info["layers"][0] - 60, info          # ~70 layer launches became one
+    assert info["persistent"][0] <= info["layers"][0] - 40, info          # the ~55 remaining layer launches (the WaveNets already run composed: 6 per flow) became one
     for i in range(len(rings)):
         assert rms(outs["persistent"][i] - ref[i]) < PCM_TOL, (i, rms(outs["persistent"][i] - ref[i]))
         assert rms(outs["layers"][i] - ref[i]) < PCM_TOL
