@@ -1102,7 +1102,12 @@ struct ModelSY {
     float *pitch_emb = nullptr;
     // qkv_f: the projection with the previous layer's second LayerNorm folded in (ModelCV::fold_ln); proj_f likewise for the last layer.
     // (The first LayerNorm of a layer feeds a 3-tap convolution with zero padding: padded positions are zero AFTER the norm, so it stays.)
-    struct Layer { ConvW qkv, o, ff1, ff2, qkv_f; float *qkv_wsum = nullptr; float *rel_k, *rel_v, *ln1_g, *ln1_b, *ln2_g, *ln2_b; };
+    struct Layer {
+        ConvW qkv, o, ff1, ff2, qkv_f; float *qkv_wsum = nullptr; float *rel_k, *rel_v, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+        // one stream: q, k and V' = (W_o[:, head] W_v[head]) x per head, for the attention block that also applies the output projection
+        // (kernels.hip.h te_attention_block_kernel); qkvx_f: with the previous layer's second LayerNorm folded in
+        ConvW qkvx, qkvx_f; float *qkvx_wsum = nullptr; float *rel_vp = nullptr, *rel_kp = nullptr; bool has_x = false;
+    };
     ConvW proj_f; float *proj_wsum = nullptr; bool has_folded = false;
     std::vector<Layer> layers;
     struct Flow {
@@ -1153,6 +1158,38 @@ struct ModelSY {
             if (H >= 128 && H % 16 == 0 && !getenv("RVC_NO_LN_FUSE")) {
                 has_folded = true;
                 if (l > 0) L.qkv_f = ModelCV::fold_ln(w.data(), bb.data(), 3 * H, H, b.w(fmt("sy.enc.l%d.ln2.g", l - 1)), b.w(fmt("sy.enc.l%d.ln2.b", l - 1)), &L.qkv_wsum);
+            }
+            if (H % 64 == 0 && H <= 256 && H % heads == 0 && (H / heads) % 16 == 0) {
+                // composed value / output projection per head (double accumulation, rounded once)
+                const int kc = H / heads, NR = 2 * window + 1, NRP = (NR + 3) / 4 * 4;
+                const float *wo = b.w(fmt("sy.enc.l%d.o.w", l)), *wv = &w[(size_t)2 * H * H], *bv = &bb[(size_t)2 * H], *relv = b.w(fmt("sy.enc.l%d.rel_v", l));
+                std::vector<float> wx((size_t)(2 + heads) * H * H), bx((size_t)(2 + heads) * H), rvp((size_t)heads * NRP * H, 0.f);
+                memcpy(wx.data(), w.data(), (size_t)2 * H * H * 4); memcpy(bx.data(), bb.data(), (size_t)2 * H * 4);
+                std::vector<double> acc(H);
+                for (int h = 0; h < heads; h++)
+                    for (int o = 0; o < H; o++) {
+                        std::fill(acc.begin(), acc.end(), 0.0);
+                        double ba = 0.0;
+                        for (int d = 0; d < kc; d++) {
+                            const double v = wo[(size_t)o * H + h * kc + d];
+                            const float *wr = wv + (size_t)(h * kc + d) * H;
+                            for (int c = 0; c < H; c++) acc[c] += v * wr[c];
+                            ba += v * bv[h * kc + d];
+                        }
+                        for (int c = 0; c < H; c++) wx[((size_t)(2 + h) * H + o) * H + c] = (float)acc[c];
+                        bx[(size_t)(2 + h) * H + o] = (float)ba;
+                        for (int r = 0; r < NR; r++) {
+                            double a = 0.0;
+                            for (int d = 0; d < kc; d++) a += (double)wo[(size_t)o * H + h * kc + d] * relv[(size_t)r * kc + d];
+                            rvp[((size_t)h * NRP + r) * H + o] = (float)a;
+                        }
+                    }
+                L.qkvx = prep_conv(wx.data(), bx.data(), (2 + heads) * H, H, 1, 1);
+                if (has_folded && l > 0) L.qkvx_f = ModelCV::fold_ln(wx.data(), bx.data(), (2 + heads) * H, H, b.w(fmt("sy.enc.l%d.ln2.g", l - 1)), b.w(fmt("sy.enc.l%d.ln2.b", l - 1)), &L.qkvx_wsum);
+                rvp.resize(rvp.size() + 512, 0.f);
+                L.rel_vp = upload_f(rvp); owned.push_back(L.rel_vp);
+                { const int PW = (NR + 15) / 16 * 16; std::vector<float> rkp((size_t)PW * kc + 512, 0.f); memcpy(rkp.data(), b.w(fmt("sy.enc.l%d.rel_k", l)), (size_t)NR * kc * 4); L.rel_kp = upload_f(rkp); owned.push_back(L.rel_kp); }
+                L.has_x = true;
             }
             layers.push_back(L);
         }
@@ -1337,7 +1374,7 @@ struct ModelSY {
     ~ModelSY()
     {
         free_conv(phone); free_conv(proj); free_conv(dec_pre); free_conv(dec_post);
-        for (auto &L : layers) { free_conv(L.qkv); free_conv(L.o); free_conv(L.ff1); free_conv(L.ff2); free_conv(L.qkv_f); if (L.qkv_wsum) (void)hipFree(L.qkv_wsum); }
+        for (auto &L : layers) { free_conv(L.qkv); free_conv(L.o); free_conv(L.ff1); free_conv(L.ff2); free_conv(L.qkv_f); if (L.qkv_wsum) (void)hipFree(L.qkv_wsum); free_conv(L.qkvx); free_conv(L.qkvx_f); if (L.qkvx_wsum) (void)hipFree(L.qkvx_wsum); }
         free_conv(proj_f); if (proj_wsum) (void)hipFree(proj_wsum);
         for (auto &F : flows) { free_conv(F.pre); free_conv(F.post); for (auto &c : F.in) free_conv(c); for (auto &c : F.rs) free_conv(c); if (composed) { free_conv(F.pre1); free_conv(F.postc); for (auto &c : F.inc) free_conv(c); } }
         for (auto &c : ups) free_conv(c);
@@ -1413,6 +1450,7 @@ static void init_kernel_attrs()
     HIPCHK(hipFuncSetAttribute((const void *)knn_dot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)relpos_attention_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)relpos_attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)te_attention_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
 
 static void init_constants(rvc_engine *e)
@@ -1985,8 +2023,33 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         // one stream: the second LayerNorm of every encoder layer is folded into the next projection (see build_contentvec)
         const bool fuse_ln = B == 1 && m.has_folded && !pl.with_taps && !getenv("RVC_NO_LN_FUSE");
         bool raw = false; const float *raw_g = nullptr, *raw_b = nullptr; float *raw_st = nullptr;
+        // one stream: attention + output projection + residual + LayerNorm as one launch (te_attention_block_kernel), fed by q | k | V' rows
+        const int te_nr = 2 * m.window + 1, te_nrp = (te_nr + 3) / 4 * 4, te_sw = (R + 15) / 16 * 16, te_pw = (te_nr + 15) / 16 * 16;
+        auto up256 = [](size_t n) { return (n + 255) / 256 * 256; };
+        const size_t te_ld = (size_t)(R + 3) / 4 * 4;                 // row stride of the q | k | V' tensor (halo 0)
+        const size_t te_lds = (up256((size_t)H * 16) + up256((size_t)H * te_ld) + up256((size_t)m.heads * H * te_ld) + up256((size_t)te_pw * kc) + up256((size_t)m.heads * te_nrp * H) +
+                               (size_t)m.heads * 16 * (te_sw + 2 * te_pw) + 128) * sizeof(float);
+        const bool te_block = B == 1 && fuse_ln && m.layers[0].has_x && R <= 64 && te_lds <= 160 * 1024 && getenv("RVC_TE_BLOCK") && atoi(getenv("RVC_TE_BLOCK")) != 0;      // opt-in: equals the three launches it replaces (measured), does not beat them
+        T1 qkvx;
+        if (te_block) qkvx = make_t1(A, B, (2 + m.heads) * H + 16, R, 0).rows(0, (2 + m.heads) * H);      // (16 spare rows: the last LDS-DMA piece of the block copy may run past the tensor)
         for (int l = 0; l < m.enc_layers; l++) {
             ModelSY::Layer &Ly = m.layers[l];
+            if (te_block) {
+                if (raw) { raw_st = A.floats((size_t)2 * R + 16); ConvOpts o; o.ln_wsum = Ly.qkvx_wsum; o.ln_stats_out = raw_st; o.ln_rows = H; add_conv1d(pl, Ly.qkvx_f, x, qkvx, 1, 0, 1, o); }
+                else add_conv1d(pl, Ly.qkvx, x, qkvx, 1, 0, 1);
+                TeAttnP tp{}; tp.qkv = qkvx.p; tp.cs = qkvx.ld; tp.bs = qkvx.bs; tp.T = R; tp.H = H; tp.heads = m.heads; tp.window = m.window;
+                tp.rel_k = Ly.rel_kp; tp.rel_vp = Ly.rel_vp; tp.scale = 1.0f / sqrtf((float)kc); tp.o_bias = Ly.o.bias;
+                tp.res = x.p; tp.res_cs = x.ld; tp.res_bs = x.bs;
+                if (raw) { tp.ln_stats_in = raw_st; tp.ln_g_in = raw_g; tp.ln_b_in = raw_b; }
+                tp.ln_g = Ly.ln1_g; tp.ln_b = Ly.ln1_b; tp.out = x.p; tp.o_cs = x.ld; tp.o_bs = x.bs;
+                tp.dbg = getenv("RVC_TE_DBG") ? atoi(getenv("RVC_TE_DBG")) : 0;
+                dim3 ag((R + 15) / 16, B);
+                pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(te_attention_block_kernel, ag, dim3(256), te_lds, s, tp); });
+                { ConvOpts o; o.act = ACT_RELU; add_conv1d(pl, Ly.ff1, x, ff, 1, m.enc_k / 2, 1, o); }
+                { ConvOpts o; o.res = x.p; o.res_cs = x.ld; o.res_bs = x.bs; add_conv1d(pl, Ly.ff2, ff, x, 1, m.enc_k / 2, 1, o); }
+                raw = true; raw_g = Ly.ln2_g; raw_b = Ly.ln2_b;
+                continue;
+            }
             if (raw) { raw_st = A.floats((size_t)2 * R + 16); ConvOpts o; o.ln_wsum = Ly.qkv_wsum; o.ln_stats_out = raw_st; o.ln_rows = H; add_conv1d(pl, Ly.qkv_f, x, qkv, 1, 0, 1, o); }
             else add_conv1d(pl, Ly.qkv, x, qkv, 1, 0, 1);
             AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = H; ap.T = R; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;

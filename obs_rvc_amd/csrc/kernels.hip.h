@@ -882,6 +882,207 @@ __global__ __launch_bounds__(256) void relpos_attention_mfma_kernel(AttnP p)
     }
 }
 
+// Text-encoder attention block as ONE launch at one stream (round 3, opt-in RVC_TE_BLOCK=1: two workgroups walking five barrier-separated
+// LDS-latency phases take as long as the three launches they replace -- 41 us per layer either way): attention with relative positions, the output projection, its bias,
+// the residual and the first LayerNorm.  The projection is linear in the attention output, so it is composed into what it multiplies at
+// load time (ModelSY): V'_h = (W_o[:, head h] W_v[head h]) x  (the qkv launch produces q, k and heads x H rows of V'), rel_v'_h[r] = W_o[:, head h] rel_v[r]:
+//   y[:, i] = b_o + res[:, i] + sum_h ( sum_j S_h[i][j] V'_h[:, j] + sum_r Ssk_h[i][r] rel_v'_h[r] ),     x1 = LayerNorm(y)
+// grid = (ceil(T / 16), streams): a workgroup owns 16 query columns, all heads, all H output channels (LayerNorm runs over the channels of a column).
+// Operands reach LDS through LDS-DMA (global_load_lds: ~30 k floats, no staging registers).  MFMA layouts as in relpos_attention_mfma_kernel.
+struct TeAttnP {
+    const float *qkv; int cs; long long bs;          // rows: q [H], k [H], V' [heads][H]
+    int T, H, heads, window;
+    const float *rel_k, *rel_vp;                     // [PW][kc], [heads][NRP][H]: padded copies (rows >= NR zero, + 256 floats of slack)
+    float scale;
+    const float *o_bias;                             // [H]
+    const float *res; int res_cs; long long res_bs;  // residual tensor; with ln_stats_in: LayerNorm(res) from published per-column (mean, rstd)
+    const float *ln_stats_in, *ln_g_in, *ln_b_in;
+    const float *ln_g, *ln_b;                        // the LayerNorm applied to the block's output
+    float *out; int o_cs; long long o_bs;
+    int dbg;                                         // tuning aid (RVC_TE_DBG): leave after phase n (timing only, results invalid)
+};
+
+__global__ __launch_bounds__(256) void te_attention_block_kernel(TeAttnP p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = p.H, heads = p.heads, kc = H / heads, T = p.T, Wd = p.window, NR = 2 * Wd + 1, NRP = (NR + 3) & ~3;
+    const int JF = (T + 15) >> 4, SW = JF * 16, RF = (NR + 15) >> 4, PW = RF * 16;
+    const int qb = blockIdx.x, b = blockIdx.y, col0 = qb * 16, nq = T - col0 < 16 ? T - col0 : 16;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), li = lane & 15, kq = lane >> 4;
+    // LDS image (every region a multiple of 256 floats: whole 1 KB LDS-DMA pieces).  k and V' keep the tensor's own row stride (a multiple of 4:
+    // they are one contiguous block of the qkv tensor, copied 16 bytes per lane; the A-operand reads of V' then meet 4-way bank conflicts,
+    // a few clocks on 72 reads), the relative-position tables are stored padded at load time.
+    auto up256 = [](int n) { return (n + 255) & ~255; };
+    const int LD = p.cs;
+    float *q = smem;                              // [heads * kc][16]
+    float *kk = q + up256(H * 16);                // [heads * kc][LD]
+    float *vp = kk + up256(H * LD);               // [heads][H][LD]
+    float *rk = vp + up256(heads * H * LD);       // [PW][kc]
+    float *rvp = rk + up256(PW * kc);             // [heads][NRP][H]
+    float *Sx = rvp + up256(heads * NRP * H);     // [heads][16][SW]
+    float *P = Sx + heads * 16 * SW;              // [heads][16][PW]
+    float *Ssk = P + heads * 16 * PW;             // [heads][16][PW]
+    float *red = Ssk + heads * 16 * PW;           // [4][16] + [4][16]
+    const float *base = p.qkv + (long long)b * p.bs;
+#define RVC_DMA16(SRC, DST) __builtin_amdgcn_global_load_lds((SRC), (__attribute__((address_space(3))) void *)(DST), 16, 0, 0)
+    {
+        // q: 16 columns of every row (4 lanes per row; columns behind T read on into valid memory: those queries are never stored)
+        for (int pc = wave; pc * 256 < H * 16; pc += 4) {
+            const int e4 = pc * 64 + lane, hd = e4 >> 2, c4 = e4 & 3;
+            RVC_DMA16(base + (long long)(hd < H ? hd : H - 1) * p.cs + col0 + c4 * 4, q + pc * 256);
+        }
+        // k, V' and the two tables: contiguous copies (the surplus of the last piece reads the rows that follow: valid memory, unused)
+        const float *ksrc = base + (long long)H * p.cs, *vsrc = base + (long long)2 * H * p.cs;
+        for (int pc = wave; pc * 256 < H * LD; pc += 4) RVC_DMA16(ksrc + pc * 256 + lane * 4, kk + pc * 256);
+        for (int pc = wave; pc * 256 < heads * H * LD; pc += 4) RVC_DMA16(vsrc + pc * 256 + lane * 4, vp + pc * 256);
+        for (int pc = wave; pc * 256 < PW * kc; pc += 4) RVC_DMA16(p.rel_k + pc * 256 + lane * 4, rk + pc * 256);
+        for (int pc = wave; pc * 256 < heads * NRP * H; pc += 4) RVC_DMA16(p.rel_vp + pc * 256 + lane * 4, rvp + pc * 256);
+    }
+#undef RVC_DMA16
+    // epilogue operands of this lane: channels c = (wave * CF + f) * 16 + kq * 4 + r, column col0 + li -- requested now, consumed last
+    constexpr int CFMAX = 4;                       // H <= 256
+    const int CF = H / 64;                         // 16-channel blocks per wave (H a multiple of 64)
+    float resv[CFMAX][4], ob[CFMAX][4], g1[CFMAX][4], b1[CFMAX][4];
+    {
+        const int n = col0 + li < T ? col0 + li : T - 1;
+        const float *rb = p.res + (long long)b * p.res_bs + n;
+        float mu = 0.f, rs = 1.f;
+        if (p.ln_stats_in) { mu = p.ln_stats_in[2 * n]; rs = p.ln_stats_in[2 * n + 1]; }
+#pragma unroll
+        for (int f = 0; f < CFMAX; f++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int c = (wave * CF + f) * 16 + kq * 4 + r;
+                const bool ok = f < CF;
+                float v = ok ? rb[(long long)c * p.res_cs] : 0.f;
+                if (p.ln_stats_in && ok) v = (v - mu) * rs * p.ln_g_in[c] + p.ln_b_in[c];
+                resv[f][r] = v; ob[f][r] = ok ? p.o_bias[c] : 0.f; g1[f][r] = ok ? p.ln_g[c] : 0.f; b1[f][r] = ok ? p.ln_b[c] : 0.f;
+            }
+    }
+    __syncthreads();
+    if (p.dbg == 1) return;
+    // scores and P: items (head, 16-column block of keys), then (head, 16-row block of relative positions)
+    for (int it = wave; it < heads * (JF + RF); it += 4) {
+        const bool is_p = it >= heads * JF;
+        const int h = is_p ? (it - heads * JF) / RF : it / JF, f = is_p ? (it - heads * JF) - h * RF : it - h * JF;
+        // operands in batches of eight k-steps: all LDS reads of a batch leave before its MFMAs (a read-then-MFMA loop pays the LDS latency
+        // and the 40-clock accumulator dependency on every step: measured 3.3 us per layer for these 96 MFMAs)
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f}, a3 = {0.f, 0.f, 0.f, 0.f};
+        const float *qa = q + (h * kc + kq) * 16 + li;
+        const float *bb = is_p ? rk + (f * 16 + li) * kc + kq : kk + (h * kc + kq) * LD + f * 16 + li;
+        const int bst = is_p ? 4 : 4 * LD;
+        const int nks = kc / 4;
+        for (int k0 = 0; k0 < nks; k0 += 8) {
+            float av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int ks = k0 + u < nks ? k0 + u : nks - 1; av[u] = qa[ks * 64]; bv[u] = bb[ks * bst]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (k0 + u >= nks) av[u] = 0.f;
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], a2, 0, 0, 0); a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], a3, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4], bv[4], a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[5], bv[5], a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[6], bv[6], a2, 0, 0, 0); a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[7], bv[7], a3, 0, 0, 0);
+        }
+        a0 += a1; a2 += a3; a0 += a2;
+        float *dst = is_p ? P + (h * 16) * PW + f * 16 : Sx + (h * 16) * SW + f * 16;
+        const int dw = is_p ? PW : SW;
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[(kq * 4 + r) * dw + li] = a0[r] * p.scale;
+    }
+    __syncthreads();
+    if (p.dbg == 2) return;
+    // softmax with the relative-position term: 16 lanes per (head, query) row
+    for (int hi = (int)threadIdx.x >> 4; hi < heads * 16; hi += 16) {
+        const int i = hi & 15, gi = col0 + i;
+        float *Sr = Sx + hi * SW, *Kr = Ssk + hi * PW;
+        const float *Pr = P + hi * PW;
+        float mx = -INFINITY;
+        if (gi < T) {
+            for (int j = li; j < T; j += 16) {
+                float a = Sr[j];
+                const int r = j - gi;
+                if (r >= -Wd && r <= Wd) a += Pr[r + Wd];
+                Sr[j] = a; mx = fmaxf(mx, a);
+            }
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+        float sum = 0.f;
+        if (gi < T) for (int j = li; j < T; j += 16) { const float ex = expf(Sr[j] - mx); Sr[j] = ex; sum += ex; }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 16);
+        const float inv = 1.0f / sum;
+        for (int j = li; j < SW; j += 16) Sr[j] = (gi < T && j < T) ? Sr[j] * inv : 0.f;
+        for (int r = li; r < PW; r += 16) { const int j = gi + r - Wd; Kr[r] = (gi < T && r < NR && j >= 0 && j < T) ? Sr[j] : 0.f; }
+    }
+    __syncthreads();
+    if (p.dbg == 3) return;
+    // y = sum_h (V'_h S_h^T + rel_v'_h^T Ssk_h^T) for this wave's channel blocks; D: row = channel kq * 4 + r, col = query li
+    float y[CFMAX][4];
+#pragma unroll
+    for (int f = 0; f < CFMAX; f++) {
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        if (f < CF) {
+            const int ch0 = (wave * CF + f) * 16;
+            for (int h = 0; h < heads; h++) {
+                const float *va = vp + ((h * H + ch0 + li)) * LD + kq, *sb = Sx + (h * 16 + li) * SW + kq;
+                const float *ra = rvp + (h * NRP + kq) * H + ch0 + li, *kb = Ssk + (h * 16 + li) * PW + kq;
+                const int n1 = (T + 3) / 4, n2 = NRP / 4;
+                // (batches of eight k-steps, reads first: see the score stage)
+                for (int k0 = 0; k0 < n1; k0 += 8) {
+                    float av[8], bv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const int ks = k0 + u < n1 ? k0 + u : n1 - 1; av[u] = va[ks * 4]; bv[u] = sb[ks * 4]; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) if (k0 + u >= n1) av[u] = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) { a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], a1, 0, 0, 0); }
+                }
+                for (int k0 = 0; k0 < n2; k0 += 8) {
+                    float av[8], bv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const int ks = k0 + u < n2 ? k0 + u : n2 - 1; av[u] = ra[ks * 4 * H]; bv[u] = kb[ks * 4]; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) if (k0 + u >= n2) av[u] = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) { a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], a1, 0, 0, 0); }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) y[f][r] = f < CF ? a0[r] + a1[r] + ob[f][r] + resv[f][r] : 0.f;
+    }
+    if (p.dbg == 4) return;
+    // LayerNorm over the H channels of column li (two passes, as the definition): lanes kq = 0..3 and the four waves hold a column's channels
+    float s = 0.f;
+#pragma unroll
+    for (int f = 0; f < CFMAX; f++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) s += y[f][r];
+    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+    if (kq == 0) red[wave * 16 + li] = s;
+    __syncthreads();
+    const float mean = (red[li] + red[16 + li] + red[32 + li] + red[48 + li]) / (float)H;
+    float qv = 0.f;
+#pragma unroll
+    for (int f = 0; f < CFMAX; f++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const float d = f < CF ? y[f][r] - mean : 0.f; qv += d * d; }
+    qv += __shfl_xor(qv, 16, 64); qv += __shfl_xor(qv, 32, 64);
+    if (kq == 0) red[64 + wave * 16 + li] = qv;
+    __syncthreads();
+    const float var = (red[64 + li] + red[80 + li] + red[96 + li] + red[112 + li]) / (float)H;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    if (li < nq) {
+        float *ob_ = p.out + (long long)b * p.o_bs + col0 + li;
+#pragma unroll
+        for (int f = 0; f < CFMAX; f++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (f < CF) ob_[(long long)((wave * CF + f) * 16 + kq * 4 + r) * p.o_cs] = (y[f][r] - mean) * rstd * g1[f][r] + b1[f][r];
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // RMVPE head: bidirectional GRU recurrence (input projections come from the implicit GEMM)
 // gi: [B][2*3H][ld] (forward gates rows 0..3H, backward rows 3H..6H; biases b_ih included)

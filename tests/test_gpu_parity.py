@@ -595,6 +595,35 @@ def test_every_tile_configuration_computes_the_same_convolution():
         L.rvc_destroy(h)
 
 
+def test_text_encoder_attention_block_matches_the_separate_launches():
+    """One stream, opt-in RVC_TE_BLOCK=1: attention + output projection (composed into V' = (W_o W_v) x per head at load time) + residual +
+    LayerNorm as one launch.  Same chunks through both paths: the audio agrees to fp32 summation order, both agree with the oracle."""
+    from oracle import oracle as O
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("full")
+    audio = voice_signal(g.sample_frame_16k * 18, seed=11)
+    rings = list(chunk_stream(audio, g.input_buffer_16k_size, g.sample_frame_16k))[-3:]
+    ora = O.OracleRvcInfer(z["data"]); ora.load_contentvec(2); ora.load_f0(1); ora.load_model(z["model"]); ora.set_noise_seed(5, 1)
+    ref = [ora.infer(r, g.sample_frame_16k, 12, g.skip_head, g.model_return_length) for r in rings]
+    outs = {}
+    try:
+        for mode in ("block", "launches"):
+            if mode == "block":
+                os.environ["RVC_TE_BLOCK"] = "1"
+            else:
+                os.environ.pop("RVC_TE_BLOCK", None)
+            eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(1); eng.load_model(z["model"]); eng.set_noise_seed(5, 1)
+            outs[mode] = [eng.infer(r, g.sample_frame_16k, 12, g.skip_head, g.model_return_length) for r in rings]
+            del eng
+    finally:
+        os.environ.pop("RVC_TE_BLOCK", None)
+    for a, b_, r in zip(outs["block"], outs["launches"], ref):
+        rms = float(np.sqrt(np.mean(np.square(r)))) + 1e-12
+        assert np.isfinite(a).all()
+        assert float(np.sqrt(np.mean(np.square(a - b_)))) / rms < 2e-4        # fp32 summation order (composed weights are rounded once)
+        assert float(np.sqrt(np.mean(np.square(a - r)))) / rms < 1e-3         # the parity gate
+
+
 def test_persistent_synth_front_matches_layer_launches():
     """One stream: text encoder + prior + flows run as ONE persistent launch (csrc/synth_front.hip, tagged-granule hand-offs between
     workgroups; opt-in through RVC_SYNTH_FRONT=1).  Same chunks through that path and through the per-layer launches: the audio must agree to fp32
