@@ -1116,7 +1116,7 @@ struct ModelSY {
         // layer weights in model order, and the composed panels
         std::vector<float> h_pre_w, h_pre_b, h_post_w, h_post_b;
         std::vector<std::vector<float>> h_in_w, h_in_b, h_rs_w, h_rs_b;
-        ConvW pre1, postc; std::vector<ConvW> inc;
+        ConvW pre1, postc, posth; std::vector<ConvW> inc; float *pair_bias = nullptr;      // postc: z_next rows, posth: the next flow's h0 rows
     };
     bool composed = false;
     std::vector<Flow> flows;
@@ -1300,74 +1300,121 @@ struct ModelSY {
     //   x_j = h0 + sum_{i<j} (R_i a_i + r_i)                      =>  in_j(x_j) = W_j * [1 | h0 | a_0 .. a_{j-1}]   with W_j(a_i) = W_j o R_i
     //   post(skip) = P (sum_j S_j a_j + s_j) + p                   =>  one 1x1 layer over [a_0 .. a_{n-1}]
     // (R_i / S_i: the residual / skip rows of res_skip layer i; the constant r_i rides on a row of ones -- zero in the halo, like the zero padding
-    // the in-layer sees -- so the edges of the window stay exact.)  Six launches per flow instead of ten.
+    // the in-layer sees -- so the edges of the window stay exact.)  The latent z rides in the same tensor ([ones | h0 | a_0 .. | z]), and a flow's
+    // post layer and the NEXT flow's pre layer become one 1x1 layer over [a_0 .. a_{n-1} | z] that writes h0_next and z_next into the other of two
+    // such tensors (two phases of one launch: same input, two outputs): five launches per flow (+ one pre at the start) instead of ten.
     void compose_flows()
     {
         if (composed) return;
-        const int H = hidden, half = inter / 2, K5 = wn_k, nl = wn_layers;
-        auto one_flow = [&](Flow &F, std::vector<std::vector<float>> &wj, std::vector<std::vector<float>> &bj, std::vector<float> &wpc, std::vector<float> &bpc) {
+        const int H = hidden, I = inter, half = inter / 2, K5 = wn_k, nl = wn_layers;
+        const int nfl = (int)flows.size();
+        // per flow: x0 / x1 rows of the latent, the full-latent pre weights [H][I] (zero on the x1 half), post rows on the x1 half
+        auto x1_row0 = [&](const Flow &F) { return F.flipped ? 0 : half; };
+        auto x0_row0 = [&](const Flow &F) { return F.flipped ? half : 0; };
+        std::vector<std::vector<std::vector<float>>> WJ(nfl), BJ(nfl);
+        std::vector<std::vector<float>> WM(nfl), BM(nfl), WH(nfl), BH(nfl), WP1(nfl), BP1(nfl);
+        auto one_flow = [&](int fi) {
+            Flow &F = flows[fi];
+            // first launch of the flow when it has no predecessor in processing order: h0 = pre(x0) from the full latent
+            WP1[fi].assign((size_t)H * I, 0.f); BP1[fi] = F.h_pre_b;
+            for (int r = 0; r < H; r++) for (int q = 0; q < half; q++) WP1[fi][(size_t)r * I + x0_row0(F) + q] = F.h_pre_w[(size_t)r * half + q];
+            // in-layers over [ones16 | h0 | a_0 .. a_{j-1}]
             for (int j = 0; j < nl; j++) {
-                const int Cin = 16 + H * (j + 1);
+                const int Cin = 16 + H * (j + 1), a0 = 16 + H;
                 std::vector<double> w((size_t)2 * H * Cin * K5, 0.0);
                 const float *W5 = F.h_in_w[j].data();                 // [2H][H][K5], model row order
                 for (int o = 0; o < 2 * H; o++)
-                    for (int m = 0; m < H; m++)
-                        for (int t = 0; t < K5; t++) w[((size_t)o * Cin + 16 + m) * K5 + t] = W5[((size_t)o * H + m) * K5 + t];
+                    for (int mm = 0; mm < H; mm++)
+                        for (int t = 0; t < K5; t++) w[((size_t)o * Cin + 16 + mm) * K5 + t] = W5[((size_t)o * H + mm) * K5 + t];
                 std::vector<double> acc(H);
                 for (int i = 0; i < j; i++) {
-                    const float *R = F.h_rs_w[i].data(), *rb = F.h_rs_b[i].data();      // rows 0..H: the residual part
+                    const float *Rr = F.h_rs_w[i].data(), *rb = F.h_rs_b[i].data();      // rows 0..H: the residual part
                     for (int o = 0; o < 2 * H; o++)
                         for (int t = 0; t < K5; t++) {
                             std::fill(acc.begin(), acc.end(), 0.0);
                             double one = 0.0;
-                            for (int m = 0; m < H; m++) {
-                                const double v = W5[((size_t)o * H + m) * K5 + t];
-                                const float *Rm = R + (size_t)m * H;
+                            for (int mm = 0; mm < H; mm++) {
+                                const double v = W5[((size_t)o * H + mm) * K5 + t];
+                                const float *Rm = Rr + (size_t)mm * H;
                                 for (int c = 0; c < H; c++) acc[c] += v * Rm[c];
-                                one += v * rb[m];
+                                one += v * rb[mm];
                             }
-                            for (int c = 0; c < H; c++) w[((size_t)o * Cin + 16 + H * (i + 1) + c) * K5 + t] = acc[c];
+                            for (int c = 0; c < H; c++) w[((size_t)o * Cin + a0 + H * i + c) * K5 + t] = acc[c];
                             w[((size_t)o * Cin) * K5 + t] += one;
                         }
                 }
-                // GLU row packing, as for the plain in-layers
                 std::vector<float> wp((size_t)2 * H * Cin * K5), pb((size_t)2 * H);
-                for (int r = 0; r < 2 * H; r++) {
+                for (int r = 0; r < 2 * H; r++) {                      // GLU row packing, as for the plain in-layers
                     const int f = r >> 4, kq = (r & 15) >> 2, rr = r & 3;
                     const int src = f * 8 + kq * 2 + (rr & 1) + (rr >= 2 ? H : 0);
                     for (size_t q = 0; q < (size_t)Cin * K5; q++) wp[(size_t)r * Cin * K5 + q] = (float)w[(size_t)src * Cin * K5 + q];
                     pb[r] = F.h_in_b[j][src];
                 }
-                wj.push_back(std::move(wp)); bj.push_back(std::move(pb));
+                WJ[fi].push_back(std::move(wp)); BJ[fi].push_back(std::move(pb));
             }
-            wpc.assign((size_t)half * nl * H, 0.f); bpc.assign(half, 0.f);
+            // composed post over [a_0 .. a_{n-1}]: P (sum_j S_j a_j + s_j) + p, rows = the x1 half in its physical order
+            const int KA = nl * H, Kin = KA + I;                       // last launch's input: [a_0 .. a_{n-1} | z]
+            std::vector<double> pc((size_t)half * KA, 0.0), pcb(half, 0.0);
             for (int r = 0; r < half; r++) {
                 double bacc = F.h_post_b[r];
                 for (int j = 0; j < nl; j++) {
-                    const int row0 = j < nl - 1 ? H : 0;                               // skip rows of res_skip layer j
+                    const int row0 = j < nl - 1 ? H : 0;               // skip rows of res_skip layer j
                     const float *S = F.h_rs_w[j].data() + (size_t)row0 * H, *sb = F.h_rs_b[j].data() + row0;
-                    std::vector<double> a(H, 0.0);
                     for (int h = 0; h < H; h++) {
                         const double v = F.h_post_w[(size_t)r * H + h];
-                        for (int c = 0; c < H; c++) a[c] += v * S[(size_t)h * H + c];
+                        for (int c = 0; c < H; c++) pc[(size_t)r * KA + (size_t)j * H + c] += v * S[(size_t)h * H + c];
                         bacc += v * sb[h];
                     }
-                    for (int c = 0; c < H; c++) wpc[(size_t)r * nl * H + (size_t)j * H + c] = (float)a[c];
                 }
-                bpc[r] = (float)bacc;
+                pcb[r] = bacc;
+            }
+            // last launch of the flow, input [A | z] (K = n H + I): z_next = z - [0 ; post(A)] on the x1 rows, and for the next flow in processing order
+            //   h0_next = pre_next(z_next) = Wn z - Wn[:, x1 rows] post(A) + (bn - Wn[:, x1 rows] p)        (two phases of one launch: same input, two outputs)
+            const bool has_next = fi > 0;
+            const int r1 = x1_row0(F);
+            std::vector<double> wz((size_t)I * Kin, 0.0), bz(I, 0.0);
+            for (int c = 0; c < I; c++) wz[(size_t)c * Kin + KA + c] = 1.0;
+            for (int r = 0; r < half; r++) {
+                for (int q = 0; q < KA; q++) wz[(size_t)(r1 + r) * Kin + q] = -pc[(size_t)r * KA + q];
+                bz[r1 + r] = -pcb[r];
+            }
+            WM[fi].resize(wz.size()); BM[fi].resize(I);
+            for (size_t q = 0; q < wz.size(); q++) WM[fi][q] = (float)wz[q];
+            for (int r = 0; r < I; r++) BM[fi][r] = (float)bz[r];
+            if (has_next) {
+                const Flow &N = flows[fi - 1];
+                std::vector<double> wh((size_t)H * Kin, 0.0);
+                WH[fi].resize(wh.size()); BH[fi].resize(H);
+                for (int r = 0; r < H; r++) {
+                    double bacc = N.h_pre_b[r];
+                    for (int q = 0; q < half; q++) {
+                        const double v = N.h_pre_w[(size_t)r * half + q];
+                        const int zc = x0_row0(N) + q;                 // latent row this weight multiplies
+                        wh[(size_t)r * Kin + KA + zc] += v;
+                        if (zc >= r1 && zc < r1 + half) {
+                            const int pr = zc - r1;
+                            for (int c = 0; c < KA; c++) wh[(size_t)r * Kin + c] -= v * pc[(size_t)pr * KA + c];
+                            bacc -= v * pcb[pr];
+                        }
+                    }
+                    BH[fi][r] = (float)bacc;
+                }
+                for (size_t q = 0; q < wh.size(); q++) WH[fi][q] = (float)wh[q];
             }
         };
-        const size_t nf = flows.size();
-        std::vector<std::vector<std::vector<float>>> WJ(nf), BJ(nf);
-        std::vector<std::vector<float>> WP(nf), BP(nf);
         std::vector<std::thread> th;
-        for (size_t i = 0; i < nf; i++) th.emplace_back([&, i]() { one_flow(flows[i], WJ[i], BJ[i], WP[i], BP[i]); });
+        for (int i = 0; i < nfl; i++) th.emplace_back([&, i]() { one_flow(i); });
         for (auto &t : th) t.join();
-        for (size_t i = 0; i < nf; i++) {
+        for (int i = 0; i < nfl; i++) {
             Flow &F = flows[i];
-            F.pre1 = prep_conv(F.h_pre_w.data(), F.h_pre_b.data(), H, half, 1, 1);
+            F.pre1 = prep_conv(WP1[i].data(), BP1[i].data(), H, I, 1, 1);
             for (int j = 0; j < nl; j++) F.inc.push_back(prep_conv(WJ[i][j].data(), BJ[i][j].data(), 2 * H, 16 + H * (j + 1), K5, 1));
-            F.postc = prep_conv(WP[i].data(), BP[i].data(), half, nl * H, 1, 1);
+            F.postc = prep_conv(WM[i].data(), BM[i].data(), I, nl * H + I, 1, 1);
+            if (i > 0) {
+                F.posth = prep_conv(WH[i].data(), BH[i].data(), H, nl * H + I, 1, 1);
+                std::vector<float> pb(BH[i]); pb.insert(pb.end(), BM[i].begin(), BM[i].end());
+                F.pair_bias = upload_f(pb); owned.push_back(F.pair_bias);
+            }
         }
         composed = true;
     }
@@ -1376,7 +1423,7 @@ struct ModelSY {
         free_conv(phone); free_conv(proj); free_conv(dec_pre); free_conv(dec_post);
         for (auto &L : layers) { free_conv(L.qkv); free_conv(L.o); free_conv(L.ff1); free_conv(L.ff2); free_conv(L.qkv_f); if (L.qkv_wsum) (void)hipFree(L.qkv_wsum); free_conv(L.qkvx); free_conv(L.qkvx_f); if (L.qkvx_wsum) (void)hipFree(L.qkvx_wsum); }
         free_conv(proj_f); if (proj_wsum) (void)hipFree(proj_wsum);
-        for (auto &F : flows) { free_conv(F.pre); free_conv(F.post); for (auto &c : F.in) free_conv(c); for (auto &c : F.rs) free_conv(c); if (composed) { free_conv(F.pre1); free_conv(F.postc); for (auto &c : F.inc) free_conv(c); } }
+        for (auto &F : flows) { free_conv(F.pre); free_conv(F.post); for (auto &c : F.in) free_conv(c); for (auto &c : F.rs) free_conv(c); if (composed) { free_conv(F.pre1); free_conv(F.postc); free_conv(F.posth); for (auto &c : F.inc) free_conv(c); } }
         for (auto &c : ups) free_conv(c);
         for (auto &c : ncs) free_conv(c);
         for (auto &s : rbs) for (auto &ch : s) for (auto &pr : ch) { free_conv(pr.first); free_conv(pr.second); }
@@ -1708,6 +1755,34 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
 
 // ------------------------------- RMVPE ------------------------------------------------
 // c1 (3x3, ReLU) -> y1 and the shortcut (1x1, no activation) -> out as the two phases of ONE launch over the shared input x
+// Two 1x1 convolutions of ONE input with the same M and K into two output tensors, as two phases of one launch (the flows' merged post / next-pre
+// layer).  pair_bias = [c0's bias | c1's bias].
+static void add_conv1d_two(Plan &pl, const ConvW &c0, const ConvW &c1, const float *pair_bias, const T1 &x, const T1 &y0, const T1 &y1)
+{
+    if (c0.M != c1.M || c0.Kp != c1.Kp || c0.KW != 1 || c1.KW != 1 || c0.Cin != x.C || y0.ld != y1.ld || y0.T != y1.T || y0.bs != y1.bs || y0.C != c0.M || y1.C != c1.M)
+        throw ShapeError("conv1d pair: shapes differ");
+    IgemmP p{};
+    p.x = x.p; p.w = c0.w; p.y = y0.p;
+    p.M = c0.M; p.N = y0.T; p.K = c0.Kp;
+    p.NW = y0.T; p.x_hs = 0; p.x_ws = 1; p.y_hm = 0; p.y_ws = 1; p.OW = y0.T;
+    p.x_bs = x.bs; p.y_bs = y0.bs; p.y_cs = y0.ld; p.y_rs = 0;
+    ConvOpts o;
+    fill_epilogue(p, c0, o);
+    p.bias = pair_bias;
+    std::vector<int> koff(c0.Kp, 0);
+    for (int ci = 0; ci < c0.Cin; ci++) koff[ci] = ci * x.ld;
+    std::vector<PhaseD> ph(2);
+    ph[0] = PhaseD{}; ph[1] = PhaseD{};
+    ph[0].nchunks = c0.Kp / 16;
+    ph[1].w_off = c1.w - c0.w;          // both are device pointers of one flat address space
+    ph[1].nchunks = c1.Kp / 16;
+    ph[1].koff_off = 0;
+    ph[1].bias_off = c0.M;
+    ph[1].act_p1 = ACT_NONE + 1;
+    ph[1].y_off = y1.p - y0.p;
+    queue_igemm(pl, p, x.B, koff, ph);
+}
+
 static void add_conv2d_with_shortcut(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &y1, const T2 &out)
 {
     if (x.H != y1.H || x.W != y1.W || out.H != x.H || out.W != x.W || y1.cs != out.cs || y1.ld != out.ld || (x.B > 1 && y1.bs != out.bs)) throw ShapeError("conv2d + shortcut: layouts differ");
@@ -2080,6 +2155,20 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
             else add_layernorm(pl, x, Ly.ln2_g, Ly.ln2_b);
         }
         add_tap(pl, "sy.enc", x);
+        // one stream: WaveNets with their res_skip layers composed away and post + next pre merged (ModelSY::compose_flows): 21 launches for
+        // four flows instead of 40.  U[k] = [ones16 | h0 (H) | a_0 .. a_{n-1} | z (I)]; flow k reads U[k & 1] and writes h0 and z of U[(k + 1) & 1]
+        const bool wn_composed = B == 1 && H % 16 == 0 && I == H && !pl.with_taps && !getenv("RVC_NO_WN_COMPOSE");
+        T1 U[2];
+        const int u_z = 16 + H + H * m.wn_layers;                     // first latent row of U
+        if (wn_composed) {
+            m.compose_flows();
+            std::vector<float> ones(R, 1.0f);
+            for (int k = 0; k < 2; k++) {
+                U[k] = make_t1(A, B, u_z + I, R, HALO);
+                HIPCHK(hipMemcpy(U[k].p, ones.data(), (size_t)R * sizeof(float), hipMemcpyHostToDevice));
+            }
+            z = U[0].rows(u_z, I);                                     // the prior sample lands in U[0]'s latent rows
+        }
         T1 stats = make_t1(A, B, 2 * I, R, 0);
         if (raw) { ConvOpts o; o.ln_wsum = m.proj_wsum; o.ln_rows = H; add_conv1d(pl, m.proj_f, x, stats, 1, 0, 1, o); }
         else add_conv1d(pl, m.proj, x, stats, 1, 0, 1);
@@ -2092,22 +2181,17 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         // hh (WaveNet state, rows 0..H) and skip (rows H..2H) share one tensor: the res_skip conv updates both in one launch
         T1 hs = make_t1(A, B, 2 * H, R, HALO), acts = make_t1(A, B, H, R, 0);
         T1 hh = hs.rows(0, H), skip = hs.rows(H, H);
-        // one stream: WaveNets with their res_skip layers composed away (ModelSY::compose_flows): 6 launches per flow instead of 10
-        const bool wn_composed = B == 1 && H % 16 == 0 && !pl.with_taps && !getenv("RVC_NO_WN_COMPOSE");
-        T1 U;
-        if (wn_composed) {
-            m.compose_flows();
-            U = make_t1(A, B, 16 + H * (m.wn_layers + 1), R, HALO);        // [ones block | h0 | a_0 .. a_{n-1}]
-            std::vector<float> ones(R, 1.0f);
-            HIPCHK(hipMemcpy(U.p, ones.data(), (size_t)R * sizeof(float), hipMemcpyHostToDevice));
-        }
         for (int fi = m.flow_n - 1; fi >= 0; fi--) {
             ModelSY::Flow &Fw = m.flows[fi];
             const T1 x0 = Fw.flipped ? z.rows(half, half) : z.rows(0, half), x1 = Fw.flipped ? z.rows(0, half) : z.rows(half, half);
             if (wn_composed) {
-                add_conv1d(pl, Fw.pre1, x0, U.rows(16, H), 1, 0, 1);
-                for (int j = 0; j < m.wn_layers; j++) { ConvOpts o; o.glu = true; add_conv1d(pl, Fw.inc[j], U.rows(0, 16 + H * (j + 1)), U.rows(16 + H * (j + 1), H), 1, (m.wn_k - 1) / 2, 1, o); }
-                { ConvOpts o; o.scale = -1.f; o.accumulate = true; add_conv1d(pl, Fw.postc, U.rows(16 + H, m.wn_layers * H), x1, 1, 0, 1, o); }
+                const int k = m.flow_n - 1 - fi;
+                const T1 &Uc = U[k & 1], &Un = U[(k + 1) & 1];
+                if (k == 0) add_conv1d(pl, Fw.pre1, Uc.rows(u_z, I), Uc.rows(16, H), 1, 0, 1);
+                for (int j = 0; j < m.wn_layers; j++) { ConvOpts o; o.glu = true; add_conv1d(pl, Fw.inc[j], Uc.rows(0, 16 + H * (j + 1)), Uc.rows(16 + H * (j + 1), H), 1, (m.wn_k - 1) / 2, 1, o); }
+                if (fi > 0) add_conv1d_two(pl, Fw.posth, Fw.postc, Fw.pair_bias, Uc.rows(16 + H, H * m.wn_layers + I), Un.rows(16, H), Un.rows(u_z, I));
+                else add_conv1d(pl, Fw.postc, Uc.rows(16 + H, H * m.wn_layers + I), Un.rows(u_z, I), 1, 0, 1);
+                if (fi == 0) z = Un.rows(u_z, I);
                 add_stamp(pl, "sy.flow");
                 continue;
             }
