@@ -1083,6 +1083,31 @@ __global__ __launch_bounds__(256) void te_attention_block_kernel(TeAttnP p)
     }
 }
 
+// Weight prefetch into the memory-side cache (one stream).  Every chunk streams more weights (ContentVec 380 MB + RMVPE 360 MB) than the 256 MB
+// Infinity Cache holds, so every launch of the serial tail (text encoder, flows, decoder: ~150 MB) finds its weights in HBM: a launch whose weights come
+// from HBM costs 0.5-1.5 us more than the same launch with them in the memory-side cache, the decoder's staged-tile launches 12 us more
+// (tests/tools/cold_gemm.sh).  This kernel runs on the side stream next to the text encoder and reads the tail's weight ranges once, in the
+// order they will be needed; nothing is kept -- the point is that the lines now sit in the memory-side cache.
+struct TouchRange { const float *p; unsigned long long n4; };        // n4: float4 count
+__global__ __launch_bounds__(256) void weight_touch_kernel(const TouchRange *r, int nr, float *sink)
+{
+    float acc = 0.f;
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+    for (int i = 0; i < nr; i++) {
+        const f32x4 *q = reinterpret_cast<const f32x4 *>(r[i].p);
+        const unsigned long long n4 = r[i].n4;
+        for (unsigned long long e = (unsigned long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += 4 * stride) {
+            // four independent 16-byte loads in flight per thread
+            const f32x4 a = q[e];
+            const f32x4 b = e + stride < n4 ? q[e + stride] : a;
+            const f32x4 c = e + 2 * stride < n4 ? q[e + 2 * stride] : a;
+            const f32x4 d = e + 3 * stride < n4 ? q[e + 3 * stride] : a;
+            acc += a[0] + b[1] + c[2] + d[3];
+        }
+    }
+    if (acc == 1.2345678e33f) sink[0] = acc;      // never true: keeps the loads
+}
+
 // ------------------------------------------------------------------------------------
 // RMVPE head: bidirectional GRU recurrence (input projections come from the implicit GEMM)
 // gi: [B][2*3H][ld] (forward gates rows 0..3H, backward rows 3H..6H; biases b_ih included)
