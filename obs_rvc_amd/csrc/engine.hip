@@ -1505,6 +1505,7 @@ static void init_kernel_attrs()
     HIPCHK(hipFuncSetAttribute((const void *)relpos_attention_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)relpos_attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)te_attention_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)relpos_attention_vp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
 
 static void init_constants(rvc_engine *e)
@@ -2112,10 +2113,41 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         const size_t te_lds = (up256((size_t)H * 16) + up256((size_t)H * te_ld) + up256((size_t)m.heads * H * te_ld) + up256((size_t)te_pw * kc) + up256((size_t)m.heads * te_nrp * H) +
                                (size_t)m.heads * 16 * (te_sw + 2 * te_pw) + 128) * sizeof(float);
         const bool te_block = B == 1 && fuse_ln && m.layers[0].has_x && R <= 64 && te_lds <= 160 * 1024 && getenv("RVC_TE_BLOCK") && atoi(getenv("RVC_TE_BLOCK")) != 0;      // opt-in: equals the three launches it replaces (measured), does not beat them
+        // opt-in (RVC_TE_VP=1; measured +8..22 us per chunk: the wider projection, the doubled P V work and the three-tensor LayerNorm cost more than the
+        // launch they save): the output projection composed into the values, its sum folded into the LayerNorm launch (relpos_attention_vp_kernel)
+        const int vp_tp = R | 1, vp_pw = te_pw;
+        const size_t vp_lds = ((size_t)kc * 16 + (size_t)kc * vp_tp + (size_t)H * vp_tp + (size_t)vp_pw * kc + (size_t)te_nrp * H + 16 * (size_t)te_sw + 2 * 16 * (size_t)vp_pw + 64) * sizeof(float);
+        const bool te_vp = !te_block && B == 1 && fuse_ln && m.layers[0].has_x && R <= 64 && H <= 1024 && vp_lds <= 160 * 1024 && getenv("RVC_TE_VP") && atoi(getenv("RVC_TE_VP")) != 0;
+        T1 parts;
+        if (te_vp) parts = make_t1(A, B, m.heads * H, R, 0);
         T1 qkvx;
-        if (te_block) qkvx = make_t1(A, B, (2 + m.heads) * H + 16, R, 0).rows(0, (2 + m.heads) * H);      // (16 spare rows: the last LDS-DMA piece of the block copy may run past the tensor)
+        if (te_block || te_vp) qkvx = make_t1(A, B, (2 + m.heads) * H + 16, R, 0).rows(0, (2 + m.heads) * H);      // (16 spare rows: the last LDS-DMA piece of the block copy may run past the tensor)
         for (int l = 0; l < m.enc_layers; l++) {
             ModelSY::Layer &Ly = m.layers[l];
+            if (te_vp) {
+                // q | k | V' projection, attention with the output projection composed into V' (per-head partial sums), then sum + bias + residual +
+                // LayerNorm: five launches per layer instead of six
+                if (raw) { raw_st = A.floats((size_t)2 * R + 16); ConvOpts o; o.ln_wsum = Ly.qkvx_wsum; o.ln_stats_out = raw_st; o.ln_rows = H; add_conv1d(pl, Ly.qkvx_f, x, qkvx, 1, 0, 1, o); }
+                else add_conv1d(pl, Ly.qkvx, x, qkvx, 1, 0, 1);
+                AttnP ap{}; ap.qkv = qkvx.p; ap.out = parts.p; ap.E = H; ap.T = R; ap.heads = m.heads; ap.cs = qkvx.ld; ap.bs = qkvx.bs; ap.o_cs = parts.ld; ap.o_bs = parts.bs;
+                ap.scale = 1.0f / sqrtf((float)kc); ap.rel_k = Ly.rel_k; ap.rel_v = Ly.rel_vp; ap.window = m.window;
+                dim3 ag(m.heads * ((R + 15) / 16), B);
+                pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(relpos_attention_vp_kernel, ag, dim3(256), vp_lds, s, ap); });
+                LnSumP lp{}; lp.part = parts.p; lp.np = m.heads; lp.part_hs = (long long)H * parts.ld; lp.p_cs = parts.ld; lp.p_bs = parts.bs; lp.bias = Ly.o.bias;
+                lp.res = x.p; lp.r_cs = x.ld; lp.r_bs = x.bs;
+                if (raw) { lp.st_in = raw_st; lp.g_in = raw_g; lp.b_in = raw_b; }
+                lp.g = Ly.ln1_g; lp.bta = Ly.ln1_b; lp.y = x.p; lp.y_cs = x.ld; lp.y_bs = x.bs; lp.C = H; lp.T = R;
+                dim3 lg((R + 3) / 4, B);
+                pl.ops.push_back([=](hipStream_t s) {
+                    if (lp.C <= 64) hipLaunchKernelGGL((layernorm_sum_kernel<1>), lg, dim3(256), 0, s, lp);
+                    else if (lp.C <= 256) hipLaunchKernelGGL((layernorm_sum_kernel<4>), lg, dim3(256), 0, s, lp);
+                    else hipLaunchKernelGGL((layernorm_sum_kernel<16>), lg, dim3(256), 0, s, lp);
+                });
+                { ConvOpts o; o.act = ACT_RELU; add_conv1d(pl, Ly.ff1, x, ff, 1, m.enc_k / 2, 1, o); }
+                { ConvOpts o; o.res = x.p; o.res_cs = x.ld; o.res_bs = x.bs; add_conv1d(pl, Ly.ff2, ff, x, 1, m.enc_k / 2, 1, o); }
+                raw = true; raw_g = Ly.ln2_g; raw_b = Ly.ln2_b;
+                continue;
+            }
             if (te_block) {
                 if (raw) { raw_st = A.floats((size_t)2 * R + 16); ConvOpts o; o.ln_wsum = Ly.qkvx_wsum; o.ln_stats_out = raw_st; o.ln_rows = H; add_conv1d(pl, Ly.qkvx_f, x, qkvx, 1, 0, 1, o); }
                 else add_conv1d(pl, Ly.qkvx, x, qkvx, 1, 0, 1);

@@ -207,6 +207,62 @@ __global__ __launch_bounds__(256) void layernorm_ct_kernel(const float *x, float
     }
 }
 
+// layernorm_ct_kernel over a sum: x = sum_h part[h] + bias + res (res optionally LayerNorm(res) from published per-column statistics): the tail of the
+// text encoder's attention block when the output projection is composed into the values (relpos_attention_vp_kernel).
+struct LnSumP {
+    const float *part; int np; long long part_hs; int p_cs; long long p_bs;     // [np][C][T] partial sums
+    const float *bias;                                                           // [C]
+    const float *res; int r_cs; long long r_bs; const float *st_in, *g_in, *b_in;
+    const float *g, *bta; float *y; int y_cs; long long y_bs; int C, T;
+};
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_sum_kernel(LnSumP p)
+{
+    __shared__ float red[4][4];
+    const int tx = threadIdx.x & 3, ty = threadIdx.x >> 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * 4 + tx, b = blockIdx.y, C = p.C;
+    const bool ok = t < p.T;
+    const int tc = ok ? t : 0;
+    float mu = 0.f, rs = 1.f;
+    if (p.st_in) { mu = p.st_in[2 * tc]; rs = p.st_in[2 * tc + 1]; }
+    float v[NV], gv[NV], bv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int c = ty + i * 64;
+        float a = 0.f;
+        if (ok && c < C) {
+            float r = p.res[(long long)b * p.r_bs + (long long)c * p.r_cs + tc];
+            if (p.st_in) r = (r - mu) * rs * p.g_in[c] + p.b_in[c];
+            a = p.bias[c] + r;
+            for (int h = 0; h < p.np; h++) a += p.part[(long long)b * p.p_bs + h * p.part_hs + (long long)c * p.p_cs + tc];
+        }
+        v[i] = a; s += a;
+        gv[i] = c < C ? p.g[c] : 0.f; bv[i] = c < C ? p.bta[c] : 0.f;
+    }
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+    if (lane < 4) red[wave][lane] = s;
+    __syncthreads();
+    const float mean = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)C;
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) { const int c = ty + i * 64; const float d = (c < C) ? v[i] - mean : 0.f; q += d * d; }
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) q += __shfl_xor(q, o, 64);
+    if (lane < 4) red[wave][lane] = q;
+    __syncthreads();
+    const float var = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)C;
+    const float inv = 1.0f / sqrtf(var + 1e-5f);
+    if (ok) {
+        float *yp = p.y + (long long)b * p.y_bs + t;
+#pragma unroll
+        for (int i = 0; i < NV; i++) { const int c = ty + i * 64; if (c < C) yp[(long long)c * p.y_cs] = (v[i] - mean) * inv * gv[i] + bv[i]; }
+    }
+}
+
 // Throughput-mode LayerNorm (many streams): a workgroup owns 32 time steps x ALL channels of one stream.  Rows are read and written as
 // full 128-byte lines (the 4-step kernel above touches 16-byte slivers of lines that other workgroups -- on other XCDs -- fetch again:
 // 156 MB of HBM/MALL reads per launch for 22 MB of data at 64 streams); the tile sits in LDS ([C][33]) for the two-pass statistics.
@@ -878,6 +934,138 @@ __global__ __launch_bounds__(256) void relpos_attention_mfma_kernel(AttnP p)
         if (col0 + li < T) {
 #pragma unroll
             for (int r = 0; r < 4; r++) p.out[(long long)b * p.o_bs + (long long)(h * kc + cf * 16 + kq * 4 + r) * p.o_cs + col0 + li] = a0[r];
+        }
+    }
+}
+
+// The same with the output projection composed into the values (ModelSY: V'_h = (W_o[:, head h] W_v[head h]) x, rel_v'_h = W_o[:, head h] rel_v): the
+// qkv tensor holds q [E], k [E], V' [heads][E]; a workgroup writes its head's PARTIAL sum of the projection's output, out[head][E][T]; the sum over
+// the heads, the projection's bias, the residual and the LayerNorm follow in layernorm_sum_kernel.  One launch per layer less than attention + projection.
+__global__ __launch_bounds__(256) void relpos_attention_vp_kernel(AttnP p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = 256;
+    const int kc = p.E / p.heads, T = p.T, TP = T | 1, Wd = p.window, NR = 2 * Wd + 1, NRP = (NR + 3) & ~3;
+    const int JF = (T + 15) >> 4, SW = JF * 16, RF = (NR + 15) >> 4, PW = RF * 16;
+    const int h = blockIdx.x / JF, qb = blockIdx.x - h * JF, b = blockIdx.y;
+    const int col0 = qb * 16, nq = T - col0 < 16 ? T - col0 : 16;
+    const int VR = p.E;                               // rows of V' per head = output channels of the projection
+    float *q = smem, *kk = q + kc * 16, *vv = kk + kc * TP, *rk = vv + VR * TP, *rv = rk + PW * kc;
+    float *Sx = rv + NRP * VR, *P = Sx + 16 * SW, *Ssk = P + 16 * PW;
+    const float *base = p.qkv + (long long)b * p.bs;
+    // staging: every global load is issued before the first LDS write (one memory round trip)
+    const int tsh = T <= 32 ? 5 : 6, tmask = (1 << tsh) - 1;
+    constexpr int KV_IT = 12, V_IT = 24, RT_IT = 12, RV_IT = 18, Q_IT = 6;
+    const int kv_n = kc << tsh, v_n = VR << tsh, rk_n = PW * kc, rv_n = NRP * VR, rt_n = NR * kc, q_n = kc * 16;
+    const float *relv = p.rel_v + (long long)h * NRP * VR;      // per head, stored padded to NRP rows
+    float kr[KV_IT], vr[V_IT], rkr[RT_IT], rvr[RV_IT], qr[Q_IT];
+#pragma unroll
+    for (int u = 0; u < Q_IT; u++) {
+        const int idx = threadIdx.x + u * NT, d = idx >> 4, c = idx & 15;
+        qr[u] = (idx < q_n && c < nq) ? base[(long long)(h * kc + d) * p.cs + col0 + c] * p.scale : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < KV_IT; u++) {
+        const int idx = threadIdx.x + u * NT, d = idx >> tsh, t = idx & tmask;
+        kr[u] = (idx < kv_n && t < T) ? base[(long long)(p.E + h * kc + d) * p.cs + t] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < V_IT; u++) {
+        const int idx = threadIdx.x + u * NT, d = idx >> tsh, t = idx & tmask;
+        vr[u] = (idx < v_n && t < T) ? base[(long long)(2 * p.E + h * VR + d) * p.cs + t] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < RT_IT; u++) { const int j = threadIdx.x + u * NT; rkr[u] = j < rt_n ? p.rel_k[j] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < RV_IT; u++) { const int j = threadIdx.x + u * NT; rvr[u] = j < rv_n ? relv[j] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < Q_IT; u++) { const int idx = threadIdx.x + u * NT; if (idx < q_n) q[idx] = qr[u]; }
+#pragma unroll
+    for (int u = 0; u < KV_IT; u++) {
+        const int idx = threadIdx.x + u * NT, d = idx >> tsh, t = idx & tmask;
+        if (idx < kv_n && t < TP) kk[d * TP + t] = kr[u];                                     // (column T of the odd padding: zero)
+    }
+#pragma unroll
+    for (int u = 0; u < V_IT; u++) {
+        const int idx = threadIdx.x + u * NT, d = idx >> tsh, t = idx & tmask;
+        if (idx < v_n && t < TP) vv[d * TP + t] = vr[u];
+    }
+#pragma unroll
+    for (int u = 0; u < RT_IT; u++) { const int j = threadIdx.x + u * NT; if (j < rk_n) rk[j] = rkr[u]; }
+#pragma unroll
+    for (int u = 0; u < RV_IT; u++) { const int j = threadIdx.x + u * NT; if (j < rv_n) rv[j] = rvr[u]; }
+    // sizes beyond the unrolled staging (no official configuration: 2 heads x 96, window 10, T <= 32)
+    for (int idx = threadIdx.x + Q_IT * NT; idx < q_n; idx += NT) { const int d = idx >> 4, c = idx & 15; q[idx] = c < nq ? base[(long long)(h * kc + d) * p.cs + col0 + c] * p.scale : 0.f; }
+    for (int idx = threadIdx.x + KV_IT * NT; idx < kv_n; idx += NT) {
+        const int d = idx >> tsh, t = idx & tmask;
+        if (t < TP) kk[d * TP + t] = t < T ? base[(long long)(p.E + h * kc + d) * p.cs + t] : 0.f;
+    }
+    for (int idx = threadIdx.x + V_IT * NT; idx < v_n; idx += NT) {
+        const int d = idx >> tsh, t = idx & tmask;
+        if (t < TP) vv[d * TP + t] = t < T ? base[(long long)(2 * p.E + h * VR + d) * p.cs + t] : 0.f;
+    }
+    for (int j = threadIdx.x + RT_IT * NT; j < rk_n; j += NT) rk[j] = j < rt_n ? p.rel_k[j] : 0.f;
+    for (int j = threadIdx.x + RV_IT * NT; j < rv_n; j += NT) rv[j] = relv[j];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
+    // scores and P: items (16-column block of keys), then (16-row block of relative positions), one per wave and pass
+    for (int it = wave; it < JF + RF; it += 4) {
+        const bool is_p = it >= JF;
+        const int f = is_p ? it - JF : it;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        const float *qa = q + kq * 16 + li;
+        const float *bb = is_p ? rk + (f * 16 + li) * kc + kq : kk + kq * TP + f * 16 + li;
+        const int bst = is_p ? 4 : 4 * TP;
+        for (int ks = 0; ks + 1 < kc / 4; ks += 2) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[ks * 64], bb[ks * bst], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[(ks + 1) * 64], bb[(ks + 1) * bst], a1, 0, 0, 0);
+        }
+        if ((kc / 4) & 1) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[(kc / 4 - 1) * 64], bb[(kc / 4 - 1) * bst], a0, 0, 0, 0);
+        a0 += a1;
+        float *dst = is_p ? P + f * 16 : Sx + f * 16;
+        const int dw = is_p ? PW : SW;
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[(kq * 4 + r) * dw + li] = a0[r];
+    }
+    __syncthreads();
+    // softmax with the relative-position term: 16 lanes per query row, keys strided over the lanes
+    {
+        const int i = threadIdx.x >> 4, gi = col0 + i;
+        float *Sr = Sx + i * SW, *Kr = Ssk + i * PW;
+        const float *Pr = P + i * PW;
+        float mx = -INFINITY;
+        if (gi < T) {
+            for (int j = li; j < T; j += 16) {
+                float a = Sr[j];
+                const int r = j - gi;
+                if (r >= -Wd && r <= Wd) a += Pr[r + Wd];
+                Sr[j] = a; mx = fmaxf(mx, a);
+            }
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+        float sum = 0.f;
+        if (gi < T) for (int j = li; j < T; j += 16) { const float ex = expf(Sr[j] - mx); Sr[j] = ex; sum += ex; }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 16);
+        const float inv = 1.0f / sum;
+        for (int j = li; j < SW; j += 16) Sr[j] = (gi < T && j < T) ? Sr[j] * inv : 0.f;
+        // (the 16 lanes of a row run in lockstep inside one wave: Sr is complete before it is read back skewed)
+        for (int r = li; r < PW; r += 16) { const int j = gi + r - Wd; Kr[r] = (gi < T && r < NR && j >= 0 && j < T) ? Sr[j] : 0.f; }
+    }
+    __syncthreads();
+    // attention output of the own columns: items = 16-channel blocks of the head
+    for (int cf = wave; cf < VR / 16; cf += 4) {
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        const float *va = vv + (cf * 16 + li) * TP + kq, *sb = Sx + li * SW + kq;
+        for (int ks = 0; ks < (T + 3) / 4; ks++) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va[ks * 4], sb[ks * 4], a0, 0, 0, 0);
+        const float *ra = rv + kq * VR + cf * 16 + li, *kb = Ssk + li * PW + kq;
+        for (int ks = 0; ks < NRP / 4; ks++) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[ks * 4 * VR], kb[ks * 4], a1, 0, 0, 0);
+        a0 += a1;
+        // D: row = channel cf * 16 + kq * 4 + r, col = query li
+        if (col0 + li < T) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) p.out[(long long)b * p.o_bs + (long long)(h * VR + cf * 16 + kq * 4 + r) * p.o_cs + col0 + li] = a0[r];      // per-head partial sums of the projection's output
         }
     }
 }

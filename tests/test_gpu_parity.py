@@ -607,21 +607,23 @@ def test_text_encoder_attention_block_matches_the_separate_launches():
     ref = [ora.infer(r, g.sample_frame_16k, 12, g.skip_head, g.model_return_length) for r in rings]
     outs = {}
     try:
-        for mode in ("block", "launches"):
+        for mode in ("block", "vp", "launches"):
+            os.environ.pop("RVC_TE_BLOCK", None); os.environ.pop("RVC_TE_VP", None)
             if mode == "block":
                 os.environ["RVC_TE_BLOCK"] = "1"
-            else:
-                os.environ.pop("RVC_TE_BLOCK", None)
+            elif mode == "vp":
+                os.environ["RVC_TE_VP"] = "1"          # projection composed into V', per-head partial sums, sum inside the LayerNorm launch
             eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(1); eng.load_model(z["model"]); eng.set_noise_seed(5, 1)
             outs[mode] = [eng.infer(r, g.sample_frame_16k, 12, g.skip_head, g.model_return_length) for r in rings]
             del eng
     finally:
-        os.environ.pop("RVC_TE_BLOCK", None)
-    for a, b_, r in zip(outs["block"], outs["launches"], ref):
-        rms = float(np.sqrt(np.mean(np.square(r)))) + 1e-12
-        assert np.isfinite(a).all()
-        assert float(np.sqrt(np.mean(np.square(a - b_)))) / rms < 2e-4        # fp32 summation order (composed weights are rounded once)
-        assert float(np.sqrt(np.mean(np.square(a - r)))) / rms < 1e-3         # the parity gate
+        os.environ.pop("RVC_TE_BLOCK", None); os.environ.pop("RVC_TE_VP", None)
+    for mode in ("block", "vp"):
+        for a, b_, r in zip(outs[mode], outs["launches"], ref):
+            rms = float(np.sqrt(np.mean(np.square(r)))) + 1e-12
+            assert np.isfinite(a).all()
+            assert float(np.sqrt(np.mean(np.square(a - b_)))) / rms < 2e-4, mode        # fp32 summation order (composed weights are rounded once)
+            assert float(np.sqrt(np.mean(np.square(a - r)))) / rms < 1e-3, mode         # the parity gate
 
 
 def test_persistent_synth_front_matches_layer_launches():
