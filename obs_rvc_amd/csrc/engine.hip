@@ -3292,6 +3292,32 @@ double rvc_debug_conv_bench(rvc_engine *e, int M, int Cin, int KW, int dil, int 
             HIPCHK(hipDeviceSynchronize());
         }
         auto run_once = [&](int i) { if (cold_p.empty()) { for (auto &op : pl.ops.v) op(e->stream); } else { for (auto &op : cold_p[i % cold_p.size()]->ops.v) op(e->stream); } };
+        // RVC_BENCH_TOUCH=1|2 (with RVC_BENCH_COLD): a line-touch kernel over the launch's weights in front of every launch (1: any workgroup any line,
+        // 2: every m-tile by a workgroup of the XCD that will consume it); the launches are then timed by their own dispatch events
+        const int touch_mode = getenv("RVC_BENCH_TOUCH") ? atoi(getenv("RVC_BENCH_TOUCH")) : 0;
+        if (touch_mode && !cold_p.empty()) {
+            float *sink; HIPCHK(hipMalloc(&sink, 64));
+            const int mt = (M + 15) / 16, nch = cw.Kp / 16;
+            double tot = 0; int cnt = 0;
+            for (int i = 0; i < iters + 3; i++) {
+                const size_t k = (size_t)i % cold_p.size();
+                Plan *q = cold_p[k];
+                if (touch_mode < 3) hipLaunchKernelGGL(weight_touch_tiles_kernel, dim3((unsigned)(touch_mode == 2 ? ((mt + 7) / 8 * 8) : 256)), dim3(256), 0, e->stream, (const float *)cold_w[k].w, mt, nch, touch_mode, sink);
+                q->profile = true; q->prof_used = 0;
+                for (auto &op : q->ops.v) op(e->stream);
+                q->profile = false;
+                HIPCHK(hipStreamSynchronize(e->stream));
+                float t = 0.f;
+                for (size_t u = 0; u < q->prof_used; u++) { float tq; HIPCHK(hipEventElapsedTime(&tq, q->prof[u].a, q->prof[u].b)); t += tq; }
+                if (i >= 3) { tot += t; cnt++; }
+            }
+            us = tot / cnt * 1e3;
+            (void)hipFree(sink);
+            for (Plan *q : cold_p) delete q;
+            for (auto &cwk : cold_w) free_conv(cwk);
+            free_conv(cw);
+            return RVC_OK;
+        }
         for (int i = 0; i < 3; i++) run_once(i);
         hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
         HIPCHK(hipEventRecord(a, e->stream));

@@ -1296,6 +1296,23 @@ __global__ __launch_bounds__(256) void weight_touch_kernel(const TouchRange *r, 
     if (acc == 1.2345678e33f) sink[0] = acc;      // never true: keeps the loads
 }
 
+// Tuning aid (rvc_debug_conv_bench, RVC_BENCH_TOUCH): read a fragment-major weight panel [mtiles][nchunks][256] one dword per 128-byte line.
+// mode 1: lines dealt to the workgroups in address order; mode 2: workgroup b reads only the m-tiles its XCD will later consume (m-tile t is read by
+// the GEMM's workgroups x = t, which run on the XCD the hardware reports for block t: same dispatch rule, so block b here takes t = b, b + grid, ...).
+__global__ __launch_bounds__(256) void weight_touch_tiles_kernel(const float *w, int mtiles, int nchunks, int mode, float *sink)
+{
+    float acc = 0.f;
+    const long long lines_per_tile = (long long)nchunks * 8;            // 1 KB per chunk = 8 lines
+    if (mode == 2) {
+        for (int t = blockIdx.x; t < mtiles; t += gridDim.x)
+            for (long long l = threadIdx.x; l < lines_per_tile; l += 256) acc += w[((long long)t * lines_per_tile + l) * 32];
+    } else {
+        const long long total = (long long)mtiles * lines_per_tile;
+        for (long long l = (long long)blockIdx.x * 256 + threadIdx.x; l < total; l += (long long)gridDim.x * 256) acc += w[l * 32];
+    }
+    if (acc == 1.2345678e33f) sink[0] = acc;
+}
+
 // ------------------------------------------------------------------------------------
 // RMVPE head: bidirectional GRU recurrence (input projections come from the implicit GEMM)
 // gi: [B][2*3H][ld] (forward gates rows 0..3H, backward rows 3H..6H; biases b_ih included)
