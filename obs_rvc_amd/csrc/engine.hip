@@ -353,11 +353,13 @@ static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &
 {
     const int mode = getenv("RVC_CONV_TILE") ? atoi(getenv("RVC_CONV_TILE")) : 1;       // 0 = off, 2 = wherever eligible (tests); read per plan
     auto no = [&](int why) { if (getenv("RVC_CONV_TILE_DEBUG")) fprintf(stderr, "conv_tile: not taken (%d) M=%d N=%d B=%d\n", why, p.M, p.N, B); return false; };
-    const int multi = getenv("RVC_CONV_TILE_MULTI") ? atoi(getenv("RVC_CONV_TILE_MULTI")) : 0;   // streams from which the wide tiles take over (0 = one stream only)
+    // streams: one always; two to four by default (narrow tiles, streams in the item table: measured -1 % / -2 % at 2 / 4 streams, nothing at 8);
+    // RVC_CONV_TILE_MULTI=n: also n streams and more (the wide tiles from RVC_CONV_TILE_WIDE streams on: measured slower than the 32x32x2 kernels)
+    const int multi = getenv("RVC_CONV_TILE_MULTI") ? atoi(getenv("RVC_CONV_TILE_MULTI")) : 0;
     if (!mode || p.fold_n || p.x_ld <= 0 || p.x_hs || p.x_ws != 1 || p.y_hm || p.lin_cs4 || p.glu || p.ln_wsum || p.ln_stats_in || p.ln_stats_out || p.part) return no(1);
-    if (B != 1 && !(multi > 0 && B >= multi)) return no(2);
+    if (B > 4 && !(multi > 0 && B >= multi)) return no(2);
     if (p.M > 128 && mode < 2) return no(3);
-    const bool wide = B != 1;
+    const bool wide = B >= (getenv("RVC_CONV_TILE_WIDE") ? atoi(getenv("RVC_CONV_TILE_WIDE")) : 16);      // few streams keep the narrow tiles (more items per CU)
     int kshares = getenv("RVC_CONV_TILE_KS") ? atoi(getenv("RVC_CONV_TILE_KS")) : (wide ? 1 : 2);      // tuning aid: 1 = one wave per fragment set
     const int t128 = getenv("RVC_CONV_TILE_128") ? atoi(getenv("RVC_CONV_TILE_128")) : 0;          // tuning aid: tile of the > 64-row layers (0 = 128 x 16, 3 = 64 x 32)
     const int w128 = getenv("RVC_CONV_TILE_W128") ? atoi(getenv("RVC_CONV_TILE_W128")) : 4;        // tuning aid: wide tile of the > 64-row layers (4 = 128 x 64, 7 = 128 x 32)
