@@ -2198,7 +2198,7 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         add_tap(pl, "sy.enc", x);
         // one stream: WaveNets with their res_skip layers composed away and post + next pre merged (ModelSY::compose_flows): 21 launches for
         // four flows instead of 40.  U[k] = [ones16 | h0 (H) | a_0 .. a_{n-1} | z (I)]; flow k reads U[k & 1] and writes h0 and z of U[(k + 1) & 1]
-        const bool wn_composed = B == 1 && H % 16 == 0 && I == H && !pl.with_taps && !getenv("RVC_NO_WN_COMPOSE");
+        const bool wn_composed = B <= 8 && H % 16 == 0 && I == H && !pl.with_taps && !getenv("RVC_NO_WN_COMPOSE");      // (launch-bound up to a few streams)
         T1 U[2];
         const int u_z = 16 + H + H * m.wn_layers;                     // first latent row of U
         if (wn_composed) {
@@ -2206,7 +2206,7 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
             std::vector<float> ones(R, 1.0f);
             for (int k = 0; k < 2; k++) {
                 U[k] = make_t1(A, B, u_z + I, R, HALO);
-                HIPCHK(hipMemcpy(U[k].p, ones.data(), (size_t)R * sizeof(float), hipMemcpyHostToDevice));
+                for (int bb = 0; bb < B; bb++) HIPCHK(hipMemcpy(U[k].p + (long long)bb * U[k].bs, ones.data(), (size_t)R * sizeof(float), hipMemcpyHostToDevice));
             }
             z = U[0].rows(u_z, I);                                     // the prior sample lands in U[0]'s latent rows
         }
