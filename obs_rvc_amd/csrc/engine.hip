@@ -1265,6 +1265,8 @@ struct ModelSY {
             }
             flows.push_back(F);
         }
+        // composed WaveNets (one to eight streams): built with the model, 20 tasks on the host's cores, so that no first chunk pays for them
+        if (hidden % 16 == 0 && inter == hidden && !getenv("RVC_NO_WN_COMPOSE")) compose_flows();
         {
             std::vector<float> bias(up_init);
             const float *cw = b.w("sy.dec.cond.w"), *cb = b.w("sy.dec.cond.b"), *pb = b.w("sy.dec.pre.b");
@@ -1322,13 +1324,10 @@ struct ModelSY {
         auto x0_row0 = [&](const Flow &F) { return F.flipped ? half : 0; };
         std::vector<std::vector<std::vector<float>>> WJ(nfl), BJ(nfl);
         std::vector<std::vector<float>> WM(nfl), BM(nfl), WH(nfl), BH(nfl), WP1(nfl), BP1(nfl);
-        auto one_flow = [&](int fi) {
+        // in-layer j of flow fi over [ones16 | h0 | a_0 .. a_{j-1}] (one task each: 1.7 GFLOP of double arithmetic in all, spread over the host's cores)
+        auto in_layer = [&](int fi, int j) {
             Flow &F = flows[fi];
-            // first launch of the flow when it has no predecessor in processing order: h0 = pre(x0) from the full latent
-            WP1[fi].assign((size_t)H * I, 0.f); BP1[fi] = F.h_pre_b;
-            for (int r = 0; r < H; r++) for (int q = 0; q < half; q++) WP1[fi][(size_t)r * I + x0_row0(F) + q] = F.h_pre_w[(size_t)r * half + q];
-            // in-layers over [ones16 | h0 | a_0 .. a_{j-1}]
-            for (int j = 0; j < nl; j++) {
+            {
                 const int Cin = 16 + H * (j + 1), a0 = 16 + H;
                 std::vector<double> w((size_t)2 * H * Cin * K5, 0.0);
                 const float *W5 = F.h_in_w[j].data();                 // [2H][H][K5], model row order
@@ -1359,8 +1358,14 @@ struct ModelSY {
                     for (size_t q = 0; q < (size_t)Cin * K5; q++) wp[(size_t)r * Cin * K5 + q] = (float)w[(size_t)src * Cin * K5 + q];
                     pb[r] = F.h_in_b[j][src];
                 }
-                WJ[fi].push_back(std::move(wp)); BJ[fi].push_back(std::move(pb));
+                WJ[fi][j] = std::move(wp); BJ[fi][j] = std::move(pb);
             }
+        };
+        auto one_flow = [&](int fi) {
+            Flow &F = flows[fi];
+            // first launch of the flow when it has no predecessor in processing order: h0 = pre(x0) from the full latent
+            WP1[fi].assign((size_t)H * I, 0.f); BP1[fi] = F.h_pre_b;
+            for (int r = 0; r < H; r++) for (int q = 0; q < half; q++) WP1[fi][(size_t)r * I + x0_row0(F) + q] = F.h_pre_w[(size_t)r * half + q];
             // composed post over [a_0 .. a_{n-1}]: P (sum_j S_j a_j + s_j) + p, rows = the x1 half in its physical order
             const int KA = nl * H, Kin = KA + I;                       // last launch's input: [a_0 .. a_{n-1} | z]
             std::vector<double> pc((size_t)half * KA, 0.0), pcb(half, 0.0);
@@ -1411,8 +1416,12 @@ struct ModelSY {
                 for (size_t q = 0; q < wh.size(); q++) WH[fi][q] = (float)wh[q];
             }
         };
+        for (int i = 0; i < nfl; i++) { WJ[i].resize(nl); BJ[i].resize(nl); }
         std::vector<std::thread> th;
-        for (int i = 0; i < nfl; i++) th.emplace_back([&, i]() { one_flow(i); });
+        for (int i = 0; i < nfl; i++) {
+            th.emplace_back([&, i]() { one_flow(i); });
+            for (int j = 0; j < nl; j++) th.emplace_back([&, i, j]() { in_layer(i, j); });
+        }
         for (auto &t : th) t.join();
         for (int i = 0; i < nfl; i++) {
             Flow &F = flows[i];
