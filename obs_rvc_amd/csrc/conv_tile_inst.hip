@@ -9,7 +9,7 @@ namespace rvc {
 void launch_conv_tile(int tile, int kshares, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
 {
 #define RVC_CT_ALL(X) X(4, 1, 2, 1, 1) X(4, 1, 1, 2, 1) X(2, 2, 1, 2, 1) X(4, 1, 2, 1, 2) X(4, 1, 1, 2, 2) X(2, 2, 1, 2, 2) X(2, 1, 2, 2, 2) \
-                      X(4, 1, 2, 4, 1) X(4, 1, 1, 4, 1) X(2, 2, 1, 4, 1) X(4, 1, 2, 4, 2) X(4, 1, 1, 4, 2) X(2, 2, 1, 4, 2) X(4, 1, 2, 2, 1) X(4, 1, 2, 2, 2)
+                      X(4, 1, 2, 4, 1) X(4, 1, 1, 4, 1) X(2, 2, 1, 4, 1) X(4, 1, 2, 4, 2) X(4, 1, 1, 4, 2) X(2, 2, 1, 4, 2) X(4, 1, 2, 2, 1) X(4, 1, 2, 2, 2) X(2, 1, 4, 1, 2)
     static const bool big_lds = [] {        // tiles of the long-dilation phases pass 64 KB
 #define RVC_CT_ATTR(a, b, c, d, e) (void)hipFuncSetAttribute((const void *)conv_tile_kernel<a, b, c, d, e>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         RVC_CT_ALL(RVC_CT_ATTR)
@@ -27,6 +27,7 @@ void launch_conv_tile(int tile, int kshares, const IgemmP &p, dim3 grid, size_t 
     case 4: if (k2) RVC_CT_GO(4, 1, 2, 4, 2) else RVC_CT_GO(4, 1, 2, 4, 1)
     case 5: if (k2) RVC_CT_GO(4, 1, 1, 4, 2) else RVC_CT_GO(4, 1, 1, 4, 1)
     case 7: if (k2) RVC_CT_GO(4, 1, 2, 2, 2) else RVC_CT_GO(4, 1, 2, 2, 1)
+    case 8: RVC_CT_GO(2, 1, 4, 1, 2)
     default: if (k2) RVC_CT_GO(2, 2, 1, 4, 2) else RVC_CT_GO(2, 2, 1, 4, 1)
     }
 #undef RVC_CT_GO

@@ -364,7 +364,7 @@ static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &
     const int t128 = getenv("RVC_CONV_TILE_128") ? atoi(getenv("RVC_CONV_TILE_128")) : 0;          // tuning aid: tile of the > 64-row layers (0 = 128 x 16, 3 = 64 x 32)
     const int w128 = getenv("RVC_CONV_TILE_W128") ? atoi(getenv("RVC_CONV_TILE_W128")) : 4;        // tuning aid: wide tile of the > 64-row layers (4 = 128 x 64, 7 = 128 x 32)
     const int tc0 = wide ? (p.M > 64 ? w128 : (p.M > 32 ? 5 : 6)) : (p.M > 64 ? t128 : (p.M > 32 ? 1 : 2));
-    if (tc0 == 3) kshares = 2;
+    if (tc0 == 3 || tc0 == 8) kshares = 2;
     const int BM = kTileBM[tc0], BN = kTileBN[tc0];
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     if (ntm > 255 || ntn > 32767 || phv.size() > 255) return no(4);
@@ -2273,6 +2273,13 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
     int c = m.up_init, Tc = R;
     if (src_join_sid > 0) pl.ops.join(src_join_sid);     // the harmonic source was produced on a side stream
     T1 xd = make_t1(A, B, c, Tc, DH);
+    if (pl.collect_touch && getenv("RVC_WEIGHT_TOUCH") && atoi(getenv("RVC_WEIGHT_TOUCH")) == 2) {
+        // diagnostic: touch the decoder's weights on the MAIN stream right here (serial: costs its own time, shows what warm weights would buy)
+        Plan *plp = &pl; const int first = (int)pl.touch_host.size();
+        pl.ops.push_back([=](hipStream_t s) {
+            if (plp->touch_n > first) hipLaunchKernelGGL(weight_touch_kernel, dim3(256), dim3(256), 0, s, (const TouchRange *)plp->touch_dev + first, plp->touch_n - first, plp->touch_sink);
+        });
+    }
     add_conv1d(pl, m.dec_pre, z, xd, 1, 3, 1);
     add_tap(pl, "sy.pre", xd);
     for (int i = 0; i < m.n_ups; i++) {
@@ -2559,7 +2566,7 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
             pl.touch_sink = pl.arena.floats(16);
             static const int touch_wgs = getenv("RVC_TOUCH_WGS") ? atoi(getenv("RVC_TOUCH_WGS")) : 64;
             pl.ops.push_back([=](hipStream_t s) {
-                if (plp->touch_n > 0) hipLaunchKernelGGL(weight_touch_kernel, dim3((unsigned)touch_wgs), dim3(256), 0, s, (const TouchRange *)plp->touch_dev, plp->touch_n, plp->touch_sink);
+                if (plp->touch_n > 0 && atoi(getenv("RVC_WEIGHT_TOUCH")) != 2) hipLaunchKernelGGL(weight_touch_kernel, dim3((unsigned)touch_wgs), dim3(256), 0, s, (const TouchRange *)plp->touch_dev, plp->touch_n, plp->touch_sink);
             });
         }
         src0 = build_nsf_source(e, pl, B, d_pitchf0);
