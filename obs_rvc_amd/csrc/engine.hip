@@ -2207,7 +2207,8 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         add_tap(pl, "sy.enc", x);
         // one stream: WaveNets with their res_skip layers composed away and post + next pre merged (ModelSY::compose_flows): 21 launches for
         // four flows instead of 40.  U[k] = [ones16 | h0 (H) | a_0 .. a_{n-1} | z (I)]; flow k reads U[k & 1] and writes h0 and z of U[(k + 1) & 1]
-        const bool wn_composed = B <= 8 && H % 16 == 0 && I == H && !pl.with_taps && !getenv("RVC_NO_WN_COMPOSE");      // (launch-bound up to a few streams)
+        static const int wn_max_b = getenv("RVC_WN_COMPOSE_MAX") ? atoi(getenv("RVC_WN_COMPOSE_MAX")) : 8;
+        const bool wn_composed = B <= wn_max_b && H % 16 == 0 && I == H && !pl.with_taps && !getenv("RVC_NO_WN_COMPOSE");      // (launch-bound up to a few streams)
         T1 U[2];
         const int u_z = 16 + H + H * m.wn_layers;                     // first latent row of U
         if (wn_composed) {
