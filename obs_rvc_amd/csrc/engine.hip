@@ -1505,14 +1505,17 @@ static void set_device(rvc_engine *e) { HIPCHK(hipSetDevice(e->device)); }
 
 static void init_kernel_attrs()
 {
-    static bool done = false;
-    if (done) return;
-    done = true;
+    // per device: function attributes belong to the device that is current when they are set (an engine on a second GPU of one process needs its own)
+    static std::mutex mu; static bool done[64] = {};
+    int dev = 0; HIPCHK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev >= 0 && dev < 64) { if (done[dev]) return; done[dev] = true; }
     HIPCHK(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)layernorm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));   // + 1.3 KB static
     HIPCHK(hipFuncSetAttribute((const void *)gru_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)knn_select_blend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));   // + ~5 KB static
     HIPCHK(hipFuncSetAttribute((const void *)knn_dot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    conv_tile_prepare_device();
     HIPCHK(hipFuncSetAttribute((const void *)relpos_attention_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)relpos_attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)te_attention_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
