@@ -22,6 +22,9 @@
 namespace rvc {
 
 #define COMMA_ ,
+#ifndef RVC_CT_DBG
+#define RVC_CT_DBG 0          // ablation builds (tests/tools/ct_ablate.sh): 1 no weight reloads, 2 no B reads, 8 no MFMAs (timing only)
+#endif
 template <int ACT, int MF, int NF>
 __device__ __forceinline__ void conv_tile_store(const IgemmP &p, const PhaseD &ph, const float *resb, float *yb, const ColOut (&cols)[NF], int m_base, const f32x4 (&acc)[MF][NF])
 {
@@ -162,10 +165,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_
         _Pragma("unroll") for (int mf = 0; mf < MF; mf++) a_old_[mf] = a_st[S][mf];                    \
         _Pragma("unroll") for (int t = 0; t < T_; t++) {                                               \
             const int j = t / (NF * MF), nf = (t / MF) % NF, mf = t % MF;                              \
-            acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_old_[mf][j], bcur[nf][j], acc[mf][nf], 0, 0, 0); \
+            if (!(RVC_CT_DBG & 8)) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_old_[mf][j], bcur[nf][j], acc[mf][nf], 0, 0, 0); \
+            else acc[mf][nf][0] += a_old_[mf][j] * bcur[nf][j];                                        \
             _Pragma("unroll") for (int r = t * R_ / T_; r < (t + 1) * R_ / T_; r++) {                  \
-                if (r < NF) bnx_[r] = *reinterpret_cast<const f32x4 *>(bl + ob_ + r * 16 * cs);        \
-                else a_st[S][r - NF] = *reinterpret_cast<const f32x4 *>(wrow[r - NF] + cn_ * 256 + lane * 4); \
+                if (r < NF) { if (!(RVC_CT_DBG & 2)) bnx_[r] = *reinterpret_cast<const f32x4 *>(bl + ob_ + r * 16 * cs); else bnx_[r] = bcur[r]; } \
+                else if (!(RVC_CT_DBG & 1)) a_st[S][r - NF] = *reinterpret_cast<const f32x4 *>(wrow[r - NF] + cn_ * 256 + lane * 4); \
             }                                                                                          \
             __builtin_amdgcn_sched_barrier(0);                                                         \
         }                                                                                              \

@@ -552,7 +552,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
         for (const PhaseD &q : phv) pl.touch_host.push_back({p.w + q.w_off, mt * (size_t)q.nchunks * 256});
     }
     const bool ln_fold = p.ln_wsum || p.ln_stats_in || phase_epi;      // folded LayerNorm lives in the register-direct kernel's K-split epilogue
-    if (!ln_fold && !getenv("RVC_NO_LDS_GEMM") && nchunks >= 2 && (size_t)nchunks * 64 + 2 * 16 * 260 * 4 <= 60 * 1024) {
+    if (!ln_fold && !getenv("RVC_NO_LDS_GEMM") && nchunks >= 2 && (size_t)nchunks * 64 + 2 * 256 * 20 * 4 <= 60 * 1024) {
         int bm = p.M >= 96 ? 128 : (p.M >= 48 ? 64 : (p.M > 16 ? 32 : 0));
         if (const char *f = getenv("RVC_G32_BM")) { const int v = atoi(f); if (v == 32 || v == 64 || v == 128) bm = v; }   // tuning aid
         const int bn = bm == 128 ? 128 : 256;
@@ -577,7 +577,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     // at two waves per SIMD): 128 x 64 tiles of the 32x32x2 kernel, four waves stacked in M over one 64-column activation tile
     // (768 x 3072 projection at 64 streams: 361 -> 342 us; small, but the same kernel)
     static const long long g32_narrow_min = getenv("RVC_G32_NARROW") ? atoll(getenv("RVC_G32_NARROW")) : 500;     // 0 = off
-    if (lds_cfg < 0 && !ln_fold && g32_narrow_min > 0 && !getenv("RVC_NO_LDS_GEMM") && !p.glu && nchunks >= 2 && p.M >= 96 && (size_t)nchunks * 64 + 2 * 16 * 68 * 4 <= 60 * 1024) {
+    if (lds_cfg < 0 && !ln_fold && g32_narrow_min > 0 && !getenv("RVC_NO_LDS_GEMM") && !p.glu && nchunks >= 2 && p.M >= 96 && (size_t)nchunks * 64 + 2 * 64 * 20 * 4 <= 60 * 1024) {
         const long long wgs = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * B * p.nphase;
         if (wgs >= g32_narrow_min) lds_cfg = 7;
     }
@@ -588,7 +588,8 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
         p.ntm = (p.M + bm - 1) / bm; p.ntn = (p.N + bn - 1) / bn;
         p.m_fast = p.fold_n ? p.ntm : 0;
         dim3 grid(p.ntm * p.ntn, B * p.nphase);
-        const size_t lds = (size_t)nchunks * 64 + (size_t)2 * 16 * (bn + 4) * 4;
+        const bool g32k = lds_cfg >= 3 && lds_cfg != 6;            // igemm32_kernel keeps its activation tile column-major, [2][bn][20]
+        const size_t lds = (size_t)nchunks * 64 + (g32k ? (size_t)2 * bn * 20 * 4 : (size_t)2 * 16 * (bn + 4) * 4);
         g_last_wgs = (int)(grid.x * grid.y); g_last_waves = 4;
         const double flops = 2.0 * p.M * (double)p.N * ksum * B;
         pl.igemm_flops += flops; pl.n_igemm++;

@@ -1182,9 +1182,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 {
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-    constexpr int RS = BN + 4;                     // LDS row stride: k-slots 0 / 1 (4 rows apart) land 16 banks apart
-    constexpr int KR = 256 / BN > 0 ? 256 / BN : 1;    // k rows staged per pass of the 256 threads
-    constexpr int EPT = 16 / KR;                   // staged elements per thread per K step
+    // The staged activation tile is kept COLUMN-major, [BN][16 k + 4 pad]: the four k-values (2u + ks) * 4 + j, j = 0..3, that a lane feeds to four
+    // consecutive MFMAs are one ds_read_b128, and a staging thread owns EPT consecutive k rows of one column (ds_write_b128).  On this chip an fp32
+    // MFMA hides none of its SIMD's other instructions (tests/tools/mfma_overlap_probe.hip: +16 clocks per ds_read_b32, +4 per VALU, +32 per 16-byte
+    // vector load, at any occupancy), so the row-major tile's 16 ds_read_b32 + 8 ds_write_b32 per K step were a sixth of the step.
+    constexpr int RSK = 20;                        // column stride in floats: 16-byte aligned, 16 lanes x 16 bytes on disjoint banks
+    constexpr int KR = 256 / BN > 0 ? 256 / BN : 1;    // staging threads per column
+    constexpr int EPT = 16 / KR;                   // consecutive k rows per staging thread per K step (4, 8 or 16)
     static_assert(BN <= 256 && 256 % BN == 0, "BN must divide 256");
     extern __shared__ __attribute__((aligned(16))) int s_mem[];
     RVC_KP(0);
@@ -1201,11 +1205,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         int4 *dst = reinterpret_cast<int4 *>(s_mem);
         for (int i = threadIdx.x; i < nchunks * 4; i += 256) dst[i] = src[i];
     }
-    float *bt = reinterpret_cast<float *>(s_mem + nchunks * 16);     // [2][16][RS]
+    float *bt = reinterpret_cast<float *>(s_mem + nchunks * 16);     // [2][BN][RSK]
     const int c32 = lane & 31, ks = lane >> 5;                       // MFMA column (B) / row (A) and k-slot of this lane
     const char *xb = reinterpret_cast<const char *>(p.x + (long long)b * p.x_bs + ph.x_off) - p.koff_bias;
-    // staging role: column n_s of the tile, k rows kr0, kr0 + KR, ...
-    const int n_s = threadIdx.x % BN, kr0 = threadIdx.x / BN;
+    // staging role: column n_s of the tile, k rows kr0 .. kr0 + EPT - 1
+    const int n_s = threadIdx.x % BN, kr0 = (threadIdx.x / BN) * EPT;
     unsigned xo_s;
     {
         int n = tn * BN + n_s;
@@ -1239,38 +1243,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     float sb[EPT];
     f32x4 a_cur[MT][2], a_nxt[MT][2];
 #pragma unroll
-    for (int i = 0; i < EPT; i++) sb[i] = *reinterpret_cast<const float *>(xb + (xo_s + (unsigned)kof[kr0 + i * KR]));
+    for (int i = 0; i < EPT; i++) sb[i] = *reinterpret_cast<const float *>(xb + (xo_s + (unsigned)kof[kr0 + i]));
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int u = 0; u < 2; u++) a_cur[mt][u] = *reinterpret_cast<const f32x4 *>(wrow[mt] + u * 128);
 #pragma unroll
-    for (int i = 0; i < EPT; i++) {
-        const float v = sb[i];
-        bt[(kr0 + i * KR) * RS + n_s] = PRE ? fmaxf(v, v * pre_slope) : v;
+    for (int i = 0; i < EPT; i += 4) {
+        f32x4 v4;
+#pragma unroll
+        for (int q = 0; q < 4; q++) v4[q] = PRE ? fmaxf(sb[i + q], sb[i + q] * pre_slope) : sb[i + q];
+        *reinterpret_cast<f32x4 *>(bt + n_s * RSK + kr0 + i) = v4;
     }
     __syncthreads();
     RVC_KP(2);
     // B operand of MFMA (u, j) for column block nt: row k = (2u + ks) * 4 + j of the staged tile
-    const float *br = bt + wn * NT * 32 + c32 + ks * 4 * RS;
+    const float *br = bt + (wn * NT * 32 + c32) * RSK + ks * 4;
     for (int c = 0; c < nchunks; c++) {
         const int cn = c + 1 < nchunks ? c + 1 : c;
-        const float *bcur = br + (c & 1) * 16 * RS;
-        float *bnxt = bt + ((c + 1) & 1) * 16 * RS;
+        const float *bcur = br + (c & 1) * BN * RSK;
+        float *bnxt = bt + ((c + 1) & 1) * BN * RSK;
         // next K step: global -> registers
 #pragma unroll
-        for (int i = 0; i < EPT; i++) sb[i] = *reinterpret_cast<const float *>(xb + (xo_s + (unsigned)kof[cn * 16 + kr0 + i * KR]));
+        for (int i = 0; i < EPT; i++) sb[i] = *reinterpret_cast<const float *>(xb + (xo_s + (unsigned)kof[cn * 16 + kr0 + i]));
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int u = 0; u < 2; u++) a_nxt[mt][u] = *reinterpret_cast<const f32x4 *>(wrow[mt] + cn * 256 + u * 128);
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            float bv[NT][4];
+            f32x4 bv[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) bv[nt][j] = bcur[(u * 8 + j) * RS + nt * 32];
+            for (int nt = 0; nt < NT; nt++) bv[nt] = *reinterpret_cast<const f32x4 *>(bcur + nt * 32 * RSK + u * 8);
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -1280,9 +1284,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][u][j], bv[nt][j], acc[mt][nt], 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < EPT; i++) {
-            const float v = sb[i];
-            bnxt[(kr0 + i * KR) * RS + n_s] = PRE ? fmaxf(v, v * pre_slope) : v;
+        for (int i = 0; i < EPT; i += 4) {
+            f32x4 v4;
+#pragma unroll
+            for (int q = 0; q < 4; q++) v4[q] = PRE ? fmaxf(sb[i + q], sb[i + q] * pre_slope) : sb[i + q];
+            *reinterpret_cast<f32x4 *>(bnxt + n_s * RSK + kr0 + i) = v4;
         }
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
