@@ -114,6 +114,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_
         wrow[mf] = p.w + ph.w_off + (long long)mt * nchunks * 256;          // wave-uniform; the lane's 16 bytes are added at the load
     }
     const int nloc = (nchunks - kh + KS - 1) / KS;     // this wave's chunks: kh, kh + KS, ...  (>= 1: nchunks >= KS is checked at plan time)
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const float *wnext[MF];              // wave-uniform: the chunk whose weights are requested next (scalar base + lane offset: no per-load address VALU)
+#pragma unroll
+    for (int mf = 0; mf < MF; mf++) wnext[mf] = wrow[mf] + (long long)(kh + DA * KS) * 256;
     f32x4 a_st[DA][MF];
 #pragma unroll
     for (int s = 0; s < DA; s++) {
@@ -147,8 +151,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_
     const int last = nloc - 1;
     // (tap, group) of a chunk index, carried incrementally: requests run 1 (B) and DA (weights) of this wave's chunks ahead of the MFMAs
     int g_b = 0, off_b = 0;                             // chunk whose B fragments are requested next (floats from bl)
-#define RVC_CT_ADV1() { g_b++; off_b += 16; if (g_b == G) { g_b = 0; off_b += dil * cs - 16 * G; } }
-#define RVC_CT_ADV() { RVC_CT_ADV1() if (KS == 2) RVC_CT_ADV1() }
+    const int wrap_b = dil * cs - 16 * G;               // from the last channel group of a tap to the first of the next
+#define RVC_CT_ADV1() { g_b++; off_b += 16; if (g_b == G) { g_b = 0; off_b += wrap_b; } }
+#define RVC_CT_ADV() { g_b += KS; off_b += 16 * KS; if (g_b >= G) { g_b -= G; off_b += wrap_b; } }      /* (KS <= G: checked at plan time) */
     if (kh) RVC_CT_ADV1()
     f32x4 bcur[NF];
 #pragma unroll
@@ -158,7 +163,6 @@ __global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_
 #define RVC_CT_STEP(S, CC)                                                                              \
     {                                                                                                  \
         const int cc_ = (CC);                                                                          \
-        const int cn_ = kh + (cc_ + DA < last ? cc_ + DA : last) * KS;                                 \
         const int ob_ = cc_ < last ? off_b : 0;                 /* the surplus request of the last chunk stays inside the tile */ \
         f32x4 bnx_[NF];                                                                                \
         f32x4 a_old_[MF];                                                                              \
@@ -169,11 +173,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_
             else acc[mf][nf][0] += a_old_[mf][j] * bcur[nf][j];                                        \
             _Pragma("unroll") for (int r = t * R_ / T_; r < (t + 1) * R_ / T_; r++) {                  \
                 if (r < NF) { if (!(RVC_CT_DBG & 2)) bnx_[r] = *reinterpret_cast<const f32x4 *>(bl + ob_ + r * 16 * cs); else bnx_[r] = bcur[r]; } \
-                else if (!(RVC_CT_DBG & 1)) a_st[S][r - NF] = *reinterpret_cast<const f32x4 *>(wrow[r - NF] + cn_ * 256 + lane * 4); \
+                else if (!(RVC_CT_DBG & 1)) a_st[S][r - NF] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(wnext[r - NF]) + lane16); \
             }                                                                                          \
             __builtin_amdgcn_sched_barrier(0);                                                         \
         }                                                                                              \
         RVC_CT_ADV()                                                                                   \
+        _Pragma("unroll") for (int mf = 0; mf < MF; mf++) wnext[mf] += KS * 256;      /* (requests past the wave's last chunk read the slack behind the panel) */ \
         _Pragma("unroll") for (int nf = 0; nf < NF; nf++) bcur[nf] = bnx_[nf];                         \
     }
     int c = 0;

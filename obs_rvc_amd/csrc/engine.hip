@@ -389,7 +389,7 @@ static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &
         for (int k = 0; k < K; k++) if (koff[q.koff_off + k] != (k / KW) * p.x_ld + dmin + (k % KW) * dil) return no(9);
         const int rl = BN + (KW - 1) * dil, rt = rl | 1, cs = cin + 8;
         q.t_tab = KW | (dil << 8); q.t_cin = cin; q.t_rs = rt; q.t_dmin = dmin;
-        if (q.nchunks < 2) return no(10);
+        if (q.nchunks < 2 || cin / 16 < kshares) return no(10);          // (every K share needs a chunk; the kernel steps its tap / group counters by the share count)
         lds_max = std::max(lds_max, (std::max<size_t>(((size_t)cin * rt + 63) / 64 * 64, (size_t)kTileWF[tc0] * 256) + (size_t)rl * cs) * 4);
         std::vector<float> wold((size_t)mt * q.nchunks * 256);
         HIPCHK(hipMemcpy(wold.data(), p.w + q.w_off, wold.size() * 4, hipMemcpyDeviceToHost));
@@ -408,6 +408,7 @@ static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &
         q.w_off = (long long)base;
     }
     if (lds_max > (wide ? 150 : 100) * 1024) return no(11);
+    wnew.resize(wnew.size() + (size_t)16 * 2 * 256, 0.f);      // slack: the kernel's weight requests run DA x KS chunks past a wave's last chunk
     p.w = pl.arena.upload(wnew);
     if (pl.collect_touch) pl.touch_host.push_back({p.w, wnew.size()});
     // work items, longest first, dealt to the CUs by longest-processing-time; block r * ncu + j = the r-th item of CU j
