@@ -42,7 +42,25 @@ UNITS = [("engine.hip", [], _ENGINE_DEPS), ("synth_front.hip", [], ("synth_front
         [("igemm_tiled_inst.hip", ["-DRVC_TILED_PART=%d" % c], ("igemm_tiled_inst.hip",) + _IGEMM_DEPS) for c in range(4)] + \
         [("conv_tile_inst.hip", [], ("conv_tile_inst.hip", "conv_tile.hip.h") + _IGEMM_DEPS)]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
-OBJ_CACHE = os.environ.get("RVC_OBJ_CACHE", "/tmp/rvc_obj_cache")
+# Object cache: content-addressed (sources + flags).  It lives under the repository's build/ directory (git- and gpurun-ignored), is
+# created 0700, and a directory that is not ours (other owner, or writable by group / others) is refused: objects are linked straight
+# into the product library, so nobody else may be able to plant one.
+OBJ_CACHE = os.environ.get("RVC_OBJ_CACHE", os.path.join(os.path.dirname(_HERE), "build", "obj_cache"))
+
+
+def _private_cache_dir() -> str:
+    os.makedirs(OBJ_CACHE, mode=0o700, exist_ok=True)
+    st = os.stat(OBJ_CACHE)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        raise RuntimeError("object cache %s is not private to uid %d (owner %d, mode %o): refusing to link objects from it"
+                           % (OBJ_CACHE, os.getuid(), st.st_uid, st.st_mode & 0o777))
+    return OBJ_CACHE
+
+
+def _tmp_name(path: str) -> str:
+    """unique per builder (several ranks may call build() at once); published with os.replace, which is atomic"""
+    import uuid
+    return "%s.%d.%s.tmp.o" % (path, os.getpid(), uuid.uuid4().hex[:8])
 
 
 def source_hash() -> str:
@@ -82,20 +100,25 @@ def compile_units(extra_flags=(), verbose=False, extra_units=()):
     """Compile every translation unit whose object is not in the cache (content-addressed: sources + flags), in parallel.
     -> list of object paths"""
     from concurrent.futures import ThreadPoolExecutor
-    os.makedirs(OBJ_CACHE, exist_ok=True)
+    _private_cache_dir()
     jobs, objs = [], []
     for src, flags, deps in list(UNITS) + list(extra_units):
         obj = os.path.join(OBJ_CACHE, _unit_key(src, flags, tuple(deps), extra_flags) + ".o")
         objs.append(obj)
         if not os.path.exists(obj):
-            jobs.append((["hipcc"] + HIPCC_FLAGS + list(flags) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj + ".tmp.o"], obj))
+            tmp = _tmp_name(obj)
+            jobs.append((["hipcc"] + HIPCC_FLAGS + list(flags) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", tmp], obj, tmp))
 
     def run(job):
-        cmd, obj = job
+        cmd, obj, tmp = job
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        os.replace(obj + ".tmp.o", obj)
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, obj)
+        finally:
+            if os.path.exists(tmp):
+                os.unlink(tmp)
     if jobs:
         with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
             list(ex.map(run, jobs))
@@ -103,15 +126,22 @@ def compile_units(extra_flags=(), verbose=False, extra_units=()):
 
 
 def link_library(objs, out, want_hash, verbose=False):
-    ver = os.path.join(OBJ_CACHE, "version-%s.o" % want_hash)
-    cmd = ["hipcc", "-O2", "-fPIC", "-c", '-DRVC_SRC_HASH="%s"' % want_hash, os.path.join(CSRC, "version.cpp"), "-o", ver]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + [ver, "-o", out, "-ldl"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    ver = _tmp_name(os.path.join(_private_cache_dir(), "version-%s" % want_hash))
+    tmp_out = "%s.%d.tmp" % (out, os.getpid())
+    try:
+        cmd = ["hipcc", "-O2", "-fPIC", "-c", '-DRVC_SRC_HASH="%s"' % want_hash, os.path.join(CSRC, "version.cpp"), "-o", ver]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + [ver, "-o", tmp_out, "-ldl"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(tmp_out, out)
+    finally:
+        for f in (ver, tmp_out):
+            if os.path.exists(f):
+                os.unlink(f)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
