@@ -28,7 +28,7 @@ SYMBOLS = [
 
 
 SOURCES = ("engine.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "igemm2_inst.hip", "igemm_tiled_inst.hip", "conv_tile.hip.h", "conv_tile_inst.hip", "version.cpp",
-           "synth_front.hip", "synth_front.h", "state.hip.h",
+           "state.hip.h",
            "resample.hip.h", "session.hip.h", "rccl_bcast.hip.h", "blob.h", "rvc_rpc.cpp")
 
 # translation units of the library: (source, extra flags, files whose contents decide whether the object is stale).  The implicit-GEMM
@@ -36,8 +36,8 @@ SOURCES = ("engine.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "igem
 # and are not rebuilt when only the engine changes.
 _IGEMM_DEPS = ("igemm.hip.h", "igemm_launch.h")
 _ENGINE_DEPS = ("engine.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "resample.hip.h", "session.hip.h", "rccl_bcast.hip.h", "blob.h",
-                "synth_front.h", "state.hip.h")
-UNITS = [("engine.hip", [], _ENGINE_DEPS), ("synth_front.hip", [], ("synth_front.hip", "synth_front.h", "state.hip.h"))] + \
+                "state.hip.h")
+UNITS = [("engine.hip", [], _ENGINE_DEPS)] + \
         [("igemm2_inst.hip", ["-DRVC_IGEMM2_CFG=%d" % c], ("igemm2_inst.hip",) + _IGEMM_DEPS) for c in range(5)] + \
         [("igemm_tiled_inst.hip", ["-DRVC_TILED_PART=%d" % c], ("igemm_tiled_inst.hip",) + _IGEMM_DEPS) for c in range(4)] + \
         [("conv_tile_inst.hip", [], ("conv_tile_inst.hip", "conv_tile.hip.h") + _IGEMM_DEPS)]

@@ -6,8 +6,7 @@
 
 namespace rvc {
 
-#define RVC_CT_ALL(X) X(4, 1, 2, 1, 1) X(4, 1, 1, 2, 1) X(2, 2, 1, 2, 1) X(4, 1, 2, 1, 2) X(4, 1, 1, 2, 2) X(2, 2, 1, 2, 2) X(2, 1, 2, 2, 2) \
-                      X(4, 1, 2, 4, 1) X(4, 1, 1, 4, 1) X(2, 2, 1, 4, 1) X(4, 1, 2, 4, 2) X(4, 1, 1, 4, 2) X(2, 2, 1, 4, 2) X(4, 1, 2, 2, 1) X(4, 1, 2, 2, 2) X(2, 1, 4, 1, 2)
+#define RVC_CT_ALL(X) X(4, 1, 2, 1, 1) X(4, 1, 1, 2, 1) X(2, 2, 1, 2, 1) X(4, 1, 2, 1, 2) X(4, 1, 1, 2, 2) X(2, 2, 1, 2, 2)
 
 // the tiles of the long-dilation phases pass 64 KB of LDS: raise the limit on the CURRENT device (called when an engine is created on it)
 void conv_tile_prepare_device()
@@ -24,13 +23,7 @@ void launch_conv_tile(int tile, int kshares, const IgemmP &p, dim3 grid, size_t 
     switch (tile) {
     case 0: if (k2) RVC_CT_GO(4, 1, 2, 1, 2) else RVC_CT_GO(4, 1, 2, 1, 1)
     case 1: if (k2) RVC_CT_GO(4, 1, 1, 2, 2) else RVC_CT_GO(4, 1, 1, 2, 1)
-    case 2: if (k2) RVC_CT_GO(2, 2, 1, 2, 2) else RVC_CT_GO(2, 2, 1, 2, 1)
-    case 3: RVC_CT_GO(2, 1, 2, 2, 2)
-    case 4: if (k2) RVC_CT_GO(4, 1, 2, 4, 2) else RVC_CT_GO(4, 1, 2, 4, 1)
-    case 5: if (k2) RVC_CT_GO(4, 1, 1, 4, 2) else RVC_CT_GO(4, 1, 1, 4, 1)
-    case 7: if (k2) RVC_CT_GO(4, 1, 2, 2, 2) else RVC_CT_GO(4, 1, 2, 2, 1)
-    case 8: RVC_CT_GO(2, 1, 4, 1, 2)
-    default: if (k2) RVC_CT_GO(2, 2, 1, 4, 2) else RVC_CT_GO(2, 2, 1, 4, 1)
+    default: if (k2) RVC_CT_GO(2, 2, 1, 2, 2) else RVC_CT_GO(2, 2, 1, 2, 1)
     }
 #undef RVC_CT_GO
 #undef RVC_CT_ALL

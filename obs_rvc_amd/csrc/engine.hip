@@ -8,7 +8,6 @@
 #include "blob.h"
 #include "kernels.hip.h"
 #include "igemm_launch.h"
-#include "synth_front.h"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -16,6 +15,7 @@
 #include <cstdarg>
 #include <cstddef>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -37,6 +37,44 @@ __attribute__((constructor)) static void rvc_runtime_defaults()
 }
 
 namespace rvc {
+
+// ---------------------------------------------------------------------------------------
+// switches
+// ---------------------------------------------------------------------------------------
+// The product library reads four environment variables and no others: GPU_MAX_HW_QUEUES (a default is planted, see above),
+// RVC_NO_RUNTIME_DEFAULTS, LOCAL_RANK (rvc_create with device < 0) and RVC_RCCL_LIB (rccl_bcast.hip.h); the rvc-rpc executable adds
+// RVC_NOISE_SEED and RVC_USE_GRAPH.  Every other switch is
+//   * a TEST HOOK (kTestHooks): set with rvc_debug_option(name, value) by the parity tests and the profiling tools -- an explicit call,
+//     never inherited from a host's environment -- to force a code path the planner would not pick for the geometry at hand; or
+//   * a TUNING switch (tune_env): compiled out of the product (the call is a constant nullptr, its branch disappears); only builds with
+//     -DRVC_TUNING (tests/tools/build_tuning.py -> librvc_tuning.so) have them, and there both kinds also fall back to the environment
+//     variable of the same name.
+static const char *const kTestHooks[] = {"RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_NO_LN_FUSE", "RVC_NO_CONV0_MULTI", "RVC_KNN_NO_GEMM",
+                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE"};
+static std::mutex g_opt_mu;
+static std::map<std::string, std::string> g_opts;
+static bool is_test_hook(const char *name)
+{
+    for (const char *h : kTestHooks) if (!strcmp(h, name)) return true;
+    return false;
+}
+static const char *opt_lookup(const char *name)
+{
+    static thread_local std::string buf;
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    auto it = g_opts.find(name);
+    if (it == g_opts.end()) return nullptr;
+    buf = it->second;
+    return buf.c_str();
+}
+#ifdef RVC_TUNING
+static const char *test_opt(const char *name) { const char *v = opt_lookup(name); return v ? v : getenv(name); }
+static const char *tune_env(const char *name) { const char *v = opt_lookup(name); return v ? v : getenv(name); }
+#else
+static const char *test_opt(const char *name) { return opt_lookup(name); }
+static inline const char *tune_env(const char *) { return nullptr; }
+#endif
+static int test_opt_int(const char *name, int dflt) { const char *v = test_opt(name); return v ? atoi(v) : dflt; }
 
 #define HIPCHK(expr)                                                                                         \
     do {                                                                                                     \
@@ -325,10 +363,6 @@ struct Plan {
     // caller needs no staging copy in front of the chunk and no copy behind it (a captured graph bakes pointers: it keeps d_in / audio)
     const float *cur_in = nullptr; float *cur_out = nullptr; long long cur_out_bs = 0;
     bool in_direct_ok = true, out_direct_ok = false;
-    unsigned long long *front_stamps = nullptr;
-    unsigned *front_epoch = nullptr;      // tag base of the persistent synthesizer front end (synth_front.h): advanced at the end of every chunk
-    // weight prefetch of the serial tail (weight_touch_kernel): ranges recorded while the tail's launches are queued
-    bool collect_touch = false; std::vector<std::pair<const float *, size_t>> touch_host; void *touch_dev = nullptr; int touch_n = 0; float *touch_sink = nullptr;
     // graph
     hipGraphExec_t graph_exec = nullptr;
     ~Plan()
@@ -351,20 +385,15 @@ static int g_last_waves = 0, g_last_wgs = 0;
 static int g_ncu = 256;
 static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phv, double ksum, bool final_out)
 {
-    const int mode = getenv("RVC_CONV_TILE") ? atoi(getenv("RVC_CONV_TILE")) : 1;       // 0 = off, 2 = wherever eligible (tests); read per plan
-    auto no = [&](int why) { if (getenv("RVC_CONV_TILE_DEBUG")) fprintf(stderr, "conv_tile: not taken (%d) M=%d N=%d B=%d\n", why, p.M, p.N, B); return false; };
-    // streams: one always; two to four by default (narrow tiles, streams in the item table: measured -1 % / -2 % at 2 / 4 streams, nothing at 8);
-    // RVC_CONV_TILE_MULTI=n: also n streams and more (the wide tiles from RVC_CONV_TILE_WIDE streams on: measured slower than the 32x32x2 kernels)
-    const int multi = getenv("RVC_CONV_TILE_MULTI") ? atoi(getenv("RVC_CONV_TILE_MULTI")) : 0;
+    const int mode = test_opt_int("RVC_CONV_TILE", 1);       // test hook: 0 = off, 2 = wherever eligible; read per plan
+    auto no = [&](int why) { (void)why; return false; };
+    // streams: one always; two to four with the same narrow tiles and the streams in the item table (measured -1 % / -2 % at 2 / 4 streams, nothing at
+    // 8; wider tiles for many streams measured slower than the 32x32x2 kernels and are gone)
     if (!mode || p.fold_n || p.x_ld <= 0 || p.x_hs || p.x_ws != 1 || p.y_hm || p.lin_cs4 || p.glu || p.ln_wsum || p.ln_stats_in || p.ln_stats_out || p.part) return no(1);
-    if (B > 4 && !(multi > 0 && B >= multi)) return no(2);
+    if (B > 4) return no(2);
     if (p.M > 128 && mode < 2) return no(3);
-    const bool wide = B >= (getenv("RVC_CONV_TILE_WIDE") ? atoi(getenv("RVC_CONV_TILE_WIDE")) : 16);      // few streams keep the narrow tiles (more items per CU)
-    int kshares = getenv("RVC_CONV_TILE_KS") ? atoi(getenv("RVC_CONV_TILE_KS")) : (wide ? 1 : 2);      // tuning aid: 1 = one wave per fragment set
-    const int t128 = getenv("RVC_CONV_TILE_128") ? atoi(getenv("RVC_CONV_TILE_128")) : 0;          // tuning aid: tile of the > 64-row layers (0 = 128 x 16, 3 = 64 x 32)
-    const int w128 = getenv("RVC_CONV_TILE_W128") ? atoi(getenv("RVC_CONV_TILE_W128")) : 4;        // tuning aid: wide tile of the > 64-row layers (4 = 128 x 64, 7 = 128 x 32)
-    const int tc0 = wide ? (p.M > 64 ? w128 : (p.M > 32 ? 5 : 6)) : (p.M > 64 ? t128 : (p.M > 32 ? 1 : 2));
-    if (tc0 == 3 || tc0 == 8) kshares = 2;
+    const int kshares = test_opt_int("RVC_CONV_TILE_KS", 2);      // test hook: 1 = one wave per fragment set
+    const int tc0 = p.M > 64 ? 0 : (p.M > 32 ? 1 : 2);            // 128 x 16, 64 x 32, 32 x 64
     const int BM = kTileBM[tc0], BN = kTileBN[tc0];
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     if (ntm > 255 || ntn > 32767 || phv.size() > 255) return no(4);
@@ -407,10 +436,9 @@ static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &
                         }
         q.w_off = (long long)base;
     }
-    if (lds_max > (wide ? 150 : 100) * 1024) return no(11);
+    if (lds_max > 100 * 1024) return no(11);
     wnew.resize(wnew.size() + (size_t)16 * 2 * 256, 0.f);      // slack: the kernel's weight requests run DA x KS chunks past a wave's last chunk
     p.w = pl.arena.upload(wnew);
-    if (pl.collect_touch) pl.touch_host.push_back({p.w, wnew.size()});
     // work items, longest first, dealt to the CUs by longest-processing-time; block r * ncu + j = the r-th item of CU j
     struct It { int w, code, b; };
     std::vector<It> items;
@@ -432,10 +460,6 @@ static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &
             bins[top.second].push_back((int)i); top.first += items[i].w;
             std::push_heap(heap.begin(), heap.end(), cmp);
         }
-    }
-    if (getenv("RVC_CONV_TILE_PLAIN")) {           // tuning aid: dispatch order = longest first, no pairing
-        for (auto &bn : bins) bn.clear();
-        for (size_t i = 0; i < items.size(); i++) bins[i % nb].push_back((int)i);
     }
     size_t rounds = 0;
     for (auto &bn : bins) rounds = std::max(rounds, bn.size());
@@ -478,7 +502,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     // every stream up to a tile.  All offsets stay below 2^31 bytes / elements for every geometry the plugin can ask for (checked).
     const int streams = B;
     if (B > 1) {
-        // many streams, stride-1 1-D convolution: the staged-tile kernel with its wide tiles, streams as a grid dimension (tried before the fold)
+        // two to four streams, stride-1 1-D convolution: the staged-tile kernel with the streams in its work-item table (tried before the fold)
         std::vector<PhaseD> phq(phases);
         double ks0 = 0;
         for (PhaseD &q : phq) { if (q.nchunks == 0) q.nchunks = p.K / 16; ks0 += q.nchunks * 16.0; }
@@ -486,7 +510,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
         IgemmP pt = p;
         if (queue_conv_tile(pl, pt, B, koff, phq, ks0, final_out)) return;
     }
-    if (B > 1 && !getenv("RVC_NO_FOLD")) {
+    if (B > 1 && !tune_env("RVC_NO_FOLD")) {
         const long long lim = (1LL << 29);
         if ((long long)B * p.x_bs < lim && (long long)B * p.y_bs < lim && (long long)B * (p.res ? p.res_bs : 0) < lim && (long long)B * p.N < (1LL << 30) &&
             (size_t)(p.K / 16) * 64 <= 60 * 1024) {      // (the two-stage grid split-K fallback keeps the batch as a grid dimension)
@@ -507,7 +531,7 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     for (PhaseD &q : phv) { if (q.nchunks == 0) q.nchunks = p.K / 16; ksum += q.nchunks * 16.0; }
     // phases of unequal length (the fused ResBlock chains: kernel sizes 3 / 7 / 11) are dispatched longest first: the grid's z axis
     // is walked last, so the workgroups of phase 0 start first and the short phases fill the tail instead of the long one forming it
-    if (!getenv("RVC_NO_LPT"))
+    if (!tune_env("RVC_NO_LPT"))
         std::stable_sort(phv.begin(), phv.end(), [](const PhaseD &a, const PhaseD &b) { return a.nchunks > b.nchunks; });
     p.ph = pl.arena.upload(phv);
     p.nphase = (int)phv.size();
@@ -548,37 +572,33 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     bool phase_epi = false;                               // per-phase activation / output tensor: igemm2 only
     for (const PhaseD &q : phv) phase_epi = phase_epi || q.act_p1 != 0 || q.y_off != 0;
     if (queue_conv_tile(pl, p, B, koff, phv, ksum, final_out)) return;
-    if (pl.collect_touch) {
-        const size_t mt = (size_t)(p.M + 15) / 16;
-        for (const PhaseD &q : phv) pl.touch_host.push_back({p.w + q.w_off, mt * (size_t)q.nchunks * 256});
-    }
     const bool ln_fold = p.ln_wsum || p.ln_stats_in || phase_epi;      // folded LayerNorm lives in the register-direct kernel's K-split epilogue
-    if (!ln_fold && !getenv("RVC_NO_LDS_GEMM") && nchunks >= 2 && (size_t)nchunks * 64 + 2 * 256 * 20 * 4 <= 60 * 1024) {
+    if (!ln_fold && !tune_env("RVC_NO_LDS_GEMM") && nchunks >= 2 && (size_t)nchunks * 64 + 2 * 256 * 20 * 4 <= 60 * 1024) {
         int bm = p.M >= 96 ? 128 : (p.M >= 48 ? 64 : (p.M > 16 ? 32 : 0));
-        if (const char *f = getenv("RVC_G32_BM")) { const int v = atoi(f); if (v == 32 || v == 64 || v == 128) bm = v; }   // tuning aid
+        if (const char *f = tune_env("RVC_G32_BM")) { const int v = atoi(f); if (v == 32 || v == 64 || v == 128) bm = v; }   // tuning aid
         const int bn = bm == 128 ? 128 : 256;
         if (bm) {
             const long long wgs = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * B * p.nphase;
-            // isolated B = 64 timings (tests/gemm_microbench.py): the LDS-tiled kernel wins for very tall (M >= 2048) and very short
+            // isolated B = 64 timings (tests/tools/gemm_microbench.py): the LDS-tiled kernel wins for very tall (M >= 2048) and very short
             // (M <= 64) weight panels, the register-direct kernel in between (cv_ff2 91 vs 73 TF/s, cv_o 77 vs 62, enc_ff1 24 vs 13)
             const bool lds_wins = p.M >= 2048 || p.M <= 64;
             if (wgs >= 384 && lds_wins) lds_cfg = bm == 128 ? 0 : (bm == 64 ? 1 : 2);
             // 32x32x2 kernel (igemm32): RVC_GEMM32 = 0 off, 1 wherever the old workgroup-tiled kernel was chosen, 2 (default) for every
             // layer with enough workgroups to fill the chip
-            static const int g32 = getenv("RVC_GEMM32") ? atoi(getenv("RVC_GEMM32")) : 2;
-            static const long long g32_min = getenv("RVC_GEMM32_MIN") ? atoll(getenv("RVC_GEMM32_MIN")) : 768;   // fewer workgroups balance badly over 256 CUs (measured: 336 -> slower)
+            static const int g32 = tune_env("RVC_GEMM32") ? atoi(tune_env("RVC_GEMM32")) : 2;
+            static const long long g32_min = tune_env("RVC_GEMM32_MIN") ? atoll(tune_env("RVC_GEMM32_MIN")) : 768;   // fewer workgroups balance badly over 256 CUs (measured: 336 -> slower)
             if (g32 == 1 && lds_cfg >= 0 && !p.glu) lds_cfg += 3;
             else if (g32 >= 2 && wgs >= g32_min && !p.glu) lds_cfg = 3 + (bm == 128 ? 0 : (bm == 64 ? 1 : 2));   // (gated layers stay on the kernels that are tested with the gate)
         }
     }
     // 48-row panels (ContentVec's grouped positional convolution: 16 groups of 48 channels, K = 6144 each): three 16-row fragments
     // exactly, instead of a 64-row tile with a quarter of its MFMAs on padding
-    if (lds_cfg == 1 && p.M == 48 && !getenv("RVC_NO_BM48")) lds_cfg = 6;
+    if (lds_cfg == 1 && p.M == 48 && !tune_env("RVC_NO_BM48")) lds_cfg = 6;
     // mid-size panels (M = 768 at 64 streams: 336 tiles of 128 x 128 balance badly over 256 CUs, and the register-direct 2 x 4 tile runs
     // at two waves per SIMD): 128 x 64 tiles of the 32x32x2 kernel, four waves stacked in M over one 64-column activation tile
     // (768 x 3072 projection at 64 streams: 361 -> 342 us; small, but the same kernel)
-    static const long long g32_narrow_min = getenv("RVC_G32_NARROW") ? atoll(getenv("RVC_G32_NARROW")) : 500;     // 0 = off
-    if (lds_cfg < 0 && !ln_fold && g32_narrow_min > 0 && !getenv("RVC_NO_LDS_GEMM") && !p.glu && nchunks >= 2 && p.M >= 96 && (size_t)nchunks * 64 + 2 * 64 * 20 * 4 <= 60 * 1024) {
+    static const long long g32_narrow_min = tune_env("RVC_G32_NARROW") ? atoll(tune_env("RVC_G32_NARROW")) : 500;     // 0 = off
+    if (lds_cfg < 0 && !ln_fold && g32_narrow_min > 0 && !tune_env("RVC_NO_LDS_GEMM") && !p.glu && nchunks >= 2 && p.M >= 96 && (size_t)nchunks * 64 + 2 * 64 * 20 * 4 <= 60 * 1024) {
         const long long wgs = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * B * p.nphase;
         if (wgs >= g32_narrow_min) lds_cfg = 7;
     }
@@ -614,14 +634,14 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     // four dword gathers (9-12 clocks each on the CU's single vector-memory path) for ONE MFMA row block; two fragments along N per wave and eight
     // K shares halve the weight loads per MFMA (isolated: 768 x 3072 18.5 -> 14.9 us, 768 x 768 6.5 -> 5.7 us; in the chain: ContentVec -22 us)
     if (cfg == 0 && wg_ks == 4 && B == 1 && !p.fold_n && p.lin_cs4 && p.nphase == 1 && p.M >= 256 && p.N > 64 && p.N <= 128 && nchunks >= 32 && !p.ln_wsum && !getenv("RVC_NO_LIN_16x32")) { cfg = 1; wg_ks = 8; }
-    if (const char *f = getenv("RVC_TUNE")) {        // tuning aid: "M,K:cfg,ks;M,K:cfg,ks;..." overrides the tile choice of matching layers
+    if (const char *f = tune_env("RVC_TUNE")) {        // tuning aid: "M,K:cfg,ks;M,K:cfg,ks;..." overrides the tile choice of matching layers
         for (const char *q = f; q && *q; ) {
             int tm = 0, tk = 0, tc = 0, tks = 1;
             if (sscanf(q, "%d,%d:%d,%d", &tm, &tk, &tc, &tks) == 4 && tm == p.M && tk == p.K) { cfg = tc; wg_ks = tks; }
             q = strchr(q, ';'); if (q) q++;
         }
     }
-    if (const char *f = getenv("RVC_FORCE_CFG")) {   // tuning aid: "cfg,ks[,mfast]"
+    if (const char *f = test_opt("RVC_FORCE_CFG")) {   // tuning aid: "cfg,ks[,mfast]"
         int fc = 0, fk = 1; if (sscanf(f, "%d,%d", &fc, &fk) >= 1) { cfg = fc; wg_ks = fk; }
     }
     if (p.ln_wsum || p.ln_stats_in) {
@@ -648,14 +668,14 @@ static void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff,
     // weight-heavy layers (short N: the transformer at T=111, RMVPE's deep levels, the synth encoder): keep all tiles that
     // read the same weight rows on one XCD so each weight byte crosses the fabric once (per-XCD L2s are private)
     bool weight_heavy = (p.N <= 512 && (long long)p.M * p.K >= 64 * 1024 && p.ntm >= 8) || (p.fold_n && p.ntm >= 2);
-    if (const char *f = getenv("RVC_FORCE_MFAST")) weight_heavy = atoi(f) != 0;
+    if (const char *f = tune_env("RVC_FORCE_MFAST")) weight_heavy = atoi(f) != 0;
     p.m_fast = weight_heavy ? (p.ntm + 7) / 8 * 8 : 0;
     const int ntiles = weight_heavy ? p.m_fast * p.ntn : p.ntm * p.ntn;
     dim3 grid(wg_ks > 1 ? ntiles : (ntiles + 3) / 4, B * p.nphase * ksplit);
     dim3 egrid((unsigned)(((long long)p.M * p.N + 255) / 256), B * p.nphase);
     // lean kernel: x = fast tile axis (m when m_fast, else n; 4 tiles per workgroup without the in-workgroup K split), y = slow axis
-    const bool lean = ksplit == 1 && !getenv("RVC_OLD_IGEMM");
-    const bool lin = lean && p.lin_cs4 != 0 && p.nphase == 1 && !pre && !getenv("RVC_NO_LIN");
+    const bool lean = ksplit == 1 && !tune_env("RVC_OLD_IGEMM");
+    const bool lin = lean && p.lin_cs4 != 0 && p.nphase == 1 && !pre && !tune_env("RVC_NO_LIN");
     size_t lds2 = 0;
     if (lean) {
         const int fast_n = weight_heavy ? p.ntm : p.ntn, slow_n = weight_heavy ? p.ntn : p.ntm;
@@ -822,7 +842,7 @@ static void add_conv2d(Plan &pl, const ConvW &cw, const T2 &x, const T2 &y, Conv
     p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.cs; p.y_rs = y.ld;
     fill_epilogue(p, cw, o);
     std::vector<int> koff;
-    if (cw.KW == 9 && x.H == 1 && !cw.host_w.empty() && !getenv("RVC_NO_TAP_PRUNE")) {
+    if (cw.KW == 9 && x.H == 1 && !cw.host_w.empty() && !tune_env("RVC_NO_TAP_PRUNE")) {
         // one-row image (RMVPE's bottleneck at Tm = 32): the kh = 0 and kh = 2 taps only ever read the zero halo rows, so two
         // thirds of the weight stream is dead.  Repack the middle row of every 3x3 filter once per plan (K = Cin*3).
         const int K3 = cw.Cin * 3, Kp3 = round16(K3);
@@ -874,7 +894,7 @@ static void add_layernorm(Plan &pl, const T1 &x, const float *g, const float *b)
     const bool small = x.C <= 256;
     // many streams: 16-column strips held in registers (float4 rows; needs 16-byte aligned rows, which every plan tensor has: ld and
     // halo are multiples of 4).  Reading the padding columns behind T is safe (inside the row), they are never written.
-    if (x.B >= 16 && x.ld % 4 == 0 && x.halo % 4 == 0 && ((x.T + 3) / 4 * 4 <= x.ld - x.halo) && !getenv("RVC_NO_LN_STRIP")) {
+    if (x.B >= 16 && x.ld % 4 == 0 && x.halo % 4 == 0 && ((x.T + 3) / 4 * 4 <= x.ld - x.halo) && !tune_env("RVC_NO_LN_STRIP")) {
         // grid x = stream, y = strip: workgroup (b, strip) runs on XCD (strip * B + b) % 8 = b % 8 when B is a multiple of 8, so the two
         // 64-byte halves of every 128-byte line (adjacent strips of one stream) are fetched by the same XCD's L2, once
         dim3 sg(x.B, (x.T + 15) / 16);
@@ -886,7 +906,7 @@ static void add_layernorm(Plan &pl, const T1 &x, const float *g, const float *b)
         });
         return;
     }
-    if (x.B >= 16 && x.C > 256 && (size_t)x.C * 33 * 4 <= 150 * 1024 && !getenv("RVC_NO_LN_TILE")) {
+    if (x.B >= 16 && x.C > 256 && (size_t)x.C * 33 * 4 <= 150 * 1024 && !tune_env("RVC_NO_LN_TILE")) {
         dim3 tg((x.T + 31) / 32, x.B);
         const size_t lds = (size_t)x.C * 33 * sizeof(float);
         pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(layernorm_tile_kernel, tg, dim3(256), lds, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs); });
@@ -900,7 +920,7 @@ static void add_layernorm(Plan &pl, const T1 &x, const float *g, const float *b)
 
 static void add_stamp(Plan &pl, const char *name)
 {
-    static const bool on = getenv("RVC_STAMPS") != nullptr;
+    const bool on = test_opt("RVC_STAMPS") != nullptr;
     if (!on) return;
     if (!pl.d_stamps) pl.d_stamps = reinterpret_cast<unsigned long long *>(pl.arena.floats(2 * 256));
     if (pl.stamp_names.size() >= 256) return;
@@ -993,7 +1013,7 @@ struct ModelCV {
             L.ff2 = prep_conv(b.w(fmt("cv.l%d.ff2.w", l)), b.w(fmt("cv.l%d.ff2.b", l)), E, ffn, 1, 1);
             L.ln1_g = own(fmt("cv.l%d.ln1.g", l)); L.ln1_b = own(fmt("cv.l%d.ln1.b", l));
             L.ln2_g = own(fmt("cv.l%d.ln2.g", l)); L.ln2_b = own(fmt("cv.l%d.ln2.b", l));
-            if (E >= 256 && E % 64 == 0 && ffn % 64 == 0 && !getenv("RVC_NO_LN_FUSE")) {
+            if (E >= 256 && E % 64 == 0 && ffn % 64 == 0 && !test_opt("RVC_NO_LN_FUSE")) {
                 has_folded = true;
                 L.ff1_f = fold_ln(b.w(fmt("cv.l%d.ff1.w", l)), b.w(fmt("cv.l%d.ff1.b", l)), ffn, E, b.w(fmt("cv.l%d.ln1.g", l)), b.w(fmt("cv.l%d.ln1.b", l)), &L.ff1_wsum);
                 if (l > 0) L.qkv_f = fold_ln(w.data(), bb.data(), 3 * E, E, b.w(fmt("cv.l%d.ln2.g", l - 1)), b.w(fmt("cv.l%d.ln2.b", l - 1)), &L.qkv_wsum);
@@ -1115,9 +1135,6 @@ struct ModelSY {
     // (The first LayerNorm of a layer feeds a 3-tap convolution with zero padding: padded positions are zero AFTER the norm, so it stays.)
     struct Layer {
         ConvW qkv, o, ff1, ff2, qkv_f; float *qkv_wsum = nullptr; float *rel_k, *rel_v, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
-        // one stream: q, k and V' = (W_o[:, head] W_v[head]) x per head, for the attention block that also applies the output projection
-        // (kernels.hip.h te_attention_block_kernel); qkvx_f: with the previous layer's second LayerNorm folded in
-        ConvW qkvx, qkvx_f; float *qkvx_wsum = nullptr; float *rel_vp = nullptr, *rel_kp = nullptr; bool has_x = false;
     };
     ConvW proj_f; float *proj_wsum = nullptr; bool has_folded = false;
     std::vector<Layer> layers;
@@ -1166,41 +1183,9 @@ struct ModelSY {
             L.rel_k = own(fmt("sy.enc.l%d.rel_k", l)); L.rel_v = own(fmt("sy.enc.l%d.rel_v", l));
             L.ln1_g = own(fmt("sy.enc.l%d.ln1.g", l)); L.ln1_b = own(fmt("sy.enc.l%d.ln1.b", l));
             L.ln2_g = own(fmt("sy.enc.l%d.ln2.g", l)); L.ln2_b = own(fmt("sy.enc.l%d.ln2.b", l));
-            if (H >= 128 && H % 16 == 0 && !getenv("RVC_NO_LN_FUSE")) {
+            if (H >= 128 && H % 16 == 0 && !test_opt("RVC_NO_LN_FUSE")) {
                 has_folded = true;
                 if (l > 0) L.qkv_f = ModelCV::fold_ln(w.data(), bb.data(), 3 * H, H, b.w(fmt("sy.enc.l%d.ln2.g", l - 1)), b.w(fmt("sy.enc.l%d.ln2.b", l - 1)), &L.qkv_wsum);
-            }
-            if (H % 64 == 0 && H <= 256 && H % heads == 0 && (H / heads) % 16 == 0) {
-                // composed value / output projection per head (double accumulation, rounded once)
-                const int kc = H / heads, NR = 2 * window + 1, NRP = (NR + 3) / 4 * 4;
-                const float *wo = b.w(fmt("sy.enc.l%d.o.w", l)), *wv = &w[(size_t)2 * H * H], *bv = &bb[(size_t)2 * H], *relv = b.w(fmt("sy.enc.l%d.rel_v", l));
-                std::vector<float> wx((size_t)(2 + heads) * H * H), bx((size_t)(2 + heads) * H), rvp((size_t)heads * NRP * H, 0.f);
-                memcpy(wx.data(), w.data(), (size_t)2 * H * H * 4); memcpy(bx.data(), bb.data(), (size_t)2 * H * 4);
-                std::vector<double> acc(H);
-                for (int h = 0; h < heads; h++)
-                    for (int o = 0; o < H; o++) {
-                        std::fill(acc.begin(), acc.end(), 0.0);
-                        double ba = 0.0;
-                        for (int d = 0; d < kc; d++) {
-                            const double v = wo[(size_t)o * H + h * kc + d];
-                            const float *wr = wv + (size_t)(h * kc + d) * H;
-                            for (int c = 0; c < H; c++) acc[c] += v * wr[c];
-                            ba += v * bv[h * kc + d];
-                        }
-                        for (int c = 0; c < H; c++) wx[((size_t)(2 + h) * H + o) * H + c] = (float)acc[c];
-                        bx[(size_t)(2 + h) * H + o] = (float)ba;
-                        for (int r = 0; r < NR; r++) {
-                            double a = 0.0;
-                            for (int d = 0; d < kc; d++) a += (double)wo[(size_t)o * H + h * kc + d] * relv[(size_t)r * kc + d];
-                            rvp[((size_t)h * NRP + r) * H + o] = (float)a;
-                        }
-                    }
-                L.qkvx = prep_conv(wx.data(), bx.data(), (2 + heads) * H, H, 1, 1);
-                if (has_folded && l > 0) L.qkvx_f = ModelCV::fold_ln(wx.data(), bx.data(), (2 + heads) * H, H, b.w(fmt("sy.enc.l%d.ln2.g", l - 1)), b.w(fmt("sy.enc.l%d.ln2.b", l - 1)), &L.qkvx_wsum);
-                rvp.resize(rvp.size() + 512, 0.f);
-                L.rel_vp = upload_f(rvp); owned.push_back(L.rel_vp);
-                { const int PW = (NR + 15) / 16 * 16; std::vector<float> rkp((size_t)PW * kc + 512, 0.f); memcpy(rkp.data(), b.w(fmt("sy.enc.l%d.rel_k", l)), (size_t)NR * kc * 4); L.rel_kp = upload_f(rkp); owned.push_back(L.rel_kp); }
-                L.has_x = true;
             }
             layers.push_back(L);
         }
@@ -1268,7 +1253,7 @@ struct ModelSY {
             flows.push_back(F);
         }
         // composed WaveNets (one to eight streams): built with the model, 20 tasks on the host's cores, so that no first chunk pays for them
-        if (hidden % 16 == 0 && inter == hidden && !getenv("RVC_NO_WN_COMPOSE")) compose_flows();
+        if (hidden % 16 == 0 && inter == hidden && !test_opt("RVC_NO_WN_COMPOSE")) compose_flows();
         {
             std::vector<float> bias(up_init);
             const float *cw = b.w("sy.dec.cond.w"), *cb = b.w("sy.dec.cond.b"), *pb = b.w("sy.dec.pre.b");
@@ -1441,7 +1426,7 @@ struct ModelSY {
     ~ModelSY()
     {
         free_conv(phone); free_conv(proj); free_conv(dec_pre); free_conv(dec_post);
-        for (auto &L : layers) { free_conv(L.qkv); free_conv(L.o); free_conv(L.ff1); free_conv(L.ff2); free_conv(L.qkv_f); if (L.qkv_wsum) (void)hipFree(L.qkv_wsum); free_conv(L.qkvx); free_conv(L.qkvx_f); if (L.qkvx_wsum) (void)hipFree(L.qkvx_wsum); }
+        for (auto &L : layers) { free_conv(L.qkv); free_conv(L.o); free_conv(L.ff1); free_conv(L.ff2); free_conv(L.qkv_f); if (L.qkv_wsum) (void)hipFree(L.qkv_wsum); }
         free_conv(proj_f); if (proj_wsum) (void)hipFree(proj_wsum);
         for (auto &F : flows) { free_conv(F.pre); free_conv(F.post); for (auto &c : F.in) free_conv(c); for (auto &c : F.rs) free_conv(c); if (composed) { free_conv(F.pre1); free_conv(F.postc); free_conv(F.posth); for (auto &c : F.inc) free_conv(c); } }
         for (auto &c : ups) free_conv(c);
@@ -1520,8 +1505,6 @@ static void init_kernel_attrs()
     conv_tile_prepare_device();
     HIPCHK(hipFuncSetAttribute((const void *)relpos_attention_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void *)relpos_attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)te_attention_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void *)relpos_attention_vp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
 
 static void init_constants(rvc_engine *e)
@@ -1595,8 +1578,8 @@ static StreamSet *acquire_stream_set(int device, int ncu, int nf0, bool want_mas
     // pool created all plain streams first: 2.17 -> 2.80 ms per chunk -- queue assignment follows creation order); the two plain
     // streams that stand in for the masked pair at more than 4 streams are created when such an engine first borrows the set
     // tuning aid: RVC_STREAM_ORDER = a permutation of "mfcs" (main, f0 masked, ContentVec masked, side), RVC_STREAM_PAD = dummy streams first
-    const char *ord = getenv("RVC_STREAM_ORDER"); if (!ord || strlen(ord) != 4) ord = "mfcs";
-    if (const char *pd = getenv("RVC_STREAM_PAD")) for (int i = 0; i < atoi(pd); i++) { hipStream_t d; HIPCHK(hipStreamCreateWithFlags(&d, hipStreamNonBlocking)); }
+    const char *ord = tune_env("RVC_STREAM_ORDER"); if (!ord || strlen(ord) != 4) ord = "mfcs";
+    if (const char *pd = tune_env("RVC_STREAM_PAD")) for (int i = 0; i < atoi(pd); i++) { hipStream_t d; HIPCHK(hipStreamCreateWithFlags(&d, hipStreamNonBlocking)); }
     m->masked_ok = want_masks;
     for (int k = 0; k < 4; k++) {
         const char w = ord[k];
@@ -1628,7 +1611,7 @@ static void configure_aux_streams(rvc_engine *e)
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, e->device));
     int ncu = prop.multiProcessorCount, nf0 = ncu / 8;
     g_ncu = ncu > 0 ? ncu : 256;
-    if (const char *f = getenv("RVC_F0_CUS")) { const int v = atoi(f); if (v >= 8 && v < ncu) nf0 = v; }   // tuning aid
+    if (const char *f = tune_env("RVC_F0_CUS")) { const int v = atoi(f); if (v >= 8 && v < ncu) nf0 = v; }   // tuning aid
     if (!e->sset) {
         e->sset = acquire_stream_set(e->device, ncu, nf0, e->partition_ok && ncu >= 64 && ncu <= 1024);
         e->stream = e->sset->main;
@@ -1661,7 +1644,7 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
     for (int i = 0; i < 7; i++) {
         int To = (T - m.conv_k[i]) / m.conv_s[i] + 1;
         T1 y = make_t1(A, B, m.conv_dim, To, 0);
-        if (i == 0 && m.conv_k[0] <= 16 && To <= 32 * 256 && m.conv0_raw && !getenv("RVC_NO_CONV0_FUSE")) {
+        if (i == 0 && m.conv_k[0] <= 16 && To <= 32 * 256 && m.conv0_raw && !tune_env("RVC_NO_CONV0_FUSE")) {
             // first layer fused: conv (Cin = 1) + per-channel GroupNorm + GELU, outputs held in registers between the passes
             dim3 grid(m.conv_dim, B);
             const float *w0 = m.conv0_raw, *gg = m.gn_g, *bb = m.gn_b; const int kt = m.conv_k[0], st = m.conv_s[0];
@@ -1670,9 +1653,9 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
             // 16 channels per workgroup share one register copy of the input samples at many streams; one stream: 2 (256 workgroups of
             // 1024 threads, half the strided gathers: 42.8 -> ~15 us, 25-30 us off the ContentVec branch; 4 and 8 measured the same / worse)
             int cpw = B >= 16 ? 16 : (B >= 4 ? 4 : 2);
-            if (const char *f = getenv("RVC_CONV0_CPW")) cpw = std::max(1, atoi(f));      // tuning aid
+            if (const char *f = tune_env("RVC_CONV0_CPW")) cpw = std::max(1, atoi(f));      // tuning aid
             while (cpw > 1 && m.conv_dim % cpw) cpw >>= 1;
-            if (kt == 10 && To <= 8 * 1024 && cpw > 1 && !getenv("RVC_NO_CONV0_MULTI")) {
+            if (kt == 10 && To <= 8 * 1024 && cpw > 1 && !test_opt("RVC_NO_CONV0_MULTI")) {
                 dim3 gridm(m.conv_dim / cpw, B);
                 const int nt1k = (To + 1023) / 1024;
                 Plan *plp = &pl;
@@ -1708,7 +1691,7 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
         x = y; T = To;
     }
     add_tap(pl, "cv.feat", x);
-    const bool fuse_ln = B == 1 && m.has_folded && !pl.with_taps && !getenv("RVC_NO_LN_FUSE");
+    const bool fuse_ln = B == 1 && m.has_folded && !pl.with_taps && !test_opt("RVC_NO_LN_FUSE");
     const int E = m.embed;
     T1 h = make_t1(A, B, E, T, m.pos_k / 2);
     if (fuse_ln && m.proj_wsum) { ConvOpts o; o.ln_wsum = m.proj_wsum; o.ln_rows = m.conv_dim; add_conv1d(pl, m.proj_f, x, h, 1, 0, 1, o); }
@@ -1740,11 +1723,11 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
         AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = E; ap.T = T; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;
         ap.scale = 1.0f / sqrtf((float)hd); ap.rel_k = nullptr; ap.rel_v = nullptr; ap.window = 0;
         dim3 ag(m.heads * ((T + 15) / 16), B);
-        if (B >= 16 && hd == 64 && T <= 256 && !getenv("RVC_ATTN_VALU") && !getenv("RVC_NO_QLOOP")) { ap.qloop = 1; ag = dim3(m.heads, B); }
-        if (hd == 64 && T <= 128 && !getenv("RVC_ATTN_VALU")) {
+        if (B >= 16 && hd == 64 && T <= 256 && !tune_env("RVC_ATTN_VALU") && !tune_env("RVC_NO_QLOOP")) { ap.qloop = 1; ag = dim3(m.heads, B); }
+        if (hd == 64 && T <= 128 && !tune_env("RVC_ATTN_VALU")) {
             const size_t mfma_lds = ((size_t)16 * (2 * 64 + 1) + 128) * sizeof(float);
             pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL((attention_mfma_kernel<64, 2>), ag, dim3(256), mfma_lds, s, ap); });
-        } else if (hd == 64 && T <= 256 && !getenv("RVC_ATTN_VALU")) {
+        } else if (hd == 64 && T <= 256 && !tune_env("RVC_ATTN_VALU")) {
             const size_t mfma_lds = ((size_t)16 * (4 * 64 + 1) + 128) * sizeof(float);
             pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL((attention_mfma_kernel<64, 4>), ag, dim3(256), mfma_lds, s, ap); });
         } else {
@@ -1823,7 +1806,7 @@ static void add_conv2d_with_shortcut(Plan &pl, const ResBlockW &w, const T2 &x, 
     std::vector<PhaseD> ph(2);
     ph[0] = PhaseD{}; ph[1] = PhaseD{};
     // phase 0: the 3x3 convolution (one-row images: only the middle tap row can hit data, see add_conv2d)
-    if (x.H == 1 && !c1.host_w.empty() && !getenv("RVC_NO_TAP_PRUNE")) {
+    if (x.H == 1 && !c1.host_w.empty() && !tune_env("RVC_NO_TAP_PRUNE")) {
         const int K3 = c1.Cin * 3, Kp3 = round16(K3);
         std::vector<float> panel((size_t)c1.M * Kp3, 0.f);
         for (int mo = 0; mo < c1.M; mo++)
@@ -1860,7 +1843,7 @@ static T2 res_block(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &out)
     T2 y1 = make_t2(A, x.B, w.co, x.H, x.W);
     // few streams: the 3x3 convolution and the 1x1 shortcut read the same input -- one launch with two phases (own K, own output tensor,
     // own activation) instead of two dependent launches (11 blocks of RMVPE have a shortcut: 11 launches off the f0 branch)
-    if (w.has_sc && w.pair_bias && x.B <= 4 && (x.B == 1 || y1.bs == out.bs) && !getenv("RVC_NO_SC_MERGE")) {      // (one stream stride for both outputs)
+    if (w.has_sc && w.pair_bias && x.B <= 4 && (x.B == 1 || y1.bs == out.bs) && !tune_env("RVC_NO_SC_MERGE")) {      // (one stream stride for both outputs)
         add_conv2d_with_shortcut(pl, w, x, y1, out);
         ConvOpts o; o.act = ACT_RELU; o.accumulate = true; add_conv2d(pl, w.c2, y1, out, o);
         return out;
@@ -1951,7 +1934,7 @@ static T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k,
         size_t lds = (size_t)4 * Hg * sizeof(float);
         float *wt = m.whhT, *bh = m.bhh;
         dim3 grid(2, B);
-        if (Hg == 256 && B <= 8 && Tm <= 256 && !getenv("RVC_GRU_GENERIC")) {
+        if (Hg == 256 && B <= 8 && Tm <= 256 && !tune_env("RVC_GRU_GENERIC")) {
             // few streams: spread each direction over 8 CUs with W_hh resident in LDS (granule hand-off per step)
             GruMultiP gp{}; gp.gi = gi.p; gp.gi_cs = gi.ld; gp.gi_bs = gi.bs; gp.whh = m.whh; gp.bhh = m.bhh; gp.out = gout.p; gp.o_cs = gout.ld; gp.o_bs = gout.bs;
             gp.Tm = Tm; gp.status = &e->d_state[0].status; gp.status_stride = (int)(sizeof(StreamState) / sizeof(int));
@@ -2049,65 +2032,7 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
     const int HALO = 4;
     if (m.enc_k / 2 > HALO || m.wn_k / 2 > HALO) throw ShapeError("synth kernel sizes exceed the halo");
     T1 z = make_t1(A, B, I, R, HALO), zf = make_t1(A, B, I, R, HALO);
-    // One stream: text encoder + prior sample + flows as ONE persistent launch (synth_front.hip: ~70 layers on a 21-column window hand
-    // their outputs from workgroup to workgroup as tagged granules instead of crossing ~70 kernel boundaries).
-    bool front_done = false;
-    // Opt-in (RVC_SYNTH_FRONT=1): with the per-step costs measured so far it equals the per-layer launches, it does
-    // not beat them yet.
-    if (B == 1 && !pl.with_taps && getenv("RVC_SYNTH_FRONT") && !getenv("RVC_NO_SYNTH_FRONT")) {
-        SynFrontP P{};
-        auto sw = [](const ConvW &cw, int M) { SfW w; w.w = cw.w; w.b = cw.bias; w.M = M; w.nchunks = cw.Kp / 16; return w; };
-        P.T = R; P.C = m.phone_dim; P.H = H; P.F = F; P.I = I; P.heads = m.heads; P.window = m.window; P.n_layers = m.enc_layers; P.n_flows = m.flow_n;
-        P.wn_layers = m.wn_layers; P.enc_k = m.enc_k; P.wn_k = m.wn_k;
-        const bool fits = m.enc_layers <= SF_MAX_LAYERS && m.flow_n <= SF_MAX_FLOWS && m.wn_layers <= 4 && phone.C == m.phone_dim;
-        if (fits) {
-            P.phone = phone.p; P.phone_ld = phone.ld; P.pitch = d_pitch; P.pitch_emb = m.pitch_emb;
-            P.phone_w = sw(m.phone, H); P.proj = sw(m.proj, 2 * I);
-            for (int l = 0; l < m.enc_layers; l++) {
-                ModelSY::Layer &Ly = m.layers[l];
-                SfLayer &D = P.layer[l];
-                D.qkv = sw(Ly.qkv, 3 * H); D.o = sw(Ly.o, H); D.ff1 = sw(Ly.ff1, F); D.ff2 = sw(Ly.ff2, H);
-                D.rel_k = Ly.rel_k; D.rel_v = Ly.rel_v; D.ln1_g = Ly.ln1_g; D.ln1_b = Ly.ln1_b; D.ln2_g = Ly.ln2_g; D.ln2_b = Ly.ln2_b;
-            }
-            for (int i = 0; i < m.flow_n; i++) {
-                ModelSY::Flow &Fw = m.flows[i];
-                SfFlow &D = P.flow[i];
-                D.pre = sw(Fw.pre, H);                         // (rows H..2H of the panel are the zero rows that clear the skip accumulator: not needed here)
-                D.post = sw(Fw.post, half); D.flipped = Fw.flipped ? 1 : 0;
-                for (int j = 0; j < m.wn_layers; j++) { D.in[j] = sw(Fw.in[j], 2 * H); D.rs[j] = sw(Fw.rs[j], j < m.wn_layers - 1 ? 2 * H : H); }
-            }
-            P.z_out = z.p; P.z_ld = z.ld; P.st = e->d_state; P.cp = e->d_cp; P.status = &e->d_state[0].status;
-            if (synth_front_supported(P)) {
-                P.gran = (unsigned long long *)A.alloc(synth_front_ws_granules(P) * sizeof(unsigned long long));
-                pl.front_epoch = (unsigned *)A.alloc(256);
-                P.epoch = pl.front_epoch;
-                if (getenv("RVC_FRONT_STAMPS")) { pl.front_stamps = (unsigned long long *)A.alloc(512 * 8); P.stamps = pl.front_stamps; }
-                // algorithmic flops of the layers inside the launch (2 M N K per layer at N = return_length), for the per-launch profile
-                double fl = 0;
-                auto add = [&](const SfW &w) { fl += 2.0 * w.M * (double)R * w.nchunks * 16.0; };
-                add(P.phone_w); add(P.proj);
-                for (int l = 0; l < m.enc_layers; l++) { add(P.layer[l].qkv); add(P.layer[l].o); add(P.layer[l].ff1); add(P.layer[l].ff2); }
-                for (int i = 0; i < m.flow_n; i++) { add(P.flow[i].pre); add(P.flow[i].post); for (int j = 0; j < m.wn_layers; j++) { add(P.flow[i].in[j]); add(P.flow[i].rs[j]); } }
-                pl.igemm_flops += fl; pl.n_igemm++;
-                { char d[160]; snprintf(d, sizeof d, "synth_front persistent: %d steps, %d workgroups, T=%d", synth_front_steps(P), synth_front_grid(P), R); pl.descs.push_back(d); }
-                const int desc_id = (int)pl.descs.size() - 1;
-                Plan *plp = &pl;
-                pl.ops.push_back([=](hipStream_t s) {
-                    ProfEvent *pe = nullptr;
-                    if (plp->profile) {
-                        if (plp->prof_used == plp->prof.size()) { ProfEvent ev; HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b)); ev.flops = 0; ev.bytes = 0; plp->prof.push_back(ev); }
-                        pe = &plp->prof[plp->prof_used++]; pe->flops = fl; pe->bytes = 0; pe->desc = desc_id;
-                        HIPCHK(hipEventRecord(pe->a, s));
-                    }
-                    launch_synth_front(P, s);
-                    if (pe) HIPCHK(hipEventRecord(pe->b, s));
-                });
-                add_stamp(pl, "sy.flow");
-                front_done = true;
-            }
-        }
-    }
-    if (!front_done) {
+    {
         T1 x = make_t1(A, B, H, R, HALO);
         add_conv1d(pl, m.phone, phone, x, 1, 0, 1);
         {
@@ -2120,66 +2045,10 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         const size_t attn_lds = ((size_t)((kc * Tp + 3) & ~3) + 16 * Tp + 16 * kc) * sizeof(float);
         if (attn_lds > 160 * 1024) throw ShapeError("synth attention: return_length too long for the LDS-resident kernel");
         // one stream: the second LayerNorm of every encoder layer is folded into the next projection (see build_contentvec)
-        const bool fuse_ln = B == 1 && m.has_folded && !pl.with_taps && !getenv("RVC_NO_LN_FUSE");
+        const bool fuse_ln = B == 1 && m.has_folded && !pl.with_taps && !test_opt("RVC_NO_LN_FUSE");
         bool raw = false; const float *raw_g = nullptr, *raw_b = nullptr; float *raw_st = nullptr;
-        // one stream: attention + output projection + residual + LayerNorm as one launch (te_attention_block_kernel), fed by q | k | V' rows
-        const int te_nr = 2 * m.window + 1, te_nrp = (te_nr + 3) / 4 * 4, te_sw = (R + 15) / 16 * 16, te_pw = (te_nr + 15) / 16 * 16;
-        auto up256 = [](size_t n) { return (n + 255) / 256 * 256; };
-        const size_t te_ld = (size_t)(R + 3) / 4 * 4;                 // row stride of the q | k | V' tensor (halo 0)
-        const size_t te_lds = (up256((size_t)H * 16) + up256((size_t)H * te_ld) + up256((size_t)m.heads * H * te_ld) + up256((size_t)te_pw * kc) + up256((size_t)m.heads * te_nrp * H) +
-                               (size_t)m.heads * 16 * (te_sw + 2 * te_pw) + 128) * sizeof(float);
-        const bool te_block = B == 1 && fuse_ln && m.layers[0].has_x && R <= 64 && te_lds <= 160 * 1024 && getenv("RVC_TE_BLOCK") && atoi(getenv("RVC_TE_BLOCK")) != 0;      // opt-in: equals the three launches it replaces (measured), does not beat them
-        // opt-in (RVC_TE_VP=1; measured +8..22 us per chunk: the wider projection, the doubled P V work and the three-tensor LayerNorm cost more than the
-        // launch they save): the output projection composed into the values, its sum folded into the LayerNorm launch (relpos_attention_vp_kernel)
-        const int vp_tp = R | 1, vp_pw = te_pw;
-        const size_t vp_lds = ((size_t)kc * 16 + (size_t)kc * vp_tp + (size_t)H * vp_tp + (size_t)vp_pw * kc + (size_t)te_nrp * H + 16 * (size_t)te_sw + 2 * 16 * (size_t)vp_pw + 64) * sizeof(float);
-        const bool te_vp = !te_block && B == 1 && fuse_ln && m.layers[0].has_x && R <= 64 && H <= 1024 && vp_lds <= 160 * 1024 && getenv("RVC_TE_VP") && atoi(getenv("RVC_TE_VP")) != 0;
-        T1 parts;
-        if (te_vp) parts = make_t1(A, B, m.heads * H, R, 0);
-        T1 qkvx;
-        if (te_block || te_vp) qkvx = make_t1(A, B, (2 + m.heads) * H + 16, R, 0).rows(0, (2 + m.heads) * H);      // (16 spare rows: the last LDS-DMA piece of the block copy may run past the tensor)
         for (int l = 0; l < m.enc_layers; l++) {
             ModelSY::Layer &Ly = m.layers[l];
-            if (te_vp) {
-                // q | k | V' projection, attention with the output projection composed into V' (per-head partial sums), then sum + bias + residual +
-                // LayerNorm: five launches per layer instead of six
-                if (raw) { raw_st = A.floats((size_t)2 * R + 16); ConvOpts o; o.ln_wsum = Ly.qkvx_wsum; o.ln_stats_out = raw_st; o.ln_rows = H; add_conv1d(pl, Ly.qkvx_f, x, qkvx, 1, 0, 1, o); }
-                else add_conv1d(pl, Ly.qkvx, x, qkvx, 1, 0, 1);
-                AttnP ap{}; ap.qkv = qkvx.p; ap.out = parts.p; ap.E = H; ap.T = R; ap.heads = m.heads; ap.cs = qkvx.ld; ap.bs = qkvx.bs; ap.o_cs = parts.ld; ap.o_bs = parts.bs;
-                ap.scale = 1.0f / sqrtf((float)kc); ap.rel_k = Ly.rel_k; ap.rel_v = Ly.rel_vp; ap.window = m.window;
-                dim3 ag(m.heads * ((R + 15) / 16), B);
-                pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(relpos_attention_vp_kernel, ag, dim3(256), vp_lds, s, ap); });
-                LnSumP lp{}; lp.part = parts.p; lp.np = m.heads; lp.part_hs = (long long)H * parts.ld; lp.p_cs = parts.ld; lp.p_bs = parts.bs; lp.bias = Ly.o.bias;
-                lp.res = x.p; lp.r_cs = x.ld; lp.r_bs = x.bs;
-                if (raw) { lp.st_in = raw_st; lp.g_in = raw_g; lp.b_in = raw_b; }
-                lp.g = Ly.ln1_g; lp.bta = Ly.ln1_b; lp.y = x.p; lp.y_cs = x.ld; lp.y_bs = x.bs; lp.C = H; lp.T = R;
-                dim3 lg((R + 3) / 4, B);
-                pl.ops.push_back([=](hipStream_t s) {
-                    if (lp.C <= 64) hipLaunchKernelGGL((layernorm_sum_kernel<1>), lg, dim3(256), 0, s, lp);
-                    else if (lp.C <= 256) hipLaunchKernelGGL((layernorm_sum_kernel<4>), lg, dim3(256), 0, s, lp);
-                    else hipLaunchKernelGGL((layernorm_sum_kernel<16>), lg, dim3(256), 0, s, lp);
-                });
-                { ConvOpts o; o.act = ACT_RELU; add_conv1d(pl, Ly.ff1, x, ff, 1, m.enc_k / 2, 1, o); }
-                { ConvOpts o; o.res = x.p; o.res_cs = x.ld; o.res_bs = x.bs; add_conv1d(pl, Ly.ff2, ff, x, 1, m.enc_k / 2, 1, o); }
-                raw = true; raw_g = Ly.ln2_g; raw_b = Ly.ln2_b;
-                continue;
-            }
-            if (te_block) {
-                if (raw) { raw_st = A.floats((size_t)2 * R + 16); ConvOpts o; o.ln_wsum = Ly.qkvx_wsum; o.ln_stats_out = raw_st; o.ln_rows = H; add_conv1d(pl, Ly.qkvx_f, x, qkvx, 1, 0, 1, o); }
-                else add_conv1d(pl, Ly.qkvx, x, qkvx, 1, 0, 1);
-                TeAttnP tp{}; tp.qkv = qkvx.p; tp.cs = qkvx.ld; tp.bs = qkvx.bs; tp.T = R; tp.H = H; tp.heads = m.heads; tp.window = m.window;
-                tp.rel_k = Ly.rel_kp; tp.rel_vp = Ly.rel_vp; tp.scale = 1.0f / sqrtf((float)kc); tp.o_bias = Ly.o.bias;
-                tp.res = x.p; tp.res_cs = x.ld; tp.res_bs = x.bs;
-                if (raw) { tp.ln_stats_in = raw_st; tp.ln_g_in = raw_g; tp.ln_b_in = raw_b; }
-                tp.ln_g = Ly.ln1_g; tp.ln_b = Ly.ln1_b; tp.out = x.p; tp.o_cs = x.ld; tp.o_bs = x.bs;
-                tp.dbg = getenv("RVC_TE_DBG") ? atoi(getenv("RVC_TE_DBG")) : 0;
-                dim3 ag((R + 15) / 16, B);
-                pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(te_attention_block_kernel, ag, dim3(256), te_lds, s, tp); });
-                { ConvOpts o; o.act = ACT_RELU; add_conv1d(pl, Ly.ff1, x, ff, 1, m.enc_k / 2, 1, o); }
-                { ConvOpts o; o.res = x.p; o.res_cs = x.ld; o.res_bs = x.bs; add_conv1d(pl, Ly.ff2, ff, x, 1, m.enc_k / 2, 1, o); }
-                raw = true; raw_g = Ly.ln2_g; raw_b = Ly.ln2_b;
-                continue;
-            }
             if (raw) { raw_st = A.floats((size_t)2 * R + 16); ConvOpts o; o.ln_wsum = Ly.qkv_wsum; o.ln_stats_out = raw_st; o.ln_rows = H; add_conv1d(pl, Ly.qkv_f, x, qkv, 1, 0, 1, o); }
             else add_conv1d(pl, Ly.qkv, x, qkv, 1, 0, 1);
             AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = H; ap.T = R; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;
@@ -2188,10 +2057,10 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
             // one stream: the matrix-core form (VALU form: 12.4 us per layer of dependent LDS reads)
             const int a_tp = R | 1, a_nr = 2 * m.window + 1, a_jf = (R + 15) / 16, a_pw = (a_nr + 15) / 16 * 16, a_nrp = (a_nr + 3) / 4 * 4;
             const size_t mfma_lds = ((size_t)kc * 16 + 2 * (size_t)kc * a_tp + (size_t)a_pw * kc + (size_t)a_nrp * kc + 16 * a_jf * 16 + 2 * 16 * a_pw + 64) * sizeof(float);
-            if (B <= 4 && R <= 64 && kc % 16 == 0 && mfma_lds <= 160 * 1024 && !getenv("RVC_NO_SMALL_ATTN") && !getenv("RVC_ATTN_VALU") && !getenv("RVC_NO_SMALL_ATTN_MFMA")) {
+            if (B <= 4 && R <= 64 && kc % 16 == 0 && mfma_lds <= 160 * 1024 && !tune_env("RVC_NO_SMALL_ATTN") && !tune_env("RVC_ATTN_VALU") && !tune_env("RVC_NO_SMALL_ATTN_MFMA")) {
                 dim3 ag(m.heads * a_jf, B);
                 pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(relpos_attention_mfma_kernel, ag, dim3(256), mfma_lds, s, ap); });
-            } else if (R <= 64 && small_lds <= 160 * 1024 && !getenv("RVC_NO_SMALL_ATTN")) {
+            } else if (R <= 64 && small_lds <= 160 * 1024 && !tune_env("RVC_NO_SMALL_ATTN")) {
                 dim3 ag(m.heads * ((R + 3) / 4), B);
                 pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(relpos_attention_small_kernel, ag, dim3(256), small_lds, s, ap); });
             } else {
@@ -2212,8 +2081,8 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         add_tap(pl, "sy.enc", x);
         // one stream: WaveNets with their res_skip layers composed away and post + next pre merged (ModelSY::compose_flows): 21 launches for
         // four flows instead of 40.  U[k] = [ones16 | h0 (H) | a_0 .. a_{n-1} | z (I)]; flow k reads U[k & 1] and writes h0 and z of U[(k + 1) & 1]
-        static const int wn_max_b = getenv("RVC_WN_COMPOSE_MAX") ? atoi(getenv("RVC_WN_COMPOSE_MAX")) : 8;
-        const bool wn_composed = B <= wn_max_b && H % 16 == 0 && I == H && !pl.with_taps && !getenv("RVC_NO_WN_COMPOSE");      // (launch-bound up to a few streams)
+        static const int wn_max_b = tune_env("RVC_WN_COMPOSE_MAX") ? atoi(tune_env("RVC_WN_COMPOSE_MAX")) : 8;
+        const bool wn_composed = B <= wn_max_b && H % 16 == 0 && I == H && !pl.with_taps && !test_opt("RVC_NO_WN_COMPOSE");      // (launch-bound up to a few streams)
         T1 U[2];
         const int u_z = 16 + H + H * m.wn_layers;                     // first latent row of U
         if (wn_composed) {
@@ -2279,13 +2148,6 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
     int c = m.up_init, Tc = R;
     if (src_join_sid > 0) pl.ops.join(src_join_sid);     // the harmonic source was produced on a side stream
     T1 xd = make_t1(A, B, c, Tc, DH);
-    if (pl.collect_touch && getenv("RVC_WEIGHT_TOUCH") && atoi(getenv("RVC_WEIGHT_TOUCH")) == 2) {
-        // diagnostic: touch the decoder's weights on the MAIN stream right here (serial: costs its own time, shows what warm weights would buy)
-        Plan *plp = &pl; const int first = (int)pl.touch_host.size();
-        pl.ops.push_back([=](hipStream_t s) {
-            if (plp->touch_n > first) hipLaunchKernelGGL(weight_touch_kernel, dim3(256), dim3(256), 0, s, (const TouchRange *)plp->touch_dev + first, plp->touch_n - first, plp->touch_sink);
-        });
-    }
     add_conv1d(pl, m.dec_pre, z, xd, 1, 3, 1);
     add_tap(pl, "sy.pre", xd);
     for (int i = 0; i < m.n_ups; i++) {
@@ -2305,7 +2167,7 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         // the n_rb ResBlock chains of a stage are independent until their average
         T1 xs = make_t1(A, B, co, Tn, DH);
         std::vector<T1> finals;
-        const bool fused = m.n_rb > 1 && m.n_rb <= 3 && B < 16 && !getenv("RVC_SERIAL_RESBLOCKS");   // many streams: every conv fills the chip by itself
+        const bool fused = m.n_rb > 1 && m.n_rb <= 3 && B < 16 && !tune_env("RVC_SERIAL_RESBLOCKS");   // many streams: every conv fills the chip by itself
         if (fused) {
             // one launch per (dilation, conv): phase j = chain j (kernel size rb_k[j]); 6 launches per stage instead of 6*n_rb
             const int nr = m.n_rb;
@@ -2450,7 +2312,7 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
             }
             // Stage A + B: approximate distances on the matrix cores in one pass over the index (HBM-bound), exact re-rank of a
             // provably sufficient candidate set; the exhaustive exact scan below only runs for streams whose candidate set overflowed.
-            const bool fast = C % 16 == 0 && !getenv("RVC_KNN_EXHAUSTIVE");
+            const bool fast = C % 16 == 0 && !test_opt("RVC_KNN_EXHAUSTIVE");
             int *d_overflow = (int *)pl.arena.alloc((size_t)B * sizeof(int));
             // many streams: all queries against the index as ONE implicit GEMM (queries = weight operand in fragment order, transposed
             // index = activation operand, -|y|^2 / 2 as a per-column residual, scale -2): one pass over the index instead of one per 16
@@ -2460,7 +2322,7 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
             // (the GEMM path addresses its operands with 32-bit byte / element offsets: the knn_dot loop, whose strides are 64-bit, takes
             // indexes beyond that range)
             const bool gemm_fits = (size_t)C * e->index_n * sizeof(float) < ((size_t)1 << 31) && (size_t)Qpad * e->index_n < ((size_t)1 << 31);
-            const bool gemm_scan = fast && Q >= 128 && gemm_fits && e->d_nhn && !getenv("RVC_KNN_NO_GEMM");
+            const bool gemm_scan = fast && Q >= 128 && gemm_fits && e->d_nhn && !test_opt("RVC_KNN_NO_GEMM");
             if (gemm_scan || !fast) ensure_index_transposed(e);
             if (fast) {
                 float *d_approx = pl.arena.floats((size_t)(gemm_scan ? Qpad : Q) * e->index_n);
@@ -2483,7 +2345,7 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
                 // per-wave candidate lists of the one-pass scan (one stream / few streams: the select stage reads n / 4 entries per query)
                 const long long nwaves = ((long long)e->index_n + 15) / 16;
                 float *wl_d = nullptr; int *wl_i = nullptr;
-                if (!gemm_scan && !getenv("RVC_KNN_NO_WAVE_LISTS")) {
+                if (!gemm_scan && !tune_env("RVC_KNN_NO_WAVE_LISTS")) {
                     wl_d = pl.arena.floats((size_t)B * nq * nwaves * 4);
                     wl_i = (int *)pl.arena.alloc((size_t)B * nq * nwaves * 4 * sizeof(int));
                 }
@@ -2492,7 +2354,7 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
                     dp.q = d_q; dp.q_bs = (long long)nq * C; dp.nq = nq; dp.q0 = q0; dp.approx = d_approx; dp.approx_bs = (long long)nq * e->index_n;
                     dp.overflow = d_overflow;
                     // persistent grid (the waves walk the index tiles; measured: 256 / 512 / 768 / 1024 / one tile per wave = 100 / 79 / 86 / 73 / 74 us per 307 MB)
-                    static const unsigned knn_wgs = getenv("RVC_KNN_WGS") ? (unsigned)atoi(getenv("RVC_KNN_WGS")) : 1024u;
+                    static const unsigned knn_wgs = tune_env("RVC_KNN_WGS") ? (unsigned)atoi(tune_env("RVC_KNN_WGS")) : 1024u;
                     dim3 grid(std::min((unsigned)((e->index_n + 63) / 64), std::max(knn_wgs / (unsigned)B, 64u)), B);
                     const size_t qlds = (size_t)16 * (C + 4) * sizeof(float);
                     if (qlds > 160 * 1024) throw ShapeError("feature dimension too large for the retrieval kernel");
@@ -2562,35 +2424,15 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         pl.ops.join(f0_sid);
         // the NSF harmonic source is first needed by the decoder: it runs on a side stream next to the text encoder and the flow
         pl.ops.fork(2); pl.ops.cur = 2;
-        // one stream: the tail's weights into the memory-side cache while the text encoder runs (weight_touch_kernel); the ranges are recorded as
-        // the tail's launches are queued below
-        // (opt-in, RVC_WEIGHT_TOUCH=1: measured -5 us per chunk with 64 workgroups, +140 us with 32 -- the source kernels behind it on this stream then
-        // hold the decoder up; the per-launch times of the decoder do not move: its weights are not what it waits for)
-        const bool touch = B == 1 && !pl.with_taps && getenv("RVC_WEIGHT_TOUCH") && atoi(getenv("RVC_WEIGHT_TOUCH")) != 0;
-        if (touch) {
-            Plan *plp = &pl;
-            pl.touch_sink = pl.arena.floats(16);
-            static const int touch_wgs = getenv("RVC_TOUCH_WGS") ? atoi(getenv("RVC_TOUCH_WGS")) : 64;
-            pl.ops.push_back([=](hipStream_t s) {
-                if (plp->touch_n > 0 && atoi(getenv("RVC_WEIGHT_TOUCH")) != 2) hipLaunchKernelGGL(weight_touch_kernel, dim3((unsigned)touch_wgs), dim3(256), 0, s, (const TouchRange *)plp->touch_dev, plp->touch_n, plp->touch_sink);
-            });
-        }
         src0 = build_nsf_source(e, pl, B, d_pitchf0);
         std::vector<T1> nz;
-        const bool side_nz = !getenv("RVC_NO_SIDE_NOISE_CONVS");
+        const bool side_nz = !tune_env("RVC_NO_SIDE_NOISE_CONVS");
         if (side_nz) nz = build_noise_convs(e, pl, B, src0);
         pl.ops.cur = 0;
-        pl.collect_touch = touch;
         build_synth(e, pl, B, phone, src0, d_pitchf, d_pitch, 2, side_nz ? &nz : nullptr);
-        pl.collect_touch = false;
-        if (touch && !pl.touch_host.empty()) {
-            std::vector<TouchRange> tr;
-            for (auto &r : pl.touch_host) tr.push_back(TouchRange{r.first, (unsigned long long)(r.second / 4)});
-            pl.touch_dev = pl.arena.upload(tr); pl.touch_n = (int)tr.size();
-        }
         StreamState *st = e->d_state;
-        unsigned *fep = pl.front_epoch; int *hst = e->h_status;      // (pinned host memory, mapped: the kernel writes the status words where the host reads them)
-        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(advance_chunk_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, B, fep, hst); });
+        int *hst = e->h_status;      // (pinned host memory, mapped: the kernel writes the status words where the host reads them)
+        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(advance_chunk_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, B, hst); });
     }
     HIPCHK(hipDeviceSynchronize());
     // bounded plan cache (each geometry owns its activation arena and graph): evict the oldest
@@ -2608,7 +2450,7 @@ static void issue_ops(rvc_engine *e, Plan &pl, bool capturing)
     // (more than 4 streams, no partition).  There a short f0 kernel that is co-scheduled with a 3 ms ContentVec GEMM is stretched to
     // the GEMM's length by the workgroup dispatcher (19 us alone, 3158 us measured); its HIP-event duration then says nothing about
     // the kernel.  With a CU partition the branches own disjoint CUs and are profiled as they run.
-    static const bool serial_env = getenv("RVC_SERIAL_BRANCHES") != nullptr;
+    const bool serial_env = test_opt("RVC_SERIAL_BRANCHES") != nullptr;
     const bool serial = serial_env || (pl.profile && !capturing && !e->partitioned);
     for (size_t k = 0; k < n; k++) {
         const size_t i = (k < ord.size() && !serial) ? (size_t)ord[k] : k;      // ops queued after the reordered prefix keep their position
@@ -2704,7 +2546,7 @@ static rvc_status check_status(rvc_engine *e)
             int zero = 0;
             for (int c = b; c < e->n_streams; c++)
                 if (e->h_status[c] != 0) HIPCHK(hipMemcpy((char *)(e->d_state + c) + offsetof(StreamState, status), &zero, sizeof(int), hipMemcpyHostToDevice));
-            if (code == 7) { e->err = "a cross-workgroup hand-off timed out (GRU recurrence / persistent synthesizer front end)"; return RVC_BACKEND; }
+            if (code == 7) { e->err = "a cross-workgroup hand-off timed out (GRU recurrence)"; return RVC_BACKEND; }
             e->err = "to_local_average_cents: index out of bounds (argmax bin >= 348), the reference panics here";
             return RVC_PANIC;
         }
@@ -2750,7 +2592,7 @@ rvc_status rvc_create(const char *data_path, int device, rvc_engine **out)
     try {
         set_device(e);
         for (int i = 0; i < 3; i++) { HIPCHK(hipEventCreateWithFlags(&e->ev_fork[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming)); }
-        e->partition_ok = !getenv("RVC_NO_CUMASK");
+        e->partition_ok = !tune_env("RVC_NO_CUMASK");
         configure_aux_streams(e);
         HIPCHK(hipEventCreate(&e->ev0)); HIPCHK(hipEventCreate(&e->ev1));
         HIPCHK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
@@ -2926,7 +2768,7 @@ static rvc_status infer_common(rvc_engine *e, const void *input, bool input_on_d
     // Device-resident callers: the first kernels read the caller's buffer and the last one writes the caller's buffer (eager launches
     // take the pointers at launch time) -- no staging copy in front of the chunk, no copy behind it.  A captured graph bakes its
     // pointers and keeps both copies; pipelined calls keep the input copy (it decouples the caller's buffer from the chunk in flight).
-    static const bool no_direct = getenv("RVC_NO_DIRECT_IO") != nullptr;
+    static const bool no_direct = tune_env("RVC_NO_DIRECT_IO") != nullptr;
     const bool direct_in = input_on_device && !pipe && !e->use_graph && pl->in_direct_ok && !no_direct;
     const bool direct_out = out_on_device && !e->use_graph && pl->out_direct_ok && !no_direct;
     pl->cur_in = direct_in ? (const float *)input : nullptr;
@@ -3229,7 +3071,19 @@ rvc_status rvc_sola_step(rvc_engine *e, float *output, size_t output_len, float 
     });
 }
 
-// tuning aid (not part of the reference surface): time one Conv1d(Cin -> M, KW taps, stride 1, "same" padding) over N positions
+// test hook (see "switches" at the top of this file): set (value != NULL) or clear one of the named hooks; 0 = done, -1 = unknown name.
+// Hooks are read when a model is loaded (RVC_NO_LN_FUSE) or a plan is built -- set them before.
+int rvc_debug_option(const char *name, const char *value)
+{
+    if (!name) return -1;
+#ifndef RVC_TUNING
+    if (!is_test_hook(name)) return -1;
+#endif
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    if (value) g_opts[name] = value; else g_opts.erase(name);
+    return 0;
+}
+
 // timeline of the last call (RVC_STAMPS=1): "name us-since-first-stamp" lines
 extern "C" int rvc_debug_stamps(rvc_engine *e, char *buf, size_t cap)
 {
@@ -3245,119 +3099,41 @@ extern "C" int rvc_debug_stamps(rvc_engine *e, char *buf, size_t cap)
     return (int)h.size();
 }
 
-double rvc_debug_conv_bench(rvc_engine *e, int M, int Cin, int KW, int dil, int N, int iters, int pre_act)
+#ifdef RVC_TUNING
+// tuning build only: time one Conv1d(Cin -> M, KW taps, dilation dil, stride 1, "same" padding) over N positions and `streams` streams,
+// through whatever kernel the planner (or RVC_FORCE_CFG) picks; returns microseconds per launch
+double rvc_debug_conv_bench(rvc_engine *e, int M, int Cin, int KW, int dil, int N, int iters, int pre_act, int streams, int act)
 {
     double us = -1.0;
     (void)guarded(e, [&]() {
         std::vector<float> w((size_t)M * Cin * KW), bias(M, 0.1f);
         for (size_t i = 0; i < w.size(); i++) w[i] = (float)((i * 2654435761u) % 1000) / 1000.0f - 0.5f;
         ConvW cw = prep_conv(w.data(), bias.data(), M, Cin, KW, 1);
-        const int Bb = getenv("RVC_BENCH_B") ? atoi(getenv("RVC_BENCH_B")) : 1;     // streams batched (throughput-mode kernels)
+        const int Bb = streams > 0 ? streams : 1;
         Plan pl; pl.B = Bb;
         const int pad = (KW - 1) * dil / 2;
         T1 x = make_t1(pl.arena, Bb, Cin, N, (pad + 3) / 4 * 4), y = make_t1(pl.arena, Bb, M, N, 0);
         std::vector<float> hx((size_t)Cin * x.ld, 0.25f);
         for (int b = 0; b < Bb; b++) HIPCHK(hipMemcpy(x.p + (long long)b * x.bs - x.halo, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
         ConvOpts o; if (pre_act) { o.pre_act = ACT_LRELU; o.pre_slope = 0.1f; }
-        if (const char *a = getenv("RVC_BENCH_ACT")) o.act = atoi(a);     // epilogue activation (ACT_* value)
+        o.act = act;
         add_conv1d(pl, cw, x, y, 1, pad, dil, o);
         HIPCHK(hipDeviceSynchronize());
-        if (const char *ev = getenv("RVC_BENCH_EVICT")) {
-            // instruction-cache experiment: the target launch timed by its own dispatch events, (a) back to back with itself,
-            // (b) after launches of other kernel instantiations on small, L2-resident data.  Returns (b); prints both.
-            struct Ev { ConvW w; int M, Cin, KW, N; };
-            const int shapes[6][4] = {{64, 64, 11, 5040}, {32, 32, 7, 10080}, {128, 128, 3, 2520}, {256, 256, 11, 252}, {512, 512, 3, 111}, {16, 16, 3, 4096}};
-            Plan pe; pe.B = 1;
-            std::vector<ConvW> ews;
-            const int nev = std::min(6, std::max(1, atoi(ev)));
-            for (int k = 0; k < nev; k++) {
-                const bool same = getenv("RVC_BENCH_EVICT_SAME") != nullptr;     // same shape = same kernel code, other buffers: data effects only
-                const int eM = same ? M : shapes[k][0], eC = same ? Cin : shapes[k][1], eK = same ? KW : shapes[k][2], eN = same ? N : shapes[k][3];
-                std::vector<float> ww((size_t)eM * eC * eK, 0.01f), bb(eM, 0.f);
-                ews.push_back(prep_conv(ww.data(), bb.data(), eM, eC, eK, 1));
-                T1 ex = make_t1(pe.arena, 1, eC, eN, 8), ey = make_t1(pe.arena, 1, eM, eN, 0);
-                ConvOpts eo; eo.act = same ? o.act : (k % 3 == 0 ? ACT_LRELU : (k % 3 == 1 ? ACT_NONE : ACT_GELU));
-                add_conv1d(pe, ews.back(), ex, ey, 1, (eK - 1) / 2 * (same ? dil : 1), same ? dil : 1, eo);
-            }
-            HIPCHK(hipDeviceSynchronize());
-            double t_same = 0, t_cold = 0;
-            for (int mode = 0; mode < 2; mode++) {
-                double tot = 0; int cnt = 0;
-                for (int i = 0; i < iters + 3; i++) {
-                    if (mode == 1) for (auto &op : pe.ops.v) op(e->stream);
-                    pl.profile = true; pl.prof_used = 0;
-                    for (auto &op : pl.ops.v) op(e->stream);
-                    pl.profile = false;
-                    HIPCHK(hipStreamSynchronize(e->stream));
-                    float t = 0.f;
-                    for (size_t q = 0; q < pl.prof_used; q++) { float tq; HIPCHK(hipEventElapsedTime(&tq, pl.prof[q].a, pl.prof[q].b)); t += tq; }
-                    if (i >= 3) { tot += t; cnt++; }
-                }
-                (mode == 0 ? t_same : t_cold) = tot / cnt * 1e3;
-            }
-            printf("target launch: %.2f us back to back with itself, %.2f us after %d other kernels\n", t_same, t_cold, nev);
-            for (auto &w : ews) free_conv(w);
-            free_conv(cw);
-            us = t_cold;
-            return RVC_OK;
-        }
-        // RVC_BENCH_COLD=<MB>: rotate through enough copies of the weights that every launch reads them from HBM (what a chunk does:
-        // the models together exceed the 256 MB memory-side cache)
-        std::vector<ConvW> cold_w; std::vector<Plan *> cold_p;
-        if (const char *cm = getenv("RVC_BENCH_COLD")) {
-            const size_t per = w.size() * 4, want = (size_t)atoi(cm) << 20;
-            const int ncopy = (int)std::min<size_t>(512, std::max<size_t>(2, (want + per - 1) / per));
-            for (int k = 0; k < ncopy; k++) {
-                cold_w.push_back(prep_conv(w.data(), bias.data(), M, Cin, KW, 1));
-                Plan *q = new Plan; q->B = Bb;
-                add_conv1d(*q, cold_w.back(), x, y, 1, pad, dil, o);
-                cold_p.push_back(q);
-            }
-            HIPCHK(hipDeviceSynchronize());
-        }
-        auto run_once = [&](int i) { if (cold_p.empty()) { for (auto &op : pl.ops.v) op(e->stream); } else { for (auto &op : cold_p[i % cold_p.size()]->ops.v) op(e->stream); } };
-        // RVC_BENCH_TOUCH=1|2 (with RVC_BENCH_COLD): a line-touch kernel over the launch's weights in front of every launch (1: any workgroup any line,
-        // 2: every m-tile by a workgroup of the XCD that will consume it); the launches are then timed by their own dispatch events
-        const int touch_mode = getenv("RVC_BENCH_TOUCH") ? atoi(getenv("RVC_BENCH_TOUCH")) : 0;
-        if (touch_mode && !cold_p.empty()) {
-            float *sink; HIPCHK(hipMalloc(&sink, 64));
-            const int mt = (M + 15) / 16, nch = cw.Kp / 16;
-            double tot = 0; int cnt = 0;
-            for (int i = 0; i < iters + 3; i++) {
-                const size_t k = (size_t)i % cold_p.size();
-                Plan *q = cold_p[k];
-                if (touch_mode < 3) hipLaunchKernelGGL(weight_touch_tiles_kernel, dim3((unsigned)(touch_mode == 2 ? ((mt + 7) / 8 * 8) : 256)), dim3(256), 0, e->stream, (const float *)cold_w[k].w, mt, nch, touch_mode, sink);
-                q->profile = true; q->prof_used = 0;
-                for (auto &op : q->ops.v) op(e->stream);
-                q->profile = false;
-                HIPCHK(hipStreamSynchronize(e->stream));
-                float t = 0.f;
-                for (size_t u = 0; u < q->prof_used; u++) { float tq; HIPCHK(hipEventElapsedTime(&tq, q->prof[u].a, q->prof[u].b)); t += tq; }
-                if (i >= 3) { tot += t; cnt++; }
-            }
-            us = tot / cnt * 1e3;
-            (void)hipFree(sink);
-            for (Plan *q : cold_p) delete q;
-            for (auto &cwk : cold_w) free_conv(cwk);
-            free_conv(cw);
-            return RVC_OK;
-        }
-        for (int i = 0; i < 3; i++) run_once(i);
+        for (int i = 0; i < 3; i++) for (auto &op : pl.ops.v) op(e->stream);
         hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
         HIPCHK(hipEventRecord(a, e->stream));
-        for (int i = 0; i < iters; i++) run_once(i + 3);
+        for (int i = 0; i < iters; i++) for (auto &op : pl.ops.v) op(e->stream);
         HIPCHK(hipEventRecord(b, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         float ms; HIPCHK(hipEventElapsedTime(&ms, a, b));
         us = ms * 1e3 / iters;
         (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-        for (Plan *q : cold_p) delete q;
-        for (auto &cwk : cold_w) free_conv(cwk);
         free_conv(cw);
         return RVC_OK;
     });
     return us;
 }
+#endif
 
 // test aid for the folded LayerNorm (IgemmP::ln_*): two launches on deterministic data against a double-precision host evaluation --
 //   (1) y1 = W1 . LN(x) + b1 through the folded weights on the RAW x, publishing the column statistics;
@@ -3442,6 +3218,7 @@ double rvc_debug_ln_fold_check(rvc_engine *e, int M, int K, int N, float offset)
     return worst;
 }
 
+#ifdef RVC_TUNING
 // tuning build only (-DRVC_KPROBE): one launch of a Conv1d with per-wave phase stamps (device wall clock, 10 ns ticks):
 // out[wave][16]; returns the number of waves (workgroups * waves per workgroup), *event_us = the dispatch's own begin..end time
 int rvc_debug_conv_probe(rvc_engine *e, int M, int Cin, int KW, int dil, int N, unsigned long long *out, size_t cap_waves, double *event_us, int *waves_per_wg)
@@ -3459,7 +3236,7 @@ int rvc_debug_conv_probe(rvc_engine *e, int M, int Cin, int KW, int dil, int N, 
         unsigned long long *d_probe; const size_t pbytes = (size_t)1 << 24;
         HIPCHK(hipMalloc(&d_probe, pbytes)); HIPCHK(hipMemset(d_probe, 0, pbytes));
         g_kprobe = d_probe;
-        ConvOpts o; if (const char *a = getenv("RVC_BENCH_ACT")) o.act = atoi(a);
+        ConvOpts o; if (const char *a = tune_env("RVC_BENCH_ACT")) o.act = atoi(a);
         add_conv1d(pl, cw, x, y, 1, pad, dil, o);
         g_kprobe = nullptr;
         HIPCHK(hipDeviceSynchronize());
@@ -3482,6 +3259,7 @@ int rvc_debug_conv_probe(rvc_engine *e, int M, int Cin, int KW, int dil, int N, 
     });
     return nw;
 }
+#endif
 
 // test aid: one Conv1d(Cin -> M, KW taps, dilation dil, "same" padding, bias, optional input LeakyReLU) over N positions and `streams`
 // streams on deterministic data, through whatever tile configuration the planner (or RVC_FORCE_CFG) picks, against a double-precision
@@ -3550,29 +3328,14 @@ rvc_status rvc_profile_last_knn(rvc_engine *e, int *launches, double *kernel_ms,
     });
 }
 
-// test aid: launches (ops) of the last call's plan and whether its synthesizer front end is the persistent kernel (synth_front.h)
-int rvc_debug_last_plan(rvc_engine *e, int *n_ops, int *persistent_front)
+// test aid: launches (ops) of the last call's plan
+int rvc_debug_last_plan(rvc_engine *e, int *n_ops)
 {
     if (!e || !e->last_plan) return 0;
     int n = 0;
     for (size_t i = 0; i < e->last_plan->ops.v.size(); i++) if (e->last_plan->ops.kind[i] == 0) n++;
     if (n_ops) *n_ops = n;
-    if (persistent_front) *persistent_front = e->last_plan->front_epoch ? 1 : 0;
     return 1;
-}
-
-// tuning aid (RVC_FRONT_STAMPS=1): step start times of the persistent synthesizer front end in the last call, us since its first step
-int rvc_debug_front_stamps(rvc_engine *e, double *out, int cap)
-{
-    if (!e || !e->last_plan || !e->last_plan->front_stamps) return 0;
-    unsigned long long h[512];
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, e->last_plan->front_stamps, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-    int n = 0;
-    for (int i = 1; i < 128 && h[i]; i++) { if (n < cap) out[n] = (double)(h[i] - h[1]) / 100.0; n++; }
-    // sub-step stamps of step i (1-based) at out[128 + i * 4 + k], us since the step's start (0 where the step has none)
-    for (int i = 1; i < 96 && 128 + i * 4 + 3 < cap; i++)
-        for (int k = 0; k < 4; k++) out[128 + i * 4 + k] = (h[128 + i * 4 + k] && h[i]) ? (double)((long long)(h[128 + i * 4 + k] - h[i])) / 100.0 : 0.0;
-    return n;
 }
 
 // tuning aid: one line per profiled launch of the last call: "<us> <gflop> <description>"

@@ -26,9 +26,9 @@ void launch_igemm_tiled_p1(int lc, bool pre, const IgemmP &p, dim3 grid, size_t 
 void launch_igemm_tiled_p2(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 void launch_igemm_tiled_p3(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 
-// conv_tile_kernel (conv_tile.hip.h) tiles: 0 = 128 x 16 (four waves stacked in M), 1 = 64 x 32, 2 = 32 x 64 (2 x 2 waves), 3 = 64 x 32 as two waves of 2 x 2
-// fragments (two K shares only); many streams: 4 = 128 x 64, 5 = 64 x 64, 6 = 32 x 128 (four fragments along N per wave).  WF = waves per K share x MF x NF.
-static const int kTileBM[9] = {128, 64, 32, 64, 128, 64, 32, 128, 128}, kTileBN[9] = {16, 32, 64, 32, 64, 64, 128, 32, 16}, kTileWF[9] = {8, 8, 8, 8, 32, 16, 16, 16, 8};      // (7 = 128 x 32, 8 = 128 x 16 as two waves of four fragments along M x two K shares)
+// conv_tile_kernel (conv_tile.hip.h) tiles: 0 = 128 x 16 (four waves stacked in M), 1 = 64 x 32, 2 = 32 x 64 (2 x 2 waves), each with one or two K shares.
+// WF = waves per K share x MF x NF.
+static const int kTileBM[3] = {128, 64, 32}, kTileBN[3] = {16, 32, 64}, kTileWF[3] = {8, 8, 8};
 void conv_tile_prepare_device();
 void launch_conv_tile(int tile, int kshares, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
 

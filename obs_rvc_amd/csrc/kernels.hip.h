@@ -207,62 +207,6 @@ __global__ __launch_bounds__(256) void layernorm_ct_kernel(const float *x, float
     }
 }
 
-// layernorm_ct_kernel over a sum: x = sum_h part[h] + bias + res (res optionally LayerNorm(res) from published per-column statistics): the tail of the
-// text encoder's attention block when the output projection is composed into the values (relpos_attention_vp_kernel).
-struct LnSumP {
-    const float *part; int np; long long part_hs; int p_cs; long long p_bs;     // [np][C][T] partial sums
-    const float *bias;                                                           // [C]
-    const float *res; int r_cs; long long r_bs; const float *st_in, *g_in, *b_in;
-    const float *g, *bta; float *y; int y_cs; long long y_bs; int C, T;
-};
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_sum_kernel(LnSumP p)
-{
-    __shared__ float red[4][4];
-    const int tx = threadIdx.x & 3, ty = threadIdx.x >> 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = blockIdx.x * 4 + tx, b = blockIdx.y, C = p.C;
-    const bool ok = t < p.T;
-    const int tc = ok ? t : 0;
-    float mu = 0.f, rs = 1.f;
-    if (p.st_in) { mu = p.st_in[2 * tc]; rs = p.st_in[2 * tc + 1]; }
-    float v[NV], gv[NV], bv[NV];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-        const int c = ty + i * 64;
-        float a = 0.f;
-        if (ok && c < C) {
-            float r = p.res[(long long)b * p.r_bs + (long long)c * p.r_cs + tc];
-            if (p.st_in) r = (r - mu) * rs * p.g_in[c] + p.b_in[c];
-            a = p.bias[c] + r;
-            for (int h = 0; h < p.np; h++) a += p.part[(long long)b * p.p_bs + h * p.part_hs + (long long)c * p.p_cs + tc];
-        }
-        v[i] = a; s += a;
-        gv[i] = c < C ? p.g[c] : 0.f; bv[i] = c < C ? p.bta[c] : 0.f;
-    }
-#pragma unroll
-    for (int o = 4; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
-    if (lane < 4) red[wave][lane] = s;
-    __syncthreads();
-    const float mean = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)C;
-    __syncthreads();
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; i++) { const int c = ty + i * 64; const float d = (c < C) ? v[i] - mean : 0.f; q += d * d; }
-#pragma unroll
-    for (int o = 4; o < 64; o <<= 1) q += __shfl_xor(q, o, 64);
-    if (lane < 4) red[wave][lane] = q;
-    __syncthreads();
-    const float var = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)C;
-    const float inv = 1.0f / sqrtf(var + 1e-5f);
-    if (ok) {
-        float *yp = p.y + (long long)b * p.y_bs + t;
-#pragma unroll
-        for (int i = 0; i < NV; i++) { const int c = ty + i * 64; if (c < C) yp[(long long)c * p.y_cs] = (v[i] - mean) * inv * gv[i] + bv[i]; }
-    }
-}
-
 // Throughput-mode LayerNorm (many streams): a workgroup owns 32 time steps x ALL channels of one stream.  Rows are read and written as
 // full 128-byte lines (the 4-step kernel above touches 16-byte slivers of lines that other workgroups -- on other XCDs -- fetch again:
 // 156 MB of HBM/MALL reads per launch for 22 MB of data at 64 streams); the tile sits in LDS ([C][33]) for the two-pass statistics.
@@ -938,381 +882,6 @@ __global__ __launch_bounds__(256) void relpos_attention_mfma_kernel(AttnP p)
     }
 }
 
-// The same with the output projection composed into the values (ModelSY: V'_h = (W_o[:, head h] W_v[head h]) x, rel_v'_h = W_o[:, head h] rel_v): the
-// qkv tensor holds q [E], k [E], V' [heads][E]; a workgroup writes its head's PARTIAL sum of the projection's output, out[head][E][T]; the sum over
-// the heads, the projection's bias, the residual and the LayerNorm follow in layernorm_sum_kernel.  One launch per layer less than attention + projection.
-__global__ __launch_bounds__(256) void relpos_attention_vp_kernel(AttnP p)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NT = 256;
-    const int kc = p.E / p.heads, T = p.T, TP = T | 1, Wd = p.window, NR = 2 * Wd + 1, NRP = (NR + 3) & ~3;
-    const int JF = (T + 15) >> 4, SW = JF * 16, RF = (NR + 15) >> 4, PW = RF * 16;
-    const int h = blockIdx.x / JF, qb = blockIdx.x - h * JF, b = blockIdx.y;
-    const int col0 = qb * 16, nq = T - col0 < 16 ? T - col0 : 16;
-    const int VR = p.E;                               // rows of V' per head = output channels of the projection
-    float *q = smem, *kk = q + kc * 16, *vv = kk + kc * TP, *rk = vv + VR * TP, *rv = rk + PW * kc;
-    float *Sx = rv + NRP * VR, *P = Sx + 16 * SW, *Ssk = P + 16 * PW;
-    const float *base = p.qkv + (long long)b * p.bs;
-    // staging: every global load is issued before the first LDS write (one memory round trip)
-    const int tsh = T <= 32 ? 5 : 6, tmask = (1 << tsh) - 1;
-    constexpr int KV_IT = 12, V_IT = 24, RT_IT = 12, RV_IT = 18, Q_IT = 6;
-    const int kv_n = kc << tsh, v_n = VR << tsh, rk_n = PW * kc, rv_n = NRP * VR, rt_n = NR * kc, q_n = kc * 16;
-    const float *relv = p.rel_v + (long long)h * NRP * VR;      // per head, stored padded to NRP rows
-    float kr[KV_IT], vr[V_IT], rkr[RT_IT], rvr[RV_IT], qr[Q_IT];
-#pragma unroll
-    for (int u = 0; u < Q_IT; u++) {
-        const int idx = threadIdx.x + u * NT, d = idx >> 4, c = idx & 15;
-        qr[u] = (idx < q_n && c < nq) ? base[(long long)(h * kc + d) * p.cs + col0 + c] * p.scale : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < KV_IT; u++) {
-        const int idx = threadIdx.x + u * NT, d = idx >> tsh, t = idx & tmask;
-        kr[u] = (idx < kv_n && t < T) ? base[(long long)(p.E + h * kc + d) * p.cs + t] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < V_IT; u++) {
-        const int idx = threadIdx.x + u * NT, d = idx >> tsh, t = idx & tmask;
-        vr[u] = (idx < v_n && t < T) ? base[(long long)(2 * p.E + h * VR + d) * p.cs + t] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < RT_IT; u++) { const int j = threadIdx.x + u * NT; rkr[u] = j < rt_n ? p.rel_k[j] : 0.f; }
-#pragma unroll
-    for (int u = 0; u < RV_IT; u++) { const int j = threadIdx.x + u * NT; rvr[u] = j < rv_n ? relv[j] : 0.f; }
-#pragma unroll
-    for (int u = 0; u < Q_IT; u++) { const int idx = threadIdx.x + u * NT; if (idx < q_n) q[idx] = qr[u]; }
-#pragma unroll
-    for (int u = 0; u < KV_IT; u++) {
-        const int idx = threadIdx.x + u * NT, d = idx >> tsh, t = idx & tmask;
-        if (idx < kv_n && t < TP) kk[d * TP + t] = kr[u];                                     // (column T of the odd padding: zero)
-    }
-#pragma unroll
-    for (int u = 0; u < V_IT; u++) {
-        const int idx = threadIdx.x + u * NT, d = idx >> tsh, t = idx & tmask;
-        if (idx < v_n && t < TP) vv[d * TP + t] = vr[u];
-    }
-#pragma unroll
-    for (int u = 0; u < RT_IT; u++) { const int j = threadIdx.x + u * NT; if (j < rk_n) rk[j] = rkr[u]; }
-#pragma unroll
-    for (int u = 0; u < RV_IT; u++) { const int j = threadIdx.x + u * NT; if (j < rv_n) rv[j] = rvr[u]; }
-    // sizes beyond the unrolled staging (no official configuration: 2 heads x 96, window 10, T <= 32)
-    for (int idx = threadIdx.x + Q_IT * NT; idx < q_n; idx += NT) { const int d = idx >> 4, c = idx & 15; q[idx] = c < nq ? base[(long long)(h * kc + d) * p.cs + col0 + c] * p.scale : 0.f; }
-    for (int idx = threadIdx.x + KV_IT * NT; idx < kv_n; idx += NT) {
-        const int d = idx >> tsh, t = idx & tmask;
-        if (t < TP) kk[d * TP + t] = t < T ? base[(long long)(p.E + h * kc + d) * p.cs + t] : 0.f;
-    }
-    for (int idx = threadIdx.x + V_IT * NT; idx < v_n; idx += NT) {
-        const int d = idx >> tsh, t = idx & tmask;
-        if (t < TP) vv[d * TP + t] = t < T ? base[(long long)(2 * p.E + h * VR + d) * p.cs + t] : 0.f;
-    }
-    for (int j = threadIdx.x + RT_IT * NT; j < rk_n; j += NT) rk[j] = j < rt_n ? p.rel_k[j] : 0.f;
-    for (int j = threadIdx.x + RV_IT * NT; j < rv_n; j += NT) rv[j] = relv[j];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
-    // scores and P: items (16-column block of keys), then (16-row block of relative positions), one per wave and pass
-    for (int it = wave; it < JF + RF; it += 4) {
-        const bool is_p = it >= JF;
-        const int f = is_p ? it - JF : it;
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-        const float *qa = q + kq * 16 + li;
-        const float *bb = is_p ? rk + (f * 16 + li) * kc + kq : kk + kq * TP + f * 16 + li;
-        const int bst = is_p ? 4 : 4 * TP;
-        for (int ks = 0; ks + 1 < kc / 4; ks += 2) {
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[ks * 64], bb[ks * bst], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[(ks + 1) * 64], bb[(ks + 1) * bst], a1, 0, 0, 0);
-        }
-        if ((kc / 4) & 1) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[(kc / 4 - 1) * 64], bb[(kc / 4 - 1) * bst], a0, 0, 0, 0);
-        a0 += a1;
-        float *dst = is_p ? P + f * 16 : Sx + f * 16;
-        const int dw = is_p ? PW : SW;
-#pragma unroll
-        for (int r = 0; r < 4; r++) dst[(kq * 4 + r) * dw + li] = a0[r];
-    }
-    __syncthreads();
-    // softmax with the relative-position term: 16 lanes per query row, keys strided over the lanes
-    {
-        const int i = threadIdx.x >> 4, gi = col0 + i;
-        float *Sr = Sx + i * SW, *Kr = Ssk + i * PW;
-        const float *Pr = P + i * PW;
-        float mx = -INFINITY;
-        if (gi < T) {
-            for (int j = li; j < T; j += 16) {
-                float a = Sr[j];
-                const int r = j - gi;
-                if (r >= -Wd && r <= Wd) a += Pr[r + Wd];
-                Sr[j] = a; mx = fmaxf(mx, a);
-            }
-        }
-#pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
-        float sum = 0.f;
-        if (gi < T) for (int j = li; j < T; j += 16) { const float ex = expf(Sr[j] - mx); Sr[j] = ex; sum += ex; }
-#pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 16);
-        const float inv = 1.0f / sum;
-        for (int j = li; j < SW; j += 16) Sr[j] = (gi < T && j < T) ? Sr[j] * inv : 0.f;
-        // (the 16 lanes of a row run in lockstep inside one wave: Sr is complete before it is read back skewed)
-        for (int r = li; r < PW; r += 16) { const int j = gi + r - Wd; Kr[r] = (gi < T && r < NR && j >= 0 && j < T) ? Sr[j] : 0.f; }
-    }
-    __syncthreads();
-    // attention output of the own columns: items = 16-channel blocks of the head
-    for (int cf = wave; cf < VR / 16; cf += 4) {
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-        const float *va = vv + (cf * 16 + li) * TP + kq, *sb = Sx + li * SW + kq;
-        for (int ks = 0; ks < (T + 3) / 4; ks++) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va[ks * 4], sb[ks * 4], a0, 0, 0, 0);
-        const float *ra = rv + kq * VR + cf * 16 + li, *kb = Ssk + li * PW + kq;
-        for (int ks = 0; ks < NRP / 4; ks++) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[ks * 4 * VR], kb[ks * 4], a1, 0, 0, 0);
-        a0 += a1;
-        // D: row = channel cf * 16 + kq * 4 + r, col = query li
-        if (col0 + li < T) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) p.out[(long long)b * p.o_bs + (long long)(h * VR + cf * 16 + kq * 4 + r) * p.o_cs + col0 + li] = a0[r];      // per-head partial sums of the projection's output
-        }
-    }
-}
-
-// Text-encoder attention block as ONE launch at one stream (round 3, opt-in RVC_TE_BLOCK=1: two workgroups walking five barrier-separated
-// LDS-latency phases take as long as the three launches they replace -- 41 us per layer either way): attention with relative positions, the output projection, its bias,
-// the residual and the first LayerNorm.  The projection is linear in the attention output, so it is composed into what it multiplies at
-// load time (ModelSY): V'_h = (W_o[:, head h] W_v[head h]) x  (the qkv launch produces q, k and heads x H rows of V'), rel_v'_h[r] = W_o[:, head h] rel_v[r]:
-//   y[:, i] = b_o + res[:, i] + sum_h ( sum_j S_h[i][j] V'_h[:, j] + sum_r Ssk_h[i][r] rel_v'_h[r] ),     x1 = LayerNorm(y)
-// grid = (ceil(T / 16), streams): a workgroup owns 16 query columns, all heads, all H output channels (LayerNorm runs over the channels of a column).
-// Operands reach LDS through LDS-DMA (global_load_lds: ~30 k floats, no staging registers).  MFMA layouts as in relpos_attention_mfma_kernel.
-struct TeAttnP {
-    const float *qkv; int cs; long long bs;          // rows: q [H], k [H], V' [heads][H]
-    int T, H, heads, window;
-    const float *rel_k, *rel_vp;                     // [PW][kc], [heads][NRP][H]: padded copies (rows >= NR zero, + 256 floats of slack)
-    float scale;
-    const float *o_bias;                             // [H]
-    const float *res; int res_cs; long long res_bs;  // residual tensor; with ln_stats_in: LayerNorm(res) from published per-column (mean, rstd)
-    const float *ln_stats_in, *ln_g_in, *ln_b_in;
-    const float *ln_g, *ln_b;                        // the LayerNorm applied to the block's output
-    float *out; int o_cs; long long o_bs;
-    int dbg;                                         // tuning aid (RVC_TE_DBG): leave after phase n (timing only, results invalid)
-};
-
-__global__ __launch_bounds__(256) void te_attention_block_kernel(TeAttnP p)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int H = p.H, heads = p.heads, kc = H / heads, T = p.T, Wd = p.window, NR = 2 * Wd + 1, NRP = (NR + 3) & ~3;
-    const int JF = (T + 15) >> 4, SW = JF * 16, RF = (NR + 15) >> 4, PW = RF * 16;
-    const int qb = blockIdx.x, b = blockIdx.y, col0 = qb * 16, nq = T - col0 < 16 ? T - col0 : 16;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), li = lane & 15, kq = lane >> 4;
-    // LDS image (every region a multiple of 256 floats: whole 1 KB LDS-DMA pieces).  k and V' keep the tensor's own row stride (a multiple of 4:
-    // they are one contiguous block of the qkv tensor, copied 16 bytes per lane; the A-operand reads of V' then meet 4-way bank conflicts,
-    // a few clocks on 72 reads), the relative-position tables are stored padded at load time.
-    auto up256 = [](int n) { return (n + 255) & ~255; };
-    const int LD = p.cs;
-    float *q = smem;                              // [heads * kc][16]
-    float *kk = q + up256(H * 16);                // [heads * kc][LD]
-    float *vp = kk + up256(H * LD);               // [heads][H][LD]
-    float *rk = vp + up256(heads * H * LD);       // [PW][kc]
-    float *rvp = rk + up256(PW * kc);             // [heads][NRP][H]
-    float *Sx = rvp + up256(heads * NRP * H);     // [heads][16][SW]
-    float *P = Sx + heads * 16 * SW;              // [heads][16][PW]
-    float *Ssk = P + heads * 16 * PW;             // [heads][16][PW]
-    float *red = Ssk + heads * 16 * PW;           // [4][16] + [4][16]
-    const float *base = p.qkv + (long long)b * p.bs;
-#define RVC_DMA16(SRC, DST) __builtin_amdgcn_global_load_lds((SRC), (__attribute__((address_space(3))) void *)(DST), 16, 0, 0)
-    {
-        // q: 16 columns of every row (4 lanes per row; columns behind T read on into valid memory: those queries are never stored)
-        for (int pc = wave; pc * 256 < H * 16; pc += 4) {
-            const int e4 = pc * 64 + lane, hd = e4 >> 2, c4 = e4 & 3;
-            RVC_DMA16(base + (long long)(hd < H ? hd : H - 1) * p.cs + col0 + c4 * 4, q + pc * 256);
-        }
-        // k, V' and the two tables: contiguous copies (the surplus of the last piece reads the rows that follow: valid memory, unused)
-        const float *ksrc = base + (long long)H * p.cs, *vsrc = base + (long long)2 * H * p.cs;
-        for (int pc = wave; pc * 256 < H * LD; pc += 4) RVC_DMA16(ksrc + pc * 256 + lane * 4, kk + pc * 256);
-        for (int pc = wave; pc * 256 < heads * H * LD; pc += 4) RVC_DMA16(vsrc + pc * 256 + lane * 4, vp + pc * 256);
-        for (int pc = wave; pc * 256 < PW * kc; pc += 4) RVC_DMA16(p.rel_k + pc * 256 + lane * 4, rk + pc * 256);
-        for (int pc = wave; pc * 256 < heads * NRP * H; pc += 4) RVC_DMA16(p.rel_vp + pc * 256 + lane * 4, rvp + pc * 256);
-    }
-#undef RVC_DMA16
-    // epilogue operands of this lane: channels c = (wave * CF + f) * 16 + kq * 4 + r, column col0 + li -- requested now, consumed last
-    constexpr int CFMAX = 4;                       // H <= 256
-    const int CF = H / 64;                         // 16-channel blocks per wave (H a multiple of 64)
-    float resv[CFMAX][4], ob[CFMAX][4], g1[CFMAX][4], b1[CFMAX][4];
-    {
-        const int n = col0 + li < T ? col0 + li : T - 1;
-        const float *rb = p.res + (long long)b * p.res_bs + n;
-        float mu = 0.f, rs = 1.f;
-        if (p.ln_stats_in) { mu = p.ln_stats_in[2 * n]; rs = p.ln_stats_in[2 * n + 1]; }
-#pragma unroll
-        for (int f = 0; f < CFMAX; f++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int c = (wave * CF + f) * 16 + kq * 4 + r;
-                const bool ok = f < CF;
-                float v = ok ? rb[(long long)c * p.res_cs] : 0.f;
-                if (p.ln_stats_in && ok) v = (v - mu) * rs * p.ln_g_in[c] + p.ln_b_in[c];
-                resv[f][r] = v; ob[f][r] = ok ? p.o_bias[c] : 0.f; g1[f][r] = ok ? p.ln_g[c] : 0.f; b1[f][r] = ok ? p.ln_b[c] : 0.f;
-            }
-    }
-    __syncthreads();
-    if (p.dbg == 1) return;
-    // scores and P: items (head, 16-column block of keys), then (head, 16-row block of relative positions)
-    for (int it = wave; it < heads * (JF + RF); it += 4) {
-        const bool is_p = it >= heads * JF;
-        const int h = is_p ? (it - heads * JF) / RF : it / JF, f = is_p ? (it - heads * JF) - h * RF : it - h * JF;
-        // operands in batches of eight k-steps: all LDS reads of a batch leave before its MFMAs (a read-then-MFMA loop pays the LDS latency
-        // and the 40-clock accumulator dependency on every step: measured 3.3 us per layer for these 96 MFMAs)
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f}, a3 = {0.f, 0.f, 0.f, 0.f};
-        const float *qa = q + (h * kc + kq) * 16 + li;
-        const float *bb = is_p ? rk + (f * 16 + li) * kc + kq : kk + (h * kc + kq) * LD + f * 16 + li;
-        const int bst = is_p ? 4 : 4 * LD;
-        const int nks = kc / 4;
-        for (int k0 = 0; k0 < nks; k0 += 8) {
-            float av[8], bv[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { const int ks = k0 + u < nks ? k0 + u : nks - 1; av[u] = qa[ks * 64]; bv[u] = bb[ks * bst]; }
-#pragma unroll
-            for (int u = 0; u < 8; u++) if (k0 + u >= nks) av[u] = 0.f;
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], a1, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], a2, 0, 0, 0); a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], a3, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4], bv[4], a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[5], bv[5], a1, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[6], bv[6], a2, 0, 0, 0); a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[7], bv[7], a3, 0, 0, 0);
-        }
-        a0 += a1; a2 += a3; a0 += a2;
-        float *dst = is_p ? P + (h * 16) * PW + f * 16 : Sx + (h * 16) * SW + f * 16;
-        const int dw = is_p ? PW : SW;
-#pragma unroll
-        for (int r = 0; r < 4; r++) dst[(kq * 4 + r) * dw + li] = a0[r] * p.scale;
-    }
-    __syncthreads();
-    if (p.dbg == 2) return;
-    // softmax with the relative-position term: 16 lanes per (head, query) row
-    for (int hi = (int)threadIdx.x >> 4; hi < heads * 16; hi += 16) {
-        const int i = hi & 15, gi = col0 + i;
-        float *Sr = Sx + hi * SW, *Kr = Ssk + hi * PW;
-        const float *Pr = P + hi * PW;
-        float mx = -INFINITY;
-        if (gi < T) {
-            for (int j = li; j < T; j += 16) {
-                float a = Sr[j];
-                const int r = j - gi;
-                if (r >= -Wd && r <= Wd) a += Pr[r + Wd];
-                Sr[j] = a; mx = fmaxf(mx, a);
-            }
-        }
-#pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
-        float sum = 0.f;
-        if (gi < T) for (int j = li; j < T; j += 16) { const float ex = expf(Sr[j] - mx); Sr[j] = ex; sum += ex; }
-#pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 16);
-        const float inv = 1.0f / sum;
-        for (int j = li; j < SW; j += 16) Sr[j] = (gi < T && j < T) ? Sr[j] * inv : 0.f;
-        for (int r = li; r < PW; r += 16) { const int j = gi + r - Wd; Kr[r] = (gi < T && r < NR && j >= 0 && j < T) ? Sr[j] : 0.f; }
-    }
-    __syncthreads();
-    if (p.dbg == 3) return;
-    // y = sum_h (V'_h S_h^T + rel_v'_h^T Ssk_h^T) for this wave's channel blocks; D: row = channel kq * 4 + r, col = query li
-    float y[CFMAX][4];
-#pragma unroll
-    for (int f = 0; f < CFMAX; f++) {
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-        if (f < CF) {
-            const int ch0 = (wave * CF + f) * 16;
-            for (int h = 0; h < heads; h++) {
-                const float *va = vp + ((h * H + ch0 + li)) * LD + kq, *sb = Sx + (h * 16 + li) * SW + kq;
-                const float *ra = rvp + (h * NRP + kq) * H + ch0 + li, *kb = Ssk + (h * 16 + li) * PW + kq;
-                const int n1 = (T + 3) / 4, n2 = NRP / 4;
-                // (batches of eight k-steps, reads first: see the score stage)
-                for (int k0 = 0; k0 < n1; k0 += 8) {
-                    float av[8], bv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) { const int ks = k0 + u < n1 ? k0 + u : n1 - 1; av[u] = va[ks * 4]; bv[u] = sb[ks * 4]; }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) if (k0 + u >= n1) av[u] = 0.f;
-#pragma unroll
-                    for (int u = 0; u < 8; u += 2) { a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], a1, 0, 0, 0); }
-                }
-                for (int k0 = 0; k0 < n2; k0 += 8) {
-                    float av[8], bv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) { const int ks = k0 + u < n2 ? k0 + u : n2 - 1; av[u] = ra[ks * 4 * H]; bv[u] = kb[ks * 4]; }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) if (k0 + u >= n2) av[u] = 0.f;
-#pragma unroll
-                    for (int u = 0; u < 8; u += 2) { a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], a1, 0, 0, 0); }
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) y[f][r] = f < CF ? a0[r] + a1[r] + ob[f][r] + resv[f][r] : 0.f;
-    }
-    if (p.dbg == 4) return;
-    // LayerNorm over the H channels of column li (two passes, as the definition): lanes kq = 0..3 and the four waves hold a column's channels
-    float s = 0.f;
-#pragma unroll
-    for (int f = 0; f < CFMAX; f++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) s += y[f][r];
-    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-    if (kq == 0) red[wave * 16 + li] = s;
-    __syncthreads();
-    const float mean = (red[li] + red[16 + li] + red[32 + li] + red[48 + li]) / (float)H;
-    float qv = 0.f;
-#pragma unroll
-    for (int f = 0; f < CFMAX; f++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) { const float d = f < CF ? y[f][r] - mean : 0.f; qv += d * d; }
-    qv += __shfl_xor(qv, 16, 64); qv += __shfl_xor(qv, 32, 64);
-    if (kq == 0) red[64 + wave * 16 + li] = qv;
-    __syncthreads();
-    const float var = (red[64 + li] + red[80 + li] + red[96 + li] + red[112 + li]) / (float)H;
-    const float rstd = 1.0f / sqrtf(var + 1e-5f);
-    if (li < nq) {
-        float *ob_ = p.out + (long long)b * p.o_bs + col0 + li;
-#pragma unroll
-        for (int f = 0; f < CFMAX; f++)
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                if (f < CF) ob_[(long long)((wave * CF + f) * 16 + kq * 4 + r) * p.o_cs] = (y[f][r] - mean) * rstd * g1[f][r] + b1[f][r];
-    }
-}
-
-// Weight prefetch into the memory-side cache (one stream).  Every chunk streams more weights (ContentVec 380 MB + RMVPE 360 MB) than the 256 MB
-// Infinity Cache holds, so every launch of the serial tail (text encoder, flows, decoder: ~150 MB) finds its weights in HBM: a launch whose weights come
-// from HBM costs 0.5-1.5 us more than the same launch with them in the memory-side cache, the decoder's staged-tile launches 12 us more
-// (tests/tools/cold_gemm.sh).  This kernel runs on the side stream next to the text encoder and reads the tail's weight ranges once, in the
-// order they will be needed; nothing is kept -- the point is that the lines now sit in the memory-side cache.
-struct TouchRange { const float *p; unsigned long long n4; };        // n4: float4 count
-__global__ __launch_bounds__(256) void weight_touch_kernel(const TouchRange *r, int nr, float *sink)
-{
-    float acc = 0.f;
-    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
-    for (int i = 0; i < nr; i++) {
-        const f32x4 *q = reinterpret_cast<const f32x4 *>(r[i].p);
-        const unsigned long long n4 = r[i].n4;
-        for (unsigned long long e = (unsigned long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += 4 * stride) {
-            // four independent 16-byte loads in flight per thread
-            const f32x4 a = q[e];
-            const f32x4 b = e + stride < n4 ? q[e + stride] : a;
-            const f32x4 c = e + 2 * stride < n4 ? q[e + 2 * stride] : a;
-            const f32x4 d = e + 3 * stride < n4 ? q[e + 3 * stride] : a;
-            acc += a[0] + b[1] + c[2] + d[3];
-        }
-    }
-    if (acc == 1.2345678e33f) sink[0] = acc;      // never true: keeps the loads
-}
-
-// Tuning aid (rvc_debug_conv_bench, RVC_BENCH_TOUCH): read a fragment-major weight panel [mtiles][nchunks][256] one dword per 128-byte line.
-// mode 1: lines dealt to the workgroups in address order; mode 2: workgroup b reads only the m-tiles its XCD will later consume (m-tile t is read by
-// the GEMM's workgroups x = t, which run on the XCD the hardware reports for block t: same dispatch rule, so block b here takes t = b, b + grid, ...).
-__global__ __launch_bounds__(256) void weight_touch_tiles_kernel(const float *w, int mtiles, int nchunks, int mode, float *sink)
-{
-    float acc = 0.f;
-    const long long lines_per_tile = (long long)nchunks * 8;            // 1 KB per chunk = 8 lines
-    if (mode == 2) {
-        for (int t = blockIdx.x; t < mtiles; t += gridDim.x)
-            for (long long l = threadIdx.x; l < lines_per_tile; l += 256) acc += w[((long long)t * lines_per_tile + l) * 32];
-    } else {
-        const long long total = (long long)mtiles * lines_per_tile;
-        for (long long l = (long long)blockIdx.x * 256 + threadIdx.x; l < total; l += (long long)gridDim.x * 256) acc += w[l * 32];
-    }
-    if (acc == 1.2345678e33f) sink[0] = acc;
-}
-
 // ------------------------------------------------------------------------------------
 // RMVPE head: bidirectional GRU recurrence (input projections come from the implicit GEMM)
 // gi: [B][2*3H][ld] (forward gates rows 0..3H, backward rows 3H..6H; biases b_ih included)
@@ -1733,15 +1302,12 @@ __global__ __launch_bounds__(1024) void nsf_source_kernel(SrcP p)
 }
 
 // bump the per-stream chunk counters after a call
-// end of a chunk: the streams' chunk counters, and the tag base of the persistent synthesizer front end (synth_front.h: 64 >= its
-// steps per launch; the base restarts before it could wrap into tag 0)
-// ...and the streams' status words, written straight into host-mapped memory (the host reads them after the call's one
+// end of a chunk: the streams' chunk counters and the streams' status words, written straight into host-mapped memory (the host reads them after the call's one
 // synchronisation: no copy kernel behind the chunk)
-__global__ void advance_chunk_kernel(StreamState *st, int B, unsigned *front_epoch, int *host_status)
+__global__ void advance_chunk_kernel(StreamState *st, int B, int *host_status)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) { st[b].chunk += 1; if (host_status) host_status[b] = st[b].status; }
-    if (b == 0 && front_epoch) { const unsigned v = *front_epoch; *front_epoch = v > 0xFFFF0000u ? 0u : v + 64u; }
 }
 
 // ------------------------------------------------------------------------------------

@@ -1,5 +1,4 @@
-// state.hip.h -- per-stream state, per-call parameters and the counter-based noise generator shared by every translation unit
-// (kernels.hip.h, synth_front.hip).
+// state.hip.h -- per-stream state, per-call parameters and the counter-based noise generator (kernels.hip.h).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

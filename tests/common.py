@@ -76,3 +76,15 @@ def compare_taps(ora, eng, rows_hint):
             rows = rows_hint[oname]
             b = b.reshape(-1, rows).T.reshape(-1)
         yield oname, rel_rms(b, a), a.size
+
+
+def set_opt(name: str, value=None) -> None:
+    """Set (or clear, value=None) one of the library's test hooks -- an explicit call on the loaded library, not an environment
+    variable (csrc/engine.hip "switches": the product reads no tuning variable from the environment)."""
+    import ctypes as C
+    from obs_rvc_amd import _native
+    L = _native.lib()
+    L.rvc_debug_option.argtypes = [C.c_char_p, C.c_char_p]
+    L.rvc_debug_option.restype = C.c_int
+    rc = L.rvc_debug_option(name.encode(), None if value is None else str(value).encode())
+    assert rc == 0, "unknown test hook %s" % name

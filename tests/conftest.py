@@ -27,3 +27,18 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture
+def hooks():
+    """Set test hooks of the loaded library for the duration of one test (tests/common.py set_opt); every hook set is cleared again."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from common import set_opt
+    used = []
+
+    def _set(name, value):
+        set_opt(name, value)
+        used.append(name)
+    yield _set
+    for n in used:
+        set_opt(n, None)

@@ -37,6 +37,36 @@ def test_library_carries_the_hash_of_its_sources():
     assert _native.lib().rvc_version().decode().endswith("rvc-mi355x-src:" + _native.source_hash())
 
 
+
+# every environment variable the product library (and the rvc-rpc executable) may read: INTEGRATION.md lists the same names
+PRODUCT_ENV = {"GPU_MAX_HW_QUEUES", "RVC_NO_RUNTIME_DEFAULTS", "LOCAL_RANK", "RVC_RCCL_LIB", "RVC_NOISE_SEED", "RVC_USE_GRAPH"}
+
+
+def test_product_reads_only_the_documented_environment():
+    # the library had become a laboratory of 64 RVC_* switches a host inherited from its environment.  Now: getenv() is
+    # called with the documented names only, outside "#ifdef RVC_TUNING" blocks; tuning switches compile to nothing in the product
+    # (tune_env is a constant nullptr) and test hooks are set by an explicit call (rvc_debug_option), never inherited.
+    csrc = _native.CSRC
+    seen = set()
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h", ".cpp")):
+            continue
+        text = open(os.path.join(csrc, f)).read()
+        text = re.sub(r"#ifdef RVC_TUNING.*?#(?:else|endif)", "", text, flags=re.S)      # the tuning build's fall-back to the environment
+        seen |= set(re.findall(r"\bgetenv\(\s*\"([A-Z0-9_]+)\"", text))
+        assert not re.findall(r"\bgetenv\(\s*[a-z_]", text), f      # no computed names
+    assert seen <= PRODUCT_ENV, seen - PRODUCT_ENV
+    assert len(seen) <= 10
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for n in seen:
+        assert n in doc, n
+    # the binary agrees with the text: no other RVC_* name sits next to a getenv call site (strings of the hooks exist, as table keys)
+    lib = _native.lib()
+    lib.rvc_debug_option.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    assert lib.rvc_debug_option(b"RVC_FORCE_CFG", b"0,4") == 0 and lib.rvc_debug_option(b"RVC_FORCE_CFG", None) == 0
+    assert lib.rvc_debug_option(b"RVC_GEMM32", b"0") == -1          # a tuning switch: not settable in the product
+    assert lib.rvc_debug_option(b"PATH", b"x") == -1
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -75,7 +75,7 @@ def test_every_stream_has_its_own_pitch_shift():
         assert np.allclose(eng.pitch_cache(s), oras[s].pitch_cache(), rtol=1e-5, atol=1e-3), s
 
 
-def test_many_stream_first_layer_matches_the_one_channel_kernel(monkeypatch):
+def test_many_stream_first_layer_matches_the_one_channel_kernel(hooks):
     # throughput mode takes other kernels than one stream does (16 channels of the first ContentVec layer per workgroup with the input
     # samples held in registers, streams folded into N, the 32x32x2 GEMM).  The first layer against the one-channel-per-workgroup kernel
     # on the same 16 streams
@@ -86,7 +86,7 @@ def test_many_stream_first_layer_matches_the_one_channel_kernel(monkeypatch):
     taps = {}
     for mode in ("multi", "single"):
         if mode == "single":
-            monkeypatch.setenv("RVC_NO_CONV0_MULTI", "1")
+            hooks("RVC_NO_CONV0_MULTI", "1")
         eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"])
         eng.set_streams(S); eng.set_noise_seed(5, 0); eng.enable_taps(True)
         y = eng.infer_batch(xin, g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
@@ -99,7 +99,7 @@ def test_many_stream_first_layer_matches_the_one_channel_kernel(monkeypatch):
     assert rms(taps["multi"][1] - taps["single"][1]) < 1e-4
 
 
-def test_many_stream_retrieval_scan_as_one_gemm(monkeypatch):
+def test_many_stream_retrieval_scan_as_one_gemm(hooks):
     # from 12 streams on, the approximate distances of ALL streams' queries come from one implicit GEMM over the transposed index
     # (queries as the weight operand) instead of one pass over the index per 16 queries.  The exact re-rank behind it is the same
     # kernel, so hits, distances and audio must be IDENTICAL to the per-16-queries scan, and stream 0 must match the oracle's search
@@ -111,7 +111,7 @@ def test_many_stream_retrieval_scan_as_one_gemm(monkeypatch):
     res = {}
     for mode in ("gemm", "scan"):
         if mode == "scan":
-            monkeypatch.setenv("RVC_KNN_NO_GEMM", "1")
+            hooks("RVC_KNN_NO_GEMM", "1")
         eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"])
         eng.set_streams(S); eng.set_noise_seed(9, 0); eng.load_index(index); eng.set_index_rate(0.75)
         y = eng.infer_batch(xin, g.sample_frame_16k, 12, g.skip_head, g.model_return_length)

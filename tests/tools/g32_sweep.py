@@ -4,13 +4,10 @@ a slope (main loop, us per K) and an intercept (prologue + epilogue + tail).   u
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-os.environ["RVC_BENCH_B"] = "64"
-if len(sys.argv) > 1:
-    os.environ["RVC_BENCH_ACT"] = sys.argv[1]
 from obs_rvc_amd import _native
 L = _native.lib()
 L.rvc_debug_conv_bench.restype = C.c_double
-L.rvc_debug_conv_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+L.rvc_debug_conv_bench.argtypes = [C.c_void_p] + [C.c_int] * 9
 h = C.c_void_p()
 assert L.rvc_create(b"/tmp", 0, C.byref(h)) == 0
 # (label, M, KW, N per stream, Cin list)
@@ -18,7 +15,7 @@ for label, M, KW, N, cins in (("cv conv (M=512, k=3, N=64x3583)", 512, 3, 3583, 
                               ("dec (M=128, k=11, N=64x2520)", 128, 11, 2520, (32, 64, 128)), ("dec (M=64, k=7, N=64x5040)", 64, 7, 5040, (32, 64, 128))):
     pts = []
     for cin in cins:
-        us = L.rvc_debug_conv_bench(h, M, cin, KW, 1, N, 10, 0)
+        us = L.rvc_debug_conv_bench(h, M, cin, KW, 1, N, 10, 0, 64, int(sys.argv[1]) if len(sys.argv) > 1 else 0)
         K = cin * KW
         pts.append((K, us))
         print("%-34s K=%5d %9.1f us %6.1f TF/s" % (label, K, us, 2.0 * M * K * N * 64 / us / 1e6))

@@ -1,4 +1,5 @@
-"""Tuning aid (not a test): isolated timings of the implicit-GEMM kernel on representative layer shapes."""
+"""Tuning aid: isolated timings of the implicit-GEMM kernel on representative layer shapes (needs the tuning build:
+RVC_TUNING=1 RVC_LIB_OVERRIDE=$(python tests/tools/build_tuning.py) python tests/tools/gemm_microbench.py [quick])."""
 import ctypes as C
 import os
 import subprocess
@@ -13,18 +14,18 @@ SHAPES = {  # name: (M, Cin, KW, dil, N)
     "d32_k3": (32, 32, 3, 1, 10080), "d32_k7": (32, 32, 7, 1, 10080), "d32_k11": (32, 32, 11, 1, 10080), "d32_k11d5": (32, 32, 11, 5, 10080),
 }
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "child":
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     from obs_rvc_amd import _native
     L = _native.lib()
     L.rvc_debug_conv_bench.restype = C.c_double
-    L.rvc_debug_conv_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.rvc_debug_conv_bench.argtypes = [C.c_void_p] + [C.c_int] * 9
     h = C.c_void_p()
     assert L.rvc_create(b"/tmp", 0, C.byref(h)) == 0
     out = []
     for name in sys.argv[2].split(","):
         M, Cin, KW, dil, N = SHAPES[name]
-        us = L.rvc_debug_conv_bench(h, M, Cin, KW, dil, N, 200 if int(os.environ.get("RVC_BENCH_B", "1")) == 1 else 20, 0)
+        us = L.rvc_debug_conv_bench(h, M, Cin, KW, dil, N, 200 if int(os.environ.get("RVC_BENCH_B", "1")) == 1 else 20, 0, int(os.environ.get("RVC_BENCH_B", "1")), 0)
         fl = 2.0 * M * Cin * KW * N * int(os.environ.get("RVC_BENCH_B", "1"))
         out.append("%s %.1fus %.1fTF" % (name, us, fl / us / 1e6))
     print(os.environ.get("RVC_FORCE_CFG", "auto"), os.environ.get("RVC_FORCE_MFAST", "-"), " | ".join(out))

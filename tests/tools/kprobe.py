@@ -11,11 +11,9 @@ import ctypes as C, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "obs_rvc_amd", "csrc")
-SO = os.path.join(CSRC, "librvc_kprobe%s.so" % os.environ.get("KPROBE_TAG", ""))
-EXTRA = os.environ.get("KPROBE_FLAGS", "").split()
-src = os.path.join(CSRC, "engine.hip")
-if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(os.path.join(CSRC, f)) for f in ("engine.hip", "kernels.hip.h", "igemm.hip.h", "conv_tile.hip.h")):
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRVC_KPROBE", "-DRVC_UNITY"] + EXTRA + [src, os.path.join(CSRC, "synth_front.hip"), "-o", SO])
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import build_tuning
+SO = build_tuning.build(os.environ.get("KPROBE_FLAGS", "").split())
 if len(sys.argv) < 6:
     raise SystemExit("built " + SO)
 M, Cin, KW, dil, N = [int(v) for v in sys.argv[1:6]]
