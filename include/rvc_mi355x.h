@@ -97,8 +97,9 @@ rvc_status rvc_rccl_unique_id(void *id128);
 rvc_status rvc_index_broadcast(rvc_engine *e, const void *unique_id128, int rank, int world, const float *vectors, size_t n, size_t dim);
 /* RVC_OK when librccl can be loaded in this process (creates no communicator).  Hosts agree on it across ranks BEFORE calling
  * rvc_index_broadcast, so that a rank without the library cannot leave the others waiting in the communicator set-up.  Inside
- * rvc_index_broadcast every local check precedes the first collective, and the ranks agree on the header (one all-reduce) before the
- * payload broadcast: they fail together. */
+ * rvc_index_broadcast nothing a single rank finds wrong with its own arguments makes it leave alone: rank 0 sends an empty header when
+ * its index is unusable, every rank checks the header against what it expects, and ONE all-reduce of the verdicts precedes the payload
+ * broadcast -- the ranks return the error together (tests/test_gpu_multi.py runs this with two ranks). */
 rvc_status rvc_rccl_available(void);
 /* the engine's last rvc_index_broadcast: ms[0] communicator set-up, ms[1] header + agreement + payload broadcast, ms[2] device-side
  * repack of the index (MFMA-fragment order + norms; the matrix never returns to the host); *ranks = ncclCommCount */
@@ -177,7 +178,9 @@ rvc_status rvc_profile_last(rvc_engine *e, int *launches, double *kernel_ms, dou
 /* same for the HBM-bound retrieval scan (knn_dot_kernel): launches, summed ms, summed algorithmic bytes (index size per pass) */
 rvc_status rvc_profile_last_knn(rvc_engine *e, int *launches, double *kernel_ms, double *bytes);
 void rvc_set_profile(rvc_engine *e, int on);
-/* named intermediate tensor of stream 0 of the last call, contiguous row-major (tests) */
+/* named intermediate tensor of stream 0 of the last call, contiguous row-major (tests).  on = 1: taps on the EXPLICIT plan (every
+ * LayerNorm its own launch, WaveNets layer by layer: each tap has the oracle's meaning); on = 2: taps on the PRODUCTION plan (folded
+ * LayerNorms, composed WaveNets: tensors that are not yet normalised there carry a ".raw" suffix); 0 = off */
 void rvc_enable_taps(rvc_engine *e, int on);
 rvc_status rvc_get_tap(rvc_engine *e, const char *name, float *out, size_t cap, size_t *n);
 void rvc_get_pitch_cache(rvc_engine *e, int stream, float *out1024);

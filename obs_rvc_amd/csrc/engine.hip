@@ -340,6 +340,7 @@ struct Plan {
     int B = 1; size_t L = 0, frame16k = 0; uint32_t skip_head = 0, R = 0;
     int T = 0, Tm = 0, C = 0; size_t N = 0;
     bool with_index = false, with_taps = false;
+    bool plain_plan = false;      // taps level 1: the explicit plan (LayerNorm launches, WaveNets layer by layer); level 2 taps the production plan
     int mode = 0;   // 0 infer, 1 hubert only, 2 pitch only
     // I/O tensors
     float *d_in = nullptr;  // [B][L]
@@ -1473,7 +1474,8 @@ struct rvc_engine {
     // plans (keyed by geometry)
     std::vector<std::unique_ptr<Plan>> plans;
     Plan *last_plan = nullptr;
-    bool taps_on = false, profile_on = false, use_graph = false;
+    int taps_on = 0;               // 0 off, 1 taps on the explicit plan, 2 taps on the production plan (rvc_enable_taps)
+    bool profile_on = false, use_graph = false;
     // offline throughput mode: consecutive unsynchronised infer_device calls overlap chunk i+1's two front branches with chunk i's
     // synthesizer (two plan slots; the branch streams are ordered by events instead of forking from the main stream)
     bool pipeline = false, pipe_now = false; int pipe_slot = 0; hipEvent_t ev_in = nullptr; const void *pipe_input = nullptr; size_t pipe_input_bytes = 0;
@@ -1691,7 +1693,7 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
         x = y; T = To;
     }
     add_tap(pl, "cv.feat", x);
-    const bool fuse_ln = B == 1 && m.has_folded && !pl.with_taps && !test_opt("RVC_NO_LN_FUSE");
+    const bool fuse_ln = B == 1 && m.has_folded && !pl.plain_plan && !test_opt("RVC_NO_LN_FUSE");
     const int E = m.embed;
     T1 h = make_t1(A, B, E, T, m.pos_k / 2);
     if (fuse_ln && m.proj_wsum) { ConvOpts o; o.ln_wsum = m.proj_wsum; o.ln_rows = m.conv_dim; add_conv1d(pl, m.proj_f, x, h, 1, 0, 1, o); }
@@ -1703,7 +1705,7 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
     T1 h2 = make_t1(A, B, E, T, 0);
     { ConvOpts o; o.act = ACT_GELU; o.res = h.p; o.res_cs = h.ld; o.res_bs = h.bs; add_conv1d(pl, m.pos, h, h2, 1, m.pos_k / 2, 1, o); }
     if (!fuse_ln) add_layernorm(pl, h2, m.encln_g, m.encln_b);      // (folded: layer 0 consumes the not yet normalised sum, see below)
-    add_tap(pl, "cv.pos", h2);
+    add_tap(pl, fuse_ln ? "cv.pos.raw" : "cv.pos", h2);
     T1 qkv = make_t1(A, B, 3 * E, T, 0), att = make_t1(A, B, E, T, 0), ff = make_t1(A, B, m.ffn, T, 0);
     const int hd = E / m.heads, Tp = T | 1;
     const size_t attn_lds = ((size_t)((hd * Tp + 3) & ~3) + 16 * Tp + 16 * hd) * sizeof(float);
@@ -1751,7 +1753,7 @@ static T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
         { ConvOpts o; o.res = h2.p; o.res_cs = h2.ld; o.res_bs = h2.bs; add_conv1d(pl, Ly.ff2, ff, h2, 1, 0, 1, o); }
         add_layernorm(pl, h2, Ly.ln2_g, Ly.ln2_b);
         }
-        if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "cv.l%d", l); add_tap(pl, nm, h2); } else if (l % 4 == 3) add_stamp(pl, "cv.l4");
+        if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, raw ? "cv.l%d.raw" : "cv.l%d", l); add_tap(pl, nm, h2); } else if (l % 4 == 3) add_stamp(pl, "cv.l4");
     }
     T1 out = h2;
     if (m.out_dim != E) { out = make_t1(A, B, m.out_dim, T, 0); add_conv1d(pl, m.final_proj, h2, out, 1, 0, 1); }
@@ -2045,7 +2047,7 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
         const size_t attn_lds = ((size_t)((kc * Tp + 3) & ~3) + 16 * Tp + 16 * kc) * sizeof(float);
         if (attn_lds > 160 * 1024) throw ShapeError("synth attention: return_length too long for the LDS-resident kernel");
         // one stream: the second LayerNorm of every encoder layer is folded into the next projection (see build_contentvec)
-        const bool fuse_ln = B == 1 && m.has_folded && !pl.with_taps && !test_opt("RVC_NO_LN_FUSE");
+        const bool fuse_ln = B == 1 && m.has_folded && !pl.plain_plan && !test_opt("RVC_NO_LN_FUSE");
         bool raw = false; const float *raw_g = nullptr, *raw_b = nullptr; float *raw_st = nullptr;
         for (int l = 0; l < m.enc_layers; l++) {
             ModelSY::Layer &Ly = m.layers[l];
@@ -2078,11 +2080,11 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
             if (fuse_ln) { raw = true; raw_g = Ly.ln2_g; raw_b = Ly.ln2_b; }
             else add_layernorm(pl, x, Ly.ln2_g, Ly.ln2_b);
         }
-        add_tap(pl, "sy.enc", x);
+        add_tap(pl, raw ? "sy.enc.raw" : "sy.enc", x);
         // one stream: WaveNets with their res_skip layers composed away and post + next pre merged (ModelSY::compose_flows): 21 launches for
         // four flows instead of 40.  U[k] = [ones16 | h0 (H) | a_0 .. a_{n-1} | z (I)]; flow k reads U[k & 1] and writes h0 and z of U[(k + 1) & 1]
         static const int wn_max_b = tune_env("RVC_WN_COMPOSE_MAX") ? atoi(tune_env("RVC_WN_COMPOSE_MAX")) : 8;
-        const bool wn_composed = B <= wn_max_b && H % 16 == 0 && I == H && !pl.with_taps && !test_opt("RVC_NO_WN_COMPOSE");      // (launch-bound up to a few streams)
+        const bool wn_composed = B <= wn_max_b && H % 16 == 0 && I == H && !pl.plain_plan && !test_opt("RVC_NO_WN_COMPOSE");      // (launch-bound up to a few streams)
         T1 U[2];
         const int u_z = 16 + H + H * m.wn_layers;                     // first latent row of U
         if (wn_composed) {
@@ -2117,7 +2119,7 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
                 if (fi > 0) add_conv1d_two(pl, Fw.posth, Fw.postc, Fw.pair_bias, Uc.rows(16 + H, H * m.wn_layers + I), Un.rows(16, H), Un.rows(u_z, I));
                 else add_conv1d(pl, Fw.postc, Uc.rows(16 + H, H * m.wn_layers + I), Un.rows(u_z, I), 1, 0, 1);
                 if (fi == 0) z = Un.rows(u_z, I);
-                add_stamp(pl, "sy.flow");
+                if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "sy.flow%d", fi); add_tap(pl, nm, Un.rows(u_z, I)); } else add_stamp(pl, "sy.flow");
                 continue;
             }
             add_conv1d(pl, Fw.pre, x0, hs, 1, 0, 1);                       // hh = pre(x0), skip = 0
@@ -2128,7 +2130,7 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
                 else add_conv1d(pl, Fw.rs[j], acts, skip, 1, 0, 1, o);
             }
             { ConvOpts o; o.scale = -1.f; o.accumulate = true; add_conv1d(pl, Fw.post, skip, x1, 1, 0, 1, o); }
-            add_stamp(pl, "sy.flow");
+            if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "sy.flow%d", fi); add_tap(pl, nm, z); } else add_stamp(pl, "sy.flow");
         }
         if (m.flow_n & 1) {
             // odd number of flips: materialise the last one
@@ -2238,11 +2240,11 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
     const bool with_index = mode == 0 && e->d_index && e->index_rate > 0.f;
     for (auto &p : e->plans)
         if (p->mode == mode && p->L == L && p->frame16k == frame16k && p->skip_head == skip_head && p->R == R && p->B == B &&
-            p->with_index == with_index && p->with_taps == e->taps_on && p->slot == slot)
+            p->with_index == with_index && p->with_taps == (e->taps_on != 0) && p->plain_plan == (e->taps_on == 1) && p->slot == slot)
             return p.get();
     std::unique_ptr<Plan> up(new Plan());
     Plan &pl = *up;
-    pl.mode = mode; pl.L = L; pl.frame16k = frame16k; pl.skip_head = skip_head; pl.R = R; pl.B = B; pl.with_index = with_index; pl.with_taps = e->taps_on;
+    pl.mode = mode; pl.L = L; pl.frame16k = frame16k; pl.skip_head = skip_head; pl.R = R; pl.B = B; pl.with_index = with_index; pl.with_taps = e->taps_on != 0; pl.plain_plan = e->taps_on == 1;
     pl.slot = slot;
     pl.d_in = pl.arena.floats((size_t)B * L + 64);
     T1 sal0, src0; float *d_pitchf0 = nullptr; int *d_pitch0 = nullptr;
@@ -2870,7 +2872,7 @@ void rvc_set_pipeline(rvc_engine *e, int on)
     (void)guarded(e, [&]() { HIPCHK(hipDeviceSynchronize()); e->pipeline = on != 0; e->pushed_valid = false; return RVC_OK; });
 }
 void rvc_set_profile(rvc_engine *e, int on) { if (e) e->profile_on = on != 0; }
-void rvc_enable_taps(rvc_engine *e, int on) { if (e) e->taps_on = on != 0; }
+void rvc_enable_taps(rvc_engine *e, int on) { if (e) e->taps_on = on == 2 ? 2 : (on != 0 ? 1 : 0); }
 float rvc_last_gpu_ms(rvc_engine *e) { return e ? e->last_ms : 0.f; }
 void rvc_set_index_rate(rvc_engine *e, float rate) { if (e) e->index_rate = rate; }
 

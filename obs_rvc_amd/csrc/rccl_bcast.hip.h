@@ -86,10 +86,14 @@ rvc_status rvc_rccl_available(void)
 rvc_status rvc_index_broadcast(rvc_engine *e, const void *unique_id128, int rank, int world, const float *vectors, size_t n, size_t dim)
 {
     return guarded(e, [&]() {
-        // every check that needs no other rank comes first: a rank that fails here has not entered any collective
+        // Only what every rank can check about ITSELF and what a host agrees on beforehand (rvc_rccl_available) may throw before the
+        // communicator exists.  Rank 0's own preconditions (vectors present, at least 4 of them) do NOT throw here: the other ranks are
+        // already on their way into ncclCommInitRank and would wait for a peer that left.  A failing rank 0 sends an empty
+        // header instead; every rank then rejects it in the agreement all-reduce and all of them return the error together.
         if (world < 1 || rank < 0 || rank >= world || !unique_id128) throw ShapeError("index broadcast: bad rank / world / unique id");
-        if (rank == 0 && !vectors && !e->d_index) throw ShapeError("index broadcast: rank 0 has neither host vectors nor a loaded index");
-        if (rank == 0 && vectors && (n < KNN_K || dim < 1)) throw ShapeError("index broadcast: index needs at least 4 vectors");
+        std::string root_err;
+        if (rank == 0 && !vectors && !e->d_index) root_err = "index broadcast: rank 0 has neither host vectors nor a loaded index";
+        else if (rank == 0 && vectors && (n < KNN_K || dim < 1)) root_err = "index broadcast: index needs at least 4 vectors";
         RcclApi &api = rccl_api();
         if (!api.lib) throw std::runtime_error(api.err);
         HIPCHK(hipDeviceSynchronize());
@@ -106,7 +110,7 @@ rvc_status rvc_index_broadcast(rvc_engine *e, const void *unique_id128, int rank
         try {
             // header first: the other ranks learn (n, dim) from rank 0
             unsigned long long hdr[2] = {0, 0};
-            if (rank == 0) { hdr[0] = vectors ? n : e->index_n; hdr[1] = vectors ? dim : e->index_dim; }
+            if (rank == 0 && root_err.empty()) { hdr[0] = vectors ? n : e->index_n; hdr[1] = vectors ? dim : e->index_dim; }
             HIPCHK(hipMalloc(&d_hdr, 4 * sizeof(unsigned long long)));
             HIPCHK(hipMemcpy(d_hdr, hdr, sizeof hdr, hipMemcpyHostToDevice));
             RCCLCHK(api, api.Broadcast(d_hdr, d_hdr, sizeof hdr, /*ncclUint8*/ 1, 0, comm, e->stream));
@@ -116,7 +120,8 @@ rvc_status rvc_index_broadcast(rvc_engine *e, const void *unique_id128, int rank
             // local verdict on the header (shape, memory), then ONE all-reduce of it: every rank leaves together or goes on together --
             // a rank that simply threw here would leave the others blocked in the payload broadcast
             int ok = 1;
-            if (bn < KNN_K || bd < 1 || bn * bd > ((size_t)1 << 36)) { ok = 0; local_err = "index broadcast: implausible index size from rank 0"; }
+            if (!root_err.empty()) { ok = 0; local_err = root_err; }
+            else if (bn < KNN_K || bd < 1 || bn * bd > ((size_t)1 << 36)) { ok = 0; local_err = "index broadcast: rank 0 sent no usable index (its arguments were rejected there, or the size is implausible)"; }
             else if (rank != 0 && n && dim && (n != bn || dim != bd)) { ok = 0; local_err = "index broadcast: this rank expected a different index shape than rank 0 sent"; }
             else if (hipMalloc(&d_new, bn * bd * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); d_new = nullptr; ok = 0; local_err = "index broadcast: out of device memory for the index"; }
             int *d_ok = reinterpret_cast<int *>(d_hdr + 2);

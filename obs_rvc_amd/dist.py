@@ -75,8 +75,13 @@ def load_shared_index(eng, vecs: Optional[np.ndarray], n: int, dim: int, rank: i
     else:
         if not _all_agree(eng.rccl_available(), world):
             raise RuntimeError("librccl is not loadable on every rank")
+        # every rank's own arguments, agreed on BEFORE any communicator exists (the engine also fails together from inside the
+        # collective, but a host that can tell earlier should not start one)
+        mine = (vecs is not None and np.ndim(vecs) == 2 and np.shape(vecs) == (n, dim) and n >= 4) if rank == 0 else (n >= 4 and dim >= 1)
+        if not _all_agree(bool(mine), world):
+            raise RuntimeError("index arguments rejected on at least one rank (rank 0 needs the (n, dim) matrix with n >= 4)")
         uid = exchange_unique_id(eng, rank, world)
-        eng.index_broadcast(uid, rank, world, vecs if rank == 0 else None)
+        eng.index_broadcast(uid, rank, world, vecs if rank == 0 else None, expect=None if rank == 0 else (n, dim))
     p, nbytes = eng.index_device_ptr()
     if nbytes != n * dim * 4:
         raise RuntimeError("index load delivered %d bytes, expected %d" % (nbytes, n * dim * 4))

@@ -116,15 +116,17 @@ class RvcInfer:
         self._chk(self._L.rvc_rccl_unique_id(buf))
         return buf.raw
 
-    def index_broadcast(self, unique_id: bytes, rank: int, world: int, vectors=None):
+    def index_broadcast(self, unique_id: bytes, rank: int, world: int, vectors=None, expect=None):
         """rvc_index_broadcast: ONE ncclBroadcast of the shared retrieval index from rank 0 into this rank's HBM (RCCL over xGMI).
-        Rank 0 passes the (n, dim) matrix (or None to send the index it already holds); the other ranks pass None."""
+        Rank 0 passes the (n, dim) matrix (or None to send the index it already holds); the other ranks pass None, optionally with the
+        shape they expect (`expect=(n, dim)`: a mismatch with what rank 0 sends makes EVERY rank fail, together)."""
         assert len(unique_id) == 128
         if vectors is not None:
             v, vp = _f32(vectors)
             self._chk(self._L.rvc_index_broadcast(self._h, unique_id, int(rank), int(world), vp, v.shape[0], v.shape[1]))
         else:
-            self._chk(self._L.rvc_index_broadcast(self._h, unique_id, int(rank), int(world), None, 0, 0))
+            n, dim = expect if expect else (0, 0)
+            self._chk(self._L.rvc_index_broadcast(self._h, unique_id, int(rank), int(world), None, int(n), int(dim)))
 
     def rccl_available(self) -> bool:
         """rvc_rccl_available: can this process load librccl?  (no communicator is created)"""
@@ -208,8 +210,17 @@ class RvcInfer:
         self._chk(self._L.rvc_profile_last_knn(self._h, C.byref(n), C.byref(ms), C.byref(by)))
         return n.value, ms.value, by.value
 
-    def enable_taps(self, on: bool = True):
-        self._L.rvc_enable_taps(self._h, 1 if on else 0)
+    def enable_taps(self, on=True):
+        """True / 1: taps on the explicit plan; 2: taps on the production plan (folded LayerNorms, composed WaveNets); False: off"""
+        self._L.rvc_enable_taps(self._h, 2 if on == 2 else (1 if on else 0))
+
+    def plan_ops(self) -> int:
+        """kernel launches / copies queued per chunk by the plan of the last call (test aid: which plan ran)"""
+        n = C.c_int(0)
+        self._L.rvc_debug_last_plan.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        self._L.rvc_debug_last_plan.restype = C.c_int
+        assert self._L.rvc_debug_last_plan(self._h, C.byref(n)) == 1
+        return int(n.value)
 
     def tap(self, name: str):
         n = C.c_size_t()

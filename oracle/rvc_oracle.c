@@ -883,6 +883,7 @@ static float *synth_forward(ora_engine *e, const float *phone /* [R][Cin] */, co
         }
         float *m = conv1d(skip, Hd, T, W(b, "sy.flow%d.post.w", fi), W(b, "sy.flow%d.post.b", fi), half, 1, 1, 0, 1, 1, &To);
         for (size_t q = 0; q < (size_t)half * T; q++) z[(size_t)half * T + q] -= m[q];
+        tapf(e, z, (size_t)I * T, "sy.flow%d", fi);      /* the latent behind coupling fi, in the order the reference holds it (flow_n - fi flips applied) */
         free(h); free(cond); free(skip); free(m);
     }
     free(tmpz);
