@@ -192,6 +192,35 @@ def timed_leg(job, eng, d_rings, d_out, g, steps, warmup):
     return elapsed, lat, step
 
 
+def committed_traffic(S):
+    """HBM traffic of the dominant kernel class from the committed rocprofv3 --pmc pass of THIS build (tests/tools/profile_round.sh ->
+    profiles/<round>_pmc_traffic*.json; PMC counters need their own rocprofv3 run, so they cannot be taken inside this process).  A file
+    whose build hash differs from the loaded library's is refused: -> (bytes per launch | None, bytes per launch of the retrieval scan | None, note)"""
+    from obs_rvc_amd import _native
+    have = _native.binary_hash()
+    import glob
+    want = "_pmc_traffic_64streams.json" if S >= 16 else "_pmc_traffic.json"
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*" + want)))
+    if not files:
+        return None, None, {"traffic_source": None, "traffic_note": "no committed PMC pass under profiles/"}
+    f = files[-1]
+    try:
+        d = json.load(open(f))
+    except Exception as ex:
+        return None, None, {"traffic_source": os.path.relpath(f, ROOT), "traffic_note": "unreadable: %s" % ex}
+    src = {"traffic_source": os.path.relpath(f, ROOT) + " (rocprofv3 --pmc FETCH_SIZE, x2 on gfx950, separate pass of `bench.py --only-headline%s`)" % (" --streams 64" if S >= 16 else " --index"),
+           "traffic_build": d.get("build"), "library_build": have}
+    if d.get("build") != have:
+        src["traffic_note"] = "REFUSED: the committed pass was taken on build %s, this library is %s -- rerun tests/tools/profile_round.sh" % (d.get("build"), have)
+        return None, None, src
+    ig = d.get("igemm_all_instantiations") or {}
+    kd = d.get("knn_dot_kernel") or {}
+    src["traffic_launches_per_step"] = ig.get("launches_per_chunk")
+    src["traffic_bytes_per_step"] = ig.get("hbm_read_bytes_per_chunk")
+    src["algorithmic_weight_bytes_per_step"] = ig.get("algorithmic_weight_bytes_per_chunk")
+    return ig.get("hbm_read_bytes_per_launch"), kd.get("hbm_read_bytes_per_launch"), src
+
+
 def roofline_of(eng, step, S, reps=5):
     """Dominant kernel class (implicit GEMM on the fp32 matrix cores): per-launch HIP events on the stream each kernel is launched on
     (hipExtLaunchKernelGGL start/stop = the dispatch's own begin/end), eager launches of the same kernels and shapes."""
@@ -209,11 +238,10 @@ def roofline_of(eng, step, S, reps=5):
         k_n += kn; k_ms += kms; k_by += kby
     eng.set_profile(False)
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-    # HBM traffic per launch: PMC counters cannot be collected inside this process -> null here; the `rocprofv3 --pmc` passes of this
-    # command (gfx950 corrections applied) are committed under profiles/ (r03_pmc_traffic*.json) and summarised in DESIGN.md section 7
+    # HBM traffic per launch: the committed `rocprofv3 --pmc` pass of this build (committed_traffic: refused when the build hashes differ)
+    t_launch, t_knn, t_src = committed_traffic(S)
     roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": None,
-            "traffic_note": "not measured in this run (PMC needs its own rocprofv3 pass): profiles/r03_pmc_traffic*.json",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": t_launch, "traffic_unit": "HBM read bytes per launch (class average)",
             "kernel": "rvc::igemm2_kernel / conv_tile_kernel / igemm32_kernel / igemm_lds_kernel (all instantiations)", "launches_per_step": n_l // reps,
             "avg_launch_us": round(tot_ms * 1e3 / max(n_l, 1), 3), "flops_per_step": tot_fl / reps,
             "sum_kernel_ms": round(tot_ms / reps, 4),
@@ -222,11 +250,12 @@ def roofline_of(eng, step, S, reps=5):
                     ("achieved = flops / SUM of per-launch durations, measured with the two front branches issued one after the other "
                      "(above 4 streams they share the CUs, and a co-scheduled short kernel's event duration is the long kernel's, not its "
                      "own); the timed steps run the branches concurrently -- frac_by_wall in the enclosing record uses their wall clock")}
+    roof.update(t_src)
     if k_n:
         ach = k_by / (k_ms * 1e-3) / 1e9
         roof["retrieval_scan"] = {"bound": "hbm", "kernel": "rvc::knn_dot_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": k_by / k_n, "avg_launch_us": round(k_ms * 1e3 / k_n, 2),
-                                  "traffic": None}
+                                  "traffic": t_knn}
     return roof
 
 
@@ -479,6 +508,10 @@ def main(argv=None):
     if not args.only_headline and full and S == 1 and not args.index:
         # Each leg raises only where every rank raises together (index broadcast: agreed through Job.all_ok; anything else is deterministic
         # per configuration), so skipping a failed leg cannot strand a rank in a collective.
+        # latency distributions of the two sub-configurations VERDICT r3 asked for come from >= 200 synchronised chunks (p99 of 20 samples
+        # is their maximum); the 64-stream plans get 8 warm-up steps (3 left a first-use outlier inside the driver's 20 timed steps)
+        sub_soak = int(os.environ.get("RVC_BENCH_SUB_SOAK", "200"))
+
         def leg(name, fn):
             try:
                 sub[name] = fn()
@@ -488,14 +521,14 @@ def main(argv=None):
             job.torch.cuda.empty_cache()
 
         def index100k():
-            rec, e2, _, d2 = run_config(job, z, g, 1, True, args.steps, args.warmup, graph, index_vecs)
+            rec, e2, _, d2 = run_config(job, z, g, 1, True, args.steps, args.warmup, graph, index_vecs, soak=sub_soak)
             del e2, d2
             return rec
 
         def streams64():
             k64 = max(10, min(args.steps, 20))
             want_index = job.world > 1 and "error" not in (sub.get("index100k") or {})      # configs[4] shares the index over RCCL
-            rec, e3, _, d3 = run_config(job, z, g, 64, want_index, k64, 3, graph, index_vecs)
+            rec, e3, _, d3 = run_config(job, z, g, 64, want_index, k64, 8, graph, index_vecs, soak=sub_soak)
             del e3, d3
             if rec:
                 rec["steps"] = k64

@@ -11,6 +11,9 @@ import torch
 from common import BASELINE_160MS as g, voice_signal, zoo
 from obs_rvc_amd.rvc import RvcInfer
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+from common import set_opt
+for a in sys.argv[3:]:          # test hooks: NAME=VALUE
+    set_opt(*a.split("=", 1))
 z = zoo(sys.argv[2] if len(sys.argv) > 2 else "full")
 eng = RvcInfer(z["data"], device=0); eng.load_contentvec(2); eng.load_f0(1); eng.load_model(z["model"]); eng.set_streams(S); eng.set_noise_seed(1, 0)
 L, chunk, N = g.input_buffer_16k_size, g.sample_frame_16k, g.model_return_size

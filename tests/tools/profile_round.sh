@@ -3,7 +3,7 @@
 # passes (separate runs, --kernel-trace only, as gpurun requires).  Raw traces stay in /tmp on the GPU box (hundreds of MB); the
 # summaries the repository keeps are written to gpurun_out/<tag>/ under their profiles/ names.
 # usage: profile_round.sh <tag> [round]      e.g. profile_round.sh r02d r02
-tag=${1:-r03}; rnd=${2:-r03}; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; raw=/tmp/prof_$tag; mkdir -p $out $raw
+tag=${1:-r04}; rnd=${2:-r04}; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; raw=/tmp/prof_$tag; mkdir -p $out $raw
 cd /tmp; export TMPDIR=/tmp
 prof() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d $raw/ks_$name -- python $R/bench.py --only-headline --no-cpu "$@" > $out/bench_$name.json 2> $out/bench_$name.err
          cp $raw/ks_$name/*/*kernel_stats.csv $out/${rnd}_kernel_stats_bench_$name.csv; }
