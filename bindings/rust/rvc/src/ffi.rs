@@ -65,6 +65,8 @@ extern "C" {
                              skip_head: u32, return_length: u32, out: *mut c_float, cap_per_stream: usize, out_len: *mut usize) -> c_int;
     pub fn rvc_infer_device_v(e: *mut RvcEngine, d_input: *const c_void, n: usize, sample_frame_16k_size: usize, pitch_shift: *const i32,
                               skip_head: u32, return_length: u32, d_out: *mut c_void, cap_per_stream: usize, out_len: *mut usize, sync: c_int) -> c_int;
+    pub fn rvc_infer_batch_g(e: *mut RvcEngine, inputs: *const *const c_float, n: *const usize, sample_frame_16k_size: *const usize, pitch_shift: *const i32,
+                             skip_head: *const u32, return_length: *const u32, outs: *const *mut c_float, caps: *const usize, out_lens: *mut usize) -> c_int;
     pub fn rvc_infer_device(e: *mut RvcEngine, d_input: *const c_void, n: usize, sample_frame_16k_size: usize, pitch_shift: i32,
                             skip_head: u32, return_length: u32, d_out: *mut c_void, cap_per_stream: usize, out_len: *mut usize,
                             sync: c_int) -> c_int;

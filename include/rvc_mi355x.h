@@ -121,6 +121,12 @@ rvc_status rvc_infer_batch_v(rvc_engine *e, const float *input, size_t n, size_t
                              uint32_t skip_head, uint32_t return_length, float *out, size_t cap_per_stream, size_t *out_len);
 rvc_status rvc_infer_device_v(rvc_engine *e, const void *d_input, size_t n, size_t sample_frame_16k_size, const int32_t *pitch_shift,
                               uint32_t skip_head, uint32_t return_length, void *d_out, size_t cap_per_stream, size_t *out_len, int sync);
+/* many streams, every stream with ITS OWN geometry (in the reference every stream is a process with its own chunk length, crossfade and
+ * extra context: obs-rvc/src/lib.rs:200-227, 694).  All arrays have n_streams entries (inputs / outs: host pointers per stream;
+ * pitch_shift may be NULL = 0 for every stream).  Streams with equal (n, sample_frame_16k_size, skip_head, return_length) run as one
+ * batch; a server can mix 160 ms and 300 ms callers in one call.  At most 8 different geometries per call. */
+rvc_status rvc_infer_batch_g(rvc_engine *e, const float *const *inputs, const size_t *n, const size_t *sample_frame_16k_size, const int32_t *pitch_shift,
+                             const uint32_t *skip_head, const uint32_t *return_length, float *const *outs, const size_t *caps, size_t *out_lens);
 rvc_status rvc_synchronize(rvc_engine *e);
 void rvc_set_use_graph(rvc_engine *e, int on);    /* replay the per-chunk launch sequence from a hipGraph */
 /* Offline throughput mode (no counterpart in the reference, whose protocol is one request at a time): with on != 0, consecutive

@@ -17,7 +17,7 @@ SYMBOLS = [
     "rvc_create", "rvc_destroy", "rvc_load_contentvec", "rvc_load_model", "rvc_load_f0", "rvc_unload_model",
     "rvc_hubert", "rvc_extract_feature", "rvc_pitch", "rvc_infer", "rvc_last_error_message",
     "rvc_load_index", "rvc_load_index_device", "rvc_set_index_rate", "rvc_get_knn", "rvc_set_noise_seed", "rvc_reset_state",
-    "rvc_set_streams", "rvc_infer_batch", "rvc_infer_device", "rvc_infer_batch_v", "rvc_infer_device_v", "rvc_synchronize", "rvc_set_use_graph", "rvc_set_pipeline",
+    "rvc_set_streams", "rvc_infer_batch", "rvc_infer_device", "rvc_infer_batch_v", "rvc_infer_device_v", "rvc_infer_batch_g", "rvc_synchronize", "rvc_set_use_graph", "rvc_set_pipeline",
     "rvc_last_gpu_ms", "rvc_profile_last", "rvc_set_profile", "rvc_enable_taps", "rvc_get_tap", "rvc_get_pitch_cache",
     "rvc_index_device_ptr", "rvc_device", "rvc_version", "rvc_envelop_mixing", "rvc_sola_step", "rvc_profile_last_knn",
     "rvc_resampler_create", "rvc_resampler_destroy", "rvc_resampler_input_frames_next", "rvc_resampler_output_frames_max",
@@ -207,6 +207,7 @@ def lib():
     L.rvc_infer_device.argtypes = [vp, vp, sz, sz, i32, u32, u32, vp, sz, C.POINTER(sz), C.c_int]
     L.rvc_infer_batch_v.argtypes = [vp, fp, sz, sz, C.POINTER(i32), u32, u32, fp, sz, C.POINTER(sz)]
     L.rvc_infer_device_v.argtypes = [vp, vp, sz, sz, C.POINTER(i32), u32, u32, vp, sz, C.POINTER(sz), C.c_int]
+    L.rvc_infer_batch_g.argtypes = [vp, C.POINTER(fp), C.POINTER(sz), C.POINTER(sz), C.POINTER(i32), C.POINTER(u32), C.POINTER(u32), C.POINTER(fp), C.POINTER(sz), C.POINTER(sz)]
     L.rvc_synchronize.argtypes = [vp]
     L.rvc_set_use_graph.argtypes = [vp, C.c_int]
     L.rvc_set_use_graph.restype = None

@@ -340,6 +340,7 @@ struct Plan {
     int B = 1; size_t L = 0, frame16k = 0; uint32_t skip_head = 0, R = 0;
     int T = 0, Tm = 0, C = 0; size_t N = 0;
     bool with_index = false, with_taps = false;
+    bool bucket = false;          // a plan of rvc_infer_batch_g: built for a subset of the streams on the gathered state block (rvc_engine::d_state_bucket)
     bool plain_plan = false;      // taps level 1: the explicit plan (LayerNorm launches, WaveNets layer by layer); level 2 taps the production plan
     int mode = 0;   // 0 infer, 1 hubert only, 2 pitch only
     // I/O tensors
@@ -1468,6 +1469,7 @@ struct rvc_engine {
     // streams
     int n_streams = 1;
     StreamState *d_state = nullptr;
+    StreamState *d_state_bucket = nullptr; int *d_bucket_idx = nullptr;      // rvc_infer_batch_g: the states of one geometry bucket, gathered contiguously, and their stream numbers
     CallParams *d_cp = nullptr, *h_cp = nullptr;   // h_cp: ring of 64 pinned blocks, one per call (an async copy reads its block later)
     unsigned cp_slot = 0; hipEvent_t ev_cp = nullptr;
     uint32_t seed = 0, stream_id0 = 0;
@@ -1630,6 +1632,8 @@ static void configure_aux_streams(rvc_engine *e)
 static void alloc_state(rvc_engine *e)
 {
     if (e->d_state) (void)hipFree(e->d_state);
+    if (e->d_state_bucket) { (void)hipFree(e->d_state_bucket); e->d_state_bucket = nullptr; }
+    if (e->d_bucket_idx) { (void)hipFree(e->d_bucket_idx); e->d_bucket_idx = nullptr; }
     HIPCHK(hipMalloc(&e->d_state, sizeof(StreamState) * e->n_streams));
     reset_state(e);
     e->plans.clear();
@@ -2234,17 +2238,24 @@ static void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T
 
 // ------------------------------- plan -------------------------------------------------
 static void ensure_index_transposed(rvc_engine *e);
-static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32_t skip_head, uint32_t R, int slot = 0)
+static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32_t skip_head, uint32_t R, int slot = 0, int bucket_B = 0)
 {
+    // bucket_B > 0 (rvc_infer_batch_g): a plan for bucket_B of the engine's streams, whose states the caller gathers into d_state_bucket.
+    // The builders read the stream count and the state block from the engine: both are swapped for the duration of the build.
+    struct Swap {
+        rvc_engine *e; int n0; StreamState *s0; bool on;
+        Swap(rvc_engine *e_, int B, StreamState *st) : e(e_), n0(e_->n_streams), s0(e_->d_state), on(B > 0) { if (on) { e->n_streams = B; e->d_state = st; } }
+        ~Swap() { if (on) { e->n_streams = n0; e->d_state = s0; } }
+    } swap_guard(e, bucket_B, e->d_state_bucket);
     const int B = e->n_streams;
     const bool with_index = mode == 0 && e->d_index && e->index_rate > 0.f;
     for (auto &p : e->plans)
         if (p->mode == mode && p->L == L && p->frame16k == frame16k && p->skip_head == skip_head && p->R == R && p->B == B &&
-            p->with_index == with_index && p->with_taps == (e->taps_on != 0) && p->plain_plan == (e->taps_on == 1) && p->slot == slot)
+            p->with_index == with_index && p->with_taps == (e->taps_on != 0) && p->plain_plan == (e->taps_on == 1) && p->slot == slot && p->bucket == (bucket_B > 0))
             return p.get();
     std::unique_ptr<Plan> up(new Plan());
     Plan &pl = *up;
-    pl.mode = mode; pl.L = L; pl.frame16k = frame16k; pl.skip_head = skip_head; pl.R = R; pl.B = B; pl.with_index = with_index; pl.with_taps = e->taps_on != 0; pl.plain_plan = e->taps_on == 1;
+    pl.mode = mode; pl.L = L; pl.frame16k = frame16k; pl.skip_head = skip_head; pl.R = R; pl.B = B; pl.with_index = with_index; pl.with_taps = e->taps_on != 0; pl.plain_plan = e->taps_on == 1; pl.bucket = bucket_B > 0;
     pl.slot = slot;
     pl.d_in = pl.arena.floats((size_t)B * L + 64);
     T1 sal0, src0; float *d_pitchf0 = nullptr; int *d_pitch0 = nullptr;
@@ -2633,6 +2644,8 @@ void rvc_destroy(rvc_engine *e)
     if (e->d_nhn) (void)hipFree(e->d_nhn);
     if (e->d_indexF) (void)hipFree(e->d_indexF);
     if (e->d_state) (void)hipFree(e->d_state);
+    if (e->d_state_bucket) (void)hipFree(e->d_state_bucket);
+    if (e->d_bucket_idx) (void)hipFree(e->d_bucket_idx);
     if (e->d_cp) (void)hipFree(e->d_cp);
     if (e->h_cp) (void)hipHostFree(e->h_cp);
     if (e->h_status) (void)hipHostFree(e->h_status);
@@ -2841,6 +2854,56 @@ rvc_status rvc_infer_device_v(rvc_engine *e, const void *d_input, size_t n, size
     return guarded(e, [&]() {
         if (!pitch_shift) throw ShapeError("infer_device_v: pitch_shift[n_streams] is required");
         return infer_common(e, d_input, true, n, sample_frame_16k_size, 0, skip_head, return_length, d_out, true, cap_per_stream, out_len, sync != 0, pitch_shift);
+    });
+}
+
+// Many streams, every stream with ITS OWN geometry.  In the reference every stream is a process of its own with its own chunk length,
+// crossfade and extra context (obs-rvc/src/lib.rs:200-227, 694, 701-707); a server that batches such callers cannot ask them to agree on
+// (n, sample_frame_16k_size, skip_head, return_length).  Streams with equal geometry form a bucket; every bucket runs as one batch through
+// its own plan on a gathered copy of its streams' states (pitch cache, counters, status), which is scattered back afterwards.
+rvc_status rvc_infer_batch_g(rvc_engine *e, const float *const *inputs, const size_t *n, const size_t *sample_frame_16k_size, const int32_t *pitch_shift,
+                             const uint32_t *skip_head, const uint32_t *return_length, float *const *outs, const size_t *caps, size_t *out_lens)
+{
+    return guarded(e, [&]() {
+        if (!inputs || !n || !sample_frame_16k_size || !skip_head || !return_length || !outs || !caps) throw ShapeError("infer_batch_g: null argument array");
+        if (!e->sy) return RVC_MODEL_NOT_LOADED;
+        if (!e->cv) return RVC_CONTENTVEC_NOT_LOADED;
+        if (!e->rm) return RVC_F0_NOT_LOADED;
+        const int S = e->n_streams;
+        if (e->pipeline || e->use_graph) throw ShapeError("infer_batch_g: not with chunk pipelining / graph replay");
+        struct Key { size_t n, f; uint32_t sh, rl; bool operator<(const Key &o) const { return std::tie(n, f, sh, rl) < std::tie(o.n, o.f, o.sh, o.rl); } };
+        std::map<Key, std::vector<int>> buckets;
+        for (int s = 0; s < S; s++) {
+            if (!inputs[s] || !outs[s]) throw ShapeError("infer_batch_g: null stream buffer");
+            buckets[Key{n[s], sample_frame_16k_size[s], skip_head[s], return_length[s]}].push_back(s);
+        }
+        if (!e->d_state_bucket) { HIPCHK(hipMalloc(&e->d_state_bucket, sizeof(StreamState) * S)); HIPCHK(hipMalloc(&e->d_bucket_idx, sizeof(int) * S)); }
+        // plans first (a geometry the engine rejects must not leave some buckets already advanced), then the work
+        std::vector<std::pair<Plan *, const std::vector<int> *>> work;
+        for (auto &kv : buckets) {
+            Plan *pl = get_plan(e, 0, kv.first.n, kv.first.f, kv.first.sh, kv.first.rl, 0, (int)kv.second.size());
+            for (int s : kv.second) { if (out_lens) out_lens[s] = pl->N; if (caps[s] < pl->N) return RVC_SHAPE; }
+            work.push_back({pl, &kv.second});
+        }
+        if (e->plans.size() < work.size()) throw ShapeError("infer_batch_g: more than 8 different geometries in one call");      // (the plan cache holds 8)
+        for (auto &w : work)           // (a later get_plan may have evicted an earlier bucket's plan: every plan of this call must still be cached)
+            { bool ok = false; for (auto &p : e->plans) ok = ok || p.get() == w.first; if (!ok) throw ShapeError("infer_batch_g: more than 8 different geometries in one call"); }
+        push_call_params(e, 0, pitch_shift);            // per-stream multipliers into the streams' own states (a null array: no shift)
+        for (auto &w : work) {
+            Plan *pl = w.first; const std::vector<int> &ids = *w.second; const int Bk = (int)ids.size();
+            HIPCHK(hipMemcpyAsync(e->d_bucket_idx, ids.data(), sizeof(int) * Bk, hipMemcpyHostToDevice, e->stream));
+            hipLaunchKernelGGL(state_gather_kernel, dim3(Bk), dim3(256), 0, e->stream, e->d_state, e->d_state_bucket, e->d_bucket_idx, 0);
+            for (int j = 0; j < Bk; j++) HIPCHK(hipMemcpyAsync(pl->d_in + (size_t)j * pl->L, inputs[ids[j]], pl->L * sizeof(float), hipMemcpyHostToDevice, e->stream));
+            pl->cur_in = nullptr; pl->cur_out = nullptr;
+            run_plan(e, *pl);
+            for (int j = 0; j < Bk; j++) HIPCHK(hipMemcpyAsync(outs[ids[j]], pl->audio.p + (size_t)j * pl->N, pl->N * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+            hipLaunchKernelGGL(state_gather_kernel, dim3(Bk), dim3(256), 0, e->stream, e->d_state, e->d_state_bucket, e->d_bucket_idx, 1);
+            HIPCHK(hipStreamSynchronize(e->stream));        // (ids / the pinned-less host buffers of this bucket are free again; the next bucket reuses the state block)
+        }
+        e->last_knn_rows = 0;
+        queue_status(e);                                     // the streams' own status words (the plans wrote bucket-local ones)
+        HIPCHK(hipStreamSynchronize(e->stream));
+        return check_status(e);
     });
 }
 

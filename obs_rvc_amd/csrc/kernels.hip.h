@@ -1301,6 +1301,15 @@ __global__ __launch_bounds__(1024) void nsf_source_kernel(SrcP p)
     }
 }
 
+// rvc_infer_batch_g: the states of one geometry bucket, gathered into a contiguous block (dir = 0) / scattered back (dir = 1); one workgroup per stream
+__global__ void state_gather_kernel(StreamState *all, StreamState *bucket, const int *idx, int dir)
+{
+    const int j = blockIdx.x, s = idx[j];
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(dir ? bucket + j : all + s);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(dir ? all + s : bucket + j);
+    for (int i = threadIdx.x; i < (int)(sizeof(StreamState) / 4); i += blockDim.x) dst[i] = src[i];
+}
+
 // bump the per-stream chunk counters after a call
 // end of a chunk: the streams' chunk counters and the streams' status words, written straight into host-mapped memory (the host reads them after the call's one
 // synchronisation: no copy kernel behind the chunk)

@@ -177,6 +177,23 @@ class RvcInfer:
                                                 int(return_length), out.ctypes.data_as(_FP), cap, C.byref(n)))
         return out[:, : n.value].copy()
 
+    def infer_batch_g(self, inputs, sample_frame_16k_size, pitch_shift, skip_head, return_length):
+        """rvc_infer_batch_g: one call for n_streams callers that do NOT share a geometry (each argument is a sequence with one entry per
+        stream; inputs[s] is that stream's 16 kHz buffer).  -> list of n_streams output arrays"""
+        S = self.n_streams
+        assert len(inputs) == len(sample_frame_16k_size) == len(skip_head) == len(return_length) == S
+        xs = [np.ascontiguousarray(x, dtype=np.float32) for x in inputs]
+        caps = [int(r) * 1024 + 16 for r in return_length]
+        outs = [np.empty(c, np.float32) for c in caps]
+        in_p = (_FP * S)(*[x.ctypes.data_as(_FP) for x in xs])
+        out_p = (_FP * S)(*[o.ctypes.data_as(_FP) for o in outs])
+        sz = C.c_size_t
+        n_a = (sz * S)(*[x.shape[0] for x in xs]); f_a = (sz * S)(*[int(v) for v in sample_frame_16k_size]); cap_a = (sz * S)(*caps); len_a = (sz * S)()
+        sh_a = (C.c_uint32 * S)(*[int(v) for v in skip_head]); rl_a = (C.c_uint32 * S)(*[int(v) for v in return_length])
+        ps_a = None if pitch_shift is None else (C.c_int32 * S)(*[int(v) for v in pitch_shift])
+        self._chk(self._L.rvc_infer_batch_g(self._h, in_p, n_a, f_a, ps_a, sh_a, rl_a, out_p, cap_a, len_a))
+        return [o[: len_a[i]].copy() for i, o in enumerate(outs)]
+
     def infer_device(self, d_in_ptr: int, n: int, sample_frame_16k_size: int, pitch_shift: int, skip_head: int, return_length: int,
                      d_out_ptr: int, cap_per_stream: int, sync: bool = False) -> int:
         nn = C.c_size_t()

@@ -78,7 +78,7 @@ def test_stage_by_stage(preset):
         assert prod.plan_ops() < eng.plan_ops() - 40
 
 
-@pytest.mark.parametrize("preset,version", [("tiny", 2), ("tiny", 1), ("full", 2)])
+@pytest.mark.parametrize("preset,version", [("tiny", 2), ("tiny", 1), ("full", 2), ("full", 1)])      # (full, 1): v1 = ContentVec-256 (layer 9 + final_proj) + the v1 synthesizer, the literal reading of BASELINE configs[1] that the bench times
 def test_stream_of_chunks(preset, version):
     # BASELINE configs[0]/[1]: a 16 kHz stream fed as 160 ms chunks through the 35 840-sample ring; state (pitch cache,
     # noise counters) carries across calls
