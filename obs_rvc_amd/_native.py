@@ -27,7 +27,7 @@ SYMBOLS = [
 ]
 
 
-SOURCES = ("engine.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "igemm2_inst.hip", "igemm_tiled_inst.hip", "conv_tile.hip.h", "conv_tile_inst.hip", "version.cpp",
+SOURCES = ("engine.hip", "engine_int.h", "plan.hip", "model_cv.hip", "model_rmvpe.hip", "model_synth.hip", "retrieval.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "igemm2_inst.hip", "igemm_tiled_inst.hip", "conv_tile.hip.h", "conv_tile_inst.hip", "version.cpp",
            "state.hip.h",
            "resample.hip.h", "session.hip.h", "rccl_bcast.hip.h", "blob.h", "rvc_rpc.cpp")
 
@@ -35,9 +35,9 @@ SOURCES = ("engine.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "igem
 # template instantiations are the bulk of the compile time; as separate units they build in parallel (5 min -> about 1.5 min on 8 cores)
 # and are not rebuilt when only the engine changes.
 _IGEMM_DEPS = ("igemm.hip.h", "igemm_launch.h")
-_ENGINE_DEPS = ("engine.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "resample.hip.h", "session.hip.h", "rccl_bcast.hip.h", "blob.h",
-                "state.hip.h")
-UNITS = [("engine.hip", [], _ENGINE_DEPS)] + \
+_INT_DEPS = ("engine_int.h", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "blob.h", "state.hip.h")
+_ENGINE_DEPS = ("engine.hip", "resample.hip.h", "session.hip.h", "rccl_bcast.hip.h") + _INT_DEPS
+UNITS = [("engine.hip", [], _ENGINE_DEPS)] + [(u, [], (u,) + _INT_DEPS) for u in ("plan.hip", "model_cv.hip", "model_rmvpe.hip", "model_synth.hip", "retrieval.hip")] + \
         [("igemm2_inst.hip", ["-DRVC_IGEMM2_CFG=%d" % c], ("igemm2_inst.hip",) + _IGEMM_DEPS) for c in range(5)] + \
         [("igemm_tiled_inst.hip", ["-DRVC_TILED_PART=%d" % c], ("igemm_tiled_inst.hip",) + _IGEMM_DEPS) for c in range(4)] + \
         [("conv_tile_inst.hip", [], ("conv_tile_inst.hip", "conv_tile.hip.h") + _IGEMM_DEPS)]

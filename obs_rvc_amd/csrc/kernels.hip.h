@@ -7,7 +7,7 @@
 namespace rvc {
 
 // second stage of a split-K launch: fixed-order (deterministic) sum of the partials + epilogue
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(IgemmP p)
+static __global__ __launch_bounds__(256) void splitk_epilogue_kernel(IgemmP p)
 {
     const int total = p.M * p.N;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void tw1024(const float *tw, int e, float &c, float &
     c = tw[2 * h]; s = tw[2 * h + 1];
     if (e & 512) { c = -c; s = -s; }
 }
-__global__ __launch_bounds__(256) void mel_frontend_kernel(MelP p)
+static __global__ __launch_bounds__(256) void mel_frontend_kernel(MelP p)
 {
     __shared__ float bufr[2][1024], bufi[2][1024];
     __shared__ float mag[516];
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void layernorm_ct_kernel(const float *x, float
 // Throughput-mode LayerNorm (many streams): a workgroup owns 32 time steps x ALL channels of one stream.  Rows are read and written as
 // full 128-byte lines (the 4-step kernel above touches 16-byte slivers of lines that other workgroups -- on other XCDs -- fetch again:
 // 156 MB of HBM/MALL reads per launch for 22 MB of data at 64 streams); the tile sits in LDS ([C][33]) for the two-pass statistics.
-__global__ __launch_bounds__(256) void layernorm_tile_kernel(const float *x, float *y, const float *g, const float *bta,
+static __global__ __launch_bounds__(256) void layernorm_tile_kernel(const float *x, float *y, const float *g, const float *bta,
                                                              int C, int T, int x_cs, long long x_bs, int y_cs, long long y_bs)
 {
     extern __shared__ __attribute__((aligned(16))) float tile[];      // [C][33]
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(1024) void conv0_gn_gelu_multi_kernel(const float *
 }
 
 // GroupNorm with one group per channel (= per-channel normalisation over time) + GELU, in place.
-__global__ __launch_bounds__(256) void groupnorm_gelu_kernel(float *x, const float *g, const float *bta, int T, int cs, long long bs)
+static __global__ __launch_bounds__(256) void groupnorm_gelu_kernel(float *x, const float *g, const float *bta, int T, int cs, long long bs)
 {
     __shared__ float red[16];
     const int c = blockIdx.x, b = blockIdx.y;
@@ -441,7 +441,7 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-__global__ __launch_bounds__(256) void attention_kernel(AttnP p)
+static __global__ __launch_bounds__(256) void attention_kernel(AttnP p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int hd = p.E / p.heads, T = p.T, Tp = T | 1;
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnP p)
 // grid = (heads * ceil(T/4), streams); a workgroup owns 4 query rows of one head (one per wave), lanes run along the key axis.
 // K, V, both relative tables and the 4 Q rows are staged "all loads into registers, then all LDS stores" in unrolled batches
 // (the kernel is a latency chain at B = 1); the dot products keep the sequential d / j order of the definition.
-__global__ __launch_bounds__(256) void relpos_attention_small_kernel(AttnP p)
+static __global__ __launch_bounds__(256) void relpos_attention_small_kernel(AttnP p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = 256;
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256) void relpos_attention_small_kernel(AttnP p)
 //   scores[i][j] = sum_d q[d][i] k[d][j]            P[i][r] = sum_d q[d][i] rel_k[r][d]        scores[i][j] += P[i][j - i + W] inside the window
 //   out[c][i]    = sum_j v[c][j] S[i][j] + sum_r rel_v[r][c] Ssk[i][r]      with Ssk[i][r] = S[i][i + r - W] (zero outside [0, T))
 // Padded k (j >= T, r >= NR) multiplies a ZEROED S / Ssk entry by a finite staged value; padded rows / columns of D are not stored.
-__global__ __launch_bounds__(256) void relpos_attention_mfma_kernel(AttnP p)
+static __global__ __launch_bounds__(256) void relpos_attention_mfma_kernel(AttnP p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = 256;
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(256) void relpos_attention_mfma_kernel(AttnP p)
 // whhT: [2][H][3H] (transposed so lanes read consecutive rows), bhh: [2][3H]
 // out: [B][2H][ld] (forward h rows 0..H, backward rows H..2H)
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void gru_kernel(const float *gi, int gi_cs, long long gi_bs, const float *whhT, const float *bhh,
+static __global__ __launch_bounds__(1024) void gru_kernel(const float *gi, int gi_cs, long long gi_bs, const float *whhT, const float *bhh,
                                                    float *out, int o_cs, long long o_bs, int H, int Tm)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -941,7 +941,7 @@ struct GruMultiP {
 // reads only h from LDS, 16 broadcast b128 reads per thread, instead of streaming 96 KB of weights through LDS every step), the
 // slice's input gates gi[Tm][96] are copied to LDS once (they were three global loads per step on the critical path), and a step
 // has two workgroup barriers instead of three.  384 threads; 98 -> ~45 us for 2 x 32 steps.
-__global__ __launch_bounds__(384) void gru_multi_kernel(GruMultiP p)
+static __global__ __launch_bounds__(384) void gru_multi_kernel(GruMultiP p)
 {
     constexpr int H = 256, G = 8, U = H / G, ROWS = 3 * U, NT = 384;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1035,7 +1035,7 @@ struct PitchP {
     int update;           // 0: decode only (RvcInfer::pitch, rvc.rs:111-131), 1: also update + slice the cache (infer)
 };
 
-__global__ __launch_bounds__(1024) void pitch_post_kernel(PitchP p)
+static __global__ __launch_bounds__(1024) void pitch_post_kernel(PitchP p)
 {
     __shared__ float f0s[1024];
     __shared__ float cache[1024];
@@ -1116,7 +1116,7 @@ __global__ __launch_bounds__(1024) void pitch_post_kernel(PitchP p)
 // small glue kernels
 // ------------------------------------------------------------------------------------
 // phone[c][r] = feats[min((skip_head + r) / 2, T - 1)][c]   (rvc.rs:99-109 + 155; Q2, Q8)
-__global__ void gather_phone_kernel(const float *cv, int cv_cs, long long cv_bs, int C, int T, int skip_head, int R,
+static __global__ void gather_phone_kernel(const float *cv, int cv_cs, long long cv_bs, int C, int T, int skip_head, int R,
                                     float *phone, int ph_cs, long long ph_bs)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
@@ -1127,7 +1127,7 @@ __global__ void gather_phone_kernel(const float *cv, int cv_cs, long long cv_bs,
 }
 
 // (1, 2T+1, C) output of RvcInfer::extract_feature (rvc.rs:99-109), contiguous
-__global__ void extract_feature_kernel(const float *cv, int cv_cs, int C, int T, float *out)
+static __global__ void extract_feature_kernel(const float *cv, int cv_cs, int C, int T, float *out)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int T2 = 2 * T + 1;
@@ -1138,7 +1138,7 @@ __global__ void extract_feature_kernel(const float *cv, int cv_cs, int C, int T,
 }
 
 // TextEncoder front: x = lrelu((lin + emb_pitch[pitch]) * sqrt(H), 0.1), in place on lin [B][H][ld]
-__global__ void embed_pitch_kernel(float *x, int cs, long long bs, const float *emb, const int *pitch, int H, int R, float sq)
+static __global__ void embed_pitch_kernel(float *x, int cs, long long bs, const float *emb, const int *pitch, int H, int R, float sq)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= H * R) return;
@@ -1153,7 +1153,7 @@ __global__ void embed_pitch_kernel(float *x, int cs, long long bs, const float *
 // (philox4x32_10 / u01 / philox_normal4: state.hip.h)
 
 // z_p = m + exp(logs) * eps * 0.66666 ; stats [B][2I][ld] -> z [B][I][ld]; eps index = c*T + t
-__global__ void prior_sample_kernel(const float *stats, int s_cs, long long s_bs, float *z, int z_cs, long long z_bs, int I, int T,
+static __global__ void prior_sample_kernel(const float *stats, int s_cs, long long s_bs, float *z, int z_cs, long long z_bs, int I, int T,
                                     const StreamState *st, const CallParams *cp)
 {
     int blk = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
@@ -1171,7 +1171,7 @@ __global__ void prior_sample_kernel(const float *stats, int s_cs, long long s_bs
 }
 
 // channel flip (Flip flow): y[c] = x[C-1-c]
-__global__ void flip_channels_kernel(const float *x, float *y, int C, int T, int cs, long long bs)
+static __global__ void flip_channels_kernel(const float *x, float *y, int C, int T, int cs, long long bs)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= C * T) return;
@@ -1180,7 +1180,7 @@ __global__ void flip_channels_kernel(const float *x, float *y, int C, int T, int
 }
 
 // WaveNet gate: acts[c] = tanh(a[c]) * sigmoid(a[H + c])   (conditioning already folded into the conv bias)
-__global__ void gate_kernel(const float *a, int a_cs, long long a_bs, float *y, int y_cs, long long y_bs, int H, int T)
+static __global__ void gate_kernel(const float *a, int a_cs, long long a_bs, float *y, int y_cs, long long y_bs, int H, int T)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= H * T) return;
@@ -1190,10 +1190,10 @@ __global__ void gate_kernel(const float *a, int a_cs, long long a_bs, float *y, 
 }
 
 // timeline probe (RVC_STAMPS=1): device wall clock (constant 100 MHz) at a point of a stream's kernel chain
-__global__ void stamp_kernel(unsigned long long *slot) { *slot = wall_clock64(); }
+static __global__ void stamp_kernel(unsigned long long *slot) { *slot = wall_clock64(); }
 
 // average of up to three ResBlock outputs: y = ((a + b) + c) * inv
-__global__ void mean3_kernel(const float *a, const float *b2, const float *c, int i_cs, long long i_bs, float *y, int y_cs, long long y_bs, int C, int T, float inv)
+static __global__ void mean3_kernel(const float *a, const float *b2, const float *c, int i_cs, long long i_bs, float *y, int y_cs, long long y_bs, int C, int T, float inv)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= C * T) return;
@@ -1206,7 +1206,7 @@ __global__ void mean3_kernel(const float *a, const float *b2, const float *c, in
 }
 
 // AvgPool2d(2,2): x [B][C][H(+2)][ld] -> y [B][C][H/2(+2)][ld2]
-__global__ void avgpool2_kernel(const float *x, int x_ld, int x_cs, long long x_bs, float *y, int y_ld, int y_cs, long long y_bs, int C, int H2, int W2)
+static __global__ void avgpool2_kernel(const float *x, int x_ld, int x_cs, long long x_bs, float *y, int y_ld, int y_cs, long long y_bs, int C, int H2, int W2)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= C * H2 * W2) return;
@@ -1216,7 +1216,7 @@ __global__ void avgpool2_kernel(const float *x, int x_ld, int x_cs, long long x_
 }
 
 // (3, Tm, n_mels) conv output image -> GRU input [B][3*n_mels][ld]: feat[c*n_mels + m][t] = img[c][t][m]
-__global__ void gru_input_kernel(const float *img, int i_ld, int i_cs, long long i_bs, float *feat, int f_cs, long long f_bs, int Tm, int n_mels)
+static __global__ void gru_input_kernel(const float *img, int i_ld, int i_cs, long long i_bs, float *feat, int f_cs, long long f_bs, int Tm, int n_mels)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= 3 * n_mels * Tm) return;
@@ -1237,7 +1237,7 @@ struct SrcP {
     const StreamState *st; const CallParams *cp;
 };
 
-__global__ __launch_bounds__(1024) void nsf_source_kernel(SrcP p)
+static __global__ __launch_bounds__(1024) void nsf_source_kernel(SrcP p)
 {
     __shared__ float rad[512], cum[512];
     __shared__ float part[1024];
@@ -1302,7 +1302,7 @@ __global__ __launch_bounds__(1024) void nsf_source_kernel(SrcP p)
 }
 
 // rvc_infer_batch_g: the states of one geometry bucket, gathered into a contiguous block (dir = 0) / scattered back (dir = 1); one workgroup per stream
-__global__ void state_gather_kernel(StreamState *all, StreamState *bucket, const int *idx, int dir)
+static __global__ void state_gather_kernel(StreamState *all, StreamState *bucket, const int *idx, int dir)
 {
     const int j = blockIdx.x, s = idx[j];
     const uint32_t *src = reinterpret_cast<const uint32_t *>(dir ? bucket + j : all + s);
@@ -1313,7 +1313,7 @@ __global__ void state_gather_kernel(StreamState *all, StreamState *bucket, const
 // bump the per-stream chunk counters after a call
 // end of a chunk: the streams' chunk counters and the streams' status words, written straight into host-mapped memory (the host reads them after the call's one
 // synchronisation: no copy kernel behind the chunk)
-__global__ void advance_chunk_kernel(StreamState *st, int B, int *host_status)
+static __global__ void advance_chunk_kernel(StreamState *st, int B, int *host_status)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) { st[b].chunk += 1; if (host_status) host_status[b] = st[b].status; }
@@ -1341,7 +1341,7 @@ struct KnnP {
     const int *overflow;     // when set: run only for streams whose candidate set overflowed (exhaustive fallback)
 };
 
-__global__ __launch_bounds__(256) void knn_scan_kernel(KnnP p)
+static __global__ __launch_bounds__(256) void knn_scan_kernel(KnnP p)
 {
     if (p.overflow && p.overflow[blockIdx.y] == 0) return;
     __shared__ float bd[KNN_MAXQ][4][KNN_K];
@@ -1421,7 +1421,7 @@ struct KnnBlendP {
 };
 
 // one workgroup per (unique query, stream): merge candidates, then blend every sliced frame that maps to it
-__global__ __launch_bounds__(256) void knn_merge_blend_kernel(KnnBlendP p)
+static __global__ __launch_bounds__(256) void knn_merge_blend_kernel(KnnBlendP p)
 {
     __shared__ float sd[KNN_K]; __shared__ int si[KNN_K];
     __shared__ float wd[4][KNN_K]; __shared__ int wi[4][KNN_K];
@@ -1506,7 +1506,7 @@ __device__ __forceinline__ void knn_cx(float &d0, int &i0, float &d1, int &i1)
     const float td = sw ? d1 : d0, ud = sw ? d0 : d1; const int ti = sw ? i1 : i0, ui = sw ? i0 : i1;
     d0 = td; i0 = ti; d1 = ud; i1 = ui;
 }
-__global__ __launch_bounds__(256) void knn_dot_kernel(KnnDotP p)
+static __global__ __launch_bounds__(256) void knn_dot_kernel(KnnDotP p)
 {
     constexpr int D = 8;
     extern __shared__ __attribute__((aligned(16))) float s_q[];      // [16][dim + 4] queries of this group (row pad: conflict-free b128 reads)
@@ -1586,7 +1586,7 @@ __global__ __launch_bounds__(256) void knn_dot_kernel(KnnDotP p)
 }
 
 // |y_i|^2 for every index vector (load time); nhn = -|y_i|^2 / 2 is the per-column "residual" of the many-stream distance GEMM
-__global__ void knn_norms_kernel(const float *index, int n, int dim, float *ynorm, float *nhn)
+static __global__ void knn_norms_kernel(const float *index, int n, int dim, float *ynorm, float *nhn)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1600,7 +1600,7 @@ __global__ void knn_norms_kernel(const float *index, int n, int dim, float *ynor
 // Load-time repack of the index on the device (the matrix arrives in HBM by upload or by the RCCL broadcast and never goes back to
 // the host): [n][dim] -> MFMA-fragment order [tile of 16 vectors][chunk of 16 dims][lane][4] for knn_dot_kernel (vectors past n zero).
 // One thread per float4 of the output; reads are 16-byte pieces of 16 neighbouring rows.
-__global__ __launch_bounds__(256) void knn_pack_index_kernel(const float *index, long long n, int dim, float *indexF, long long total4)
+static __global__ __launch_bounds__(256) void knn_pack_index_kernel(const float *index, long long n, int dim, float *indexF, long long total4)
 {
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= total4) return;
@@ -1615,7 +1615,7 @@ __global__ __launch_bounds__(256) void knn_pack_index_kernel(const float *index,
 }
 // [n][dim] -> [dim][n] through a 32 x 33 LDS tile (only plans that need the transposed copy build it: the many-stream distance GEMM
 // and the forced exhaustive scan)
-__global__ __launch_bounds__(256) void knn_transpose_kernel(const float *index, long long n, int dim, float *indexT)
+static __global__ __launch_bounds__(256) void knn_transpose_kernel(const float *index, long long n, int dim, float *indexT)
 {
     __shared__ float tile[32][33];
     const long long v0 = (long long)blockIdx.x * 32; const int d0 = blockIdx.y * 32;
@@ -1628,7 +1628,7 @@ __global__ __launch_bounds__(256) void knn_transpose_kernel(const float *index, 
 // Many streams: the queries of all streams as the WEIGHT operand of one implicit GEMM against the transposed index (approx[q][i] =
 // |y_i|^2 - 2 x_q . y_i for every stream's queries in ONE pass over the index instead of one pass per 16 queries): [Q][dim] ->
 // MFMA-fragment order [tile of 16 queries][chunk of 16 dims][lane][4], rows past Q zero.  grid = (Qpad / 16, dim / 16), 64 threads.
-__global__ __launch_bounds__(64) void knn_pack_queries_kernel(const float *q, int Q, int dim, float *qf)
+static __global__ __launch_bounds__(64) void knn_pack_queries_kernel(const float *q, int Q, int dim, float *qf)
 {
     const int t = blockIdx.x, c = blockIdx.y, l = threadIdx.x, v = t * 16 + (l & 15);
     f32x4 x = {0.f, 0.f, 0.f, 0.f};
@@ -1653,7 +1653,7 @@ struct KnnSelP {
     int *out_idx; float *out_dist; int *overflow;
     const float *wl_d; const int *wl_i; long long wl_bs;      // per-wave candidate lists of knn_dot_kernel (or nullptr: scan the approximations)
 };
-__global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p)
+static __global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p)
 {
     __shared__ float wd[16][KNN_K]; __shared__ int wi[16][KNN_K];
     __shared__ float sd[KNN_K]; __shared__ int si[KNN_K];
@@ -1853,7 +1853,7 @@ __global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p)
 }
 
 // unique query rows for retrieval: q[j][c] = cv[c][first_raw + j]
-__global__ void knn_queries_kernel(const float *cv, int cv_cs, long long cv_bs, int C, int first_raw, int nq, float *q)
+static __global__ void knn_queries_kernel(const float *cv, int cv_cs, long long cv_bs, int C, int first_raw, int nq, float *q)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= nq * C) return;
@@ -1866,7 +1866,7 @@ __global__ void knn_queries_kernel(const float *cv, int cv_cs, long long cv_bs, 
 // ------------------------------------------------------------------------------------
 // rt_utils.rs:94-103: zero-pad frame/2, square, windowed mean (window frame, step hop), sqrt.  One workgroup per frame.
 // (all post-processing kernels take a stream index in blockIdx.y -- blockIdx.x for post_sola_kernel -- and per-stream strides)
-__global__ __launch_bounds__(256) void post_rms_kernel(const float *y, int n, int frame, int hop, float *out, long long y_bs, long long out_bs)
+static __global__ __launch_bounds__(256) void post_rms_kernel(const float *y, int n, int frame, int hop, float *out, long long y_bs, long long out_bs)
 {
     __shared__ float red[16];
     y += blockIdx.y * y_bs; out += blockIdx.y * out_bs;
@@ -1893,7 +1893,7 @@ __device__ __forceinline__ float lerp_align_corners_at(const float *in, int n_in
 }
 // rt_utils.rs:119-132
 // mix_power_v: per-stream exponent (or nullptr: mix_power for every stream); an exponent of 0 leaves the stream untouched (powf(x, 0) = 1)
-__global__ void post_mix_kernel(float *out, int n, const float *r1, int n1, const float *r2, int n2, float mix_power, long long out_bs, long long r_bs, const float *mix_power_v)
+static __global__ void post_mix_kernel(float *out, int n, const float *r1, int n1, const float *r2, int n2, float mix_power, long long out_bs, long long r_bs, const float *mix_power_v)
 {
     if (mix_power_v) mix_power = mix_power_v[blockIdx.y];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1907,7 +1907,7 @@ __global__ void post_mix_kernel(float *out, int n, const float *r1, int n1, cons
 // sin^2 crossfade with the previous tail, new tail saved, first `frame` samples returned.
 // normalised cross-correlation of get_sola_offset (rt_utils.rs:60-77), one wave per lag: cor[l] = <out[l..], sola> / sqrt(<out[l..], out[l..]> + 1e-8)
 // with f64 accumulation (the reference's FFT convolution carries f32 rounding noise of the same order as an f32 direct sum)
-__global__ __launch_bounds__(256) void post_sola_corr_kernel(const float *output, const float *sola, int sola_len, int search, float *cor,
+static __global__ __launch_bounds__(256) void post_sola_corr_kernel(const float *output, const float *sola, int sola_len, int search, float *cor,
                                                              long long out_bs, long long sola_bs, long long cor_bs)
 {
     const int lane = threadIdx.x & 63, l = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1922,7 +1922,7 @@ __global__ __launch_bounds__(256) void post_sola_corr_kernel(const float *output
 
 // arg-max with the reference's tie rule (the LAST maximum wins, rt_utils.rs:79-88), sin^2 crossfade with the previous tail, tail save and
 // frame extraction (lib.rs:768-794)
-__global__ __launch_bounds__(1024) void post_sola_kernel(float *output, float *sola, int sola_len, int search, int frame, float *frame_out, int *offset_out,
+static __global__ __launch_bounds__(1024) void post_sola_kernel(float *output, float *sola, int sola_len, int search, int frame, float *frame_out, int *offset_out,
                                                          const float *cor_g, long long out_bs, long long sola_bs, long long frame_bs, long long cor_bs)
 {
     __shared__ float cor[1024];

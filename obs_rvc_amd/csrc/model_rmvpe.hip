@@ -1,0 +1,204 @@
+// model_rmvpe.hip -- RMVPE f0 estimator (mel front end, U-Net, BiGRU, salience) and the decode / pitch-cache step as a plan (reference: rvc/src/f0/rmvpe.rs:118-133, 225-248; rvc/src/rvc.rs:111-131, 167-180)
+#include "engine_int.h"
+
+namespace rvc {
+
+static void add_conv2d_with_shortcut(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &y1, const T2 &out)
+{
+    if (x.H != y1.H || x.W != y1.W || out.H != x.H || out.W != x.W || y1.cs != out.cs || y1.ld != out.ld || (x.B > 1 && y1.bs != out.bs)) throw ShapeError("conv2d + shortcut: layouts differ");
+    const ConvW &c1 = w.c1, &sc = w.sc;
+    IgemmP p{};
+    p.x = x.p; p.y = y1.p;
+    p.M = c1.M; p.N = x.H * x.W;
+    p.NW = x.W; p.x_hs = x.ld; p.x_ws = 1; p.y_hm = 1; p.y_ws = 1; p.OW = y1.W;
+    p.x_bs = x.bs; p.y_bs = y1.bs; p.y_cs = y1.cs; p.y_rs = y1.ld;
+    ConvOpts o; o.act = ACT_RELU;
+    fill_epilogue(p, c1, o);
+    p.bias = w.pair_bias;
+    std::vector<int> koff;
+    std::vector<PhaseD> ph(2);
+    ph[0] = PhaseD{}; ph[1] = PhaseD{};
+    // phase 0: the 3x3 convolution (one-row images: only the middle tap row can hit data, see add_conv2d)
+    if (x.H == 1 && !c1.host_w.empty() && !tune_env("RVC_NO_TAP_PRUNE")) {
+        const int K3 = c1.Cin * 3, Kp3 = round16(K3);
+        std::vector<float> panel((size_t)c1.M * Kp3, 0.f);
+        for (int mo = 0; mo < c1.M; mo++)
+            for (int ci = 0; ci < c1.Cin; ci++)
+                for (int kw = 0; kw < 3; kw++) panel[(size_t)mo * Kp3 + ci * 3 + kw] = c1.host_w[(size_t)mo * c1.K + ci * 9 + 3 + kw];
+        float *dw = upload_fragments(panel, 1, c1.M, Kp3);
+        pl.owned_dev.push_back(dw);
+        p.w = dw; ph[0].nchunks = Kp3 / 16;
+        koff.assign(Kp3, 0);
+        for (int ci = 0; ci < c1.Cin; ci++) for (int kw = 0; kw < 3; kw++) koff[ci * 3 + kw] = ci * x.cs + (kw - 1);
+    } else {
+        p.w = c1.w; ph[0].nchunks = c1.Kp / 16;
+        koff.assign(c1.Kp, 0);
+        for (int ci = 0; ci < c1.Cin; ci++) for (int k = 0; k < 9; k++) koff[ci * 9 + k] = ci * x.cs + (k / 3 - 1) * x.ld + (k % 3 - 1);
+    }
+    // phase 1: the shortcut: its own weights (offset from phase 0's: both are device pointers of one flat address space), K, bias
+    // slice, output tensor and (no) activation
+    ph[1].w_off = sc.w - p.w;
+    ph[1].nchunks = sc.Kp / 16;
+    ph[1].koff_off = (int)koff.size();
+    ph[1].bias_off = c1.M;
+    ph[1].act_p1 = ACT_NONE + 1;
+    ph[1].y_off = out.p - y1.p;
+    const size_t base = koff.size();
+    koff.resize(base + sc.Kp, 0);
+    for (int ci = 0; ci < sc.Cin; ci++) koff[base + ci] = ci * x.cs;
+    p.K = std::max(ph[0].nchunks, ph[1].nchunks) * 16;
+    queue_igemm(pl, p, x.B, koff, ph);
+}
+
+static T2 res_block(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &out)
+{
+    Arena &A = pl.arena;
+    T2 y1 = make_t2(A, x.B, w.co, x.H, x.W);
+    // few streams: the 3x3 convolution and the 1x1 shortcut read the same input -- one launch with two phases (own K, own output tensor,
+    // own activation) instead of two dependent launches (11 blocks of RMVPE have a shortcut: 11 launches off the f0 branch)
+    if (w.has_sc && w.pair_bias && x.B <= 4 && (x.B == 1 || y1.bs == out.bs) && !tune_env("RVC_NO_SC_MERGE")) {      // (one stream stride for both outputs)
+        add_conv2d_with_shortcut(pl, w, x, y1, out);
+        ConvOpts o; o.act = ACT_RELU; o.accumulate = true; add_conv2d(pl, w.c2, y1, out, o);
+        return out;
+    }
+    { ConvOpts o; o.act = ACT_RELU; add_conv2d(pl, w.c1, x, y1, o); }
+    if (w.has_sc) {
+        add_conv2d(pl, w.sc, x, out);
+        ConvOpts o; o.act = ACT_RELU; o.accumulate = true; add_conv2d(pl, w.c2, y1, out, o);
+    } else {
+        ConvOpts o; o.act = ACT_RELU; o.res = x.p; o.res_cs = x.cs; o.res_bs = x.bs; o.res_rs = x.ld; add_conv2d(pl, w.c2, y1, out, o);
+    }
+    return out;
+}
+
+T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k, bool update_cache)
+{
+    ModelRM &m = *e->rm;
+    Arena &A = pl.arena;
+    const size_t fr = 5120 * ((frame16k + 800 - 1) / 5120 + 1) - 160;     // rmvpe.rs:256
+    if (fr > L) throw PanicError("input shorter than f0_extractor_frame");
+    const int Tm = (int)(1 + fr / 160);
+    if (Tm % 32 != 0) throw PanicError("mel frame count is not a multiple of 32 (rmvpe.rs:229-233 branch)");
+    if (Tm > 1024) throw ShapeError("f0 window too long");
+    pl.Tm = Tm;
+    const int H0 = Tm, W0 = m.n_mels;
+    if ((H0 >> m.levels) < 1 || (W0 >> m.levels) < 1) throw ShapeError("RMVPE: input too small for the U-Net depth");
+    T2 img = make_t2(A, B, 1, H0, W0);
+    float *d_mel = A.floats((size_t)B * 128 * Tm);
+    {
+        MelP mp{};
+        mp.audio = pl.d_in; mp.audio_bs = (long long)L; mp.n = (int)L; mp.frame = (int)fr; mp.Tm = Tm;
+        mp.window = e->d_window; mp.twiddle = e->d_twiddle; mp.basis = e->d_basis; mp.band = e->d_band;
+        mp.mel = d_mel; mp.img = img.p; mp.img_bs = img.bs; mp.img_ld = img.ld; mp.bn_scale = m.bn_scale; mp.bn_shift = m.bn_shift;
+        dim3 grid(Tm, B);
+        Plan *plp = &pl;
+        pl.ops.push_back([=](hipStream_t s) { MelP m2 = mp; if (plp->cur_in) m2.audio = plp->cur_in; hipLaunchKernelGGL(mel_frontend_kernel, grid, dim3(256), 0, s, m2); });
+        add_stamp(pl, "rm.mel0");
+        if (pl.with_taps) { T1 t; t.p = d_mel; t.B = B; t.C = 128; t.T = Tm; t.ld = Tm; t.halo = 0; t.bs = 128LL * Tm; add_tap(pl, "rm.mel", t); }
+    }
+    // encoder; every level's pre-pool output is written straight into the second half of the decoder's concat buffer
+    std::vector<T2> cat(m.levels);
+    {
+        int H = H0, W = W0, co = m.en_out;
+        for (int lv = 0; lv < m.levels; lv++) { cat[lv] = make_t2(A, B, 2 * co, H, W); H /= 2; W /= 2; co *= 2; }
+    }
+    T2 x = img;
+    int H = H0, W = W0;
+    for (int lv = 0; lv < m.levels; lv++) {
+        const int co = m.enc[lv][0].co;
+        for (int j = 0; j < m.n_blocks; j++) {
+            T2 out = (j == m.n_blocks - 1) ? cat[lv].chans(co, co) : make_t2(A, B, co, H, W);
+            x = res_block(pl, m.enc[lv][j], x, out);
+        }
+        if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "rm.enc%d", lv); add_tap2(pl, nm, x); }
+        T2 p = make_t2(A, B, co, H / 2, W / 2);
+        {
+            T2 xi = x;
+            dim3 grid((co * (H / 2) * (W / 2) + 255) / 256, B);
+            pl.ops.push_back([=](hipStream_t s) {
+                hipLaunchKernelGGL(avgpool2_kernel, grid, dim3(256), 0, s, xi.p, xi.ld, xi.cs, xi.bs, p.p, p.ld, p.cs, p.bs, co, p.H, p.W);
+            });
+        }
+        x = p; H /= 2; W /= 2;
+    }
+    for (int lv = 0; lv < m.inter_layers; lv++)
+        for (int j = 0; j < m.n_blocks; j++) { T2 out = make_t2(A, B, m.inter[lv][j].co, H, W); x = res_block(pl, m.inter[lv][j], x, out); }
+    add_tap2(pl, "rm.int", x);
+    for (int lv = 0; lv < m.levels; lv++) {
+        const int sl = m.levels - 1 - lv, co = m.up[lv].Cout;
+        H *= 2; W *= 2;
+        { ConvOpts o; o.act = ACT_RELU; add_convT2d(pl, m.up[lv], x, cat[sl].chans(0, co), o); }
+        x = cat[sl];
+        for (int j = 0; j < m.n_blocks; j++) { T2 out = make_t2(A, B, co, H, W); x = res_block(pl, m.dec[lv][j], x, out); }
+        if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "rm.dec%d", lv); add_tap2(pl, nm, x); }
+    }
+    T2 cn = make_t2(A, B, 3, H, W);
+    add_conv2d(pl, m.cnn, x, cn);
+    const int Hg = m.gru_hidden, I = 3 * m.n_mels;
+    T1 feat = make_t1(A, B, I, Tm, 0), gi = make_t1(A, B, 6 * Hg, Tm, 0), gout = make_t1(A, B, 2 * Hg, Tm, 0), sal = make_t1(A, B, m.n_out, Tm, 0);
+    {
+        dim3 grid((3 * m.n_mels * Tm + 255) / 256, B); int nm = m.n_mels;
+        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(gru_input_kernel, grid, dim3(256), 0, s, cn.p, cn.ld, cn.cs, cn.bs, feat.p, feat.ld, feat.bs, Tm, nm); });
+    }
+    add_conv1d(pl, m.gru_ih, feat, gi, 1, 0, 1);
+    {
+        if (3 * Hg > 1024) throw ShapeError("GRU hidden size too large for the single-workgroup recurrence");
+        int threads = (3 * Hg + 63) / 64 * 64;
+        size_t lds = (size_t)4 * Hg * sizeof(float);
+        float *wt = m.whhT, *bh = m.bhh;
+        dim3 grid(2, B);
+        if (Hg == 256 && B <= 8 && Tm <= 256 && !tune_env("RVC_GRU_GENERIC")) {
+            // few streams: spread each direction over 8 CUs with W_hh resident in LDS (granule hand-off per step)
+            GruMultiP gp{}; gp.gi = gi.p; gp.gi_cs = gi.ld; gp.gi_bs = gi.bs; gp.whh = m.whh; gp.bhh = m.bhh; gp.out = gout.p; gp.o_cs = gout.ld; gp.o_bs = gout.bs;
+            gp.Tm = Tm; gp.status = &e->d_state[0].status; gp.status_stride = (int)(sizeof(StreamState) / sizeof(int));
+            const size_t gbytes = (size_t)B * 2 * 2 * 256 * sizeof(unsigned long long);
+            gp.gran = (unsigned long long *)pl.arena.alloc(gbytes);
+            const size_t lds3 = (size_t)(256 + 96 + (size_t)Tm * 96) * sizeof(float);      // h, gate pre-activations, this slice's input gates for all steps
+            const dim3 g3(8, 2, B);
+            pl.ops.push_back([=](hipStream_t s) {
+                HIPCHK(hipMemsetAsync(gp.gran, 0, gbytes, s));
+                hipLaunchKernelGGL(gru_multi_kernel, g3, dim3(384), lds3, s, gp);
+            });
+        } else {
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(gru_kernel, grid, dim3(threads), lds, s, gi.p, gi.ld, gi.bs, wt, bh, gout.p, gout.ld, gout.bs, Hg, Tm); });
+        }
+    }
+    { ConvOpts o; o.act = ACT_SIGMOID; add_conv1d(pl, m.fc, gout, sal, 1, 0, 1, o); }
+    if (pl.with_taps) { add_tap(pl, "rm.sal_ct", sal); add_tap(pl, "rm.gru_ct", gout); add_tap(pl, "rm.cnn_ct", feat); } else add_stamp(pl, "rm.sal");
+    return sal;
+}
+
+// decode + pitch shift + pitch cache + get_f0_post (rmvpe.rs:118-133,243-248; rvc.rs:121,167-180; f0/mod.rs:7-12)
+void build_pitch_post(rvc_engine *e, Plan &pl, int B, const T1 &sal, bool update_cache, size_t frame16k, size_t hubert_length,
+                             float **pitchf_out, int **pitch_out)
+{
+    Arena &A = pl.arena;
+    const int Tm = pl.Tm;
+    pl.d_f0 = A.floats((size_t)B * Tm);
+    PitchP pp{};
+    pp.sal = sal.p; pp.sal_cs = sal.ld; pp.sal_bs = sal.bs; pp.Tm = Tm;
+    pp.st = e->d_state; pp.cp = e->d_cp; pp.f0 = pl.d_f0; pp.threshold = 0.03f;   // rvc.rs:122
+    if (update_cache) {
+        const int R = (int)pl.R;
+        const size_t shift = frame16k / 160;                                   // rvc.rs:168
+        if (shift > 1024 || Tm < 5) throw PanicError("pitch cache shift out of range");
+        const long long cache_start = 1024 + 4 - Tm;                            // rvc.rs:172
+        const long long read_start = 1024 - (long long)hubert_length + pl.skip_head;   // rvc.rs:176
+        if (cache_start < 0 || read_start < 0 || read_start + R > 1024) throw PanicError("pitch cache slice out of range");
+        pp.pitchf = A.floats((size_t)B * R);
+        pp.pitch = (int *)A.alloc((size_t)B * R * sizeof(int));
+        pp.shift = (int)shift; pp.cache_start = (int)cache_start; pp.read_start = (int)read_start; pp.R = R;
+        *pitchf_out = pp.pitchf; *pitch_out = pp.pitch;
+    } else {
+        pp.R = 0; pp.shift = 0; pp.cache_start = 1 << 30; pp.read_start = 0; pp.pitchf = nullptr; pp.pitch = nullptr;
+    }
+    pp.update = update_cache ? 1 : 0;
+    pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(pitch_post_kernel, dim3(B), dim3(1024), 0, s, pp); });
+}
+
+
+void rmvpe_kernel_attrs()
+{
+    HIPCHK(hipFuncSetAttribute((const void *)gru_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+}
+}  // namespace rvc

@@ -1,0 +1,767 @@
+// plan.hip -- the planner of the MI355X-native RVC engine: test-hook table, device memory helpers, prepared convolution weights (MFMA-fragment
+// order), and the translation of a layer (Conv1d / ConvT1d / Conv2d / ConvT2d / Linear, fused variants) into implicit-GEMM launches: tile
+// choice, in-workgroup K split, streams folded into N, staged-tile convolution, 32x32x2 throughput kernels.
+#include "engine_int.h"
+
+namespace rvc {
+
+static const char *const kTestHooks[] = {"RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_NO_LN_FUSE", "RVC_NO_CONV0_MULTI", "RVC_KNN_NO_GEMM",
+                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE"};
+static std::mutex g_opt_mu;
+static std::map<std::string, std::string> g_opts;
+static bool is_test_hook(const char *name)
+{
+    for (const char *h : kTestHooks) if (!strcmp(h, name)) return true;
+    return false;
+}
+static const char *opt_lookup(const char *name)
+{
+    static thread_local std::string buf;
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    auto it = g_opts.find(name);
+    if (it == g_opts.end()) return nullptr;
+    buf = it->second;
+    return buf.c_str();
+}
+#ifdef RVC_TUNING
+const char *test_opt(const char *name) { const char *v = opt_lookup(name); return v ? v : getenv(name); }
+const char *tune_env(const char *name) { const char *v = opt_lookup(name); return v ? v : getenv(name); }
+#else
+const char *test_opt(const char *name) { return opt_lookup(name); }
+#endif
+int test_opt_int(const char *name, int dflt) { const char *v = test_opt(name); return v ? atoi(v) : dflt; }
+
+float *upload_f(const std::vector<float> &v)
+{
+    float *d;
+    HIPCHK(hipMalloc(&d, std::max<size_t>(v.size(), 4) * sizeof(float)));
+    if (!v.empty()) HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return d;
+}
+float *upload_f(const float *p, size_t n) { return upload_f(std::vector<float>(p, p + n)); }
+
+// [nphase][M][Kp] row-major panels -> MFMA-fragment-major [nphase][m_tile][chunk][lane][4] (M padded to 16 with zeros)
+float *upload_fragments(const std::vector<float> &panel, int nphase, int M, int Kp)
+{
+    const int mt = (M + 15) / 16, nch = Kp / 16;
+    std::vector<float> out((size_t)nphase * mt * nch * 256, 0.f);
+    for (int ph = 0; ph < nphase; ph++)
+        for (int t = 0; t < mt; t++)
+            for (int c = 0; c < nch; c++)
+                for (int l = 0; l < 64; l++) {
+                    const int m = t * 16 + (l & 15);
+                    if (m >= M) continue;
+                    const float *src = &panel[((size_t)ph * M + m) * Kp + c * 16 + (l >> 4) * 4];
+                    float *dst = &out[(((size_t)ph * mt + t) * nch + c) * 256 + l * 4];
+                    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+                }
+    return upload_f(out);
+}
+
+// Conv (any rank flattened to K = Cin/groups * KW taps): w [Cout][Cin/groups][KW]
+ConvW prep_conv(const float *w, const float *bias, int Cout, int Cin, int KW, int groups)
+{
+    ConvW c;
+    c.Cin = Cin; c.Cout = Cout; c.KW = KW; c.groups = groups; c.nphase = groups;
+    int cig = Cin / groups, cog = Cout / groups;
+    c.M = cog; c.K = cig * KW; c.Kp = round16(c.K);
+    std::vector<float> panel((size_t)Cout * c.Kp, 0.f);
+    for (int co = 0; co < Cout; co++) memcpy(&panel[(size_t)co * c.Kp], w + (size_t)co * c.K, (size_t)c.K * sizeof(float));
+    c.w = upload_fragments(panel, groups, cog, c.Kp);
+    if (bias) c.bias = upload_f(bias, Cout);
+    if (KW == 9 && groups == 1 && c.K >= 1024) c.host_w.assign(w, w + (size_t)Cout * c.K);
+    return c;
+}
+// ConvTranspose1d: w [Cin][Cout][K], stride S -> S polyphase sub-convolutions with ntaps = ceil(K/S) taps:
+//   out[co][q*S + p - pad] = sum_ci sum_j w[ci][co][p + j*S] * in[ci][q - j]
+ConvW prep_convT1d(const float *w, const float *bias, int Cin, int Cout, int K, int S)
+{
+    ConvW c;
+    c.transposed = true; c.Cin = Cin; c.Cout = Cout; c.KW = K; c.S = S; c.ntaps = (K + S - 1) / S; c.nphase = S;
+    c.M = Cout; c.K = Cin * c.ntaps; c.Kp = round16(c.K);
+    std::vector<float> panel((size_t)S * Cout * c.Kp, 0.f);
+    for (int p = 0; p < S; p++)
+        for (int co = 0; co < Cout; co++)
+            for (int ci = 0; ci < Cin; ci++)
+                for (int j = 0; j < c.ntaps; j++) {
+                    int k = p + j * S;
+                    if (k < K) panel[((size_t)p * Cout + co) * c.Kp + ci * c.ntaps + j] = w[((size_t)ci * Cout + co) * K + k];
+                }
+    c.w = upload_fragments(panel, S, Cout, c.Kp);
+    if (bias) c.bias = upload_f(bias, Cout);
+    return c;
+}
+// ConvTranspose2d 3x3 stride 2 pad 1 output_pad 1: w [Cin][Cout][3][3] -> 4 phases (oh&1, ow&1), 2x2 taps each
+//   out[2a+ph][2b+pw] = sum_ci sum_{jh,jw} Wp[ph,pw][co][ci][jh][jw] * in[a+jh][b+jw]
+//   even output row: kh = 1 (jh = 0); odd: kh = 2 (jh = 0), kh = 0 (jh = 1); same along w
+ConvW prep_convT2d(const float *w, const float *bias, int Cin, int Cout)
+{
+    ConvW c;
+    c.transposed = true; c.Cin = Cin; c.Cout = Cout; c.KW = 9; c.S = 2; c.ntaps = 4; c.nphase = 4;
+    c.M = Cout; c.K = Cin * 4; c.Kp = round16(c.K);
+    std::vector<float> panel((size_t)4 * Cout * c.Kp, 0.f);
+    auto ktap = [](int par, int j) { return par == 0 ? (j == 0 ? 1 : -1) : (j == 0 ? 2 : 0); };
+    for (int ph = 0; ph < 2; ph++)
+        for (int pw = 0; pw < 2; pw++)
+            for (int co = 0; co < Cout; co++)
+                for (int ci = 0; ci < Cin; ci++)
+                    for (int jh = 0; jh < 2; jh++)
+                        for (int jw = 0; jw < 2; jw++) {
+                            int kh = ktap(ph, jh), kw = ktap(pw, jw);
+                            if (kh < 0 || kw < 0) continue;
+                            panel[((size_t)(ph * 2 + pw) * Cout + co) * c.Kp + ci * 4 + jh * 2 + jw] = w[(((size_t)ci * Cout + co) * 3 + kh) * 3 + kw];
+                        }
+    c.w = upload_fragments(panel, 4, Cout, c.Kp);
+    if (bias) c.bias = upload_f(bias, Cout);
+    return c;
+}
+void free_conv(ConvW &c)
+{
+    if (c.owns) {
+        if (c.w) (void)hipFree(c.w);
+        if (c.bias) (void)hipFree(c.bias);
+    }
+    c.w = c.bias = nullptr;
+}
+// Re-home the weights of several convolutions in ONE device allocation (the first one owns it), so that a fused launch can
+// address them as phases of one weight buffer (PhaseD::w_off / bias_off are offsets from the first conv's pointers).
+void merge_convs(const std::vector<ConvW *> &cs)
+{
+    size_t tw = 0, tb = 0;
+    for (ConvW *c : cs) { if (!c->owns || !c->bias) throw std::runtime_error("merge_convs: unexpected conv"); tw += (size_t)c->nphase * phase_stride(*c); tb += (size_t)c->Cout; }
+    float *W, *Bv;
+    HIPCHK(hipMalloc(&W, tw * sizeof(float))); HIPCHK(hipMalloc(&Bv, std::max<size_t>(tb, 4) * sizeof(float)));
+    size_t ow = 0, ob = 0;
+    for (size_t i = 0; i < cs.size(); i++) {
+        ConvW *c = cs[i];
+        const size_t nw = (size_t)c->nphase * phase_stride(*c);
+        HIPCHK(hipMemcpy(W + ow, c->w, nw * sizeof(float), hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(Bv + ob, c->bias, (size_t)c->Cout * sizeof(float), hipMemcpyDeviceToDevice));
+        (void)hipFree(c->w); (void)hipFree(c->bias);
+        c->w = W + ow; c->bias = Bv + ob; c->owns = i == 0;
+        ow += nw; ob += c->Cout;
+    }
+}
+
+// (launch_igemm2 / launch_igemm_v1 / launch_igemm_tiled: igemm_launch.h -- the template instantiations are separate translation units)
+
+unsigned long long *g_kprobe = nullptr;   // tuning build (-DRVC_KPROBE): destination of the per-wave phase stamps
+int g_last_waves = 0, g_last_wgs = 0;
+
+// One stream, stride-1 1-D convolution with a long output: conv_tile_kernel (conv_tile.hip.h) stages the input rows once per workgroup.
+// Builds the LDS-offset tables (k -> row * RS + tap column) from the layer's gather table and a work-item table that balances the
+// unequal phases of a fused launch over the CUs (workgroup b lands on CU b % ncu: tests/tools/place_probe.hip).  false = not eligible.
+int g_ncu = 256;
+static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phv, double ksum, bool final_out)
+{
+    const int mode = test_opt_int("RVC_CONV_TILE", 1);       // test hook: 0 = off, 2 = wherever eligible; read per plan
+    auto no = [&](int why) { (void)why; return false; };
+    // streams: one always; two to four with the same narrow tiles and the streams in the item table (measured -1 % / -2 % at 2 / 4 streams, nothing at
+    // 8; wider tiles for many streams measured slower than the 32x32x2 kernels and are gone)
+    if (!mode || p.fold_n || p.x_ld <= 0 || p.x_hs || p.x_ws != 1 || p.y_hm || p.lin_cs4 || p.glu || p.ln_wsum || p.ln_stats_in || p.ln_stats_out || p.part) return no(1);
+    if (B > 4) return no(2);
+    if (p.M > 128 && mode < 2) return no(3);
+    const int kshares = test_opt_int("RVC_CONV_TILE_KS", 2);      // test hook: 1 = one wave per fragment set
+    const int tc0 = p.M > 64 ? 0 : (p.M > 32 ? 1 : 2);            // 128 x 16, 64 x 32, 32 x 64
+    const int BM = kTileBM[tc0], BN = kTileBN[tc0];
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    if (ntm > 255 || ntn > 32767 || phv.size() > 255) return no(4);
+    const long long nitems = (long long)ntm * ntn * (long long)phv.size() * B;
+    if (mode < 2 && nitems < 3 * g_ncu / 2) return no(5);                // short outputs: the K-split kernel fills the chip better
+    // per phase: (channel, tap) of every k from the gather table (entries are ci * ld + tap * dil - pad, k = ci * KW + tap); the kernel walks K
+    // tap-major in chunks of 16 channels, so the phase's weights are repacked: chunk t * G + g, slot kk <- k = (g * 16 + kk) * KW + t
+    std::vector<PhaseD> phs(phv);
+    std::vector<float> wnew;
+    size_t lds_max = 0;
+    const int mt = (p.M + 15) / 16;
+    for (PhaseD &q : phs) {
+        const int K = q.nchunks * 16;
+        int cin = 1;
+        for (int k = 0; k < K; k++) cin = std::max(cin, (int)std::floor((double)koff[q.koff_off + k] / p.x_ld + 0.5) + 1);
+        if (cin % 16 != 0 || K % cin != 0) return no(6);
+        const int KW = K / cin;
+        if (KW > 255) return no(7);
+        const int dmin = koff[q.koff_off];
+        const int dil = KW > 1 ? koff[q.koff_off + 1] - koff[q.koff_off] : 1;
+        if (dil < 1 || dil > 255 || dmin > 0 || dmin < p.x_lo) return no(8);
+        for (int k = 0; k < K; k++) if (koff[q.koff_off + k] != (k / KW) * p.x_ld + dmin + (k % KW) * dil) return no(9);
+        const int rl = BN + (KW - 1) * dil, rt = rl | 1, cs = cin + 8;
+        q.t_tab = KW | (dil << 8); q.t_cin = cin; q.t_rs = rt; q.t_dmin = dmin;
+        if (q.nchunks < 2 || cin / 16 < kshares) return no(10);          // (every K share needs a chunk; the kernel steps its tap / group counters by the share count)
+        lds_max = std::max(lds_max, (std::max<size_t>(((size_t)cin * rt + 63) / 64 * 64, (size_t)kTileWF[tc0] * 256) + (size_t)rl * cs) * 4);
+        std::vector<float> wold((size_t)mt * q.nchunks * 256);
+        HIPCHK(hipMemcpy(wold.data(), p.w + q.w_off, wold.size() * 4, hipMemcpyDeviceToHost));
+        const size_t base = wnew.size();
+        wnew.resize(base + wold.size());
+        const int G = cin / 16;
+        for (int t = 0; t < mt; t++)
+            for (int tap = 0; tap < KW; tap++)
+                for (int g = 0; g < G; g++)
+                    for (int l = 0; l < 64; l++)
+                        for (int j = 0; j < 4; j++) {
+                            const int k = (g * 16 + (l >> 4) * 4 + j) * KW + tap;          // the source's k
+                            wnew[base + (((size_t)t * q.nchunks + tap * G + g) * 64 + l) * 4 + j] =
+                                wold[(((size_t)t * q.nchunks + k / 16) * 64 + (((k % 16) / 4) << 4 | (l & 15))) * 4 + (k % 4)];
+                        }
+        q.w_off = (long long)base;
+    }
+    if (lds_max > 100 * 1024) return no(11);
+    wnew.resize(wnew.size() + (size_t)16 * 2 * 256, 0.f);      // slack: the kernel's weight requests run DA x KS chunks past a wave's last chunk
+    p.w = pl.arena.upload(wnew);
+    // work items, longest first, dealt to the CUs by longest-processing-time; block r * ncu + j = the r-th item of CU j
+    struct It { int w, code, b; };
+    std::vector<It> items;
+    for (int bb = 0; bb < B; bb++)
+        for (size_t f = 0; f < phs.size(); f++)
+            for (int tm = 0; tm < ntm; tm++)
+                for (int tn = 0; tn < ntn; tn++) items.push_back({phs[f].nchunks + 12, (int)f | (tm << 8) | (tn << 16), bb});
+    std::stable_sort(items.begin(), items.end(), [](const It &a, const It &b) { return a.w > b.w; });
+    const int nb = g_ncu;
+    std::vector<std::vector<int>> bins(nb);          // indices into items
+    {
+        std::vector<std::pair<long long, int>> heap;        // (load, bin): min-heap by load, then bin
+        for (int j = 0; j < nb; j++) heap.push_back({0, j});
+        auto cmp = [](const std::pair<long long, int> &a, const std::pair<long long, int> &b) { return a > b; };
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        for (size_t i = 0; i < items.size(); i++) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            auto &top = heap.back();
+            bins[top.second].push_back((int)i); top.first += items[i].w;
+            std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+    }
+    size_t rounds = 0;
+    for (auto &bn : bins) rounds = std::max(rounds, bn.size());
+    std::vector<int> order(rounds * nb * 2, -1);
+    for (int j = 0; j < nb; j++)
+        for (size_t r = 0; r < bins[j].size(); r++) { order[(r * nb + j) * 2] = items[bins[j][r]].code; order[(r * nb + j) * 2 + 1] = items[bins[j][r]].b; }
+    p.items = pl.arena.upload(order);
+    p.ttab = nullptr;
+    p.ph = pl.arena.upload(phs);
+    p.nphase = (int)phs.size();
+    p.ph0 = phs[0];
+    p.ntm = ntm; p.ntn = ntn; p.ksplit = 1; p.nbatch = B; p.m_fast = 0;
+    const dim3 grid((unsigned)(order.size() / 2), 1u);
+    g_last_wgs = (int)nitems; g_last_waves = 4;
+    const double flops = 2.0 * p.M * (double)p.N * ksum * B;
+    pl.igemm_flops += flops; pl.n_igemm++;
+    Plan *plp = &pl;
+    { char d[200]; snprintf(d, sizeof d, "tile M=%d N=%d K=%d B=%d nph=%d tile=%dx%d items=%lld grid=%u lds=%zu pre=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, BM, BN, nitems, grid.x, lds_max, (int)(p.pre_act != ACT_NONE), ksum); pl.descs.push_back(d); }
+    const int desc_id = (int)pl.descs.size() - 1;
+    const IgemmP pc = p;
+    pl.ops.push_back([=](hipStream_t s) {
+        ProfEvent *pe = nullptr;
+        if (plp->profile) {
+            if (plp->prof_used == plp->prof.size()) { ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; e.bytes = 0; plp->prof.push_back(e); }
+            pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
+        }
+        hipEvent_t ea = pe ? pe->a : nullptr, eb = pe ? pe->b : nullptr;
+        if (final_out && plp->cur_out) { IgemmP q = pc; q.y = plp->cur_out; q.y_bs = plp->cur_out_bs; launch_conv_tile(tc0, kshares, q, grid, lds_max, s, ea, eb); }
+        else launch_conv_tile(tc0, kshares, pc, grid, lds_max, s, ea, eb);
+    });
+    return true;
+}
+
+// generic: the caller fills geometry (N, NW, strides, koff, phases); this picks the tile + split-K and queues the op
+void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases, bool final_out)
+{
+    p.probe = g_kprobe;
+    // many streams: fold them into the N axis (one launch-wide column index instead of a grid dimension), so that tiles are cut from
+    // B * N columns -- the ContentVec window (N = 111), the text encoder (N = 21) or RMVPE's deep levels (N = 4..64) no longer pad
+    // every stream up to a tile.  All offsets stay below 2^31 bytes / elements for every geometry the plugin can ask for (checked).
+    const int streams = B;
+    if (B > 1) {
+        // two to four streams, stride-1 1-D convolution: the staged-tile kernel with the streams in its work-item table (tried before the fold)
+        std::vector<PhaseD> phq(phases);
+        double ks0 = 0;
+        for (PhaseD &q : phq) { if (q.nchunks == 0) q.nchunks = p.K / 16; ks0 += q.nchunks * 16.0; }
+        std::stable_sort(phq.begin(), phq.end(), [](const PhaseD &a, const PhaseD &b) { return a.nchunks > b.nchunks; });
+        IgemmP pt = p;
+        if (queue_conv_tile(pl, pt, B, koff, phq, ks0, final_out)) return;
+    }
+    if (B > 1 && !tune_env("RVC_NO_FOLD")) {
+        const long long lim = (1LL << 29);
+        if ((long long)B * p.x_bs < lim && (long long)B * p.y_bs < lim && (long long)B * (p.res ? p.res_bs : 0) < lim && (long long)B * p.N < (1LL << 30) &&
+            (size_t)(p.K / 16) * 64 <= 60 * 1024) {      // (the two-stage grid split-K fallback keeps the batch as a grid dimension)
+            p.fold_n = p.N; p.N = B * p.N; B = 1;
+        }
+    }
+    (void)streams;
+    // table entries become non-negative byte offsets; the kernel moves the base pointer back by koff_bias bytes
+    std::vector<int> kb(koff);
+    int kmin = 0;
+    for (int v : kb) kmin = std::min(kmin, v);
+    for (int &v : kb) v = (v - kmin) * 4;
+    p.koff_bias = -kmin * 4;
+    const bool pre = p.pre_act != ACT_NONE;
+    p.koff = pl.arena.upload(kb);
+    std::vector<PhaseD> phv(phases);
+    double ksum = 0;   // sum of the phases' K (phases of a fused launch may differ; p.K is the maximum)
+    for (PhaseD &q : phv) { if (q.nchunks == 0) q.nchunks = p.K / 16; ksum += q.nchunks * 16.0; }
+    // phases of unequal length (the fused ResBlock chains: kernel sizes 3 / 7 / 11) are dispatched longest first: the grid's z axis
+    // is walked last, so the workgroups of phase 0 start first and the short phases fill the tail instead of the long one forming it
+    if (!tune_env("RVC_NO_LPT"))
+        std::stable_sort(phv.begin(), phv.end(), [](const PhaseD &a, const PhaseD &b) { return a.nchunks > b.nchunks; });
+    p.ph = pl.arena.upload(phv);
+    p.nphase = (int)phv.size();
+    p.ph0 = phv[0];
+    const int nchunks = p.K / 16;
+    auto tiles = [&](int c) {
+        long long tm = (p.M + 16 * kMF[c] - 1) / (16 * kMF[c]), tn = (p.N + 16 * kNF[c] - 1) / (16 * kNF[c]);
+        return tm * tn * B * p.nphase;
+    };
+    // Pick the largest tile that still yields >= 1024 waves (one per SIMD), using the in-workgroup K split
+    // (KS = 4/8/16 waves per tile) when the layer has too few tiles.  A wave keeps >= 4 chunks of K.
+    const int order_big[3] = {4, 3, 0}, order_small[3] = {2, 1, 0};
+    // a panel whose 32-row tiling would be >= 25 % padding (48 rows: the grouped positional convolution) takes the 16-row tiles
+    // (measured at one stream: 16 x 32, K split 8: 25 us against 37 us for the 32 x 32 tile the size rule picked)
+    const bool pad32 = p.M > 16 && (((p.M + 31) / 32 * 32 - p.M) * 4 >= p.M);
+    const int *order = (p.M > 16 && !pad32) ? order_big : order_small;
+    int cfg = 0, wg_ks = 1;
+    long long best_waves = -1;
+    bool found = false;
+    // phases of unequal length (fused ResBlock chains, kernel sizes 3/7/11) are all co-resident: finer tiles even out the
+    // per-SIMD load (measured on the decoder: 32x32 tiles 185 vs 200 us at C = 128, 127 vs 133 us at C = 64; folding the
+    // chains' average into one K-concatenated GEMM was also measured: no gain)
+    bool uneven = false;
+    for (const PhaseD &q : phv) uneven = uneven || q.nchunks != phv[0].nchunks;
+    const long long want_waves = (uneven && p.M >= 64) ? 2048 : 1024;
+    for (int oi = 0; oi < 3 && !found; oi++) {
+        const int c = order[oi];
+        for (int ks = 1; ks <= 16; ks = ks == 1 ? 4 : ks * 2) {
+            if (ks > 1 && (nchunks / ks < 4 || ks * kMF[c] * kNF[c] > 32)) break;
+            if ((size_t)nchunks * 64 + (ks > 1 ? (size_t)ks * kMF[c] * kNF[c] * 1024 : 0) > 60 * 1024) break;
+            const long long w = tiles(c) * ks;
+            if (w > best_waves) { best_waves = w; cfg = c; wg_ks = ks; }
+            if (w >= want_waves) { cfg = c; wg_ks = ks; found = true; break; }
+        }
+    }
+    // throughput mode (many streams): workgroup-tiled kernel with the activation tile shared through LDS
+    int lds_cfg = -1;
+    bool phase_epi = false;                               // per-phase activation / output tensor: igemm2 only
+    for (const PhaseD &q : phv) phase_epi = phase_epi || q.act_p1 != 0 || q.y_off != 0;
+    if (queue_conv_tile(pl, p, B, koff, phv, ksum, final_out)) return;
+    const bool ln_fold = p.ln_wsum || p.ln_stats_in || phase_epi;      // folded LayerNorm lives in the register-direct kernel's K-split epilogue
+    if (!ln_fold && !tune_env("RVC_NO_LDS_GEMM") && nchunks >= 2 && (size_t)nchunks * 64 + 2 * 256 * 20 * 4 <= 60 * 1024) {
+        int bm = p.M >= 96 ? 128 : (p.M >= 48 ? 64 : (p.M > 16 ? 32 : 0));
+        if (const char *f = tune_env("RVC_G32_BM")) { const int v = atoi(f); if (v == 32 || v == 64 || v == 128) bm = v; }   // tuning aid
+        const int bn = bm == 128 ? 128 : 256;
+        if (bm) {
+            const long long wgs = (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * B * p.nphase;
+            // isolated B = 64 timings (tests/tools/gemm_microbench.py): the LDS-tiled kernel wins for very tall (M >= 2048) and very short
+            // (M <= 64) weight panels, the register-direct kernel in between (cv_ff2 91 vs 73 TF/s, cv_o 77 vs 62, enc_ff1 24 vs 13)
+            const bool lds_wins = p.M >= 2048 || p.M <= 64;
+            if (wgs >= 384 && lds_wins) lds_cfg = bm == 128 ? 0 : (bm == 64 ? 1 : 2);
+            // 32x32x2 kernel (igemm32): RVC_GEMM32 = 0 off, 1 wherever the old workgroup-tiled kernel was chosen, 2 (default) for every
+            // layer with enough workgroups to fill the chip
+            static const int g32 = tune_env("RVC_GEMM32") ? atoi(tune_env("RVC_GEMM32")) : 2;
+            static const long long g32_min = tune_env("RVC_GEMM32_MIN") ? atoll(tune_env("RVC_GEMM32_MIN")) : 768;   // fewer workgroups balance badly over 256 CUs (measured: 336 -> slower)
+            if (g32 == 1 && lds_cfg >= 0 && !p.glu) lds_cfg += 3;
+            else if (g32 >= 2 && wgs >= g32_min && !p.glu) lds_cfg = 3 + (bm == 128 ? 0 : (bm == 64 ? 1 : 2));   // (gated layers stay on the kernels that are tested with the gate)
+        }
+    }
+    // 48-row panels (ContentVec's grouped positional convolution: 16 groups of 48 channels, K = 6144 each): three 16-row fragments
+    // exactly, instead of a 64-row tile with a quarter of its MFMAs on padding
+    if (lds_cfg == 1 && p.M == 48 && !tune_env("RVC_NO_BM48")) lds_cfg = 6;
+    // mid-size panels (M = 768 at 64 streams: 336 tiles of 128 x 128 balance badly over 256 CUs, and the register-direct 2 x 4 tile runs
+    // at two waves per SIMD): 128 x 64 tiles of the 32x32x2 kernel, four waves stacked in M over one 64-column activation tile
+    // (768 x 3072 projection at 64 streams: 361 -> 342 us; small, but the same kernel)
+    static const long long g32_narrow_min = tune_env("RVC_G32_NARROW") ? atoll(tune_env("RVC_G32_NARROW")) : 500;     // 0 = off
+    if (lds_cfg < 0 && !ln_fold && g32_narrow_min > 0 && !tune_env("RVC_NO_LDS_GEMM") && !p.glu && nchunks >= 2 && p.M >= 96 && (size_t)nchunks * 64 + 2 * 64 * 20 * 4 <= 60 * 1024) {
+        const long long wgs = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * B * p.nphase;
+        if (wgs >= g32_narrow_min) lds_cfg = 7;
+    }
+    if (lds_cfg >= 0) {
+        const int bm = lds_cfg == 7 ? 128 : (lds_cfg == 6 ? 48 : (lds_cfg % 3 == 0 ? 128 : (lds_cfg % 3 == 1 ? 64 : 32)));
+        const int bn = lds_cfg == 7 ? 64 : ((lds_cfg != 6 && lds_cfg % 3 == 0) ? 128 : 256);
+        p.ksplit = 1; p.chunks_per_split = nchunks;
+        p.ntm = (p.M + bm - 1) / bm; p.ntn = (p.N + bn - 1) / bn;
+        p.m_fast = p.fold_n ? p.ntm : 0;
+        dim3 grid(p.ntm * p.ntn, B * p.nphase);
+        const bool g32k = lds_cfg >= 3 && lds_cfg != 6;            // igemm32_kernel keeps its activation tile column-major, [2][bn][20]
+        const size_t lds = (size_t)nchunks * 64 + (g32k ? (size_t)2 * bn * 20 * 4 : (size_t)2 * 16 * (bn + 4) * 4);
+        g_last_wgs = (int)(grid.x * grid.y); g_last_waves = 4;
+        const double flops = 2.0 * p.M * (double)p.N * ksum * B;
+        pl.igemm_flops += flops; pl.n_igemm++;
+        Plan *plp = &pl;
+        const int lc = lds_cfg;
+        { char d[160]; snprintf(d, sizeof d, "%s M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%u", (lds_cfg >= 3 && lds_cfg != 6) ? "g32" : "lds", p.M, p.N, p.K, B, p.nphase, bm, bn, grid.x, grid.y); pl.descs.push_back(d); }
+        const int desc_id = (int)pl.descs.size() - 1;
+        pl.ops.push_back([=](hipStream_t s) {
+            ProfEvent *pe = nullptr;
+            if (plp->profile) {
+                if (plp->prof_used == plp->prof.size()) { ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; e.bytes = 0; plp->prof.push_back(e); }
+                pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
+            }
+            hipEvent_t ea = pe ? pe->a : nullptr, eb = pe ? pe->b : nullptr;
+            if (final_out && plp->cur_out) { IgemmP q = p; q.y = plp->cur_out; q.y_bs = plp->cur_out_bs; launch_igemm_tiled(lc, pre, q, grid, lds, s, ea, eb); }
+            else launch_igemm_tiled(lc, pre, p, grid, lds, s, ea, eb);
+        });
+        return;
+    }
+    // one stream, table-free layers of the ContentVec window (N = 111) that the size rule sends to lone 16 x 16 fragments: every B fragment costs
+    // four dword gathers (9-12 clocks each on the CU's single vector-memory path) for ONE MFMA row block; two fragments along N per wave and eight
+    // K shares halve the weight loads per MFMA (isolated: 768 x 3072 18.5 -> 14.9 us, 768 x 768 6.5 -> 5.7 us; in the chain: ContentVec -22 us)
+    if (cfg == 0 && wg_ks == 4 && B == 1 && !p.fold_n && p.lin_cs4 && p.nphase == 1 && p.M >= 256 && p.N > 64 && p.N <= 128 && nchunks >= 32 && !p.ln_wsum && !getenv("RVC_NO_LIN_16x32")) { cfg = 1; wg_ks = 8; }
+    if (const char *f = tune_env("RVC_TUNE")) {        // tuning aid: "M,K:cfg,ks;M,K:cfg,ks;..." overrides the tile choice of matching layers
+        for (const char *q = f; q && *q; ) {
+            int tm = 0, tk = 0, tc = 0, tks = 1;
+            if (sscanf(q, "%d,%d:%d,%d", &tm, &tk, &tc, &tks) == 4 && tm == p.M && tk == p.K) { cfg = tc; wg_ks = tks; }
+            q = strchr(q, ';'); if (q) q++;
+        }
+    }
+    if (const char *f = test_opt("RVC_FORCE_CFG")) {   // tuning aid: "cfg,ks[,mfast]"
+        int fc = 0, fk = 1; if (sscanf(f, "%d,%d", &fc, &fk) >= 1) { cfg = fc; wg_ks = fk; }
+    }
+    if (p.ln_wsum || p.ln_stats_in) {
+        // folded LayerNorm: one stream, in-workgroup K split (the statistics / the normalised residual live in that epilogue)
+        if (lds_cfg >= 0 || B != 1 || p.fold_n || p.nphase != 1) throw std::logic_error("folded LayerNorm outside its supported launch shape");
+        if (wg_ks == 1) {
+            wg_ks = 4;
+            while (cfg > 0 && (nchunks / wg_ks < 4 || wg_ks * kMF[cfg] * kNF[cfg] > 32)) cfg = cfg == 4 ? 3 : (cfg == 3 ? 1 : 0);
+        }
+        if (p.ln_wsum && (p.lin_cs4 == 0 || pre || nchunks / wg_ks < 1)) throw std::logic_error("LayerNorm consumer must be a table-free 1x1 layer");
+    }
+    int ksplit = 1;
+    if ((size_t)nchunks * 64 > 60 * 1024 && (p.glu || phase_epi)) throw ShapeError("fused conv too long for the in-workgroup K split");
+    if ((size_t)nchunks * 64 > 60 * 1024) {     // koff slice would not fit in LDS: grid-level split (two-stage, rare)
+        ksplit = (int)(((size_t)nchunks * 64 + 60 * 1024 - 1) / (60 * 1024));
+        cfg = 0; wg_ks = 1;
+    }
+    int cps = (nchunks + ksplit - 1) / ksplit;
+    ksplit = (nchunks + cps - 1) / cps;
+    p.ksplit = ksplit; p.chunks_per_split = cps;
+    p.ntm = (p.M + 16 * kMF[cfg] - 1) / (16 * kMF[cfg]);
+    p.ntn = (p.N + 16 * kNF[cfg] - 1) / (16 * kNF[cfg]);
+    if (ksplit > 1) p.part = pl.arena.floats((size_t)B * p.nphase * ksplit * p.M * p.N);
+    // weight-heavy layers (short N: the transformer at T=111, RMVPE's deep levels, the synth encoder): keep all tiles that
+    // read the same weight rows on one XCD so each weight byte crosses the fabric once (per-XCD L2s are private)
+    bool weight_heavy = (p.N <= 512 && (long long)p.M * p.K >= 64 * 1024 && p.ntm >= 8) || (p.fold_n && p.ntm >= 2);
+    if (const char *f = tune_env("RVC_FORCE_MFAST")) weight_heavy = atoi(f) != 0;
+    p.m_fast = weight_heavy ? (p.ntm + 7) / 8 * 8 : 0;
+    const int ntiles = weight_heavy ? p.m_fast * p.ntn : p.ntm * p.ntn;
+    dim3 grid(wg_ks > 1 ? ntiles : (ntiles + 3) / 4, B * p.nphase * ksplit);
+    dim3 egrid((unsigned)(((long long)p.M * p.N + 255) / 256), B * p.nphase);
+    // lean kernel: x = fast tile axis (m when m_fast, else n; 4 tiles per workgroup without the in-workgroup K split), y = slow axis
+    const bool lean = ksplit == 1 && !tune_env("RVC_OLD_IGEMM");
+    const bool lin = lean && p.lin_cs4 != 0 && p.nphase == 1 && !pre && !tune_env("RVC_NO_LIN");
+    size_t lds2 = 0;
+    if (lean) {
+        const int fast_n = weight_heavy ? p.ntm : p.ntn, slow_n = weight_heavy ? p.ntn : p.ntm;
+        unsigned gx = (unsigned)(wg_ks > 1 ? fast_n : (fast_n + 3) / 4);
+        // workgroup (x, y) runs on XCD x % 8 when gridDim.x is a multiple of 8: all tiles of one weight-row block then share one
+        // XCD's L2.  Only when the padding is cheap and every XCD still gets live workgroups (a short axis padded to 8 would park
+        // all the work on a few XCDs: measured 3.6x slower at 64 streams)
+        if (weight_heavy && ((wg_ks > 1 && gx >= 8) || gx >= 16)) gx = (gx + 7) / 8 * 8;
+        grid = dim3(gx, (unsigned)slow_n, (unsigned)(B * p.nphase));
+        if (grid.y > 65535 || grid.z > 65535) throw ShapeError("implicit GEMM grid too large");
+        p.nbatch = B;
+        lds2 = (lin ? 0 : (size_t)nchunks * 64) + (wg_ks > 1 ? (size_t)wg_ks * kMF[cfg] * kNF[cfg] * 1024 : 0) + (p.ln_wsum ? (size_t)wg_ks * kNF[cfg] * 16 * 2 * 4 : 0);
+        if (p.ln_wsum && !lin) throw std::logic_error("LayerNorm consumer did not get the table-free kernel");
+    }
+    g_last_wgs = (int)(grid.x * grid.y * grid.z); g_last_waves = wg_ks > 1 ? wg_ks : 4;
+    const double flops = 2.0 * p.M * (double)p.N * ksum * B;
+    pl.igemm_flops += flops;
+    pl.n_igemm++;
+    Plan *plp = &pl;
+    { char d[200]; snprintf(d, sizeof d, "reg M=%d N=%d K=%d B=%d nph=%d tile=%dx%d ks=%d mfast=%d grid=%ux%ux%u pre=%d lin=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, 16 * kMF[cfg], 16 * kNF[cfg], wg_ks, p.m_fast, grid.x, grid.y, grid.z, (int)pre, (int)lin, ksum); pl.descs.push_back(d); }
+    const int desc_id = (int)pl.descs.size() - 1;
+    pl.ops.push_back([=](hipStream_t s) {
+        ProfEvent *pe = nullptr;
+        if (plp->profile) {
+            if (plp->prof_used == plp->prof.size()) {
+                ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; e.bytes = 0; plp->prof.push_back(e);
+            }
+            pe = &plp->prof[plp->prof_used++];
+            pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
+            if (ksplit > 1) HIPCHK(hipEventRecord(pe->a, s));
+        }
+        if (lean && final_out && plp->cur_out) { IgemmP q = p; q.y = plp->cur_out; q.y_bs = plp->cur_out_bs; launch_igemm2(cfg, wg_ks, pre, lin, q, grid, lds2, s, pe ? pe->a : nullptr, pe ? pe->b : nullptr); }
+        else if (lean) launch_igemm2(cfg, wg_ks, pre, lin, p, grid, lds2, s, pe ? pe->a : nullptr, pe ? pe->b : nullptr);
+        else launch_igemm_v1(pre, p, grid, s);
+        if (ksplit > 1) hipLaunchKernelGGL(splitk_epilogue_kernel, egrid, dim3(256), 0, s, p);
+        if (pe && ksplit > 1) HIPCHK(hipEventRecord(pe->b, s));
+    });
+}
+
+void fill_epilogue(IgemmP &p, const ConvW &cw, const ConvOpts &o)
+{
+    p.bias = (o.no_bias || !cw.bias) ? nullptr : cw.bias + o.m_off;
+    p.res = o.res; p.res_cs = o.res_cs; p.res_bs = o.res_bs; p.res_rs = o.res_rs;
+    p.act = o.act; p.slope = o.slope; p.scale = o.scale; p.accumulate = o.accumulate ? 1 : 0;
+    if (o.pre_act != ACT_NONE && o.pre_act != ACT_LRELU) throw std::runtime_error("only LeakyReLU can be fused on the input side");
+    p.pre_act = o.pre_act; p.pre_slope = o.pre_act == ACT_LRELU ? o.pre_slope : 1.0f;
+    p.part = nullptr;
+    p.glu = o.glu ? 1 : 0;
+    p.ln_wsum = o.ln_wsum; p.ln_stats_out = o.ln_stats_out; p.ln_stats_in = o.ln_stats_in; p.ln_g = o.ln_g; p.ln_bt = o.ln_b;
+    p.ln_eps = 1e-5f; p.ln_inv_rows = o.ln_rows > 0 ? 1.0f / (float)o.ln_rows : 0.f;
+    if (o.ln_stats_in && !(o.res && o.ln_g && o.ln_b)) throw std::logic_error("normalised residual without residual / scale / shift");
+    if (o.glu && (p.bias == nullptr || o.res || o.accumulate || o.act != ACT_NONE)) throw std::runtime_error("glu epilogue takes bias only");
+}
+
+// Conv1d (stride s, dilation d, symmetric zero padding pad, groups) on halo'd rows
+void add_conv1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int stride, int pad, int dil, ConvOpts o)
+{
+    if (cw.transposed) throw std::runtime_error("add_conv1d on transposed weights");
+    const int cig = cw.Cin / cw.groups, KW = cw.KW;
+    const int Tout = (x.T + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+    if (Tout != y.T && !(Tout == y.T + 1)) throw ShapeError("conv1d output length mismatch");
+    if (x.halo < pad || (y.T - 1) * stride + (KW - 1) * dil - pad > x.T - 1 + x.halo) throw ShapeError("conv1d halo too small");
+    IgemmP p{};
+    if (o.m_off % 16 != 0) throw std::runtime_error("output-row sub-range must start at a multiple of 16");
+    p.x = x.p; p.w = cw.w + (long long)o.m_off * cw.Kp; p.y = y.p;
+    p.M = o.m_cnt >= 0 ? o.m_cnt : cw.M; p.N = y.T; p.K = cw.Kp;
+    p.NW = y.T; p.x_hs = 0; p.x_ws = stride; p.y_hm = 0; p.y_ws = 1; p.OW = y.T;
+    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.ld; p.y_rs = 0;
+    p.x_ld = x.ld; p.x_lo = -x.halo; p.x_lim = x.T - 1 + x.halo;
+    fill_epilogue(p, cw, o);
+    // 1x1 convolution with a whole number of 16-row chunks: operand row k sits at k * channel stride, no offset table (igemm2 LIN)
+    if (KW == 1 && cw.groups == 1 && pad == 0 && cw.K == cw.Kp) p.lin_cs4 = x.ld * 4;
+    if (cw.groups > 1 && (o.m_off != 0 || o.m_cnt >= 0)) throw std::runtime_error("row sub-range on grouped conv");
+    std::vector<int> koff(cw.Kp, 0);
+    for (int ci = 0; ci < cig; ci++) for (int k = 0; k < KW; k++) koff[ci * KW + k] = ci * x.ld + k * dil - pad;
+    std::vector<PhaseD> ph(cw.groups);
+    for (int g = 0; g < cw.groups; g++) {
+        ph[g] = PhaseD{};
+        ph[g].w_off = (long long)g * phase_stride(cw);
+        ph[g].x_off = g * cig * x.ld;
+        ph[g].y_c0 = g * cw.M;
+        ph[g].y_pos = 0;
+        ph[g].bias_off = g * cw.M;
+        ph[g].koff_off = 0;
+    }
+    queue_igemm(pl, p, x.B, koff, ph, o.final_out);
+}
+
+// Several stride-1 convs of the same Cin/Cout but different kernel size / dilation as ONE launch (phase j = conv j): the
+// HiFiGAN stage's parallel ResBlock chains.  x is either shared by all convs or a [n*Cin] tensor holding conv j's input in rows
+// j*Cin..; y is a [n*Cout] tensor (conv j writes rows j*Cout..); the residual is shared or grouped likewise.
+void add_conv1d_multi(Plan &pl, const std::vector<const ConvW *> &cws, const T1 &x, bool x_grouped, const T1 &y,
+                             const std::vector<int> &pads, const std::vector<int> &dils, ConvOpts o, bool res_grouped)
+{
+    const int n = (int)cws.size();
+    const ConvW &c0 = *cws[0];
+    IgemmP p{};
+    p.x = x.p; p.w = c0.w; p.y = y.p;
+    p.M = c0.M; p.N = y.T; p.K = 0;
+    p.NW = y.T; p.x_hs = 0; p.x_ws = 1; p.y_hm = 0; p.y_ws = 1; p.OW = y.T;
+    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.ld; p.y_rs = 0;
+    p.x_ld = x.ld; p.x_lo = -x.halo; p.x_lim = x.T - 1 + x.halo;
+    fill_epilogue(p, c0, o);
+    p.res_nogroup = res_grouped ? 0 : 1;
+    std::vector<int> koff;
+    std::vector<PhaseD> ph(n);
+    for (int j = 0; j < n; j++) {
+        const ConvW &cw = *cws[j];
+        if (cw.transposed || cw.groups != 1 || cw.Cin != c0.Cin || cw.Cout != c0.Cout || (x_grouped ? x.C != n * cw.Cin : x.C != cw.Cin) || y.C != n * cw.Cout)
+            throw std::runtime_error("add_conv1d_multi: incompatible convs");
+        const int KW = cw.KW, pad = pads[j], dil = dils[j];
+        if (x.T + 2 * pad - dil * (KW - 1) != y.T) throw ShapeError("conv1d_multi output length mismatch");
+        if (x.halo < pad || (KW - 1) * dil - pad > x.halo) throw ShapeError("conv1d_multi halo too small");
+        ph[j] = PhaseD{};
+        ph[j].w_off = cw.w - c0.w;                       // same allocation (merge_convs)
+        ph[j].bias_off = (int)(cw.bias - c0.bias);
+        ph[j].x_off = x_grouped ? j * cw.Cin * x.ld : 0;
+        ph[j].y_c0 = j * cw.Cout;
+        ph[j].koff_off = (int)koff.size();
+        ph[j].nchunks = cw.Kp / 16;
+        p.K = std::max(p.K, cw.Kp);
+        const size_t base = koff.size();
+        koff.resize(base + cw.Kp, 0);
+        for (int ci = 0; ci < cw.Cin; ci++) for (int k = 0; k < KW; k++) koff[base + ci * KW + k] = ci * x.ld + k * dil - pad;
+    }
+    queue_igemm(pl, p, x.B, koff, ph);
+}
+
+// ConvTranspose1d (polyphase), pad = (K - S) / 2 as in HiFiGAN
+void add_convT1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int pad, ConvOpts o)
+{
+    const int S = cw.S, nt = cw.ntaps;
+    const int Tout = (x.T - 1) * S - 2 * pad + cw.KW;
+    if (Tout != y.T) throw ShapeError("convT1d output length mismatch");
+    if (x.halo < nt) throw ShapeError("convT1d halo too small");
+    IgemmP p{};
+    p.x = x.p; p.w = cw.w; p.y = y.p;
+    p.M = cw.M; p.N = x.T + nt - 1; p.K = cw.Kp;
+    p.NW = p.N; p.x_hs = 0; p.x_ws = 1; p.y_hm = 0; p.y_ws = S; p.OW = y.T;
+    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.ld; p.y_rs = 0;
+    fill_epilogue(p, cw, o);
+    std::vector<int> koff(cw.Kp, 0);
+    for (int ci = 0; ci < cw.Cin; ci++) for (int j = 0; j < nt; j++) koff[ci * nt + j] = ci * x.ld - j;
+    std::vector<PhaseD> ph(S);
+    for (int q = 0; q < S; q++) {
+        ph[q] = PhaseD{};
+        ph[q].w_off = (long long)q * phase_stride(cw);
+        ph[q].x_off = 0;
+        ph[q].y_pos = q - pad;
+        ph[q].bias_off = 0;
+        ph[q].koff_off = 0;
+    }
+    queue_igemm(pl, p, x.B, koff, ph);
+}
+
+// Conv2d 3x3 pad 1 (KW = 9) or 1x1 (KW = 1) on halo'd images
+void add_conv2d(Plan &pl, const ConvW &cw, const T2 &x, const T2 &y, ConvOpts o)
+{
+    if (x.H != y.H || x.W != y.W) throw ShapeError("conv2d shape mismatch");
+    IgemmP p{};
+    p.x = x.p; p.w = cw.w; p.y = y.p;
+    p.M = cw.M; p.N = x.H * x.W; p.K = cw.Kp;
+    p.NW = x.W; p.x_hs = x.ld; p.x_ws = 1; p.y_hm = 1; p.y_ws = 1; p.OW = y.W;
+    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.cs; p.y_rs = y.ld;
+    fill_epilogue(p, cw, o);
+    std::vector<int> koff;
+    if (cw.KW == 9 && x.H == 1 && !cw.host_w.empty() && !tune_env("RVC_NO_TAP_PRUNE")) {
+        // one-row image (RMVPE's bottleneck at Tm = 32): the kh = 0 and kh = 2 taps only ever read the zero halo rows, so two
+        // thirds of the weight stream is dead.  Repack the middle row of every 3x3 filter once per plan (K = Cin*3).
+        const int K3 = cw.Cin * 3, Kp3 = round16(K3);
+        std::vector<float> panel((size_t)cw.M * Kp3, 0.f);
+        for (int mo = 0; mo < cw.M; mo++)
+            for (int ci = 0; ci < cw.Cin; ci++)
+                for (int kw = 0; kw < 3; kw++) panel[(size_t)mo * Kp3 + ci * 3 + kw] = cw.host_w[(size_t)mo * cw.K + ci * 9 + 3 + kw];
+        float *dw = upload_fragments(panel, 1, cw.M, Kp3);
+        pl.owned_dev.push_back(dw);
+        p.w = dw; p.K = Kp3;
+        koff.assign(Kp3, 0);
+        for (int ci = 0; ci < cw.Cin; ci++) for (int kw = 0; kw < 3; kw++) koff[ci * 3 + kw] = ci * x.cs + (kw - 1);
+    } else {
+        koff.assign(cw.Kp, 0);
+        if (cw.KW == 9) { for (int ci = 0; ci < cw.Cin; ci++) for (int k = 0; k < 9; k++) koff[ci * 9 + k] = ci * x.cs + (k / 3 - 1) * x.ld + (k % 3 - 1); }
+        else { for (int ci = 0; ci < cw.Cin; ci++) koff[ci] = ci * x.cs; }
+    }
+    std::vector<PhaseD> ph(1);
+    ph[0] = PhaseD{};
+    queue_igemm(pl, p, x.B, koff, ph);
+}
+
+void add_convT2d(Plan &pl, const ConvW &cw, const T2 &x, const T2 &y, ConvOpts o)
+{
+    if (y.H != 2 * x.H || y.W != 2 * x.W) throw ShapeError("convT2d shape mismatch");
+    IgemmP p{};
+    p.x = x.p; p.w = cw.w; p.y = y.p;
+    p.M = cw.M; p.N = x.H * x.W; p.K = cw.Kp;
+    p.NW = x.W; p.x_hs = x.ld; p.x_ws = 1; p.y_hm = 2; p.y_ws = 2; p.OW = y.W;
+    p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.cs; p.y_rs = y.ld;
+    fill_epilogue(p, cw, o);
+    std::vector<int> koff(cw.Kp, 0);
+    for (int ci = 0; ci < cw.Cin; ci++) for (int jh = 0; jh < 2; jh++) for (int jw = 0; jw < 2; jw++) koff[ci * 4 + jh * 2 + jw] = ci * x.cs + jh * x.ld + jw;
+    std::vector<PhaseD> ph(4);
+    for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) {
+        PhaseD d{};
+        d.w_off = (long long)(a * 2 + b) * phase_stride(cw);
+        d.y_h0 = a;
+        d.y_pos = b;
+        ph[a * 2 + b] = d;
+    }
+    queue_igemm(pl, p, x.B, koff, ph);
+}
+
+void add_layernorm(Plan &pl, const T1 &x, const float *g, const float *b)
+{
+    dim3 grid((x.T + 3) / 4, x.B);
+    if (x.C > 1024) throw ShapeError("layernorm: more than 1024 channels");
+    const bool small = x.C <= 256;
+    // many streams: 16-column strips held in registers (float4 rows; needs 16-byte aligned rows, which every plan tensor has: ld and
+    // halo are multiples of 4).  Reading the padding columns behind T is safe (inside the row), they are never written.
+    if (x.B >= 16 && x.ld % 4 == 0 && x.halo % 4 == 0 && ((x.T + 3) / 4 * 4 <= x.ld - x.halo) && !tune_env("RVC_NO_LN_STRIP")) {
+        // grid x = stream, y = strip: workgroup (b, strip) runs on XCD (strip * B + b) % 8 = b % 8 when B is a multiple of 8, so the two
+        // 64-byte halves of every 128-byte line (adjacent strips of one stream) are fetched by the same XCD's L2, once
+        dim3 sg(x.B, (x.T + 15) / 16);
+        const int nr = (x.C + 63) / 64;
+        pl.ops.push_back([=](hipStream_t s) {
+            if (nr <= 4) hipLaunchKernelGGL((layernorm_strip_kernel<4>), sg, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
+            else if (nr <= 12) hipLaunchKernelGGL((layernorm_strip_kernel<12>), sg, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
+            else hipLaunchKernelGGL((layernorm_strip_kernel<16>), sg, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
+        });
+        return;
+    }
+    if (x.B >= 16 && x.C > 256 && (size_t)x.C * 33 * 4 <= 150 * 1024 && !tune_env("RVC_NO_LN_TILE")) {
+        dim3 tg((x.T + 31) / 32, x.B);
+        const size_t lds = (size_t)x.C * 33 * sizeof(float);
+        pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(layernorm_tile_kernel, tg, dim3(256), lds, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs); });
+        return;
+    }
+    pl.ops.push_back([=](hipStream_t s) {
+        if (small) hipLaunchKernelGGL((layernorm_ct_kernel<4>), grid, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
+        else hipLaunchKernelGGL((layernorm_ct_kernel<16>), grid, dim3(256), 0, s, x.p, x.p, g, b, x.C, x.T, x.ld, x.bs, x.ld, x.bs);
+    });
+}
+
+void add_stamp(Plan &pl, const char *name)
+{
+    const bool on = test_opt("RVC_STAMPS") != nullptr;
+    if (!on) return;
+    if (!pl.d_stamps) pl.d_stamps = reinterpret_cast<unsigned long long *>(pl.arena.floats(2 * 256));
+    if (pl.stamp_names.size() >= 256) return;
+    unsigned long long *slot = pl.d_stamps + pl.stamp_names.size();
+    pl.stamp_names.push_back(name);
+    pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, s, slot); });
+}
+void add_tap(Plan &pl, const char *name, const T1 &t)
+{
+    add_stamp(pl, name);
+    if (!pl.with_taps) return;
+    // snapshot into a private contiguous-row tensor so later in-place ops do not clobber it
+    T1 snap = make_t1(pl.arena, 1, t.C, t.T, 0);
+    pl.ops.push_back([=](hipStream_t s) {
+        HIPCHK(hipMemcpy2DAsync(snap.p, (size_t)snap.ld * 4, t.p, (size_t)t.ld * 4, (size_t)t.T * 4, t.C, hipMemcpyDeviceToDevice, s));
+    });
+    TapRec r; r.name = name; r.rank = 1; r.t1 = snap; pl.taps.push_back(r);
+}
+void add_tap2(Plan &pl, const char *name, const T2 &t)
+{
+    add_stamp(pl, name);
+    if (!pl.with_taps) return;
+    TapRec r; r.name = name; r.rank = 2; r.t2 = t; pl.taps.push_back(r);   // RMVPE images are never overwritten
+}
+
+// Two 1x1 convolutions of ONE input with the same M and K into two output tensors, as two phases of one launch (the flows' merged post / next-pre
+// layer).  pair_bias = [c0's bias | c1's bias].
+void add_conv1d_two(Plan &pl, const ConvW &c0, const ConvW &c1, const float *pair_bias, const T1 &x, const T1 &y0, const T1 &y1)
+{
+    if (c0.M != c1.M || c0.Kp != c1.Kp || c0.KW != 1 || c1.KW != 1 || c0.Cin != x.C || y0.ld != y1.ld || y0.T != y1.T || y0.bs != y1.bs || y0.C != c0.M || y1.C != c1.M)
+        throw ShapeError("conv1d pair: shapes differ");
+    IgemmP p{};
+    p.x = x.p; p.w = c0.w; p.y = y0.p;
+    p.M = c0.M; p.N = y0.T; p.K = c0.Kp;
+    p.NW = y0.T; p.x_hs = 0; p.x_ws = 1; p.y_hm = 0; p.y_ws = 1; p.OW = y0.T;
+    p.x_bs = x.bs; p.y_bs = y0.bs; p.y_cs = y0.ld; p.y_rs = 0;
+    ConvOpts o;
+    fill_epilogue(p, c0, o);
+    p.bias = pair_bias;
+    std::vector<int> koff(c0.Kp, 0);
+    for (int ci = 0; ci < c0.Cin; ci++) koff[ci] = ci * x.ld;
+    std::vector<PhaseD> ph(2);
+    ph[0] = PhaseD{}; ph[1] = PhaseD{};
+    ph[0].nchunks = c0.Kp / 16;
+    ph[1].w_off = c1.w - c0.w;          // both are device pointers of one flat address space
+    ph[1].nchunks = c1.Kp / 16;
+    ph[1].koff_off = 0;
+    ph[1].bias_off = c0.M;
+    ph[1].act_p1 = ACT_NONE + 1;
+    ph[1].y_off = y1.p - y0.p;
+    queue_igemm(pl, p, x.B, koff, ph);
+}
+
+
+void plan_kernel_attrs()
+{
+    HIPCHK(hipFuncSetAttribute((const void *)layernorm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));   // + 1.3 KB static
+    conv_tile_prepare_device();
+}
+
+}  // namespace rvc
+
+// test hook (see "switches" in engine_int.h): set (value != NULL) or clear one of the named hooks; 0 = done, -1 = unknown name.
+// Hooks are read when a model is loaded (RVC_NO_LN_FUSE) or a plan is built -- set them before.
+extern "C" int rvc_debug_option(const char *name, const char *value)
+{
+    using namespace rvc;
+    if (!name) return -1;
+#ifndef RVC_TUNING
+    if (!is_test_hook(name)) return -1;
+#endif
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    if (value) g_opts[name] = value; else g_opts.erase(name);
+    return 0;
+}
