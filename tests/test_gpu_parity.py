@@ -546,13 +546,22 @@ def test_plugin_maximum_settings():
     x = voice_signal(gg.input_buffer_16k_size, seed=23)
     ho, he = ora.hubert(x), eng.hubert(x)
     assert he.shape == ho.shape == (1, 768, 332) and rel_rms(he, ho) < 1e-4
-    # with the synthetic full-size RMVPE weights some of the 160 frames decode to a bin >= 348, where the reference indexes out of
-    # bounds (rmvpe.rs:124) and panics: both sides must report exactly that
-    with pytest.raises(Exception) as eo:
-        ora.infer(x, gg.sample_frame_16k, 7, gg.skip_head, gg.model_return_length)
-    with pytest.raises(RvcInferError) as ee:
-        eng.infer(x, gg.sample_frame_16k, 7, gg.skip_head, gg.model_return_length)
-    assert "Panic" in str(eo.value) and ee.value.kind == "Panic"
+    # the whole chunk at full size (zoo revision 2: the RMVPE head's edge bins are switched off, so the 160 frames decode inside the table).
+    # 160 frames of the synthetic head's flat salience hold near-ties: the arg-max of one frame can resolve differently under two fp32
+    # summation orders ("discrete decisions": measured here, frame 97, 183.4 vs 181.3 Hz with the saliences equal to
+    # 4e-7).  So: every arithmetic stage must agree, the decisions are compared as decisions, and the audio is compared when they agree.
+    ora.enable_taps(True); eng.enable_taps(2)
+    yo = ora.infer(x, gg.sample_frame_16k, 7, gg.skip_head, gg.model_return_length)
+    ye = eng.infer(x, gg.sample_frame_16k, 7, gg.skip_head, gg.model_return_length)
+    assert ye.shape == yo.shape == (155 * 480,) and np.isfinite(ye).all()
+    assert rel_rms(eng.tap("rm.sal_ct").reshape(-1, 160).T.reshape(-1), ora.tap("rm.sal")) < 1e-5
+    assert rel_rms(eng.tap("cv.out"), ora.tap("cv.out")) < 1e-4
+    fo, fe = ora.tap("f0"), eng.tap("f0")
+    flips = np.abs(fe - fo) > 1e-3 * np.abs(fo) + 1e-3
+    assert flips.sum() <= 2 and np.all(np.abs(fe - fo)[flips] <= 0.03 * np.abs(fo)[flips] + 1e-3), (int(flips.sum()), fo[flips], fe[flips])      # at most two frames, one or two 20-cent bins
+    if not flips.any():
+        assert rms(ye - yo) < PCM_TOL, rms(ye - yo)
+    ora.enable_taps(False); eng.enable_taps(False)
     # the whole chunk at these sizes on the small model (same code paths, well-behaved salience)
     z = zoo("tiny")
     ora = O.OracleRvcInfer(z["data"]); ora.load_contentvec(2); ora.load_f0(1); ora.load_model(z["model"]); ora.set_noise_seed(8, 0)
@@ -562,6 +571,33 @@ def test_plugin_maximum_settings():
         ye = eng.infer(x, gg.sample_frame_16k, 7, gg.skip_head, gg.model_return_length)
         assert ye.shape == yo.shape == (155 * 48,) and rms(ye - yo) < PCM_TOL, rms(ye - yo)
     assert np.allclose(eng.pitch_cache(), ora.pitch_cache(), rtol=1e-5, atol=1e-3)
+
+
+def test_salience_peak_at_the_table_edge_panics_like_the_reference(tmp_path):
+    # rmvpe.rs:124: a frame whose arg-max bin is >= 348 makes the reference index out of bounds (it slices the UNPADDED salience with a
+    # centre found on the padded one) and panic.  A model whose head puts its bump at bin 354 must produce exactly that on both sides
+    # (the zoo's own heads keep away from the edge: trained heads do, and the bench's plugin chain should not count panic chunks).
+    import shutil
+    from oracle import oracle as O
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("tiny")
+    data = str(tmp_path / "data")
+    shutil.copytree(z["data"], data)
+    cfg, t = W.read_blob(os.path.join(data, "f0", "rmvpe.rvcw"))
+    bins = np.arange(t["rm.fc.b"].shape[0], dtype=np.float64)
+    t["rm.fc.b"] = (12.0 * np.exp(-0.5 * ((bins - 354.0) / 3.0) ** 2) - 6.0).astype(np.float32)
+    W.write_blob(os.path.join(data, "f0", "rmvpe.rvcw"), cfg, t)
+    ora = O.OracleRvcInfer(data); ora.load_contentvec(2); ora.load_f0(1); ora.load_model(z["model"]); ora.set_noise_seed(8, 0)
+    eng = RvcInfer(data); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"]); eng.set_noise_seed(8, 0)
+    x = voice_signal(g.input_buffer_16k_size, seed=23)
+    with pytest.raises(Exception) as eo:
+        ora.infer(x, g.sample_frame_16k, 7, g.skip_head, g.model_return_length)
+    with pytest.raises(RvcInferError) as ee:
+        eng.infer(x, g.sample_frame_16k, 7, g.skip_head, g.model_return_length)
+    assert "Panic" in str(eo.value) and ee.value.kind == "Panic"
+    # the engine is usable afterwards (the status word was cleared): a well-behaved model on the same engine object's sibling
+    ok = RvcInfer(z["data"]); ok.load_contentvec(2); ok.load_f0(); ok.load_model(z["model"]); ok.set_noise_seed(8, 0)
+    assert np.isfinite(ok.infer(x, g.sample_frame_16k, 7, g.skip_head, g.model_return_length)).all()
 
 
 def test_pipelined_chunks_equal_serial_chunks():
