@@ -346,10 +346,16 @@ static void push_call_params(rvc_engine *e, int32_t pitch_shift, const int32_t *
         h->chunk_base = 0;
         HIPCHK(hipMemcpyAsync(e->d_cp, h, sizeof(CallParams), hipMemcpyHostToDevice, e->stream));
     }
-    float *hu = e->h_up + (size_t)(e->up_slot++ & 7u) * 4096;
+    // a block is rewritten only after the strided copy that last read it has completed (nine unsynchronised calls with changing shifts
+    // would otherwise overwrite a block whose copy is still pending: ADVICE r3)
+    const unsigned us = e->up_slot++ & 7u;
+    if (e->ev_up_used[us]) HIPCHK(hipEventSynchronize(e->ev_up[us]));
+    float *hu = e->h_up + (size_t)us * 4096;
     e->pushed_up.resize(B);
     for (int b = 0; b < B; b++) hu[b] = e->pushed_up[b] = uppower(shifts ? shifts[b] : pitch_shift);
     HIPCHK(hipMemcpy2DAsync((char *)e->d_state + offsetof(StreamState, uppower), sizeof(StreamState), hu, sizeof(float), sizeof(float), (size_t)B, hipMemcpyHostToDevice, e->stream));
+    if (!e->ev_up[us]) HIPCHK(hipEventCreateWithFlags(&e->ev_up[us], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(e->ev_up[us], e->stream)); e->ev_up_used[us] = true;
     e->pushed_seed = e->seed; e->pushed_valid = true;
     if (e->pipeline) {
         // pipelined calls do not fork the front branches from the main stream: order them behind the parameter copy explicitly
@@ -458,6 +464,7 @@ void rvc_destroy(rvc_engine *e)
     if (e->h_cp) (void)hipHostFree(e->h_cp);
     if (e->h_status) (void)hipHostFree(e->h_status);
     if (e->h_up) (void)hipHostFree(e->h_up);
+    for (int i = 0; i < 8; i++) if (e->ev_up[i]) (void)hipEventDestroy(e->ev_up[i]);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -593,7 +600,8 @@ static rvc_status infer_common(rvc_engine *e, const void *input, bool input_on_d
     // pointers and keeps both copies; pipelined calls keep the input copy (it decouples the caller's buffer from the chunk in flight).
     static const bool no_direct = tune_env("RVC_NO_DIRECT_IO") != nullptr;
     const bool direct_in = input_on_device && !pipe && !e->use_graph && pl->in_direct_ok && !no_direct;
-    const bool direct_out = out_on_device && !e->use_graph && pl->out_direct_ok && !no_direct;
+    // (folded streams address the output with 32-bit offsets stream * cap: a caller-chosen cap beyond that range keeps the copy)
+    const bool direct_out = out_on_device && !e->use_graph && pl->out_direct_ok && !no_direct && (long long)pl->B * (long long)cap < (1LL << 29);
     pl->cur_in = direct_in ? (const float *)input : nullptr;
     pl->cur_out = direct_out ? (float *)out : nullptr; pl->cur_out_bs = (long long)cap;
     if (pipe) {

@@ -163,6 +163,11 @@ void merge_convs(const std::vector<ConvW *> &cs);
 // ---------------------------------------------------------------------------------------
 // op list ("plan") construction
 // ---------------------------------------------------------------------------------------
+// LayerNorm folded into the neighbouring GEMMs (ModelCV::fold_ln): one stream only.  The folded form works on streams folded into N as well
+// (parity-tested in round 4), but the LayerNorm-consumer GEMM (two waves per SIMD, statistics in the operand stream) loses more on the wider
+// N than the 31 launches save: 2 / 4 / 8 streams measured 3.33 / 5.09 / 8.30 ms with the fold against 3.30 / 4.83 / 7.85 without.
+constexpr int LN_FOLD_MAX_STREAMS = 1;
+
 struct ConvOpts {
     int act = ACT_NONE; float slope = 0.f; float scale = 1.f; bool accumulate = false;
     int pre_act = ACT_NONE; float pre_slope = 0.f;
@@ -232,6 +237,7 @@ struct Plan {
     // caller needs no staging copy in front of the chunk and no copy behind it (a captured graph bakes pointers: it keeps d_in / audio)
     const float *cur_in = nullptr; float *cur_out = nullptr; long long cur_out_bs = 0;
     bool in_direct_ok = true, out_direct_ok = false;
+    bool final_out_honoured = false;     // the chunk's last convolution was queued on a launch path that writes Plan::cur_out (queue_igemm reports it)
     // graph
     hipGraphExec_t graph_exec = nullptr;
     ~Plan()
@@ -795,6 +801,7 @@ struct rvc_engine {
     bool pipeline = false, pipe_now = false; int pipe_slot = 0; hipEvent_t ev_in = nullptr; const void *pipe_input = nullptr; size_t pipe_input_bytes = 0;
     std::vector<float> pushed_up; uint32_t pushed_seed = 0; bool pushed_valid = false;      // what the device holds: per-stream multipliers, seed
     float *h_up = nullptr; unsigned up_slot = 0;        // pinned ring of 8 blocks of 4096 per-stream multipliers (async strided copies read them later)
+    hipEvent_t ev_up[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool ev_up_used[8] = {false, false, false, false, false, false, false, false};      // completion of the copy that last read a block
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
     size_t last_knn_rows = 0;

@@ -60,7 +60,7 @@ T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
         x = y; T = To;
     }
     add_tap(pl, "cv.feat", x);
-    const bool fuse_ln = B == 1 && m.has_folded && !pl.plain_plan && !test_opt("RVC_NO_LN_FUSE");
+    const bool fuse_ln = B <= LN_FOLD_MAX_STREAMS && m.has_folded && !pl.plain_plan && !test_opt("RVC_NO_LN_FUSE");
     const int E = m.embed;
     T1 h = make_t1(A, B, E, T, m.pos_k / 2);
     if (fuse_ln && m.proj_wsum) { ConvOpts o; o.ln_wsum = m.proj_wsum; o.ln_rows = m.conv_dim; add_conv1d(pl, m.proj_f, x, h, 1, 0, 1, o); }

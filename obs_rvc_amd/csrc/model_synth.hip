@@ -65,7 +65,7 @@ void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T1 &src,
         const size_t attn_lds = ((size_t)((kc * Tp + 3) & ~3) + 16 * Tp + 16 * kc) * sizeof(float);
         if (attn_lds > 160 * 1024) throw ShapeError("synth attention: return_length too long for the LDS-resident kernel");
         // one stream: the second LayerNorm of every encoder layer is folded into the next projection (see build_contentvec)
-        const bool fuse_ln = B == 1 && m.has_folded && !pl.plain_plan && !test_opt("RVC_NO_LN_FUSE");
+        const bool fuse_ln = B <= LN_FOLD_MAX_STREAMS && m.has_folded && !pl.plain_plan && !test_opt("RVC_NO_LN_FUSE");
         bool raw = false; const float *raw_g = nullptr, *raw_b = nullptr; float *raw_st = nullptr;
         for (int l = 0; l < m.enc_layers; l++) {
             ModelSY::Layer &Ly = m.layers[l];
@@ -239,7 +239,7 @@ void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T1 &src,
     pl.audio = make_t1(A, B, 1, Tc, 0);
     { ConvOpts o; o.pre_act = ACT_LRELU; o.pre_slope = 0.01f; o.act = ACT_TANH; o.no_bias = true; o.final_out = true; add_conv1d(pl, m.dec_post, xd, pl.audio, 1, 3, 1, o); }
     pl.N = (size_t)Tc;
-    pl.out_direct_ok = pl.audio.ld == Tc && !pl.with_taps;     // (the split-K fallback writes through a second kernel: ksplit > 1 never happens for this 7-tap layer)
+    pl.out_direct_ok = pl.audio.ld == Tc && !pl.with_taps && pl.final_out_honoured;     // (queue_igemm says whether the launch path it chose writes the caller's buffer)
     if (pl.audio.ld != Tc) {
         // make the output rows contiguous [B][N] for the device-pointer API
         T1 a2; a2.p = A.floats((size_t)B * Tc); a2.B = B; a2.C = 1; a2.T = Tc; a2.ld = Tc; a2.halo = 0; a2.bs = Tc;

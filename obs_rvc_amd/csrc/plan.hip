@@ -249,6 +249,7 @@ static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &
     { char d[200]; snprintf(d, sizeof d, "tile M=%d N=%d K=%d B=%d nph=%d tile=%dx%d items=%lld grid=%u lds=%zu pre=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, BM, BN, nitems, grid.x, lds_max, (int)(p.pre_act != ACT_NONE), ksum); pl.descs.push_back(d); }
     const int desc_id = (int)pl.descs.size() - 1;
     const IgemmP pc = p;
+    if (final_out) pl.final_out_honoured = true;
     pl.ops.push_back([=](hipStream_t s) {
         ProfEvent *pe = nullptr;
         if (plp->profile) {
@@ -387,6 +388,7 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         const int lc = lds_cfg;
         { char d[160]; snprintf(d, sizeof d, "%s M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%u", (lds_cfg >= 3 && lds_cfg != 6) ? "g32" : "lds", p.M, p.N, p.K, B, p.nphase, bm, bn, grid.x, grid.y); pl.descs.push_back(d); }
         const int desc_id = (int)pl.descs.size() - 1;
+        if (final_out) pl.final_out_honoured = true;
         pl.ops.push_back([=](hipStream_t s) {
             ProfEvent *pe = nullptr;
             if (plp->profile) {
@@ -402,7 +404,7 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
     // one stream, table-free layers of the ContentVec window (N = 111) that the size rule sends to lone 16 x 16 fragments: every B fragment costs
     // four dword gathers (9-12 clocks each on the CU's single vector-memory path) for ONE MFMA row block; two fragments along N per wave and eight
     // K shares halve the weight loads per MFMA (isolated: 768 x 3072 18.5 -> 14.9 us, 768 x 768 6.5 -> 5.7 us; in the chain: ContentVec -22 us)
-    if (cfg == 0 && wg_ks == 4 && B == 1 && !p.fold_n && p.lin_cs4 && p.nphase == 1 && p.M >= 256 && p.N > 64 && p.N <= 128 && nchunks >= 32 && !p.ln_wsum && !getenv("RVC_NO_LIN_16x32")) { cfg = 1; wg_ks = 8; }
+    if (cfg == 0 && wg_ks == 4 && B == 1 && !p.fold_n && p.lin_cs4 && p.nphase == 1 && p.M >= 256 && p.N > 64 && p.N <= 128 && nchunks >= 32 && !p.ln_wsum && !tune_env("RVC_NO_LIN_16x32")) { cfg = 1; wg_ks = 8; }
     if (const char *f = tune_env("RVC_TUNE")) {        // tuning aid: "M,K:cfg,ks;M,K:cfg,ks;..." overrides the tile choice of matching layers
         for (const char *q = f; q && *q; ) {
             int tm = 0, tk = 0, tc = 0, tks = 1;
@@ -414,8 +416,9 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         int fc = 0, fk = 1; if (sscanf(f, "%d,%d", &fc, &fk) >= 1) { cfg = fc; wg_ks = fk; }
     }
     if (p.ln_wsum || p.ln_stats_in) {
-        // folded LayerNorm: one stream, in-workgroup K split (the statistics / the normalised residual live in that epilogue)
-        if (lds_cfg >= 0 || B != 1 || p.fold_n || p.nphase != 1) throw std::logic_error("folded LayerNorm outside its supported launch shape");
+        // folded LayerNorm: one stream or a few folded into N (statistics are per launch column), in-workgroup K split (the statistics / the
+        // normalised residual live in that epilogue)
+        if (lds_cfg >= 0 || B != 1 || p.nphase != 1) throw std::logic_error("folded LayerNorm outside its supported launch shape");
         if (wg_ks == 1) {
             wg_ks = 4;
             while (cfg > 0 && (nchunks / wg_ks < 4 || wg_ks * kMF[cfg] * kNF[cfg] > 32)) cfg = cfg == 4 ? 3 : (cfg == 3 ? 1 : 0);
@@ -466,6 +469,7 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
     Plan *plp = &pl;
     { char d[200]; snprintf(d, sizeof d, "reg M=%d N=%d K=%d B=%d nph=%d tile=%dx%d ks=%d mfast=%d grid=%ux%ux%u pre=%d lin=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, 16 * kMF[cfg], 16 * kNF[cfg], wg_ks, p.m_fast, grid.x, grid.y, grid.z, (int)pre, (int)lin, ksum); pl.descs.push_back(d); }
     const int desc_id = (int)pl.descs.size() - 1;
+    if (final_out && lean) pl.final_out_honoured = true;      // (the two-stage grid split-K fallback writes through a second kernel: it keeps the plan's own tensor)
     pl.ops.push_back([=](hipStream_t s) {
         ProfEvent *pe = nullptr;
         if (plp->profile) {

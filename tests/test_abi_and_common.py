@@ -53,7 +53,7 @@ def test_product_reads_only_the_documented_environment():
             continue
         text = open(os.path.join(csrc, f)).read()
         text = re.sub(r"#ifdef RVC_TUNING.*?#(?:else|endif)", "", text, flags=re.S)      # the tuning build's fall-back to the environment
-        seen |= set(re.findall(r"\bgetenv\(\s*\"([A-Z0-9_]+)\"", text))
+        seen |= set(re.findall(r"\bgetenv\(\s*\"([^\"]+)\"", text))
         assert not re.findall(r"\bgetenv\(\s*[a-z_]", text), f      # no computed names
     assert seen <= PRODUCT_ENV, seen - PRODUCT_ENV
     assert len(seen) <= 10
