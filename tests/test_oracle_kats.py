@@ -62,6 +62,24 @@ def test_mel_filterbank():
     assert (fb >= 0).all() and (fb.sum(1) > 0).all()
 
 
+def test_mel_filterbank_against_an_independent_implementation():
+    # the filterbank was pinned only to this file's own numpy restatement of the librosa construction that the
+    # `mel_spec` crate (0.2.2, not vendored in /root/reference: rmvpe.rs:147) documents itself to follow.  transformers.audio_utils
+    # ships an independently written HTK-scale / Slaney-normalised triangular filterbank (the one Whisper-style feature extractors use):
+    # same arguments as rmvpe.rs:146-148 -> same matrix.
+    tr = pytest.importorskip("transformers.audio_utils")
+    ref = tr.mel_filter_bank(num_frequency_bins=513, num_mel_filters=128, min_frequency=30.0, max_frequency=8000.0, sampling_rate=16000,
+                             norm="slaney", mel_scale="htk").T          # (128, 513)
+    fb = O.mel_filterbank()
+    assert fb.shape == ref.shape == (128, 513)
+    assert np.abs(fb - ref).max() < 2e-7 * max(1.0, float(np.abs(ref).max()))
+    # structure: every filter is a non-negative triangle, the peaks ascend, Slaney normalisation = unit area in Hz
+    peaks = fb.argmax(axis=1)
+    assert (fb >= 0).all() and (np.diff(peaks) >= 0).all() and peaks[0] >= 1 and peaks[-1] <= 512
+    area = fb.sum(axis=1) * (8000.0 / 512)
+    assert np.allclose(area, 1.0, atol=0.12)                 # (sampled triangles: the narrow low filters are a few bins wide)
+
+
 def test_mel_extract_shape_and_floor():
     x = np.zeros(4960, np.float32)
     m = O.mel_extract(x)
