@@ -220,7 +220,10 @@ def _run_two_ranks(tmp_path, scenario, world=2):
     env = dict(os.environ, RVC_RCCL_LIB=_fake_rccl(), FAKE_RCCL_TIMEOUT_S="90", HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", "0"))
     work = str(tmp_path / scenario); os.makedirs(work)
     worker = os.path.join(ROOT, "tests", "tools", "two_rank_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), work, scenario], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    import socket
+    with socket.socket() as sk:                       # a free rendezvous port for the "dist" scenario's gloo group
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), work, scenario, str(port)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = []
     for p in procs:
         try:
@@ -255,6 +258,16 @@ def test_index_broadcast_two_ranks_through_the_c_abi(tmp_path):
     io, _ = o.knn()
     assert np.array_equal(np.array(r1["hits"], np.int32), io)
     assert rms(np.array(r1["pcm"], np.float32) - yo[:256]) < PCM_TOL
+
+
+def test_load_shared_index_two_ranks_the_way_bench_does_it(tmp_path):
+    # the host-side path of `bench.py --gpus N`: obs_rvc_amd.dist.load_shared_index over a torch.distributed group (gloo between the two
+    # processes here, RCCL on a real node) -- agreement on librccl and on the arguments, the unique id through broadcast_object_list, then
+    # rvc_index_broadcast.  Same end state as the direct C-ABI test above.
+    r0, r1 = _run_two_ranks(tmp_path, "dist")
+    assert r0["error"] is None and r1["error"] is None, (r0["error"], r1["error"])
+    assert r0["ranks"] == 2 and r1["ranks"] == 2 and r0["index_bytes"] == r1["index_bytes"] > 0
+    assert r0["hits"] == r1["hits"] and r0["dist"] == r1["dist"] and r0["pcm"] == r1["pcm"]
 
 
 @pytest.mark.parametrize("scenario", ["mismatch", "root_bad"])

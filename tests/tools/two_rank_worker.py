@@ -4,7 +4,9 @@ with RVC_RCCL_LIB = tests/tools/fake_rccl.cpp's library).  Rank 0 creates the un
 file (the "any host-side means" of include/rvc_mi355x.h); every rank calls rvc_index_broadcast, runs one chunk with retrieval on the
 same input and writes what it got as JSON.
 
-usage: two_rank_worker.py <rank> <world> <workdir> <scenario>     scenario: ok | mismatch (rank 1 expects another shape) | root_bad (rank 0 passes 2 vectors)"""
+usage: two_rank_worker.py <rank> <world> <workdir> <scenario> [port]
+scenario: ok | mismatch (rank 1 expects another shape) | root_bad (rank 0 passes 2 vectors) | dist (the host-side path bench.py --gpus N takes:
+obs_rvc_amd.dist.load_shared_index over a torch.distributed group -- gloo here -- which agrees on librccl, on the arguments, hands the id round)"""
 import json
 import os
 import sys
@@ -26,7 +28,19 @@ dim = eng.hubert(voice_signal(g.input_buffer_16k_size, seed=1)).shape[1]
 N = 3000
 index = W.make_index(N, dim, seed=5)
 uid_path = os.path.join(work, "uid.bin")
-if rank == 0:
+res = {"rank": rank, "scenario": scenario}
+if scenario == "dist":
+    import torch.distributed as tdist
+    from obs_rvc_amd import dist as rdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[5]
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rdist.load_shared_index(eng, index if rank == 0 else None, N, dim, rank, world)
+        res["error"] = None
+    except Exception as ex:      # noqa: BLE001
+        res["error"] = "%s: %s" % (type(ex).__name__, ex)
+    tdist.barrier(); tdist.destroy_process_group()
+elif rank == 0:
     uid = eng.rccl_unique_id()
     with open(uid_path + ".tmp", "wb") as f:
         f.write(uid)
@@ -37,16 +51,16 @@ else:
         time.sleep(0.01)
         assert time.time() - t0 < 120, "rank 0 never published the unique id"
     uid = open(uid_path, "rb").read()
-res = {"rank": rank, "scenario": scenario}
-try:
-    if rank == 0:
-        eng.index_broadcast(uid, 0, world, index[:2] if scenario == "root_bad" else index)
-    else:
-        expect = (N + 1, dim) if (scenario == "mismatch" and rank == 1) else (N, dim)
-        eng.index_broadcast(uid, rank, world, None, expect=expect)
-    res["error"] = None
-except Exception as ex:      # noqa: BLE001 -- the failure IS the result
-    res["error"] = "%s: %s" % (type(ex).__name__, ex)
+if scenario != "dist":
+    try:
+        if rank == 0:
+            eng.index_broadcast(uid, 0, world, index[:2] if scenario == "root_bad" else index)
+        else:
+            expect = (N + 1, dim) if (scenario == "mismatch" and rank == 1) else (N, dim)
+            eng.index_broadcast(uid, rank, world, None, expect=expect)
+        res["error"] = None
+    except Exception as ex:      # noqa: BLE001 -- the failure IS the result
+        res["error"] = "%s: %s" % (type(ex).__name__, ex)
 if res["error"] is None:
     info = eng.index_broadcast_info()
     ptr, nbytes = eng.index_device_ptr()
