@@ -145,6 +145,7 @@ static void configure_aux_streams(rvc_engine *e)
     const bool want = e->partition_ok && e->sset->masked_ok && e->n_streams <= 4;
     if (!want) for (int i = 0; i < 3; i += 2) if (!e->sset->plain[i]) HIPCHK(hipStreamCreateWithFlags(&e->sset->plain[i], hipStreamNonBlocking));
     e->partitioned = want;
+    e->cv_cus = want ? g_ncu - nf0 : g_ncu;
     e->aux[0] = want ? e->sset->f0 : e->sset->plain[0];
     e->aux[1] = e->sset->plain[1];
     e->aux[2] = want ? e->sset->cv : e->sset->plain[2];

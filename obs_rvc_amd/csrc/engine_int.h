@@ -772,6 +772,7 @@ struct rvc_engine {
     // in total: the runtime multiplexes streams onto 4 hardware queues, a fifth stream would share (and serialise with) another.
     hipStream_t stream = nullptr, aux[3] = {nullptr, nullptr, nullptr};
     struct rvc::StreamSet *sset = nullptr;             // the engine's streams are borrowed from a per-device pool (never destroyed)
+    int cv_cus = 256;                                 // CUs the ContentVec branch (and the retrieval behind it) runs on: all, or all minus the f0 partition
     bool partition_ok = false, partitioned = false;   // CU-masked streams available / currently in use (n_streams <= 4)
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_join[3] = {nullptr, nullptr, nullptr};
     std::unique_ptr<ModelCV> cv;

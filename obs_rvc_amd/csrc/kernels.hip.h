@@ -1479,26 +1479,14 @@ static __global__ __launch_bounds__(256) void knn_merge_blend_kernel(KnnBlendP p
         }
         for (int c = threadIdx.x; c < p.dim; c += 256) {
             float acc = 0.f;
-            for (int k = 0; k < KNN_K; k++) if (si[k] >= 0 && si[k] != 0x7fffffff) acc += (w[k] / ws) * p.index[(long long)si[k] * p.dim + c];   // no valid hit for a non-finite query
-            p.phone[(long long)b * p.ph_bs + (long long)c * p.ph_cs + r] = p.rate * acc + (1.0f - p.rate) * qv[c];
+            for (int k = 0; k < KNN_K; k++) if (si[k] >= 0 && si[k] != 0x7fffffff) acc = fmaf(w[k] / ws, p.index[(long long)si[k] * p.dim + c], acc);   // no valid hit for a non-finite query
+            p.phone[(long long)b * p.ph_bs + (long long)c * p.ph_cs + r] = fmaf(p.rate, acc, (1.0f - p.rate) * qv[c]);      // (explicit fmaf: the three blend kernels agree bit for bit)
         }
     }
 }
 
 // ---- HBM-roofline retrieval: approximate distances on the matrix cores, exact re-rank of a provably sufficient candidate set ----
-// Stage A (knn_dot_kernel): one pass over the row-major index.  A wave owns 16 consecutive index vectors (a contiguous
-// 16*dim*4-byte block of HBM, read exactly once) against up to 16 queries: dot products on v_mfma_f32_16x16x4_f32, then
-// approx[q][i] = |y_i|^2 - 2 x_q.y_i  (|x_q|^2 is constant per query).  Algorithmic traffic: n*dim*4 bytes per query group.
-struct KnnDotP {
-    const float *indexF;     // index repacked at load in MFMA-fragment order [tile of 16 vectors][chunk of 16 dims][lane][4]
-    const float *ynorm; int n, dim;
-    const float *q; long long q_bs; int nq, q0;
-    float *approx; long long approx_bs;        // approx[b][q][n]
-    int *overflow;                              // [B], cleared here, raised by the select stage
-    // per-wave candidate lists: the 4 smallest approximate distances (ascending by (distance, index)) of every wave's 16 vectors,
-    // per query -- the select stage reads these n / 4 entries instead of the n approximations (the global top-4 is in their union)
-    float *wl_d; int *wl_i; long long wl_bs;   // [b][q][waves][4]
-};
+// Stage A for one stream / few streams lives in knn_scan_select_kernel (below); with many streams it is one implicit GEMM (retrieval.hip).
 // compare-exchange of two (distance, index) pairs, ascending, ties by index (deterministic)
 __device__ __forceinline__ void knn_cx(float &d0, int &i0, float &d1, int &i1)
 {
@@ -1506,82 +1494,462 @@ __device__ __forceinline__ void knn_cx(float &d0, int &i0, float &d1, int &i1)
     const float td = sw ? d1 : d0, ud = sw ? d0 : d1; const int ti = sw ? i1 : i0, ui = sw ? i0 : i1;
     d0 = td; i0 = ti; d1 = ud; i1 = ui;
 }
-static __global__ __launch_bounds__(256) void knn_dot_kernel(KnnDotP p)
+// One stream / few streams: the WHOLE retrieval as one launch (round 4; before: knn_queries + knn_dot + knn_select_blend + two idle
+// fallback launches = 116 us of kernels for a 307 MB scan).
+//  * scan: a workgroup owns tiles of 16 consecutive index vectors (a contiguous 16*dim*4-byte block of HBM in MFMA-fragment order, read
+//    exactly once; tiles blockIdx.x, + gridDim.x, ...) against up to 16 queries; its four waves split the K range of every tile (dot
+//    products on v_mfma_f32_16x16x4_f32, each wave streams its 12 KB of the tile with the NEXT tile's fragments requested as the slots
+//    free up), the partial 16 x 16 tiles meet in LDS and one wave (in turn) forms approx = |y|^2 - 2 x.y and keeps a running top-4 per
+//    query.  Splitting K instead of handing whole tiles to waves makes the unit of work a quarter as long: 6 250 tiles over 768
+//    workgroups is 8 or 9 each, where 3 072 waves had 2 or 3 (the last third of the launch ran at 3 % occupancy).  The queries are
+//    gathered straight from the ContentVec output; NO approximate distance is written: the workgroup publishes 4 {distance, index}
+//    granules per query (agent-scope stores, no cache maintenance), then takes a ticket;
+//  * select: the last S = min(queries, workgroups) arrivals stay, wait until every list of their stream is published and each runs
+//    stages 1-4 of knn_select_blend_kernel for its query: the global top-4 of the approximations is in the union of the workgroups'
+//    lists; a workgroup whose 4th entry is inside the margin may hide a 5th candidate ("flagged"): ALL of its vectors become candidates,
+//    so no approximation array and no second pass exist, and nothing can overflow (a degenerate index costs exact distances for the
+//    flagged workgroups' vectors, 8 per round).  Same candidate superset, same exact re-rank, same hits as the three-launch form.
+struct KnnFusedP {
+    const float *indexF, *index, *ynorm; int n, dim;
+    const float *cv; int cv_cs; long long cv_bs; int first_raw, nq, q0;
+    unsigned long long *lists;         // [B][16][gridDim.x][4] granules: low word = distance bits, high word = index
+    unsigned *ticket;                  // [B][2]: arrivals, selectors done; zero between launches
+    int skip_head, T, R; float rate;
+    float *phone; int ph_cs; long long ph_bs;
+    int *out_idx; float *out_dist;
+    int *status; int status_stride;
+#ifdef RVC_KNN_STAMPS
+    long long *stamps;                 // tests/tools/knn_probe.hip: [gridDim.x][16] wall-clock stamps of thread 0
+#endif
+};
+#ifdef RVC_KNN_STAMPS
+#define KNN_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.y == 0) p.stamps[blockIdx.x * 16 + (i)] = (long long)wall_clock64(); } while (0)
+#else
+#define KNN_STAMP(i) do { } while (0)
+#endif
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // a 16-byte global load from a dword-aligned address
+#define KNN_FUSED_MAXG 1024            // workgroups per stream (a selector thread keeps 4 workgroup lists in registers)
+#define KNN_FUSED_ROWS 8               // candidate rows staged per round of the exact re-rank
+// dynamic LDS, in floats: scan = query rows + two buffers of partial tiles; select = query row + candidate ids + staged rows
+__host__ __device__ inline size_t knn_fused_lds_floats(int dim, int nqg, int G)
 {
-    constexpr int D = 8;
-    extern __shared__ __attribute__((aligned(16))) float s_q[];      // [16][dim + 4] queries of this group (row pad: conflict-free b128 reads)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && p.q0 == 0) p.overflow[b] = 0;
-    const int QS = p.dim + 4;
+    const size_t QS = (size_t)dim + 4, scan = (size_t)nqg * QS + 2 * 4 * 256, sel = QS + (((size_t)3 * G + 3) & ~(size_t)3) + (size_t)KNN_FUSED_ROWS * QS;
+    return scan > sel ? scan : sel;
+}
+static __global__ __launch_bounds__(256) void knn_scan_select_kernel(KnnFusedP p)
+{
+    constexpr int D = 12;
+    extern __shared__ __attribute__((aligned(16))) float s_q[];
+    __shared__ float wl_d[4][16][KNN_K]; __shared__ int wl_i[4][16][KNN_K];
+    __shared__ __attribute__((aligned(16))) float wd[4][KNN_K];
+    __shared__ float sd[KNN_K]; __shared__ int si[KNN_K];
+    __shared__ float s_red[4];
+    __shared__ int s_role, s_cnt, s_dead;
+    __shared__ unsigned s_flag[KNN_FUSED_MAXG / 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, G = gridDim.x;
+    const int QS = p.dim + 4, nc = p.dim >> 4;
+    const int li = lane & 15, kq = lane >> 4;
+    const int nqg = p.nq - p.q0 < 16 ? p.nq - p.q0 : 16;
+    const int F0 = wave * nc / 4, F = (wave + 1) * nc / 4 - F0;          // this wave's fragments of every tile
+    const long long ntile = ((long long)p.n + 15) >> 4;
+    long long t = blockIdx.x;
+    KNN_STAMP(0);
+    // the first tile's fragments are requested before the queries are gathered
+    f32x4 a_st[D];
     {
-        const float *qb = p.q + (long long)b * p.q_bs;
-        const int nv = p.dim >> 2;
-        for (int i = threadIdx.x; i < 16 * nv; i += 256) {
-            const int r = i / nv, c4 = i - r * nv;
-            int qq = p.q0 + r; qq = qq < p.nq ? qq : p.nq - 1;
-            *reinterpret_cast<f32x4 *>(s_q + r * QS + c4 * 4) = *reinterpret_cast<const f32x4 *>(qb + (long long)qq * p.dim + c4 * 4);
+        const float *ar = p.indexF + (t * nc + F0) * 256 + lane * 4;
+#pragma unroll
+        for (int s = 0; s < D; s++)
+            if (s < F && t < ntile) a_st[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(ar + s * 256));
+    }
+    // queries: s_q[r][c] = cv[c][first_raw + q0 + r], r < nqg.  A lane takes 4 consecutive queries of one channel -- one dword-aligned
+    // 16-byte load where all four exist --, 16 channels per wave instruction; LDS writes conflict-free
+    const float *cvb = p.cv + (long long)b * p.cv_bs + p.first_raw;
+    {
+        const int r0 = (lane & 3) * 4;
+        const bool whole = r0 + 3 < nqg;
+        for (int c = (tid >> 2); c < p.dim; c += 64) {
+            const float *src = cvb + (long long)c * p.cv_cs + p.q0;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (whole) v = *reinterpret_cast<const f32x4u *>(src + r0);
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) if (r0 + i < nqg) v[i] = src[r0 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) if (r0 + i < nqg) s_q[(r0 + i) * QS + c] = v[i];
         }
     }
+    float *part = s_q + (size_t)nqg * QS;                                 // [2][4 waves][64 lanes][4]
     __syncthreads();
-    const int li = lane & 15, kq = lane >> 4;
-    const int nc = p.dim >> 4;
-    // persistent workgroups: the 48 KB query block is staged once per workgroup, then its waves walk the index tiles
-    for (int i0 = (blockIdx.x * 4 + wave) * 16; i0 < p.n; i0 += gridDim.x * 64) {
-    // one wave-wide dwordx4 load = one 1 KiB fragment, fully contiguous: the wave streams its 16 vectors as nc consecutive KiB
-    const float *ar = p.indexF + (long long)(i0 >> 4) * nc * 256 + lane * 4;
-    const float *br = s_q + li * QS + kq * 4;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 a_st[D];
+    KNN_STAMP(1);
+    float rd[KNN_K]; int ri[KNN_K];
 #pragma unroll
-    for (int s = 0; s < D; s++)
-        if (s < nc) a_st[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(ar + s * 256));
-    for (int c = 0; c < nc; c += D) {
+    for (int k = 0; k < KNN_K; k++) { rd[k] = INFINITY; ri[k] = 0x7fffffff; }
+    // (query columns past the last query of the group repeat it: their results are never read)
+    const float *br = s_q + (li < nqg ? li : nqg - 1) * QS + kq * 4;
+    for (int it = 0; t < ntile; t += G, it++) {
+        const float *ar = p.indexF + (t * nc + F0) * 256 + lane * 4;
+        const bool more = t + G < ntile;
+        const float *an = p.indexF + ((t + G) * nc + F0) * 256 + lane * 4;
+        const int ew = it & 3;                                            // the wave that ranks this tile
+        const long long i0 = t * 16;
+        // |y|^2 of the lane's four vectors: requested now, consumed behind the dot products
+        float yn[4] = {0.f, 0.f, 0.f, 0.f};
+        if (wave == ew) {
 #pragma unroll
-        for (int s = 0; s < D; s++) {
-            if (c + s < nc) {
-                const f32x4 bq = *reinterpret_cast<const f32x4 *>(br + (c + s) * 16);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[s][0], bq[0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[s][1], bq[1], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[s][2], bq[2], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[s][3], bq[3], acc1, 0, 0, 0);
-                if (c + s + D < nc) a_st[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(ar + (c + s + D) * 256));
+            for (int r = 0; r < 4; r++) { const long long v = i0 + kq * 4 + r; yn[r] = v < p.n ? p.ynorm[v] : 0.f; }
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < F; c += D) {
+#pragma unroll
+            for (int s = 0; s < D; s++) {
+                if (c + s < F) {
+                    const f32x4 bq = *reinterpret_cast<const f32x4 *>(br + (F0 + c + s) * 16);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[s][0], bq[0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[s][1], bq[1], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[s][2], bq[2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[s][3], bq[3], acc1, 0, 0, 0);
+                    // the wave's fragment stream continues into the workgroup's next tile: after its last use in this tile, slot s takes fragment s of the next
+                    if (c + s + D < F) a_st[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(ar + (c + s + D) * 256));
+                    else if (more) a_st[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(an + s * 256));
+                }
             }
         }
-    }
-    // D layout: row (index vector) = (lane >> 4) * 4 + r, column (query) = lane & 15
-    const int qcol = p.q0 + li;
-    float vd[4]; int vi[4];
+        float *pb = part + (it & 1) * 1024;
+        {
+            f32x4 a01;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int v = i0 + kq * 4 + r;
-        vd[r] = v < p.n ? p.ynorm[v] - 2.0f * (acc0[r] + acc1[r]) : INFINITY;
-        vi[r] = v < p.n ? v : 0x7fffffff;
-    }
-    if (qcol < p.nq) {
-        float *out = p.approx + (long long)b * p.approx_bs + (long long)qcol * p.n;
-#pragma unroll
-        for (int r = 0; r < 4; r++) if (vi[r] != 0x7fffffff) out[vi[r]] = vd[r];
-    }
-    if (p.wl_d) {
-        // this wave's 4 smallest of its 16 vectors, per query column: sort the lane's 4, then two bitonic merges with the lanes that
-        // hold the other rows of the column (lane ^ 16, lane ^ 32): min(a[k], b[3 - k]) keeps the 4 smallest of two sorted 4-lists
-        knn_cx(vd[0], vi[0], vd[1], vi[1]); knn_cx(vd[2], vi[2], vd[3], vi[3]); knn_cx(vd[0], vi[0], vd[2], vi[2]);
-        knn_cx(vd[1], vi[1], vd[3], vi[3]); knn_cx(vd[1], vi[1], vd[2], vi[2]);
-#pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {
-            float od[4]; int oi[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) { od[r] = __shfl_xor(vd[3 - r], o, 64); oi[r] = __shfl_xor(vi[3 - r], o, 64); }
-#pragma unroll
-            for (int r = 0; r < 4; r++) { const bool t = od[r] < vd[r] || (od[r] == vd[r] && oi[r] < vi[r]); vd[r] = t ? od[r] : vd[r]; vi[r] = t ? oi[r] : vi[r]; }
-            knn_cx(vd[0], vi[0], vd[2], vi[2]); knn_cx(vd[1], vi[1], vd[3], vi[3]); knn_cx(vd[0], vi[0], vd[1], vi[1]); knn_cx(vd[2], vi[2], vd[3], vi[3]);
+            for (int r = 0; r < 4; r++) a01[r] = acc0[r] + acc1[r];
+            *reinterpret_cast<f32x4 *>(pb + wave * 256 + lane * 4) = a01;
         }
-        if (kq == 0 && qcol < p.nq) {
-            const long long o4 = (long long)b * p.wl_bs + ((long long)qcol * ((p.n + 15) >> 4) + (i0 >> 4)) * 4;
-            *reinterpret_cast<f32x4 *>(p.wl_d + o4) = (f32x4){vd[0], vd[1], vd[2], vd[3]};
-            *reinterpret_cast<int4 *>(p.wl_i + o4) = make_int4(vi[0], vi[1], vi[2], vi[3]);
+        __syncthreads();        // (one barrier per tile: buffer it & 1 is rewritten two tiles later, behind the next barrier, which the ranking wave reaches after reading it)
+        if (wave == ew) {
+            // D layout: row (index vector) = (lane >> 4) * 4 + r, column (query) = lane & 15; partial tiles summed in wave order
+            const f32x4 p0 = *reinterpret_cast<const f32x4 *>(pb + lane * 4), p1 = *reinterpret_cast<const f32x4 *>(pb + 256 + lane * 4);
+            const f32x4 p2 = *reinterpret_cast<const f32x4 *>(pb + 512 + lane * 4), p3 = *reinterpret_cast<const f32x4 *>(pb + 768 + lane * 4);
+            float vd[4]; int vi[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const long long v = i0 + kq * 4 + r;
+                const float a = yn[r] - 2.0f * (((p0[r] + p1[r]) + p2[r]) + p3[r]);
+                vd[r] = (v < p.n && a == a) ? a : INFINITY;            // (a NaN never is a candidate; as +inf it cannot upset the sorting networks either)
+                vi[r] = v < p.n ? (int)v : 0x7fffffff;
+            }
+            // the tile's 4 smallest per query column: sort the lane's 4, two bitonic merges with the lanes holding the column's other rows
+            knn_cx(vd[0], vi[0], vd[1], vi[1]); knn_cx(vd[2], vi[2], vd[3], vi[3]); knn_cx(vd[0], vi[0], vd[2], vi[2]);
+            knn_cx(vd[1], vi[1], vd[3], vi[3]); knn_cx(vd[1], vi[1], vd[2], vi[2]);
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                float od[4]; int oi[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) { od[r] = __shfl_xor(vd[3 - r], o, 64); oi[r] = __shfl_xor(vi[3 - r], o, 64); }
+#pragma unroll
+                for (int r = 0; r < 4; r++) { const bool tk = od[r] < vd[r] || (od[r] == vd[r] && oi[r] < vi[r]); vd[r] = tk ? od[r] : vd[r]; vi[r] = tk ? oi[r] : vi[r]; }
+                knn_cx(vd[0], vi[0], vd[2], vi[2]); knn_cx(vd[1], vi[1], vd[3], vi[3]); knn_cx(vd[0], vi[0], vd[1], vi[1]); knn_cx(vd[2], vi[2], vd[3], vi[3]);
+            }
+            // ... merged into the wave's running list (both sorted: min(a[k], b[3 - k]) keeps the 4 smallest, then the bitonic clean-up)
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const bool tk = vd[3 - r] < rd[r] || (vd[3 - r] == rd[r] && vi[3 - r] < ri[r]); rd[r] = tk ? vd[3 - r] : rd[r]; ri[r] = tk ? vi[3 - r] : ri[r]; }
+            knn_cx(rd[0], ri[0], rd[2], ri[2]); knn_cx(rd[1], ri[1], rd[3], ri[3]); knn_cx(rd[0], ri[0], rd[1], ri[1]); knn_cx(rd[2], ri[2], rd[3], ri[3]);
         }
     }
+    if (kq == 0) {
+#pragma unroll
+        for (int k = 0; k < KNN_K; k++) { wl_d[wave][li][k] = rd[k]; wl_i[wave][li][k] = ri[k]; }
+    }
+    __syncthreads();
+    KNN_STAMP(2);
+    // the workgroup's list per query: merge of its four waves' lists, published as 4 granules; then the ticket (same wave: program order)
+    if (tid < 16) {
+        int pos[4] = {0, 0, 0, 0};
+        unsigned long long *out = p.lists + (((long long)b * 16 + tid) * G + blockIdx.x) * KNN_K;
+#pragma unroll
+        for (int k = 0; k < KNN_K; k++) {
+            float md = INFINITY; int mi = 0x7fffffff, mw = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int pw = pos[w] < KNN_K ? pos[w] : KNN_K - 1;
+                const float od = wl_d[w][tid][pw]; const int oi = wl_i[w][tid][pw];
+                if (pos[w] < KNN_K && (od < md || (od == md && oi < mi))) { md = od; mi = oi; mw = w; }
+            }
+#pragma unroll
+            for (int w = 0; w < 4; w++) pos[w] += (w == mw && mi != 0x7fffffff) ? 1 : 0;
+            __hip_atomic_store(out + k, ((unsigned long long)(unsigned)mi << 32) | (unsigned long long)__float_as_uint(md), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (wave == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the granules have left (write-through) before the ticket is taken
+        if (tid == 0) s_role = (int)__hip_atomic_fetch_add(p.ticket + b * 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    KNN_STAMP(3);
+    const int S = nqg < G ? nqg : G;
+    if (s_role < G - S) return;
+    const int sel = s_role - (G - S);
+    if (tid == 0) {
+        unsigned spins = 0; int dead = 0;
+        while (__hip_atomic_load(p.ticket + b * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G) {
+            if (++spins > (1u << 22)) { dead = 1; p.status[b * p.status_stride] = 7; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        s_dead = dead;
+    }
+    __syncthreads();
+    KNN_STAMP(4);
+    // select-phase layout of the dynamic LDS: query row | candidate ids (<= 3 per unflagged workgroup) | KNN_FUSED_ROWS staged rows
+    float *s_x = s_q;
+    int *cand = reinterpret_cast<int *>(s_q + QS);
+    float *s_rows = s_q + QS + ((3 * G + 3) & ~3);
+    const int nv = p.dim >> 2;
+    for (int jq = sel; jq < nqg && !s_dead; jq += S) {
+        const int j = p.q0 + jq;
+        __syncthreads();
+        // the query (exact arithmetic below reads it from LDS) and |x|^2 (only scales the error margin): still in the scan's LDS rows for
+        // the selector's first query, gathered again for further ones (the select-phase layout has overwritten them)
+        float xn = 0.f;
+        if (jq == sel) {
+            for (int c = tid; c < p.dim; c += 256) { const float v = s_q[jq * QS + c]; if (jq) s_x[c] = v; xn += v * v; }     // (row jq -> row 0: disjoint)
+        } else {
+            for (int c = tid; c < p.dim; c += 256) { const float v = cvb[(long long)c * p.cv_cs + j]; s_x[c] = v; xn += v * v; }
+        }
+        xn = wave_sum(xn);
+        if (lane == 0) s_red[wave] = xn;
+        if (tid < KNN_FUSED_MAXG / 32) s_flag[tid] = 0u;
+        if (tid == 0) s_cnt = 0;
+        // this thread's workgroup lists: w = tid + 256 * u
+        float ld_[4][KNN_K]; int li_[4][KNN_K];
+        const unsigned long long *lq = p.lists + ((long long)b * 16 + jq) * G * KNN_K;
+        {
+            unsigned long long x[4][KNN_K];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int w = tid + 256 * u;
+#pragma unroll
+                for (int k = 0; k < KNN_K; k++) {
+                    x[u][k] = 0x7fffffff7f800000ull;      // {+inf, no index}
+                    if (w < G) x[u][k] = __hip_atomic_load(lq + (long long)w * KNN_K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+#pragma unroll
+                for (int k = 0; k < KNN_K; k++) { ld_[u][k] = __uint_as_float((unsigned)x[u][k]); li_[u][k] = (int)(unsigned)(x[u][k] >> 32); }
+            }
+        }
+#ifdef RVC_KNN_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KNN_STAMP(12);
+#endif
+        // 1. the 4th smallest approximate distance: per-thread sorted top-4 (static indices only), wave extraction, 4-way merge
+        float td[KNN_K];
+#pragma unroll
+        for (int k = 0; k < KNN_K; k++) td[k] = INFINITY;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (int k = 0; k < KNN_K; k++) {
+                const float d = ld_[u][k];
+                if (d < td[KNN_K - 1]) {
+#pragma unroll
+                    for (int q = KNN_K - 1; q >= 1; q--) {
+                        const bool left = d < td[q - 1], here = !left && d < td[q];
+                        td[q] = left ? td[q - 1] : (here ? d : td[q]);
+                    }
+                    if (d < td[0]) td[0] = d;
+                }
+            }
+        }
+        {
+            int pos = 0;
+            for (int k = 0; k < KNN_K; k++) {
+                const float d0 = pos == 0 ? td[0] : pos == 1 ? td[1] : pos == 2 ? td[2] : pos == 3 ? td[3] : INFINITY;
+                float md = d0; int ml = lane;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float od = __shfl_xor(md, o, 64); const int ol = __shfl_xor(ml, o, 64);
+                    if (od < md || (od == md && ol < ml)) { md = od; ml = ol; }
+                }
+                if (ml == lane && md < INFINITY) pos++;
+                if (lane == 0) wd[wave][k] = md;
+            }
+        }
+        KNN_STAMP(13);
+        __syncthreads();
+        // (every thread merges the four waves' lists itself: 16 broadcast reads instead of a one-thread merge between two barriers)
+        float a4;
+        {
+            float m4[KNN_K];
+#pragma unroll
+            for (int k = 0; k < KNN_K; k++) m4[k] = INFINITY;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(&wd[w][0]);
+#pragma unroll
+                for (int k = 0; k < KNN_K; k++) {
+                    const float d = wv[k];
+                    if (d < m4[KNN_K - 1]) {
+#pragma unroll
+                        for (int q = KNN_K - 1; q >= 1; q--) {
+                            const bool left = d < m4[q - 1], here = !left && d < m4[q];
+                            m4[q] = left ? m4[q - 1] : (here ? d : m4[q]);
+                        }
+                        if (d < m4[0]) m4[0] = d;
+                    }
+                }
+            }
+            a4 = m4[KNN_K - 1];
+        }
+        KNN_STAMP(5);
+        // 2. candidates within the error margin of the approximate 4th distance (bound and margin as in knn_select_blend_kernel)
+        const float s_xn = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        const float margin = 2e-3f * (fabsf(a4 + s_xn) + s_xn + 1e-3f);
+        const float thr = a4 + margin;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int w = tid + 256 * u;
+            if (w < G) {
+                if (ld_[u][KNN_K - 1] <= thr) atomicOr(&s_flag[w >> 5], 1u << (w & 31));     // may hide a 5th candidate: expanded below
+                else {
+#pragma unroll
+                    for (int k = 0; k < KNN_K - 1; k++) if (ld_[u][k] <= thr) cand[atomicAdd(&s_cnt, 1)] = li_[u][k];
+                }
+            }
+        }
+        __syncthreads();
+        // 3. exact distances in the reference's order (ascending-d sequential fmaf).  The rows are fetched with coalesced 16-byte loads
+        //    and staged in LDS as DIFFERENCES x - y (every thread subtracts what it fetched), so that the one thread per row that walks
+        //    the chain issues a single dependent fmaf per dimension; thread r < KNN_FUSED_ROWS keeps a sorted top-4 of what it has seen
+        float bd[KNN_K]; int bi[KNN_K];
+#pragma unroll
+        for (int k = 0; k < KNN_K; k++) { bd[k] = INFINITY; bi[k] = 0x7fffffff; }
+        auto round = [&](auto row_of, int nrows) {
+            __syncthreads();
+            for (int i = tid; i < nrows * nv; i += 256) {
+                const int r = i / nv, c4 = i - r * nv;
+                const f32x4 y = *reinterpret_cast<const f32x4 *>(p.index + (long long)row_of(r) * p.dim + c4 * 4);
+                *reinterpret_cast<f32x4 *>(s_rows + r * QS + c4 * 4) = *reinterpret_cast<const f32x4 *>(s_x + c4 * 4) - y;
+            }
+            __syncthreads();
+            KNN_STAMP(11);
+            if (tid < nrows) {
+                const float *v = s_rows + tid * QS;
+                float acc = 0.f;
+#ifdef RVC_KNN_STAMPS
+                const long long cyc0 = clock64();
+#endif
+                // two register sets of 32 differences each: one is consumed while the other is on its way from LDS
+                auto fetch = [&](f32x4 (&r)[8], int d) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) r[u] = *reinterpret_cast<const f32x4 *>(v + (d + 4 * u < p.dim ? d + 4 * u : 0));
+                };
+                auto chain = [&](const f32x4 (&r)[8], int d) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (d + 4 * u < p.dim) {
+#pragma unroll
+                            for (int i = 0; i < 4; i++) acc = fmaf(r[u][i], r[u][i], acc);
+                        }
+                    }
+                };
+                f32x4 ra[8], rb[8];
+                fetch(ra, 0);
+                for (int d = 0; d < p.dim; d += 64) {
+                    fetch(rb, d + 32);
+                    chain(ra, d);
+                    fetch(ra, d + 64);
+                    chain(rb, d + 32);
+                }
+#ifdef RVC_KNN_STAMPS
+                if (tid == 0 && blockIdx.y == 0) p.stamps[blockIdx.x * 16 + 1] = clock64() - cyc0 + (acc == 1.2345f ? 1 : 0);
+#endif
+                float cd = acc; int ci = row_of(tid);
+                // sorted insert by (distance, index); a NaN distance never enters
+#pragma unroll
+                for (int k = 0; k < KNN_K; k++) {
+                    const bool sw = cd < bd[k] || (cd == bd[k] && ci < bi[k]);
+                    const float t0 = sw ? bd[k] : cd; const int t1 = sw ? bi[k] : ci;
+                    bd[k] = sw ? cd : bd[k]; bi[k] = sw ? ci : bi[k];
+                    cd = t0; ci = t1;
+                }
+            }
+        };
+        const int ncand = s_cnt;
+        KNN_STAMP(10);
+        for (int base = 0; base < ncand; base += KNN_FUSED_ROWS) {
+            const int nr = ncand - base < KNN_FUSED_ROWS ? ncand - base : KNN_FUSED_ROWS;
+            round([&](int r) { return cand[base + r]; }, nr);
+        }
+        for (int fw = 0; fw < (G + 31) / 32; fw++) {
+            unsigned m = s_flag[fw];
+            while (m) {
+                const int w = fw * 32 + __builtin_ctz(m); m &= m - 1;
+                // every vector the flagged workgroup scanned: tiles w, w + G, ...
+                for (long long t0 = (long long)w * 16; t0 < p.n; t0 += (long long)G * 16) {
+                    const int nt = p.n - t0 < 16 ? (int)(p.n - t0) : 16;
+                    for (int base = 0; base < nt; base += KNN_FUSED_ROWS) {
+                        const int nr = nt - base < KNN_FUSED_ROWS ? nt - base : KNN_FUSED_ROWS;
+                        round([&](int r) { return (int)t0 + base + r; }, nr);
+                    }
+                }
+            }
+        }
+        KNN_STAMP(6);
+        // the final four: wave 0 holds every list (threads < KNN_FUSED_ROWS); four rounds of a minimum by (distance, index) over those lanes
+        if (wave == 0) {
+            int pos = 0;
+            for (int k = 0; k < KNN_K; k++) {
+                float md = pos == 0 ? bd[0] : pos == 1 ? bd[1] : pos == 2 ? bd[2] : pos == 3 ? bd[3] : INFINITY;
+                int mi = pos == 0 ? bi[0] : pos == 1 ? bi[1] : pos == 2 ? bi[2] : pos == 3 ? bi[3] : 0x7fffffff;
+                int ml = lane;
+#pragma unroll
+                for (int o = KNN_FUSED_ROWS / 2; o > 0; o >>= 1) {
+                    const float od = __shfl_xor(md, o, 64); const int oi = __shfl_xor(mi, o, 64), ol = __shfl_xor(ml, o, 64);
+                    if (oi != 0x7fffffff && (mi == 0x7fffffff || od < md || (od == md && oi < mi))) { md = od; mi = oi; ml = ol; }
+                }
+                if (ml == lane && mi != 0x7fffffff) pos++;
+                if (lane == 0) { sd[k] = mi == 0x7fffffff ? INFINITY : md; si[k] = mi; }
+            }
+        }
+        __syncthreads();
+        KNN_STAMP(8);
+        // 4. blend: w = (1/d)^2 normalised, feat = rate * sum w_i y_i + (1 - rate) * feat; computed once per
+        //    query, written to every sliced frame that duplicates it (a contiguous range of r: frames (skip_head + r) / 2, clamped to T - 1)
+        float wn[KNN_K], ws = 0.f;
+#pragma unroll
+        for (int k = 0; k < KNN_K; k++) { const float inv = 1.0f / sd[k]; wn[k] = inv * inv; ws += wn[k]; }
+#pragma unroll
+        for (int k = 0; k < KNN_K; k++) wn[k] = wn[k] / ws;
+        const int raw = j + p.first_raw;
+        int r_lo = 2 * raw - p.skip_head, r_hi = raw >= p.T - 1 ? p.R : 2 * raw + 2 - p.skip_head;
+        r_lo = r_lo < 0 ? 0 : r_lo; r_hi = r_hi > p.R ? p.R : r_hi;
+        float *ph = p.phone + (long long)b * p.ph_bs;
+        for (int c = tid; c < p.dim; c += 256) {
+            float y[KNN_K];
+#pragma unroll
+            for (int k = 0; k < KNN_K; k++) y[k] = (si[k] >= 0 && si[k] != 0x7fffffff) ? p.index[(long long)si[k] * p.dim + c] : 0.f;   // (no valid hit for a non-finite query)
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < KNN_K; k++) if (si[k] >= 0 && si[k] != 0x7fffffff) acc = fmaf(wn[k], y[k], acc);
+            const float val = fmaf(p.rate, acc, (1.0f - p.rate) * s_x[c]);
+            for (int r = r_lo; r < r_hi; r++) ph[(long long)c * p.ph_cs + r] = val;
+        }
+        KNN_STAMP(9);
+        if (tid < KNN_K)
+            for (int r = r_lo; r < r_hi; r++) {
+                p.out_idx[((long long)b * p.R + r) * KNN_K + tid] = si[tid] == 0x7fffffff ? -1 : si[tid];   // -1: no hit (non-finite query)
+                p.out_dist[((long long)b * p.R + r) * KNN_K + tid] = sd[tid];
+            }
+    }
+    __syncthreads();
+    KNN_STAMP(7);
+    // the last selector to leave re-arms the counters for the next launch
+    if (tid == 0) {
+        const unsigned d = __hip_atomic_fetch_add(p.ticket + b * 2 + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)d == S - 1) {
+            __hip_atomic_store(p.ticket + b * 2 + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.ticket + b * 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -1598,7 +1966,7 @@ static __global__ void knn_norms_kernel(const float *index, int n, int dim, floa
 }
 
 // Load-time repack of the index on the device (the matrix arrives in HBM by upload or by the RCCL broadcast and never goes back to
-// the host): [n][dim] -> MFMA-fragment order [tile of 16 vectors][chunk of 16 dims][lane][4] for knn_dot_kernel (vectors past n zero).
+// the host): [n][dim] -> MFMA-fragment order [tile of 16 vectors][chunk of 16 dims][lane][4] for knn_scan_select_kernel (vectors past n zero).
 // One thread per float4 of the output; reads are 16-byte pieces of 16 neighbouring rows.
 static __global__ __launch_bounds__(256) void knn_pack_index_kernel(const float *index, long long n, int dim, float *indexF, long long total4)
 {
@@ -1651,7 +2019,6 @@ struct KnnSelP {
     int skip_head, T, R, first_raw; float rate;
     float *phone; int ph_cs; long long ph_bs;
     int *out_idx; float *out_dist; int *overflow;
-    const float *wl_d; const int *wl_i; long long wl_bs;      // per-wave candidate lists of knn_dot_kernel (or nullptr: scan the approximations)
 };
 static __global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p)
 {
@@ -1693,26 +2060,6 @@ static __global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p
     // data-dependent branch behind it made this pass ~100 dependent round trips: 80 us for 100 k vectors, more than the scan that
     // produced the distances).  Only the VALUE of the 4th smallest is used below, so the visiting order does not matter.
     const int n4 = ((p.n & 3) == 0 && (reinterpret_cast<size_t>(a) & 15) == 0) ? p.n >> 2 : 0;
-    // One stream (knn_dot_kernel left per-wave lists): the global top-4 of the approximations is in the union of the waves' top-4
-    // lists -- n / 4 (distance, index) entries instead of n distances (round 2: this pass over 11 x 400 KB took two-thirds of the
-    // scan's own time).  min4 = the smallest 4th entry seen: a wave whose 4th entry is inside the margin may hide a 5th candidate.
-    float min4 = INFINITY;
-    if (p.wl_d) {
-        const int nw = (p.n + 15) >> 4;
-        const float *wd_ = p.wl_d + (long long)b * p.wl_bs + (long long)j * nw * 4;
-        const int *wi_ = p.wl_i + (long long)b * p.wl_bs + (long long)j * nw * 4;
-        for (int w0 = tid; w0 < nw; w0 += 4 * 1024) {
-            f32x4 dv[4]; int4 iv[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int w = w0 + u * 1024 < nw ? w0 + u * 1024 : w0; dv[u] = *reinterpret_cast<const f32x4 *>(wd_ + 4 * (long long)w); iv[u] = *reinterpret_cast<const int4 *>(wi_ + 4 * (long long)w); }
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (w0 + u * 1024 < nw) {
-                    keep(dv[u][0], iv[u].x); keep(dv[u][1], iv[u].y); keep(dv[u][2], iv[u].z); keep(dv[u][3], iv[u].w);
-                    min4 = fminf(min4, dv[u][3]);
-                }
-        }
-    } else {
     for (int i4 = tid; i4 < n4; i4 += 4 * 1024) {
         f32x4 v[4];
 #pragma unroll
@@ -1727,7 +2074,6 @@ static __global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p
         }
     }
     for (int i = 4 * n4 + tid; i < p.n; i += 1024) keep(a[i], i);
-    }
     int pos = 0;
     for (int k = 0; k < KNN_K; k++) {
         float md = pos < KNN_K ? ld[pos] : INFINITY; int mi = pos < KNN_K ? li_[pos] : 0x7fffffff;
@@ -1765,7 +2111,7 @@ static __global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p
     __syncthreads();
     // The candidates are among the per-thread top-4 lists unless some thread holds MORE than four values within the margin (its list is
     // then truncated: its 4th entry is still <= thr).  Common case: collect from the lists, no second pass over the n distances.
-    if (ld[KNN_K - 1] <= thr || min4 <= thr) atomicOr(&cnt, 0x40000000);       // (a truncated list -- this thread's or a wave's -- sends the stream through the full pass below)
+    if (ld[KNN_K - 1] <= thr) atomicOr(&cnt, 0x40000000);       // (a truncated list sends the stream through the full pass below)
     __syncthreads();
     const bool truncated = (cnt & 0x40000000) != 0;
     __syncthreads();
@@ -1846,8 +2192,8 @@ static __global__ __launch_bounds__(1024) void knn_select_blend_kernel(KnnSelP p
         for (int c = tid; c < p.dim; c += 1024) {
             float acc = 0.f;
 #pragma unroll
-            for (int k = 0; k < KNN_K; k++) if (si[k] >= 0 && si[k] != 0x7fffffff) acc += (w[k] / ws) * p.index[(long long)si[k] * p.dim + c];   // no valid hit for a non-finite query
-            p.phone[(long long)b * p.ph_bs + (long long)c * p.ph_cs + r] = p.rate * acc + (1.0f - p.rate) * qv[c];
+            for (int k = 0; k < KNN_K; k++) if (si[k] >= 0 && si[k] != 0x7fffffff) acc = fmaf(w[k] / ws, p.index[(long long)si[k] * p.dim + c], acc);   // no valid hit for a non-finite query
+            p.phone[(long long)b * p.ph_bs + (long long)c * p.ph_cs + r] = fmaf(p.rate, acc, (1.0f - p.rate) * qv[c]);      // (explicit fmaf: the three blend kernels agree bit for bit)
         }
     }
 }

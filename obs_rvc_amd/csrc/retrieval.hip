@@ -12,65 +12,42 @@ void build_retrieval(rvc_engine *e, Plan &pl, int B, int T, int C, uint32_t skip
         // unique raw frames behind the sliced frames (Q2): first_raw .. last_raw
         const int first_raw = std::min((int)skip_head / 2, T - 1), last_raw = std::min((int)(skip_head + R - 1) / 2, T - 1);
         const int nq = last_raw - first_raw + 1;
-        float *d_q = pl.arena.floats((size_t)B * nq * C);
         const int nblk = (int)((e->index_n + 255) / 256);
-        float *cand_d = pl.arena.floats((size_t)B * nq * nblk * KNN_K);
-        int *cand_i = (int *)pl.arena.alloc((size_t)B * nq * nblk * KNN_K * sizeof(int));
         pl.d_knn_idx = (int *)pl.arena.alloc((size_t)B * R * KNN_K * sizeof(int));
         pl.d_knn_dist = pl.arena.floats((size_t)B * R * KNN_K);
         T1 cvo = pl.cv_out;
-        {
-            dim3 grid((nq * C + 255) / 256, B);
-            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(knn_queries_kernel, grid, dim3(256), 0, s, cvo.p, cvo.ld, cvo.bs, C, first_raw, nq, d_q); });
-        }
         // Stage A + B: approximate distances on the matrix cores in one pass over the index (HBM-bound), exact re-rank of a
-        // provably sufficient candidate set; the exhaustive exact scan below only runs for streams whose candidate set overflowed.
+        // provably sufficient candidate set.
         const bool fast = C % 16 == 0 && !test_opt("RVC_KNN_EXHAUSTIVE");
-        int *d_overflow = (int *)pl.arena.alloc((size_t)B * sizeof(int));
         // many streams: all queries against the index as ONE implicit GEMM (queries = weight operand in fragment order, transposed
         // index = activation operand, -|y|^2 / 2 as a per-column residual, scale -2): one pass over the index instead of one per 16
         // queries (64 streams x 11 queries: 44 passes, 3.5 ms -> one ~1 ms MFMA-bound launch).  Same approximate distances up to
         // fp32 summation order; the exact re-rank behind it is unchanged.
         const int Q = B * nq, Qpad = (Q + 127) / 128 * 128;
-        // (the GEMM path addresses its operands with 32-bit byte / element offsets: the knn_dot loop, whose strides are 64-bit, takes
+        // (the GEMM path addresses its operands with 32-bit byte / element offsets: the one-pass scan, whose strides are 64-bit, takes
         // indexes beyond that range)
         const bool gemm_fits = (size_t)C * e->index_n * sizeof(float) < ((size_t)1 << 31) && (size_t)Qpad * e->index_n < ((size_t)1 << 31);
         const bool gemm_scan = fast && Q >= 128 && gemm_fits && e->d_nhn && !test_opt("RVC_KNN_NO_GEMM");
         if (gemm_scan || !fast) ensure_index_transposed(e);
-        if (fast) {
-            float *d_approx = pl.arena.floats((size_t)(gemm_scan ? Qpad : Q) * e->index_n);
-            if (gemm_scan) {
-                float *d_qf = pl.arena.floats((size_t)Qpad * C);
-                const int n_idx = (int)e->index_n;
-                {
-                    dim3 grid(Qpad / 16, C / 16); int *ovf = d_overflow; const int nb = B;
-                    pl.ops.push_back([=](hipStream_t s) {
-                        HIPCHK(hipMemsetAsync(ovf, 0, (size_t)nb * sizeof(int), s));
-                        hipLaunchKernelGGL(knn_pack_queries_kernel, grid, dim3(64), 0, s, d_q, Q, C, d_qf);
-                    });
-                }
-                ConvW qw; qw.w = d_qf; qw.bias = nullptr; qw.M = Qpad; qw.K = C; qw.Kp = C; qw.Cin = C; qw.Cout = Qpad; qw.KW = 1; qw.groups = 1; qw.nphase = 1; qw.owns = false;
-                T1 xi; xi.p = e->d_indexT; xi.B = 1; xi.C = C; xi.T = n_idx; xi.ld = n_idx; xi.halo = 0; xi.bs = (long long)C * n_idx;
-                T1 ya; ya.p = d_approx; ya.B = 1; ya.C = Qpad; ya.T = n_idx; ya.ld = n_idx; ya.halo = 0; ya.bs = (long long)Qpad * n_idx;
-                ConvOpts o; o.no_bias = true; o.res = e->d_nhn; o.res_cs = 0; o.res_bs = 0; o.scale = -2.0f;
-                add_conv1d(pl, qw, xi, ya, 1, 0, 1, o);
-            }
-            // per-wave candidate lists of the one-pass scan (one stream / few streams: the select stage reads n / 4 entries per query)
-            const long long nwaves = ((long long)e->index_n + 15) / 16;
-            float *wl_d = nullptr; int *wl_i = nullptr;
-            if (!gemm_scan && !tune_env("RVC_KNN_NO_WAVE_LISTS")) {
-                wl_d = pl.arena.floats((size_t)B * nq * nwaves * 4);
-                wl_i = (int *)pl.arena.alloc((size_t)B * nq * nwaves * 4 * sizeof(int));
-            }
-            for (int q0 = 0; q0 < nq && !gemm_scan; q0 += 16) {
-                KnnDotP dp{}; dp.indexF = e->d_indexF; dp.wl_d = wl_d; dp.wl_i = wl_i; dp.wl_bs = (long long)nq * nwaves * 4; dp.ynorm = e->d_ynorm; dp.n = (int)e->index_n; dp.dim = C;
-                dp.q = d_q; dp.q_bs = (long long)nq * C; dp.nq = nq; dp.q0 = q0; dp.approx = d_approx; dp.approx_bs = (long long)nq * e->index_n;
-                dp.overflow = d_overflow;
-                // persistent grid (the waves walk the index tiles; measured: 256 / 512 / 768 / 1024 / one tile per wave = 100 / 79 / 86 / 73 / 74 us per 307 MB)
-                static const unsigned knn_wgs = tune_env("RVC_KNN_WGS") ? (unsigned)atoi(tune_env("RVC_KNN_WGS")) : 1024u;
-                dim3 grid(std::min((unsigned)((e->index_n + 63) / 64), std::max(knn_wgs / (unsigned)B, 64u)), B);
-                const size_t qlds = (size_t)16 * (C + 4) * sizeof(float);
-                if (qlds > 160 * 1024) throw ShapeError("feature dimension too large for the retrieval kernel");
+        if (fast && !gemm_scan) {
+            // one stream / few streams: ONE launch per group of 16 queries (knn_scan_select_kernel: scan, select, exact re-rank, blend)
+            // three workgroups per CU of the stream this runs on, all resident at once (the ContentVec branch is CU-masked at <= 4 streams)
+            const unsigned knn_wgs = tune_env("RVC_KNN_WGS") ? (unsigned)atoi(tune_env("RVC_KNN_WGS")) : 3u * (unsigned)e->cv_cus;
+            const unsigned G = std::min(std::min((unsigned)((e->index_n + 63) / 64), std::max(knn_wgs / (unsigned)B, 64u)), (unsigned)KNN_FUSED_MAXG);
+            const int ngroups = (nq + 15) / 16;
+            unsigned long long *lists = (unsigned long long *)pl.arena.alloc((size_t)ngroups * B * 16 * G * KNN_K * sizeof(unsigned long long));
+            unsigned *ticket = (unsigned *)pl.arena.alloc((size_t)ngroups * B * 2 * sizeof(unsigned));
+            HIPCHK(hipMemset(ticket, 0, (size_t)ngroups * B * 2 * sizeof(unsigned)));
+            for (int gi = 0; gi < ngroups; gi++) {
+                const size_t lds = knn_fused_lds_floats(C, std::min(16, nq - gi * 16), (int)G) * sizeof(float);
+                if (lds > 128 * 1024) throw ShapeError("feature dimension too large for the retrieval kernel");
+                KnnFusedP fp{}; fp.indexF = e->d_indexF; fp.index = e->d_index; fp.ynorm = e->d_ynorm; fp.n = (int)e->index_n; fp.dim = C;
+                fp.cv = cvo.p; fp.cv_cs = cvo.ld; fp.cv_bs = cvo.bs; fp.first_raw = first_raw; fp.nq = nq; fp.q0 = gi * 16;
+                fp.lists = lists + (size_t)gi * B * 16 * G * KNN_K; fp.ticket = ticket + (size_t)gi * B * 2;
+                fp.skip_head = (int)skip_head; fp.T = T; fp.R = (int)R; fp.rate = e->index_rate;
+                fp.phone = phone.p; fp.ph_cs = phone.ld; fp.ph_bs = phone.bs; fp.out_idx = pl.d_knn_idx; fp.out_dist = pl.d_knn_dist;
+                fp.status = &e->d_state[0].status; fp.status_stride = (int)(sizeof(StreamState) / sizeof(int));
+                dim3 grid(G, B);
                 Plan *plp = &pl;
                 const double scan_bytes = (double)e->index_n * C * sizeof(float) * B;     // algorithmic bytes: the index, read once per query group
                 pl.ops.push_back([=](hipStream_t s) {
@@ -79,14 +56,42 @@ void build_retrieval(rvc_engine *e, Plan &pl, int B, int T, int C, uint32_t skip
                         if (plp->prof_used == plp->prof.size()) { ProfEvent ev; HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b)); ev.flops = 0; ev.bytes = 0; plp->prof.push_back(ev); }
                         pe = &plp->prof[plp->prof_used++]; pe->flops = 0; pe->bytes = scan_bytes;
                     }
-                    if (pe) hipExtLaunchKernelGGL(knn_dot_kernel, grid, dim3(256), (uint32_t)qlds, s, pe->a, pe->b, 0, dp);
-                    else hipLaunchKernelGGL(knn_dot_kernel, grid, dim3(256), qlds, s, dp);
+                    if (pe) hipExtLaunchKernelGGL(knn_scan_select_kernel, grid, dim3(256), (uint32_t)lds, s, pe->a, pe->b, 0, fp);
+                    else hipLaunchKernelGGL(knn_scan_select_kernel, grid, dim3(256), lds, s, fp);
                 });
             }
+            return;
+        }
+        // many streams (GEMM scan) or the exhaustive definition: explicit query rows, candidate lists per 256-vector block
+        float *d_q = pl.arena.floats((size_t)B * nq * C);
+        float *cand_d = pl.arena.floats((size_t)B * nq * nblk * KNN_K);
+        int *cand_i = (int *)pl.arena.alloc((size_t)B * nq * nblk * KNN_K * sizeof(int));
+        {
+            dim3 grid((nq * C + 255) / 256, B);
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(knn_queries_kernel, grid, dim3(256), 0, s, cvo.p, cvo.ld, cvo.bs, C, first_raw, nq, d_q); });
+        }
+        // the exhaustive exact scan below runs for every stream (the definition), or only for streams whose candidate set overflowed
+        int *d_overflow = (int *)pl.arena.alloc((size_t)B * sizeof(int));
+        if (fast) {
+            float *d_approx = pl.arena.floats((size_t)Qpad * e->index_n);
+            float *d_qf = pl.arena.floats((size_t)Qpad * C);
+            const int n_idx = (int)e->index_n;
+            {
+                dim3 grid(Qpad / 16, C / 16); int *ovf = d_overflow; const int nb = B;
+                pl.ops.push_back([=](hipStream_t s) {
+                    HIPCHK(hipMemsetAsync(ovf, 0, (size_t)nb * sizeof(int), s));
+                    hipLaunchKernelGGL(knn_pack_queries_kernel, grid, dim3(64), 0, s, d_q, Q, C, d_qf);
+                });
+            }
+            ConvW qw; qw.w = d_qf; qw.bias = nullptr; qw.M = Qpad; qw.K = C; qw.Kp = C; qw.Cin = C; qw.Cout = Qpad; qw.KW = 1; qw.groups = 1; qw.nphase = 1; qw.owns = false;
+            T1 xi; xi.p = e->d_indexT; xi.B = 1; xi.C = C; xi.T = n_idx; xi.ld = n_idx; xi.halo = 0; xi.bs = (long long)C * n_idx;
+            T1 ya; ya.p = d_approx; ya.B = 1; ya.C = Qpad; ya.T = n_idx; ya.ld = n_idx; ya.halo = 0; ya.bs = (long long)Qpad * n_idx;
+            ConvOpts o; o.no_bias = true; o.res = e->d_nhn; o.res_cs = 0; o.res_bs = 0; o.scale = -2.0f;
+            add_conv1d(pl, qw, xi, ya, 1, 0, 1, o);
             KnnSelP sp{}; sp.approx = d_approx; sp.approx_bs = (long long)nq * e->index_n; sp.n = (int)e->index_n; sp.dim = C; sp.nq = nq;
             sp.index = e->d_index; sp.q = d_q; sp.q_bs = (long long)nq * C; sp.skip_head = (int)skip_head; sp.T = T; sp.R = (int)R; sp.first_raw = first_raw;
             sp.rate = e->index_rate; sp.phone = phone.p; sp.ph_cs = phone.ld; sp.ph_bs = phone.bs; sp.out_idx = pl.d_knn_idx; sp.out_dist = pl.d_knn_dist;
-            sp.overflow = d_overflow; sp.wl_d = wl_d; sp.wl_i = wl_i; sp.wl_bs = (long long)nq * nwaves * 4;
+            sp.overflow = d_overflow;
             dim3 sgrid(nq, B);
             const size_t slds = (size_t)33 * (C + 4) * sizeof(float);
             if (slds > 128 * 1024) throw ShapeError("feature dimension too large for the retrieval kernel");
@@ -159,7 +164,7 @@ void ensure_index_transposed(rvc_engine *e)
 void retrieval_kernel_attrs()
 {
     HIPCHK(hipFuncSetAttribute((const void *)knn_select_blend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));   // + ~5 KB static
-    HIPCHK(hipFuncSetAttribute((const void *)knn_dot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void *)knn_scan_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
 }
 
 }  // namespace rvc

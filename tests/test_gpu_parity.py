@@ -353,6 +353,31 @@ def test_retrieval_degenerate_index_takes_exhaustive_fallback():
     assert rms(ye - yo) < PCM_TOL
 
 
+def test_retrieval_runs_of_duplicates_expand_the_workgroups_that_hide_them():
+    # one-launch retrieval (knn_scan_select_kernel): a workgroup publishes only its 4 best per query.  A run of near-identical vectors
+    # next to each other in the index (silence frames of a training set) puts more than four candidates inside ONE workgroup's slice: its
+    # list is saturated ("flagged") and the selector must re-rank every vector that workgroup scanned.  300 copies of the stream's own
+    # query rows (exact duplicates: ties by ascending index) in three runs, one of them across a workgroup boundary; the GPU's own
+    # un-blended queries go through the oracle's search: indices and distances bit-identical.
+    from oracle import oracle as O
+    z, ora, eng = _pair("tiny", taps=True)
+    x = voice_signal(g.input_buffer_16k_size, seed=3)
+    index = W.make_index(9000, 48, seed=11)
+    eng.load_index(index); eng.set_index_rate(0.0)
+    eng.infer(x, 2560, 12, 200, 21)
+    q = eng.tap("phone_ct").reshape(48, 21).T.copy()                  # un-blended queries
+    index[1000:1100] = q[4]                                           # a run inside one wave's tiles
+    index[4090:4190] = q[10] + np.float32(1e-4) * index[4090:4190]     # near-duplicates, not exact
+    index[8950:9000] = q[16]                                          # a run that ends with the index
+    eng.load_index(index); eng.reset_state(); eng.set_index_rate(0.5)
+    eng.infer(x, 2560, 12, 200, 21)
+    ie, de = eng.knn()
+    io, do = O.knn_search(index, q, 4)
+    assert np.array_equal(ie, io) and np.array_equal(de, do)
+    assert ie[4].tolist() == [1000, 1001, 1002, 1003] and ie[16].tolist() == [8950, 8951, 8952, 8953]
+    assert 4090 <= ie[10].min() and ie[10].max() < 4190
+
+
 def test_batched_streams_match_single_stream_oracles():
     # BASELINE config 4 in miniature: S concurrent streams batched per stage, each with its own state
     from oracle import oracle as O

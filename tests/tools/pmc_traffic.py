@@ -13,7 +13,7 @@ def load(path, counter):
     rows = []
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"])))
+            rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"]), int(r.get("Grid_Size") or 0) // max(1, int(r.get("Workgroup_Size") or 1))))
     rows.sort()
     return rows
 
@@ -25,10 +25,22 @@ def per_class(rows):
     body = rows[ends[1] + 1: ends[-1] + 1]          # skip warm-up chunk(s)
     n_chunks = len(ends) - 2
     acc = collections.defaultdict(lambda: [0, 0.0])
-    for _, name, v in body:
+    for _, name, v, _g in body:
         key = "igemm_all_instantiations" if ("igemm_kernel" in name or "igemm_lds_kernel" in name or "igemm2_kernel" in name or "igemm32_kernel" in name or "conv_tile_kernel" in name) else ("knn_dot_kernel" if "knn_dot_kernel" in name else None)
         if key:
             acc[key][0] += 1; acc[key][1] += v
+    return n_chunks, acc
+
+
+def by_kernel(rows, top=24):
+    """every kernel of the profiled chunks by (name, workgroups): where the bytes go"""
+    ends = [i for i, r in enumerate(rows) if "advance_chunk" in r[1]]
+    body = rows[ends[1] + 1: ends[-1] + 1]
+    n_chunks = len(ends) - 2
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for _, name, v, g in body:
+        short = name.replace("void rvc::", "").replace("rvc::", "").split("(")[0]
+        acc[(short, g)][0] += 1; acc[(short, g)][1] += v
     return n_chunks, acc
 
 
@@ -53,5 +65,13 @@ for key, (n, kib) in fa.items():
     else:
         d["algorithmic_bytes_per_launch"] = 307200000
     out[key] = d
+# the same passes per (kernel, workgroups): read bytes with the x2 correction, WRITE_SIZE raw KiB -> bytes
+nb, fk = by_kernel(fetch)
+wk = by_kernel(load(sys.argv[2], "WRITE_SIZE"))[1] if sys.argv[2] != "-" else {}
+tot = sum(v[1] for v in fk.values()) or 1.0
+out["by_kernel_note"] = "all kernels of a chunk by (kernel, workgroups), largest readers first; read_mb = 2 * FETCH_SIZE KiB * 1024 / 1e6 per launch, write_mb = WRITE_SIZE KiB * 1024 / 1e6 per launch (uncalibrated)"
+out["by_kernel"] = [{"kernel": k[0], "workgroups": k[1], "launches_per_chunk": round(n / nb, 2), "read_mb_per_launch": round(2 * 1024 * kib / n / 1e6, 2),
+                     "write_mb_per_launch": (round(1024 * wk[k][1] / wk[k][0] / 1e6, 2) if k in wk and wk[k][0] else None), "share_of_reads": round(kib / tot, 4)}
+                    for k, (n, kib) in sorted(fk.items(), key=lambda kv: -kv[1][1])[:40]]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
