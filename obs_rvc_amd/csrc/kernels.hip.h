@@ -1528,8 +1528,21 @@ struct KnnFusedP {
 #define KNN_STAMP(i) do { } while (0)
 #endif
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // a 16-byte global load from a dword-aligned address
+// minimum over the 64 lanes without LDS-crossbar shuffles: four DPP row rotations (every lane then holds its 16-lane row's minimum), the four
+// rows' values through v_readlane.  No NaN may come in.
+__device__ __forceinline__ float wave_min_dpp(float v)
+{
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false)));      // row_ror:1
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false)));      // row_ror:2
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false)));      // row_ror:4
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false)));      // row_ror:8
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return fminf(fminf(r0, r1), fminf(r2, r3));
+}
 #define KNN_FUSED_MAXG 1024            // workgroups per stream (a selector thread keeps 4 workgroup lists in registers)
-#define KNN_FUSED_ROWS 8               // candidate rows staged per round of the exact re-rank
+#define KNN_FUSED_ROWS 10              // candidate rows staged per round of the exact re-rank (<= 16: the final four are found among lanes 0..15)
 // dynamic LDS, in floats: scan = query rows + two buffers of partial tiles; select = query row + candidate ids + staged rows
 __host__ __device__ inline size_t knn_fused_lds_floats(int dim, int nqg, int G)
 {
@@ -1761,16 +1774,13 @@ static __global__ __launch_bounds__(256) void knn_scan_select_kernel(KnnFusedP p
             }
         }
         {
+            // the wave's four smallest, with multiplicity: the minimum of the lanes' heads, the lowest lane holding it moves on
             int pos = 0;
             for (int k = 0; k < KNN_K; k++) {
                 const float d0 = pos == 0 ? td[0] : pos == 1 ? td[1] : pos == 2 ? td[2] : pos == 3 ? td[3] : INFINITY;
-                float md = d0; int ml = lane;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float od = __shfl_xor(md, o, 64); const int ol = __shfl_xor(ml, o, 64);
-                    if (od < md || (od == md && ol < ml)) { md = od; ml = ol; }
-                }
-                if (ml == lane && md < INFINITY) pos++;
+                const float md = wave_min_dpp(d0);
+                const unsigned long long holders = __ballot(d0 == md && md < INFINITY);
+                if (holders && lane == __ffsll((long long)holders) - 1) pos++;
                 if (lane == 0) wd[wave][k] = md;
             }
         }
@@ -1903,7 +1913,7 @@ static __global__ __launch_bounds__(256) void knn_scan_select_kernel(KnnFusedP p
                 int mi = pos == 0 ? bi[0] : pos == 1 ? bi[1] : pos == 2 ? bi[2] : pos == 3 ? bi[3] : 0x7fffffff;
                 int ml = lane;
 #pragma unroll
-                for (int o = KNN_FUSED_ROWS / 2; o > 0; o >>= 1) {
+                for (int o = 8; o > 0; o >>= 1) {
                     const float od = __shfl_xor(md, o, 64); const int oi = __shfl_xor(mi, o, 64), ol = __shfl_xor(ml, o, 64);
                     if (oi != 0x7fffffff && (mi == 0x7fffffff || od < md || (od == md && oi < mi))) { md = od; mi = oi; ml = ol; }
                 }
