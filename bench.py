@@ -214,7 +214,7 @@ def committed_traffic(S):
         src["traffic_note"] = "REFUSED: the committed pass was taken on build %s, this library is %s -- rerun tests/tools/profile_round.sh" % (d.get("build"), have)
         return None, None, src
     ig = d.get("igemm_all_instantiations") or {}
-    kd = d.get("knn_dot_kernel") or {}
+    kd = d.get("knn_scan_select_kernel") or d.get("knn_dot_kernel") or {}
     src["traffic_launches_per_step"] = ig.get("launches_per_chunk")
     src["traffic_bytes_per_step"] = ig.get("hbm_read_bytes_per_chunk")
     src["algorithmic_weight_bytes_per_step"] = ig.get("algorithmic_weight_bytes_per_chunk")
@@ -253,7 +253,7 @@ def roofline_of(eng, step, S, reps=5):
     roof.update(t_src)
     if k_n:
         ach = k_by / (k_ms * 1e-3) / 1e9
-        roof["retrieval_scan"] = {"bound": "hbm", "kernel": "rvc::knn_dot_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof["retrieval_scan"] = {"bound": "hbm", "kernel": "rvc::knn_scan_select_kernel (one launch: scan + select + exact re-rank + blend; the duration is the whole launch)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": k_by / k_n, "avg_launch_us": round(k_ms * 1e3 / k_n, 2),
                                   "traffic": t_knn}
     return roof

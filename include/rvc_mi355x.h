@@ -181,7 +181,7 @@ float rvc_last_gpu_ms(rvc_engine *e);
 /* HIP-event timing of the dominant (implicit-GEMM) kernel class over the last infer call:
  * number of launches, summed milliseconds, summed algorithmic FLOPs (2*M*N*K per launch) */
 rvc_status rvc_profile_last(rvc_engine *e, int *launches, double *kernel_ms, double *flops);
-/* same for the HBM-bound retrieval scan (knn_dot_kernel): launches, summed ms, summed algorithmic bytes (index size per pass) */
+/* same for the HBM-bound retrieval launch (knn_scan_select_kernel: scan, select, exact re-rank and blend in one launch): launches, summed ms, summed algorithmic bytes (index size per pass) */
 rvc_status rvc_profile_last_knn(rvc_engine *e, int *launches, double *kernel_ms, double *bytes);
 void rvc_set_profile(rvc_engine *e, int on);
 /* named intermediate tensor of stream 0 of the last call, contiguous row-major (tests).  on = 1: taps on the EXPLICIT plan (every

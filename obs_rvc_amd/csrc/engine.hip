@@ -1114,7 +1114,7 @@ int rvc_debug_profile_dump(rvc_engine *e, char *buf, size_t cap)
         float t = 0.f;
         if (hipEventElapsedTime(&t, pl.prof[i].a, pl.prof[i].b) != hipSuccess) continue;
         char ln[320];
-        snprintf(ln, sizeof ln, "%.2f %.4f %s\n", t * 1e3, pl.prof[i].flops * 1e-9, pl.prof[i].desc >= 0 ? pl.descs[pl.prof[i].desc].c_str() : (pl.prof[i].bytes > 0 ? "knn_dot" : "?"));
+        snprintf(ln, sizeof ln, "%.2f %.4f %s\n", t * 1e3, pl.prof[i].flops * 1e-9, pl.prof[i].desc >= 0 ? pl.descs[pl.prof[i].desc].c_str() : (pl.prof[i].bytes > 0 ? "knn_scan_select" : "?"));
         out += ln;
     }
     if (out.size() + 1 > cap) return -1;

@@ -436,6 +436,27 @@ __global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) void igemm_kernel(IgemmP p)
     }
 }
 
+// Workgroups reach the 8 XCDs round-robin in dispatch order (block b of a launch on XCD (b + c) % 8, tests/tools/xcd_probe.hip), and every XCD
+// has its own L2.  With m-fastest tile order on the raw block index the m-tiles of one activation tile sat on ntm DIFFERENT XCDs, and every
+// one of them fetched the tile again (round 4 PMC pass per kernel: the 768 x 3072 projection at 64 streams read 471 MB per launch for 118 MB
+// of operands, the first stride-2 stem convolution 4.4 GB for 0.94).  xcd_tile_id gives the workgroups that one XCD receives CONSECUTIVE tile
+// ids: an XCD then owns whole activation tiles (each fetched once), and only the weights -- the small operand when streams are folded into N --
+// are fetched once per XCD.  Scalar arithmetic, once per workgroup.  (The tiled kernels take m_fast = 1 for this order and m_fast = 2 for the raw
+// block index: when the m-tile count is a multiple of 8 AND the weights exceed an L2 -- ContentVec's 3072 x 768 projection, 24 m-tiles, 9.4 MB --
+// the raw order keeps every weight-row block on ONE XCD and streams the small activation tensor through all eight: 218 MB per launch against 319.)
+__device__ __forceinline__ int xcd_tile_id(int x, int gx, int row_start)
+{
+    const int off = row_start & 7, c = (x + off) & 7;
+    int base = 0;
+#pragma unroll
+    for (int cc = 0; cc < 8; cc++) {
+        const int f = (cc - off) & 7;
+        const int cnt = f < gx ? (gx - f + 7) >> 3 : 0;
+        base += cc < c ? cnt : 0;
+    }
+    return base + ((x - ((c - off) & 7)) >> 3);
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // igemm2_kernel -- the same tile computation as igemm_kernel with a lean launch prologue / epilogue for the one-stream
 // latency chain (measured with tests/tools/kprobe.py: of the 16 us a 0.5 GFLOP ContentVec GEMM took, 2.0 us went from wave
@@ -998,9 +1019,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     extern __shared__ __attribute__((aligned(16))) int s_mem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    // m fastest when the streams are folded into N: consecutive workgroups (= consecutive XCDs) take the m-tiles of ONE activation
-    // tile, so a weight-row block stays in one XCD's L2 while the activations stream through once per XCD
-    const int tn = p.m_fast ? (int)blockIdx.x / p.ntm : (int)blockIdx.x % p.ntn, tm = p.m_fast ? (int)blockIdx.x % p.ntm : (int)blockIdx.x / p.ntn;
+    // m fastest when the streams are folded into N, over XCD-local tile ids (xcd_tile_id): the m-tiles of ONE activation tile run on one XCD
+    const int tid_x = p.m_fast == 1 ? xcd_tile_id((int)blockIdx.x, (int)gridDim.x, (int)(blockIdx.y * gridDim.x)) : (int)blockIdx.x;
+    const int tn = p.m_fast ? tid_x / p.ntm : tid_x % p.ntn, tm = p.m_fast ? tid_x % p.ntm : tid_x / p.ntn;
     int z = blockIdx.y;
     const int phase = z % p.nphase;
     const int b = z / p.nphase;
@@ -1194,7 +1215,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     RVC_KP(0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int tn = p.m_fast ? (int)blockIdx.x / p.ntm : (int)blockIdx.x % p.ntn, tm = p.m_fast ? (int)blockIdx.x % p.ntm : (int)blockIdx.x / p.ntn;
+    const int tid_x = p.m_fast == 1 ? xcd_tile_id((int)blockIdx.x, (int)gridDim.x, (int)(blockIdx.y * gridDim.x)) : (int)blockIdx.x;
+    const int tn = p.m_fast ? tid_x / p.ntm : tid_x % p.ntn, tm = p.m_fast ? tid_x % p.ntm : tid_x / p.ntn;
     int z = blockIdx.y;
     const int phase = z % p.nphase;
     const int b = z / p.nphase;

@@ -377,7 +377,9 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         const int bn = lds_cfg == 7 ? 64 : ((lds_cfg != 6 && lds_cfg % 3 == 0) ? 128 : 256);
         p.ksplit = 1; p.chunks_per_split = nchunks;
         p.ntm = (p.M + bm - 1) / bm; p.ntn = (p.N + bn - 1) / bn;
-        p.m_fast = p.fold_n ? p.ntm : 0;
+        // tile order of the tiled kernels when the streams are folded into N: m fastest over XCD-local tile ids (1), or over the raw block index (2)
+        // where that keeps a large weight matrix partitioned over the XCDs (igemm.hip.h, xcd_tile_id)
+        p.m_fast = p.fold_n ? ((p.ntm % 8 == 0 && (size_t)p.M * (size_t)ksum * sizeof(float) > ((size_t)4 << 20)) ? 2 : 1) : 0;
         dim3 grid(p.ntm * p.ntn, B * p.nphase);
         const bool g32k = lds_cfg >= 3 && lds_cfg != 6;            // igemm32_kernel keeps its activation tile column-major, [2][bn][20]
         const size_t lds = (size_t)nchunks * 64 + (g32k ? (size_t)2 * bn * 20 * 4 : (size_t)2 * 16 * (bn + 4) * 4);

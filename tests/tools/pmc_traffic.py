@@ -26,7 +26,7 @@ def per_class(rows):
     n_chunks = len(ends) - 2
     acc = collections.defaultdict(lambda: [0, 0.0])
     for _, name, v, _g in body:
-        key = "igemm_all_instantiations" if ("igemm_kernel" in name or "igemm_lds_kernel" in name or "igemm2_kernel" in name or "igemm32_kernel" in name or "conv_tile_kernel" in name) else ("knn_dot_kernel" if "knn_dot_kernel" in name else None)
+        key = "igemm_all_instantiations" if ("igemm_kernel" in name or "igemm_lds_kernel" in name or "igemm2_kernel" in name or "igemm32_kernel" in name or "conv_tile_kernel" in name) else ("knn_scan_select_kernel" if "knn_scan_select_kernel" in name else None)
         if key:
             acc[key][0] += 1; acc[key][1] += v
     return n_chunks, acc
