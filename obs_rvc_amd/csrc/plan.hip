@@ -366,6 +366,16 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
             static const long long g32_min = tune_env("RVC_GEMM32_MIN") ? atoll(tune_env("RVC_GEMM32_MIN")) : 768;   // fewer workgroups balance badly over 256 CUs (measured: 336 -> slower)
             if (g32 == 1 && lds_cfg >= 0 && !p.glu) lds_cfg += 3;
             else if (g32 >= 2 && wgs >= g32_min && !p.glu) lds_cfg = 3 + (bm == 128 ? 0 : (bm == 64 ? 1 : 2));   // (gated layers stay on the kernels that are tested with the gate)
+            // ... and from 500 workgroups wherever the 16x16x4 LDS kernel would run (tall panels at 32 streams: 2133 -> 2081, 1470 -> 1454 us)
+            else if (g32 >= 2 && lds_cfg >= 0 && wgs >= 500 && !p.glu && !tune_env("RVC_NO_G32_SHORT")) lds_cfg = 3 + (bm == 128 ? 0 : (bm == 64 ? 1 : 2));
+            else if (g32 >= 2 && !p.glu && p.M <= 64 && p.M > 16 && !tune_env("RVC_NO_G32_SHORT")) {
+                // short weight panels below that count (the decoder's 64- and 32-channel stages at 16-32 streams): 32-row tiles double the
+                // workgroups of a 64-channel layer, and from ~600 of them the 32x32x2 kernel beats both the register-direct kernel and the
+                // 16x16x4 LDS kernel (round 4, 16 streams, per layer: M = 64: 807 / 542 / 307 -> 606 / 408 / 210 us; M = 32: 354 / 247 / 143 ->
+                // 330 / 232 / 132 us; with 64-row tiles -- 315 workgroups -- 688 / 460 / 236)
+                const long long wgs32 = (long long)((p.M + 31) / 32) * ((p.N + 255) / 256) * B * p.nphase;
+                if (wgs32 >= 600) lds_cfg = 3 + 2;
+            }
         }
     }
     // 48-row panels (ContentVec's grouped positional convolution: 16 groups of 48 channels, K = 6144 each): three 16-row fragments
@@ -374,7 +384,10 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
     // mid-size panels (M = 768 at 64 streams: 336 tiles of 128 x 128 balance badly over 256 CUs, and the register-direct 2 x 4 tile runs
     // at two waves per SIMD): 128 x 64 tiles of the 32x32x2 kernel, four waves stacked in M over one 64-column activation tile
     // (768 x 3072 projection at 64 streams: 361 -> 342 us; small, but the same kernel)
-    static const long long g32_narrow_min = tune_env("RVC_G32_NARROW") ? atoll(tune_env("RVC_G32_NARROW")) : 500;     // 0 = off
+    // (round 4, per layer at 8 / 32 streams: from 250 workgroups for panels of >= 512 rows -- 3072 x 768 at 8 streams 886 -> 800 us, 768 x 3072 at 32
+    // streams 3006 -> 2774, 768 x 768 883 -> 771 --; a 256-row panel with 252 workgroups loses to the register-direct kernel, 731 -> 1103)
+    static const long long g32_narrow_env = tune_env("RVC_G32_NARROW") ? atoll(tune_env("RVC_G32_NARROW")) : -1;     // 0 = off
+    const long long g32_narrow_min = g32_narrow_env >= 0 ? g32_narrow_env : (p.M >= 512 ? 250 : 500);
     if (lds_cfg < 0 && !ln_fold && g32_narrow_min > 0 && !tune_env("RVC_NO_LDS_GEMM") && !p.glu && nchunks >= 2 && p.M >= 96 && (size_t)nchunks * 64 + 2 * 64 * 20 * 4 <= 60 * 1024) {
         const long long wgs = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * B * p.nphase;
         if (wgs >= g32_narrow_min) lds_cfg = 7;

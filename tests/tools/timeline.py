@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Tuning aid: section timeline of one chunk (RVC_STAMPS=1 device timestamps) for a given stream count / model version.
+"""Tuning aid: section timeline of one chunk (test hook RVC_STAMPS: device timestamps) for a given stream count / model version.
 usage: python tests/tools/timeline.py [streams] [version]"""
 import ctypes
 import os
@@ -7,14 +7,14 @@ import sys
 
 import numpy as np
 
-os.environ["RVC_STAMPS"] = "1"
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
-from common import BASELINE_160MS as g, voice_signal, zoo  # noqa: E402
+from common import BASELINE_160MS as g, set_opt, voice_signal, zoo  # noqa: E402
 from obs_rvc_amd.rvc import RvcInfer  # noqa: E402
 
+set_opt("RVC_STAMPS", "1")          # test hook (rvc_debug_option): device timestamps at the section boundaries
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 ver = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 z = zoo("full", ver)
