@@ -333,7 +333,8 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
     // chains' average into one K-concatenated GEMM was also measured: no gain)
     bool uneven = false;
     for (const PhaseD &q : phv) uneven = uneven || q.nchunks != phv[0].nchunks;
-    const long long want_waves = (uneven && p.M >= 64) ? 2048 : 1024;
+    long long want_waves = (uneven && p.M >= 64) ? 2048 : 1024;
+    if (const char *f = tune_env("RVC_WANT_WAVES")) { if (p.fold_n) want_waves = atoll(f); }      // tuning aid
     for (int oi = 0; oi < 3 && !found; oi++) {
         const int c = order[oi];
         for (int ks = 1; ks <= 16; ks = ks == 1 ? 4 : ks * 2) {
@@ -341,6 +342,13 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
             if ((size_t)nchunks * 64 + (ks > 1 ? (size_t)ks * kMF[c] * kNF[c] * 1024 : 0) > 60 * 1024) break;
             const long long w = tiles(c) * ks;
             if (w > best_waves) { best_waves = w; cfg = c; wg_ks = ks; }
+            // streams folded into N: the workgroups must also spread evenly over the CUs (768 x 3072 at 8 streams: 336 workgroups of 32 x 64 tiles
+            // are one or two per CU, 52 TF/s; 672 of 32 x 32 tiles 68 TF/s).  Below four rounds a last round under 80 % full sends the choice on
+            // to the next smaller tile.  (One stream keeps its own, latency-tuned rule.)
+            if (p.fold_n && oi == 0 && !tune_env("RVC_NO_BALANCE")) {         // (one step down only: the 16 x 16 tile loses more than an uneven last round costs)
+                const long long wgs = ks > 1 ? tiles(c) : (tiles(c) + 3) / 4, rounds = (wgs + g_ncu - 1) / g_ncu;
+                if (rounds < 4 && wgs * 5 < rounds * g_ncu * 4) continue;
+            }
             if (w >= want_waves) { cfg = c; wg_ks = ks; found = true; break; }
         }
     }
