@@ -59,6 +59,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="accepted for compatibility: eager launches are the default")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--dry-launch", action="store_true", help="multi-rank plumbing only (gloo, no GPU work)")
+    ap.add_argument("--legs", default="", help="measurement aid: run only these sub_configs legs (comma-separated names; default: all)")
     ap.add_argument("--preset", default="full")
     return ap.parse_args(argv)
 
@@ -291,7 +292,8 @@ def run_config(job, z, g, S, with_index, steps, warmup, graph, index_vecs, want_
     d_rings = torch.from_numpy(rings).cuda()
     d_out = torch.empty((S, g.model_return_size), dtype=torch.float32, device="cuda")
     elapsed, lat, step = timed_leg(job, eng, d_rings, d_out, g, steps, warmup)
-    soak_lat = []
+    gpu_ms_last = eng.last_gpu_ms()            # device time of the last timed chunk (events around the call's launches): next to the wall clock, it
+    soak_lat = []                              # tells a slow GPU from a slow submitting thread
     for i in range(soak):                        # latency distribution: more synchronised chunks behind the timed region
         t1 = time.perf_counter(); step(i); soak_lat.append(time.perf_counter() - t1)
     lat_all = job.gather(lat)
@@ -307,6 +309,7 @@ def run_config(job, z, g, S, with_index, steps, warmup, graph, index_vecs, want_
                "retrieval": "100k x768 flat-L2 k=4 rate 0.75" if with_index else "off",
                "latency_ms": {"p50": pct(allat, 50), "p99": pct(allat, 99), "p99.9": pct(allat, 99.9), "max": round(float(allat.max()) * 1e3, 4),
                               "samples": int(allat.size)},
+               "gpu_ms_last_chunk": round(float(gpu_ms_last), 4),
                "rtf": round(float(np.percentile(allat, 99)) / 0.160, 5),
                "per_rank_frames_per_s": [round(v, 1) for v in per_rank]}
         if with_index:
@@ -513,6 +516,8 @@ def main(argv=None):
         sub_soak = int(os.environ.get("RVC_BENCH_SUB_SOAK", "200"))
 
         def leg(name, fn):
+            if args.legs and name not in args.legs.split(","):
+                return
             try:
                 sub[name] = fn()
             except Exception as ex:

@@ -79,7 +79,6 @@ struct IgemmP {
     unsigned long long *probe;   // tuning build only (-DRVC_KPROBE): per-wave phase timestamps
     int m_fast;              // XCD-aware tile order: >0 = ntm rounded up to 8, m fastest (workgroup b runs on XCD b%8, so all
                              // n-tiles of one weight-row block share one XCD's L2); 0 = n fastest (activation-heavy layers)
-    int xcd_n;               // igemm2, n-fastest order: != 0 = blockIdx.x goes through xcd_tile_id (an XCD owns a contiguous range of n-tiles for every m-tile)
     int nbatch;              // igemm2: streams in the launch (grid z = batch * nphase + phase)
     int fold_n;              // > 0: the streams of the launch are folded into the N axis: position n = stream (n / fold_n), local position
                              // (n % fold_n); N = streams * fold_n and the launch has one batch (tiles may straddle streams, nothing is padded per stream)
@@ -601,8 +600,7 @@ void igemm2_kernel(IgemmP p)
     RVC_KP(0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int bx = p.xcd_n ? xcd_tile_id((int)blockIdx.x, (int)gridDim.x, (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x)) : (int)blockIdx.x;
-    const int fast = KS > 1 ? bx : bx * 4 + wave, slow = (int)blockIdx.y;
+    const int fast = KS > 1 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave, slow = (int)blockIdx.y;
     const int tm = p.m_fast ? fast : slow, tn = p.m_fast ? slow : fast;
     int phase = 0, b = 0;
     {

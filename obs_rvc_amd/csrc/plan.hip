@@ -236,7 +236,8 @@ static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &
     // XCDs every tile fetched its own copy of the lines it shares with its neighbours (a 16-column tile with a 50-column halo on each side reads
     // five cache lines and owns half of one; round 4 PMC pass per kernel: 30.6 MB per launch for 2 MB of operands).  Slot j of a round therefore
     // takes bin (j % 8) * (nb / 8) + j / 8: an XCD gets CONSECUTIVE bins = consecutive n-tiles.
-    auto slot_bin = [&](int j) { return nb % 8 == 0 ? (j % 8) * (nb / 8) + j / 8 : j; };
+    const bool xcd_bins = nb % 8 == 0 && !tune_env("RVC_NO_TILE_XCD");
+    auto slot_bin = [&](int j) { return xcd_bins ? (j % 8) * (nb / 8) + j / 8 : j; };
     std::vector<int> order(rounds * nb * 2, -1);
     for (int j = 0; j < nb; j++) {
         const std::vector<int> &bn = bins[slot_bin(j)];
@@ -488,9 +489,6 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         if (weight_heavy && ((wg_ks > 1 && gx >= 8) || gx >= 16)) gx = (gx + 7) / 8 * 8;
         grid = dim3(gx, (unsigned)slow_n, (unsigned)(B * p.nphase));
         if (grid.y > 65535 || grid.z > 65535) throw ShapeError("implicit GEMM grid too large");
-        // activation-heavy layers (n fastest): neighbouring n-tiles share cache lines and halos, and every XCD has its own L2 -- an XCD takes a
-        // contiguous range of n-tiles, the same range for every m-tile (ContentVec's first stride-2 convolution read 83.6 MB for 18 MB of operands)
-        p.xcd_n = (!weight_heavy && gx >= 16 && !tune_env("RVC_NO_XCD_N")) ? 1 : 0;
         p.nbatch = B;
         lds2 = (lin ? 0 : (size_t)nchunks * 64) + (wg_ks > 1 ? (size_t)wg_ks * kMF[cfg] * kNF[cfg] * 1024 : 0) + (p.ln_wsum ? (size_t)wg_ks * kNF[cfg] * 16 * 2 * 4 : 0);
         if (p.ln_wsum && !lin) throw std::logic_error("LayerNorm consumer did not get the table-free kernel");
