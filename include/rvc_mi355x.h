@@ -79,7 +79,8 @@ const char *rvc_last_error_message(rvc_engine *e);
 rvc_status rvc_load_index(rvc_engine *e, const float *vectors, size_t n, size_t dim);
 rvc_status rvc_load_index_device(rvc_engine *e, const void *d_vectors, size_t n, size_t dim);  /* already in HBM (RCCL-broadcast) */
 void rvc_set_index_rate(rvc_engine *e, float rate);
-/* kNN hits of the last infer: idx[rows][4], squared distances */
+/* kNN hits of the last infer: idx[rows][4], squared distances; rows = return_length for stream 0, followed (stream-major) by the rows of as many
+   further streams of a batched call as cap_rows holds whole */
 rvc_status rvc_get_knn(rvc_engine *e, int32_t *idx, float *dist, size_t cap_rows, size_t *rows);
 /* the synthesizer's two noise inputs are explicit counter-based (Philox4x32-10) streams */
 void rvc_set_noise_seed(rvc_engine *e, uint32_t seed, uint32_t stream_id);

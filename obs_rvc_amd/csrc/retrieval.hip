@@ -216,9 +216,10 @@ rvc_status rvc_get_knn(rvc_engine *e, int32_t *idx, float *dist, size_t cap_rows
     return guarded(e, [&]() {
         Plan *pl = e->last_plan;
         if (!pl || !pl->with_index) { if (rows) *rows = 0; return RVC_OK; }
-        const size_t r = pl->R;
+        // stream 0's return_length rows always; the further streams' rows (stream-major) as far as the caller's capacity holds whole streams
+        if (cap_rows < pl->R) { if (rows) *rows = pl->R; return RVC_SHAPE; }
+        const size_t r = pl->R * std::min((size_t)pl->B, cap_rows / pl->R);
         if (rows) *rows = r;
-        if (cap_rows < r) return RVC_SHAPE;
         HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMemcpy(idx, pl->d_knn_idx, r * KNN_K * sizeof(int), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(dist, pl->d_knn_dist, r * KNN_K * sizeof(float), hipMemcpyDeviceToHost));

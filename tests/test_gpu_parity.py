@@ -378,6 +378,40 @@ def test_retrieval_runs_of_duplicates_expand_the_workgroups_that_hide_them():
     assert 4090 <= ie[10].min() and ie[10].max() < 4190
 
 
+def test_retrieval_two_query_groups_and_three_streams_in_one_launch_each():
+    # knn_scan_select_kernel takes 16 queries per launch and one grid row per stream.  The plugin's default 300 ms chunk slices 35 frames =
+    # 18 unique queries: two launches (16 + 2 queries, the second with fewer selectors than a full group); three streams with their own inputs
+    # share the launches (grid.y = 3, a third of the workgroups each).  Hits of every stream against its own oracle, bit-exact.
+    from common import derive
+    from oracle import oracle as O
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("tiny")
+    q = derive(48000, 0.30, 0.07, 2.0, 48000)
+    assert (q.skip_head + q.model_return_length - 1) // 2 - q.skip_head // 2 + 1 > 16          # really two groups
+    S = 3
+    index = W.make_index(6000, 48, seed=13)
+    eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"])
+    eng.set_streams(S); eng.set_noise_seed(77, 5); eng.load_index(index); eng.set_index_rate(0.6)
+    oras = []
+    for s in range(S):
+        o = O.OracleRvcInfer(z["data"]); o.load_contentvec(2); o.load_f0(1); o.load_model(z["model"]); o.set_noise_seed(77, 5 + s)
+        o.load_index(index); o.set_index_rate(0.6)
+        oras.append(o)
+    for tick in range(2):
+        xin = np.stack([voice_signal(q.input_buffer_16k_size, seed=400 + 10 * tick + s) for s in range(S)])
+        ye = eng.infer_batch(xin, q.sample_frame_16k, [12, 0, -5], q.skip_head, q.model_return_length)
+        ie, de = eng.knn(rows_cap=S * 64)
+        R = q.model_return_length
+        assert ie.shape == (S * R, 4)
+        for s in range(S):
+            yo = oras[s].infer(xin[s], q.sample_frame_16k, [12, 0, -5][s], q.skip_head, q.model_return_length)
+            io, do = oras[s].knn()
+            assert np.array_equal(ie[s * R:(s + 1) * R], io), (tick, s)
+            assert np.allclose(de[s * R:(s + 1) * R], do, rtol=1e-4)
+            assert rms(ye[s] - yo) < PCM_TOL, (tick, s)
+    eng.close()
+
+
 def test_batched_streams_match_single_stream_oracles():
     # BASELINE config 4 in miniature: S concurrent streams batched per stage, each with its own state
     from oracle import oracle as O
