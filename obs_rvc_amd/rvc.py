@@ -143,6 +143,8 @@ class RvcInfer:
         self._L.rvc_set_index_rate(self._h, float(rate))
 
     def knn(self, rows_cap: int = 4096):
+        """hits of the last infer: (rows, 4) indices and squared distances; rows = return_length per stream, stream-major, for as many streams
+        of a batched call as rows_cap holds whole"""
         idx = np.empty((rows_cap, 4), np.int32)
         dist = np.empty((rows_cap, 4), np.float32)
         rows = C.c_size_t()

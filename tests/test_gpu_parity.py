@@ -378,6 +378,24 @@ def test_retrieval_runs_of_duplicates_expand_the_workgroups_that_hide_them():
     assert 4090 <= ie[10].min() and ie[10].max() < 4190
 
 
+@pytest.mark.parametrize("n", [4, 5, 17, 130])
+def test_retrieval_index_smaller_than_the_grid(n):
+    # the one-launch retrieval sizes its grid by the index: fewer 16-vector tiles than queries means fewer selectors than queries (each
+    # takes several in turn), one tile means ONE workgroup that scans, publishes, waits for itself and selects all eleven queries
+    from oracle import oracle as O
+    z, ora, eng = _pair("tiny", taps=True)
+    index = W.make_index(n, 48, seed=21 + n)
+    ora.load_index(index); ora.set_index_rate(0.5)
+    eng.load_index(index); eng.set_index_rate(0.5)
+    x = voice_signal(g.input_buffer_16k_size, seed=3)
+    for _ in range(2):
+        yo = ora.infer(x, 2560, 12, 200, 21)
+        ye = eng.infer(x, 2560, 12, 200, 21)
+        io, do = ora.knn(); ie, de = eng.knn()
+        assert np.array_equal(ie, io) and np.allclose(de, do, rtol=1e-4)
+        assert rms(ye - yo) < PCM_TOL
+
+
 def test_retrieval_two_query_groups_and_three_streams_in_one_launch_each():
     # knn_scan_select_kernel takes 16 queries per launch and one grid row per stream.  The plugin's default 300 ms chunk slices 35 frames =
     # 18 unique queries: two launches (16 + 2 queries, the second with fewer selectors than a full group); three streams with their own inputs
