@@ -1848,27 +1848,52 @@ static __global__ __launch_bounds__(256) void knn_scan_select_kernel(KnnFusedP p
 #ifdef RVC_KNN_STAMPS
                 const long long cyc0 = clock64();
 #endif
-                // two register sets of 32 differences each: one is consumed while the other is on its way from LDS
-                auto fetch = [&](f32x4 (&r)[8], int d) {
+                // two register sets of 32 differences each: one is consumed while the other is on its way from LDS.  Dimensions that are a
+                // multiple of 64 (768, 256) take the loop without per-group guards (the guards compile to a select and five scalar
+                // instructions per four dimensions, in the middle of the dependent chain)
+                f32x4 ra[8], rb[8];
+                if ((p.dim & 63) == 0) {
 #pragma unroll
-                    for (int u = 0; u < 8; u++) r[u] = *reinterpret_cast<const f32x4 *>(v + (d + 4 * u < p.dim ? d + 4 * u : 0));
-                };
-                auto chain = [&](const f32x4 (&r)[8], int d) {
+                    for (int u = 0; u < 8; u++) ra[u] = *reinterpret_cast<const f32x4 *>(v + 4 * u);
+                    for (int d = 0; d < p.dim; d += 64) {
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        if (d + 4 * u < p.dim) {
+                        for (int u = 0; u < 8; u++) rb[u] = *reinterpret_cast<const f32x4 *>(v + d + 32 + 4 * u);
 #pragma unroll
-                            for (int i = 0; i < 4; i++) acc = fmaf(r[u][i], r[u][i], acc);
+                        for (int u = 0; u < 8; u++) {
+#pragma unroll
+                            for (int i = 0; i < 4; i++) acc = fmaf(ra[u][i], ra[u][i], acc);
+                        }
+                        if (d + 64 < p.dim) {
+#pragma unroll
+                            for (int u = 0; u < 8; u++) ra[u] = *reinterpret_cast<const f32x4 *>(v + d + 64 + 4 * u);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+#pragma unroll
+                            for (int i = 0; i < 4; i++) acc = fmaf(rb[u][i], rb[u][i], acc);
                         }
                     }
-                };
-                f32x4 ra[8], rb[8];
-                fetch(ra, 0);
-                for (int d = 0; d < p.dim; d += 64) {
-                    fetch(rb, d + 32);
-                    chain(ra, d);
-                    fetch(ra, d + 64);
-                    chain(rb, d + 32);
+                } else {
+                    auto fetch = [&](f32x4 (&r)[8], int d) {
+#pragma unroll
+                        for (int u = 0; u < 8; u++) r[u] = *reinterpret_cast<const f32x4 *>(v + (d + 4 * u < p.dim ? d + 4 * u : 0));
+                    };
+                    auto chain = [&](const f32x4 (&r)[8], int d) {
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            if (d + 4 * u < p.dim) {
+#pragma unroll
+                                for (int i = 0; i < 4; i++) acc = fmaf(r[u][i], r[u][i], acc);
+                            }
+                        }
+                    };
+                    fetch(ra, 0);
+                    for (int d = 0; d < p.dim; d += 64) {
+                        fetch(rb, d + 32);
+                        chain(ra, d);
+                        fetch(ra, d + 64);
+                        chain(rb, d + 32);
+                    }
                 }
 #ifdef RVC_KNN_STAMPS
                 if (tid == 0 && blockIdx.y == 0) p.stamps[blockIdx.x * 16 + 1] = clock64() - cyc0 + (acc == 1.2345f ? 1 : 0);
