@@ -506,6 +506,16 @@ def test_graph_replay_equals_eager_and_device_api():
         assert n == len(ya)
         assert np.array_equal(d_out.cpu().numpy(), ya)                 # same kernels, same order -> bitwise equal
     assert eng2.last_gpu_ms() > 0
+    # ... and with retrieval: the one-launch kernel re-arms its own ticket counters, so a replayed graph finds them as the capture did
+    index = W.make_index(4000, 48, seed=17)
+    for e in (eng, eng2):
+        e.load_index(index); e.set_index_rate(0.5)
+    for i in range(4):
+        ya = eng.infer(x, 2560, 12, 200, 21)
+        n = eng2.infer_device(d_in.data_ptr(), len(x), 2560, 12, 200, 21, d_out.data_ptr(), d_out.numel(), sync=True)
+        assert n == len(ya) and np.array_equal(d_out.cpu().numpy(), ya)
+        ia, da = eng.knn(); ib, db = eng2.knn()
+        assert np.array_equal(ia, ib) and np.array_equal(da, db) and ia.shape == (21, 4)
 
 
 def test_linearity_of_retrieval_free_feature_path_properties():
