@@ -18,7 +18,7 @@ void launch_igemm2_cfg3(int ks, bool pre, bool lin, const IgemmP &p, dim3 grid, 
 void launch_igemm2_cfg4(int ks, bool pre, bool lin, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 // the first-generation kernel remains for the two-stage grid-level split-K (offset table too long for LDS): 16x16 tiles only
 void launch_igemm_v1(bool pre, const IgemmP &p, dim3 grid, hipStream_t s);
-// workgroup-tiled throughput kernels: lc 0-2 / 6 = igemm_lds_kernel (128x128, 64x256, 32x256, 48x256), 3-5 / 7 = igemm32_kernel
+// workgroup-tiled throughput kernels: lc 0-2 / 6 = igemm_lds_kernel (128x128, 64x256, 32x256, 48x256), 3-5 / 7 / 8 = igemm32_kernel
 void launch_igemm_tiled(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
 
 void launch_igemm_tiled_p0(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);

@@ -32,7 +32,7 @@ void launch_igemm_v1(bool pre, const IgemmP &p, dim3 grid, hipStream_t s)
 void launch_igemm_tiled(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
 {
     if (lc == 0 || lc == 1) launch_igemm_tiled_p0(lc, pre, p, grid, lds, s, ea, eb);
-    else if (lc == 2 || lc == 6) launch_igemm_tiled_p1(lc, pre, p, grid, lds, s, ea, eb);
+    else if (lc == 2 || lc == 6 || lc == 8) launch_igemm_tiled_p1(lc, pre, p, grid, lds, s, ea, eb);
     else if (lc == 3 || lc == 4) launch_igemm_tiled_p2(lc, pre, p, grid, lds, s, ea, eb);
     else launch_igemm_tiled_p3(lc, pre, p, grid, lds, s, ea, eb);
 }
@@ -44,7 +44,7 @@ void launch_igemm_tiled(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds
 void launch_igemm_tiled_p0(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb) { if (lc == 0) RVC_LG(2, 2, 4, 4) else RVC_LG(1, 4, 4, 4) }
 #endif
 #if RVC_TILED_PART == 1 || defined(RVC_UNITY)
-void launch_igemm_tiled_p1(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb) { if (lc == 2) RVC_LG(1, 4, 2, 4) else RVC_LG(1, 4, 3, 4) }
+void launch_igemm_tiled_p1(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb) { if (lc == 2) RVC_LG(1, 4, 2, 4) else if (lc == 8) RVC_LG32(2, 2, 1, 1) else RVC_LG(1, 4, 3, 4) }
 #endif
 #if RVC_TILED_PART == 2 || defined(RVC_UNITY)
 void launch_igemm_tiled_p2(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb) { if (lc == 3) RVC_LG32(2, 2, 2, 2) else RVC_LG32(1, 4, 2, 2) }

@@ -400,10 +400,13 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
     if (lds_cfg < 0 && !ln_fold && g32_narrow_min > 0 && !tune_env("RVC_NO_LDS_GEMM") && !p.glu && nchunks >= 2 && p.M >= 96 && (size_t)nchunks * 64 + 2 * 64 * 20 * 4 <= 60 * 1024) {
         const long long wgs = (long long)((p.M + 127) / 128) * ((p.N + 63) / 64) * B * p.nphase;
         if (wgs >= g32_narrow_min) lds_cfg = 7;
+        // between one and two workgroups per CU the 128 x 64 tile leaves half of the slots empty: 64 x 64 tiles (one 32 x 32 accumulator per wave) double them
+        // (round 4, same box: 3072 x 768 / 2304 x 768 at 8 streams 803 / 660 -> 692 / 575 us, 768 x 3072 / 768 x 768 at 32 streams 2761 / 771 -> 2413 / 675 us)
+        if (lds_cfg == 7 && wgs < 500 && !tune_env("RVC_NO_G32_SQ64")) lds_cfg = 8;
     }
     if (lds_cfg >= 0) {
-        const int bm = lds_cfg == 7 ? 128 : (lds_cfg == 6 ? 48 : (lds_cfg % 3 == 0 ? 128 : (lds_cfg % 3 == 1 ? 64 : 32)));
-        const int bn = lds_cfg == 7 ? 64 : ((lds_cfg != 6 && lds_cfg % 3 == 0) ? 128 : 256);
+        const int bm = lds_cfg == 8 ? 64 : (lds_cfg == 7 ? 128 : (lds_cfg == 6 ? 48 : (lds_cfg % 3 == 0 ? 128 : (lds_cfg % 3 == 1 ? 64 : 32))));
+        const int bn = (lds_cfg == 7 || lds_cfg == 8) ? 64 : ((lds_cfg != 6 && lds_cfg % 3 == 0) ? 128 : 256);
         p.ksplit = 1; p.chunks_per_split = nchunks;
         p.ntm = (p.M + bm - 1) / bm; p.ntn = (p.N + bn - 1) / bn;
         // tile order of the tiled kernels when the streams are folded into N: m fastest over XCD-local tile ids (1), or over the raw block index (2)

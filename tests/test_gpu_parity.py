@@ -749,6 +749,11 @@ def test_every_tile_configuration_computes_the_same_convolution():
             for (M, Cin, KW, dil, N, pre) in shapes + [(128, 128, 7, 3, 2520, 1), (768, 256, 1, 1, 111, 0), (48, 48, 15, 1, 5000, 0), (32, 32, 11, 1, 10080, 1), (64, 64, 7, 1, 5040, 0)]:
                 e2 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, streams, pre)
                 assert 0 <= e2 < 2e-5, (streams, M, Cin, KW, dil, N, pre, e2)
+        # tall panels with few streams: the 64 x 64 tile of the 32x32x2 kernel (250-500 workgroups of 128 x 64) at 8 streams, the 128 x 64 tile at 16
+        for streams in (8, 16):
+            for (M, Cin, KW, dil, N, pre) in [(3072, 32, 1, 1, 111, 0), (2304, 48, 1, 1, 111, 1), (600, 32, 3, 1, 500, 0)]:
+                e4 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, streams, pre)
+                assert 0 <= e4 < 2e-5, ("tall", streams, M, Cin, KW, dil, N, pre, e4)
     finally:
         for k in ("RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS"):
             set_opt(k, None)
