@@ -576,7 +576,7 @@ def main(argv=None):
     if job.rank == 0:
         out = {
             "metric": "audio frames/sec (10 ms hops of new input, 160 ms chunks @16 kHz)", "value": head["frames_per_s"], "unit": "frames/s",
-            "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "gpu_ms_last_chunk": head.get("gpu_ms_last_chunk"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: %d stream(s)/GPU, ContentVec v2-768 + RMVPE + NSF-HiFiGAN v2-48k, retrieval %s, preset %s"
                                    % (2 if args.index else (1 if S == 1 else 3), S, "100k x768 flat-L2 k=4" if args.index else "off", args.preset),
