@@ -385,7 +385,14 @@ static rvc_status check_status(rvc_engine *e)
             int zero = 0;
             for (int c = b; c < e->n_streams; c++)
                 if (e->h_status[c] != 0) HIPCHK(hipMemcpy((char *)(e->d_state + c) + offsetof(StreamState, status), &zero, sizeof(int), hipMemcpyHostToDevice));
-            if (code == 7) { e->err = "a cross-workgroup hand-off timed out (GRU recurrence)"; return RVC_BACKEND; }
+            if (code == 7) {
+                // a kernel that gave up waiting left its hand-off state behind (the retrieval's ticket counters are re-armed by the LAST selector
+                // only): the plans are rebuilt before the next call, with fresh counters
+                HIPCHK(hipDeviceSynchronize());
+                e->plans.clear(); e->last_plan = nullptr;
+                e->err = "a cross-workgroup hand-off timed out (GRU recurrence / retrieval tickets)";
+                return RVC_BACKEND;
+            }
             e->err = "to_local_average_cents: index out of bounds (argmax bin >= 348), the reference panics here";
             return RVC_PANIC;
         }
