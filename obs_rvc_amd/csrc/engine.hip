@@ -143,12 +143,16 @@ static void configure_aux_streams(rvc_engine *e)
         if (!e->sset->masked_ok) e->partition_ok = false;
     }
     const bool want = e->partition_ok && e->sset->masked_ok && e->n_streams <= 4;
-    if (!want) for (int i = 0; i < 3; i += 2) if (!e->sset->plain[i]) HIPCHK(hipStreamCreateWithFlags(&e->sset->plain[i], hipStreamNonBlocking));
     e->partitioned = want;
     e->cv_cus = want ? g_ncu - nf0 : g_ncu;
-    e->aux[0] = want ? e->sset->f0 : e->sset->plain[0];
+    // Without the partition (more than 4 streams) ContentVec runs on the main stream and the f0 branch on the SIDE stream: the side work (NSF source,
+    // noise convolutions) is forked behind the join of the f0 branch, so the two never need the stream at the same time, and an engine needs no
+    // stream beyond the set's four.  (Round 3 created two more plain streams for such engines.  A one-stream engine that runs late in a long
+    // process -- the bench's last leg -- sometimes has its f0 branch at 1 150 us instead of 1 085 (chunk 2.06 -> 2.15-2.25 ms); with two streams
+    // fewer in the process that happened in 3 of 6 bench runs instead of 4 of 6: not the cause, or not the only one.  DESIGN.md section 7.)
+    e->aux[0] = want ? e->sset->f0 : e->sset->plain[1];
     e->aux[1] = e->sset->plain[1];
-    e->aux[2] = want ? e->sset->cv : e->sset->plain[2];
+    e->aux[2] = want ? e->sset->cv : e->sset->plain[1];
 }
 
 static void alloc_state(rvc_engine *e)
