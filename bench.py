@@ -60,6 +60,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--dry-launch", action="store_true", help="multi-rank plumbing only (gloo, no GPU work)")
     ap.add_argument("--legs", default="", help="measurement aid: run only these sub_configs legs (comma-separated names; default: all)")
+    ap.add_argument("--serial-branches", action="store_true", help="profiling aid: issue the f0 and ContentVec branches one after the other on the main stream "
+                    "(test hook RVC_SERIAL_BRANCHES through rvc_debug_option; the product reads no such variable from the environment), so that a "
+                    "rocprofv3 kernel trace of many streams shows every kernel's own duration")
     ap.add_argument("--preset", default="full")
     return ap.parse_args(argv)
 
@@ -193,24 +196,30 @@ def timed_leg(job, eng, d_rings, d_out, g, steps, warmup):
     return elapsed, lat, step
 
 
-def committed_traffic(S):
-    """HBM traffic of the dominant kernel class from the committed rocprofv3 --pmc pass of THIS build (tests/tools/profile_round.sh ->
-    profiles/<round>_pmc_traffic*.json; PMC counters need their own rocprofv3 run, so they cannot be taken inside this process).  A file
-    whose build hash differs from the loaded library's is refused: -> (bytes per launch | None, bytes per launch of the retrieval scan | None, note)"""
+def committed_traffic(S, with_index=False, version=2, preset="full"):
+    """HBM traffic of the dominant kernel class from the committed rocprofv3 --pmc pass of THIS build AND THIS configuration
+    (tests/tools/profile_round.sh -> profiles/<round>_pmc_traffic*.json; PMC counters need their own rocprofv3 run, so they cannot be taken
+    inside this process).  A file whose build hash differs from the loaded library's, or whose recorded configuration (streams, index,
+    model version, preset) is not the running one, is refused: -> (bytes per launch | None, bytes per launch of the retrieval scan | None, note)"""
     from obs_rvc_amd import _native
     have = _native.binary_hash()
     import glob
-    want = "_pmc_traffic_64streams.json" if S >= 16 else "_pmc_traffic.json"
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*" + want)))
-    if not files:
-        return None, None, {"traffic_source": None, "traffic_note": "no committed PMC pass under profiles/"}
-    f = files[-1]
-    try:
-        d = json.load(open(f))
-    except Exception as ex:
-        return None, None, {"traffic_source": os.path.relpath(f, ROOT), "traffic_note": "unreadable: %s" % ex}
-    src = {"traffic_source": os.path.relpath(f, ROOT) + " (rocprofv3 --pmc FETCH_SIZE, x2 on gfx950, separate pass of `bench.py --only-headline%s`)" % (" --streams 64" if S >= 16 else " --index"),
-           "traffic_build": d.get("build"), "library_build": have}
+    want_cfg = {"streams": int(S), "index": bool(with_index), "version": int(version), "preset": preset}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True)
+    cands = []
+    for f in files:
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("config") == want_cfg:
+            cands.append((f, d))
+    if not cands:
+        return None, None, {"traffic_source": None, "traffic_note": "no committed PMC pass of this configuration (%s) under profiles/" % json.dumps(want_cfg, sort_keys=True)}
+    match = [c for c in cands if c[1].get("build") == have]
+    f, d = (match or cands)[0]
+    src = {"traffic_source": os.path.relpath(f, ROOT) + " (rocprofv3 --pmc FETCH_SIZE, x2 on gfx950, separate pass of the same configuration)",
+           "traffic_config": d.get("config"), "traffic_build": d.get("build"), "library_build": have}
     if d.get("build") != have:
         src["traffic_note"] = "REFUSED: the committed pass was taken on build %s, this library is %s -- rerun tests/tools/profile_round.sh" % (d.get("build"), have)
         return None, None, src
@@ -219,10 +228,41 @@ def committed_traffic(S):
     src["traffic_launches_per_step"] = ig.get("launches_per_chunk")
     src["traffic_bytes_per_step"] = ig.get("hbm_read_bytes_per_chunk")
     src["algorithmic_weight_bytes_per_step"] = ig.get("algorithmic_weight_bytes_per_chunk")
+    src["algorithmic_bytes_per_step_estimate"] = ig.get("algorithmic_bytes_per_chunk_estimate")
     return ig.get("hbm_read_bytes_per_launch"), kd.get("hbm_read_bytes_per_launch"), src
 
 
-def roofline_of(eng, step, S, reps=5):
+def committed_serial_pass(S, sum_kernel_ms):
+    """Above 4 streams the two front branches share the CUs, and per-launch durations only mean something when the branches are issued one after
+    the other.  roofline.frac of such a configuration is printed only when the committed rocprofv3 kernel trace of `bench.py --serial-branches`
+    (profiles/<round>_serial_<S>streams.json, written by tests/tools/serial_pass.py from the kernel-stats CSV next to it) was taken on THIS build
+    and its sum of implicit-GEMM kernel time per step agrees with this run's HIP-event sum within 3 %.  -> (ok, record)"""
+    from obs_rvc_amd import _native
+    import glob
+    have = _native.binary_hash()
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_serial_%dstreams.json" % S)), reverse=True)
+    if not files:
+        return False, {"serial_pass": None, "serial_pass_note": "no committed serial-branch rocprofv3 pass for %d streams under profiles/" % S}
+    f = files[0]
+    try:
+        d = json.load(open(f))
+    except Exception as ex:
+        return False, {"serial_pass": os.path.relpath(f, ROOT), "serial_pass_note": "unreadable: %s" % ex}
+    rec = {"serial_pass": os.path.relpath(f, ROOT), "serial_pass_csv": d.get("csv"), "serial_pass_build": d.get("build"), "library_build": have,
+           "serial_pass_sum_igemm_ms_per_step": d.get("sum_igemm_ms_per_step")}
+    if d.get("build") != have:
+        rec["serial_pass_note"] = "REFUSED: the committed pass was taken on build %s, this library is %s" % (d.get("build"), have)
+        return False, rec
+    ref = float(d.get("sum_igemm_ms_per_step") or 0.0)
+    dev = abs(ref - sum_kernel_ms) / max(ref, 1e-9)
+    rec["serial_pass_deviation"] = round(dev, 4)
+    if dev > 0.03:
+        rec["serial_pass_note"] = "REFUSED: rocprofv3 says %.3f ms of implicit-GEMM kernel time per step, this run's HIP events %.3f (%.1f %% apart, limit 3 %%)" % (ref, sum_kernel_ms, dev * 100)
+        return False, rec
+    return True, rec
+
+
+def roofline_of(eng, step, S, reps=5, with_index=False, version=2, preset="full"):
     """Dominant kernel class (implicit GEMM on the fp32 matrix cores): per-launch HIP events on the stream each kernel is launched on
     (hipExtLaunchKernelGGL start/stop = the dispatch's own begin/end), eager launches of the same kernels and shapes."""
     eng.set_profile(True)
@@ -240,7 +280,7 @@ def roofline_of(eng, step, S, reps=5):
     eng.set_profile(False)
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     # HBM traffic per launch: the committed `rocprofv3 --pmc` pass of this build (committed_traffic: refused when the build hashes differ)
-    t_launch, t_knn, t_src = committed_traffic(S)
+    t_launch, t_knn, t_src = committed_traffic(S, with_index, version, preset)
     roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": t_launch, "traffic_unit": "HBM read bytes per launch (class average)",
             "kernel": "rvc::igemm2_kernel / conv_tile_kernel / igemm32_kernel / igemm_lds_kernel (all instantiations)", "launches_per_step": n_l // reps,
@@ -252,6 +292,14 @@ def roofline_of(eng, step, S, reps=5):
                      "(above 4 streams they share the CUs, and a co-scheduled short kernel's event duration is the long kernel's, not its "
                      "own); the timed steps run the branches concurrently -- frac_by_wall in the enclosing record uses their wall clock")}
     roof.update(t_src)
+    if S > 4:
+        # many streams: frac stands only on a committed serial-branch rocprofv3 pass of this build that reproduces the sum (VERDICT r4 #1b)
+        ok, srec = committed_serial_pass(S, roof["sum_kernel_ms"])
+        roof.update(srec)
+        roof["frac_by_events"] = roof["frac"]
+        if not ok:
+            roof["frac"] = None
+            roof["frac_note"] = "frac withheld: " + srec.get("serial_pass_note", "no matching serial pass") + "; frac_by_events is this run's HIP-event figure, frac_by_wall the wall-clock one"
     if k_n:
         ach = k_by / (k_ms * 1e-3) / 1e9
         roof["retrieval_scan"] = {"bound": "hbm", "kernel": "rvc::knn_scan_select_kernel (one launch: scan + select + exact re-rank + blend; the duration is the whole launch)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -260,7 +308,7 @@ def roofline_of(eng, step, S, reps=5):
     return roof
 
 
-def run_config(job, z, g, S, with_index, steps, warmup, graph, index_vecs, want_roofline=True, version=2, soak=0):
+def run_config(job, z, g, S, with_index, steps, warmup, graph, index_vecs, want_roofline=True, version=2, soak=0, preset="full"):
     """One configuration on every rank: S streams per GPU, retrieval on/off.  soak > 0: that many more synchronised chunks after the
     timed region for the latency distribution (p99.9 needs >= 1000 samples).  -> record (rank 0) / None"""
     from obs_rvc_amd import dist as rdist
@@ -300,7 +348,7 @@ def run_config(job, z, g, S, with_index, steps, warmup, graph, index_vecs, want_
     soak_all = job.gather(soak_lat) if soak else []
     per_rank = [FRAMES_PER_CHUNK * steps * S / float(np.sum(l)) for l in lat_all]
     rec = None
-    roof = roofline_of(eng, step, S) if (job.rank == 0 and want_roofline) else None
+    roof = roofline_of(eng, step, S, with_index=with_index, version=version, preset=preset) if (job.rank == 0 and want_roofline) else None
     if job.rank == 0:
         allat = np.concatenate(lat_all + soak_all)
         value = FRAMES_PER_CHUNK * steps * S * job.world / elapsed
@@ -476,12 +524,15 @@ def main(argv=None):
     z = zoo(args.preset)
     graph = bool(args.graph and not args.no_graph)
     full = args.preset == "full"
+    if args.serial_branches:
+        from common import set_opt
+        set_opt("RVC_SERIAL_BRANCHES", "1")
     index_vecs = W.make_index() if (job.rank == 0 and full) else None      # only rank 0 ever holds the host copy
 
     # ---- headline: BASELINE configs[1] (or what --streams / --index ask for) on every rank
     S = args.streams
     soak_n = int(os.environ.get("RVC_BENCH_SOAK", "1000")) if (S == 1 and full and not args.only_headline) else 0
-    head, eng, rings, d_rings = run_config(job, z, g, S, args.index and full, args.steps, args.warmup, graph, index_vecs, soak=soak_n)
+    head, eng, rings, d_rings = run_config(job, z, g, S, args.index and full, args.steps, args.warmup, graph, index_vecs, soak=soak_n, preset=args.preset)
     extra = {}
     if job.rank == 0 and not args.only_headline:
         skip = os.environ.get("RVC_BENCH_SKIP", "").split(",")     # debugging aid: leg names to leave out
@@ -542,7 +593,7 @@ def main(argv=None):
         def sweep(S2):
             def fn():
                 k = max(10, min(args.steps, 30))
-                rec, e4, _, d4 = run_config(job, z, g, S2, False, k, 3, graph, index_vecs, want_roofline=False)
+                rec, e4, _, d4 = run_config(job, z, g, S2, False, k, 3, graph, index_vecs, want_roofline=False, soak=sub_soak)
                 del e4, d4
                 if rec:
                     rec["steps"] = k
@@ -551,7 +602,7 @@ def main(argv=None):
 
         def streams64_index100k():
             k64 = max(10, min(args.steps, 20))
-            rec, e5, _, d5 = run_config(job, z, g, 64, True, k64, 3, graph, index_vecs, want_roofline=False)
+            rec, e5, _, d5 = run_config(job, z, g, 64, True, k64, 3, graph, index_vecs, want_roofline=False, soak=sub_soak)
             del e5, d5
             if rec:
                 rec["steps"] = k64
@@ -560,7 +611,7 @@ def main(argv=None):
 
         def v1_256():
             z1 = zoo(args.preset, 1)
-            rec, e6, _, d6 = run_config(job, z1, g, 1, False, args.steps, args.warmup, graph, index_vecs, version=1)
+            rec, e6, _, d6 = run_config(job, z1, g, 1, False, args.steps, args.warmup, graph, index_vecs, version=1, soak=sub_soak)
             del e6, d6
             if rec:
                 rec["config"] = "BASELINE configs[1] read literally: ContentVec-256 (v1: layer 9 + final_proj, enums.rs:10-23) + RMVPE + v1 NSF-HiFiGAN 48k"
@@ -574,6 +625,8 @@ def main(argv=None):
         leg("v1_256", v1_256)
 
     if job.rank == 0:
+        if args.serial_branches:
+            head["serial_branches"] = True
         out = {
             "metric": "audio frames/sec (10 ms hops of new input, 160 ms chunks @16 kHz)", "value": head["frames_per_s"], "unit": "frames/s",
             "n_gpus": job.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "gpu_ms_last_chunk": head.get("gpu_ms_last_chunk"),
@@ -594,6 +647,7 @@ def main(argv=None):
             "plugin_chain_ms_per_chunk": (extra.get("plugin_chain") or {}).get("ms_per_chunk"),
             "offline_pipelined_frames_per_s": extra.get("offline_pipelined_frames_per_s"),
             "roofline": head.get("roofline"), "cpu_baseline": cpu, "sub_configs": sub or None,
+            "serial_branches": bool(args.serial_branches),
         }
         if args.index and head.get("index_broadcast"):
             out["index_broadcast"] = head["index_broadcast"]

@@ -80,8 +80,13 @@ rvc_status rvc_load_index(rvc_engine *e, const float *vectors, size_t n, size_t 
 rvc_status rvc_load_index_device(rvc_engine *e, const void *d_vectors, size_t n, size_t dim);  /* already in HBM (RCCL-broadcast) */
 void rvc_set_index_rate(rvc_engine *e, float rate);
 /* kNN hits of the last infer: idx[rows][4], squared distances; rows = return_length for stream 0, followed (stream-major) by the rows of as many
-   further streams of a batched call as cap_rows holds whole */
+   further streams of a batched call as cap_rows holds whole.  After rvc_infer_batch_g (streams bucketed by geometry) no rows are reported: *rows = 0. */
 rvc_status rvc_get_knn(rvc_engine *e, int32_t *idx, float *dist, size_t cap_rows, size_t *rows);
+/* The one-launch retrieval (up to 11 streams) hands its partial lists from workgroup to workgroup inside the launch; if a workgroup does not arrive
+   in time (a GPU shared with another process), the engine recomputes that chunk's retrieval through the exhaustive scan and the rest of the chunk,
+   and the call still returns RVC_OK with the same hits.  This counts such chunks (0 on a GPU of one's own).  Unsynchronised calls (sync = 0) cannot
+   be recomputed in order: there the time-out is reported by rvc_synchronize as RVC_BACKEND. */
+long long rvc_retrieval_recoveries(rvc_engine *e);
 /* the synthesizer's two noise inputs are explicit counter-based (Philox4x32-10) streams */
 void rvc_set_noise_seed(rvc_engine *e, uint32_t seed, uint32_t stream_id);
 void rvc_reset_state(rvc_engine *e);     /* zero the 1024-entry pitch cache and the chunk counter */
@@ -125,11 +130,20 @@ rvc_status rvc_infer_device_v(rvc_engine *e, const void *d_input, size_t n, size
 /* many streams, every stream with ITS OWN geometry (in the reference every stream is a process with its own chunk length, crossfade and
  * extra context: obs-rvc/src/lib.rs:200-227, 694).  All arrays have n_streams entries (inputs / outs: host pointers per stream;
  * pitch_shift may be NULL = 0 for every stream).  Streams with equal (n, sample_frame_16k_size, skip_head, return_length) run as one
- * batch; a server can mix 160 ms and 300 ms callers in one call.  At most 8 different geometries per call. */
+ * batch; a server can mix 160 ms and 300 ms callers in one call.  At most as many different geometries per call as the plan cache holds
+ * (8 unless rvc_set_plan_cache raised it). */
 rvc_status rvc_infer_batch_g(rvc_engine *e, const float *const *inputs, const size_t *n, const size_t *sample_frame_16k_size, const int32_t *pitch_shift,
                              const uint32_t *skip_head, const uint32_t *return_length, float *const *outs, const size_t *caps, size_t *out_lens);
 rvc_status rvc_synchronize(rvc_engine *e);
 void rvc_set_use_graph(rvc_engine *e, int on);    /* replay the per-chunk launch sequence from a hipGraph */
+/* Plan cache.  The engine keeps one "plan" per call geometry (n, sample_frame_16k_size, skip_head, return_length, stream count, retrieval on/off):
+ * its activation arena, plan-time weight copies and launch list.  Every plugin instance has its own geometry (obs-rvc/src/lib.rs:200-227), so a
+ * server sees as many plans as it has distinct caller settings.  The cache holds n_plans of them (default 8, 2..256), least recently used evicted
+ * first.  A MISS costs a plan build: arena allocation (tens of MB at one stream, GBs at 64), composed weights and a device synchronisation --
+ * tens of milliseconds; a server that rotates through more geometries than the cache holds pays that on every call.  rvc_plan_cache_info reports
+ * capacity, plans currently cached and plans built since rvc_create (-> 1 on a valid engine). */
+rvc_status rvc_set_plan_cache(rvc_engine *e, int n_plans);
+int rvc_plan_cache_info(rvc_engine *e, int *capacity, int *cached, long long *builds);
 /* Offline throughput mode (no counterpart in the reference, whose protocol is one request at a time): with on != 0, consecutive
  * rvc_infer_device(..., sync = 0) calls overlap chunk i+1's ContentVec / f0 branches with chunk i's synthesizer (two plan slots).
  * Results are identical to the serial order; every call needs its own output buffer until rvc_synchronize. */

@@ -23,6 +23,7 @@ SYMBOLS = [
     "rvc_resampler_create", "rvc_resampler_destroy", "rvc_resampler_input_frames_next", "rvc_resampler_output_frames_max",
     "rvc_resampler_reset", "rvc_resampler_process", "rvc_resampler_process_device",
     "rvc_rccl_unique_id", "rvc_index_broadcast", "rvc_rccl_available", "rvc_index_broadcast_info",
+    "rvc_set_plan_cache", "rvc_plan_cache_info", "rvc_retrieval_recoveries",
     "rvc_session_create", "rvc_session_destroy", "rvc_session_process", "rvc_session_frame_size", "rvc_session_set_params", "rvc_session_set_params_stream", "rvc_session_geometry",
 ]
 
@@ -211,6 +212,10 @@ def lib():
     L.rvc_synchronize.argtypes = [vp]
     L.rvc_set_use_graph.argtypes = [vp, C.c_int]
     L.rvc_set_use_graph.restype = None
+    L.rvc_set_plan_cache.argtypes = [vp, C.c_int]
+    L.rvc_plan_cache_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
+    L.rvc_retrieval_recoveries.argtypes = [vp]
+    L.rvc_retrieval_recoveries.restype = C.c_longlong
     L.rvc_set_pipeline.argtypes = [vp, C.c_int]
     L.rvc_set_pipeline.restype = None
     L.rvc_last_gpu_ms.argtypes = [vp]

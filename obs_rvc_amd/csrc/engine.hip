@@ -178,14 +178,27 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
     } swap_guard(e, bucket_B, e->d_state_bucket);
     const int B = e->n_streams;
     const bool with_index = mode == 0 && e->d_index && e->index_rate > 0.f;
+    // plans built before a test hook changed are stale (the hooks are process-global and not part of the key)
+    const unsigned gen = g_opt_gen.load();
+    for (size_t i = 0; i < e->plans.size();)
+        if (e->plans[i]->opt_gen != gen) {
+            HIPCHK(hipDeviceSynchronize());
+            if (e->last_plan == e->plans[i].get()) e->last_plan = nullptr;
+            e->plans.erase(e->plans.begin() + i);
+        } else i++;
     for (auto &p : e->plans)
         if (p->mode == mode && p->L == L && p->frame16k == frame16k && p->skip_head == skip_head && p->R == R && p->B == B &&
-            p->with_index == with_index && p->with_taps == (e->taps_on != 0) && p->plain_plan == (e->taps_on == 1) && p->slot == slot && p->bucket == (bucket_B > 0))
-            return p.get();
+            p->with_index == with_index && p->with_taps == (e->taps_on != 0) && p->plain_plan == (e->taps_on == 1) && p->slot == slot && p->bucket == (bucket_B > 0)) {
+            // least recently used first: a hit moves to the back, so eviction (front) never takes a plan the current call has just fetched
+            Plan *hit = p.get();
+            std::rotate(&p, &p + 1, e->plans.data() + e->plans.size());
+            return hit;
+        }
+    e->plan_builds++;
     std::unique_ptr<Plan> up(new Plan());
     Plan &pl = *up;
     pl.mode = mode; pl.L = L; pl.frame16k = frame16k; pl.skip_head = skip_head; pl.R = R; pl.B = B; pl.with_index = with_index; pl.with_taps = e->taps_on != 0; pl.plain_plan = e->taps_on == 1; pl.bucket = bucket_B > 0;
-    pl.slot = slot;
+    pl.slot = slot; pl.opt_gen = gen;
     pl.d_in = pl.arena.floats((size_t)B * L + 64);
     T1 sal0, src0; float *d_pitchf0 = nullptr; int *d_pitch0 = nullptr;
     size_t rm_begin = 0, rm_end = 0;
@@ -230,13 +243,16 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         if (R < 1) throw ShapeError("return_length must be >= 1");
         if (e->sy->phone_dim != C) throw std::runtime_error("synthesizer phone dimension does not match the ContentVec output");
         T1 phone = make_t1(pl.arena, B, C, (int)R, 0);
+        pl.op_phone = pl.ops.v.size();
         {
             T1 cvo = pl.cv_out; dim3 grid((C * (int)R + 255) / 256, B);
             pl.ops.push_back([=](hipStream_t s) {
                 hipLaunchKernelGGL(gather_phone_kernel, grid, dim3(256), 0, s, cvo.p, cvo.ld, cvo.bs, C, T, (int)skip_head, (int)R, phone.p, phone.ld, phone.bs);
             });
         }
+        pl.op_ret_begin = pl.ops.v.size();
         if (with_index) build_retrieval(e, pl, B, T, C, skip_head, R, phone);
+        pl.op_ret_end = pl.ops.v.size();
         add_tap(pl, "phone_ct", phone);
         float *d_pitchf = d_pitchf0; int *d_pitch = d_pitch0;
         (void)hubert_length;
@@ -272,8 +288,8 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(advance_chunk_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, B, hst); });
     }
     HIPCHK(hipDeviceSynchronize());
-    // bounded plan cache (each geometry owns its activation arena and graph): evict the oldest
-    while (e->plans.size() >= 8) { if (e->last_plan == e->plans.front().get()) e->last_plan = nullptr; e->plans.erase(e->plans.begin()); }
+    // bounded plan cache (each geometry owns its activation arena and graph; rvc_set_plan_cache): evict the least recently used
+    while ((int)e->plans.size() >= e->plan_cap) { if (e->last_plan == e->plans.front().get()) e->last_plan = nullptr; e->plans.erase(e->plans.begin()); }
     e->plans.push_back(std::move(up));
     return e->plans.back().get();
 }
@@ -379,27 +395,59 @@ static void queue_status(rvc_engine *e)
     e->status_queued = true;
 }
 
+// -> RVC_OK / RVC_PANIC / RVC_BACKEND, or RVC_KNN_RETRY (internal): only the one-launch retrieval reported (ST_KNN_TIMEOUT) -- its counters are
+// re-armed here and the caller may recompute the chunk from the retrieval on (recover_retrieval).  Every stream's word is looked at before anything
+// is decided: a lost GRU hand-off on ANY stream means the plans are rebuilt, whatever a lower-numbered stream reported.
+static const rvc_status RVC_KNN_RETRY = (rvc_status)100;
 static rvc_status check_status(rvc_engine *e)
 {
     if (!e->status_queued) { queue_status(e); HIPCHK(hipStreamSynchronize(e->stream)); }
     e->status_queued = false;
-    for (int b = 0; b < e->n_streams; b++)
-        if (e->h_status[b] != 0) {
-            const int code = e->h_status[b];
-            int zero = 0;
-            for (int c = b; c < e->n_streams; c++)
-                if (e->h_status[c] != 0) HIPCHK(hipMemcpy((char *)(e->d_state + c) + offsetof(StreamState, status), &zero, sizeof(int), hipMemcpyHostToDevice));
-            if (code == 7) {
-                // a kernel that gave up waiting left its hand-off state behind (the retrieval's ticket counters are re-armed by the LAST selector
-                // only): the plans are rebuilt before the next call, with fresh counters
-                HIPCHK(hipDeviceSynchronize());
-                e->plans.clear(); e->last_plan = nullptr;
-                e->err = "a cross-workgroup hand-off timed out (GRU recurrence / retrieval tickets)";
-                return RVC_BACKEND;
-            }
-            e->err = "to_local_average_cents: index out of bounds (argmax bin >= 348), the reference panics here";
-            return RVC_PANIC;
-        }
+    int any = 0;
+    for (int b = 0; b < e->n_streams; b++) any |= e->h_status[b];
+    if (!any) return RVC_OK;
+    const int zero = 0;
+    for (int c = 0; c < e->n_streams; c++)
+        if (e->h_status[c] != 0) { HIPCHK(hipMemcpy((char *)(e->d_state + c) + offsetof(StreamState, status), &zero, sizeof(int), hipMemcpyHostToDevice)); e->h_status[c] = 0; }
+    if (any & ST_HANDOFF) {
+        // a GRU step that gave up waiting left its hand-off granules behind: the plans are rebuilt before the next call
+        HIPCHK(hipDeviceSynchronize());
+        e->plans.clear(); e->last_plan = nullptr;
+        e->err = "a cross-workgroup hand-off timed out (GRU recurrence)";
+        return RVC_BACKEND;
+    }
+    if (any & ST_KNN_TIMEOUT) {
+        // the retrieval's counters were poisoned by the selector that gave up (kernels.hip.h): re-arm them, whatever else happens
+        HIPCHK(hipDeviceSynchronize());
+        for (auto &p : e->plans) if (p->knn_ticket) HIPCHK(hipMemset(p->knn_ticket, 0, p->knn_ticket_bytes));
+    }
+    if (any & ST_PANIC) {
+        e->err = "to_local_average_cents: index out of bounds (argmax bin >= 348), the reference panics here";
+        return RVC_PANIC;
+    }
+    e->err = "the one-launch retrieval's hand-off timed out";
+    return RVC_KNN_RETRY;
+}
+
+// A selector of knn_scan_select_kernel gave up (a workgroup of the launch did not arrive in time -- e.g. a GPU shared with another process): some
+// queries of the chunk were not blended.  Nothing is lost: the inputs of the retrieval (ContentVec output, pitch) are still in the plan's arena.
+// Rewind the chunk counters, then run [phone gather] + [exhaustive exact scan, merge, blend: the definition] + [everything behind the retrieval]
+// in list order on the main stream.  Same hits (the one-launch form is tested bit-exact against this scan), same PCM.
+static rvc_status final_status(rvc_engine *e)      // callers that cannot recompute the chunk: the internal retry code becomes an error
+{
+    const rvc_status st = check_status(e);
+    return st == RVC_KNN_RETRY ? RVC_BACKEND : st;
+}
+static rvc_status recover_retrieval(rvc_engine *e, Plan &pl)
+{
+    if (pl.knn_fallback.empty() || pl.op_ret_end <= pl.op_ret_begin) { e->err = "the one-launch retrieval's hand-off timed out (no fallback on this plan)"; return RVC_BACKEND; }
+    hipLaunchKernelGGL(rewind_chunk_kernel, dim3((pl.B + 63) / 64), dim3(64), 0, e->stream, e->d_state, pl.B);
+    const size_t n = pl.ops.v.size();
+    for (size_t i = pl.op_phone; i < pl.op_ret_begin; i++) if (pl.ops.kind[i] == 0) pl.ops.v[i](e->stream);
+    for (auto &op : pl.knn_fallback) op(e->stream);
+    for (size_t i = pl.op_ret_end; i < n; i++) if (pl.ops.kind[i] == 0) pl.ops.v[i](e->stream);
+    HIPCHK(hipGetLastError());
+    e->knn_recoveries++;
     return RVC_OK;
 }
 
@@ -590,7 +638,7 @@ rvc_status rvc_pitch(rvc_engine *e, const float *input, size_t n, int32_t pitch_
         HIPCHK(hipMemcpyAsync(out, pl->d_f0, (size_t)pl->Tm * sizeof(float), hipMemcpyDeviceToHost, e->stream));
         queue_status(e);
         HIPCHK(hipStreamSynchronize(e->stream));
-        return check_status(e);
+        return final_status(e);
     });
 }
 
@@ -641,7 +689,20 @@ static rvc_status infer_common(rvc_engine *e, const void *input, bool input_on_d
     if (!sync) return RVC_OK;
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1));
-    return check_status(e);
+    rvc_status st = check_status(e);
+    if (st == RVC_KNN_RETRY) {
+        // degrade, don't fail: the chunk's retrieval through the exhaustive launches, the rest of the chunk again, the output copy again
+        st = recover_retrieval(e, *pl);
+        if (st != RVC_OK) return st;
+        if (!direct_out)
+            HIPCHK(hipMemcpy2DAsync(out, cap * sizeof(float), pl->audio.p, pl->N * sizeof(float), pl->N * sizeof(float), B,
+                                    out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream));
+        e->status_queued = true;
+        HIPCHK(hipStreamSynchronize(e->stream));
+        st = check_status(e);
+        if (st == RVC_KNN_RETRY) st = RVC_BACKEND;
+    }
+    return st;
 }
 
 // rvc.rs:133-220
@@ -705,6 +766,9 @@ rvc_status rvc_infer_batch_g(rvc_engine *e, const float *const *inputs, const si
             if (!inputs[s] || !outs[s]) throw ShapeError("infer_batch_g: null stream buffer");
             buckets[Key{n[s], sample_frame_16k_size[s], skip_head[s], return_length[s]}].push_back(s);
         }
+        // every bucket's plan must stay cached until the call has run it: the cache is LRU and the call's plans are its most recent entries, so the
+        // only way to lose one is more buckets than slots
+        if ((int)buckets.size() > e->plan_cap) throw ShapeError("infer_batch_g: more different geometries in one call than the plan cache holds (rvc_set_plan_cache)");
         if (!e->d_state_bucket) { HIPCHK(hipMalloc(&e->d_state_bucket, sizeof(StreamState) * S)); HIPCHK(hipMalloc(&e->d_bucket_idx, sizeof(int) * S)); }
         // plans first (a geometry the engine rejects must not leave some buckets already advanced), then the work
         std::vector<std::pair<Plan *, const std::vector<int> *>> work;
@@ -713,9 +777,8 @@ rvc_status rvc_infer_batch_g(rvc_engine *e, const float *const *inputs, const si
             for (int s : kv.second) { if (out_lens) out_lens[s] = pl->N; if (caps[s] < pl->N) return RVC_SHAPE; }
             work.push_back({pl, &kv.second});
         }
-        if (e->plans.size() < work.size()) throw ShapeError("infer_batch_g: more than 8 different geometries in one call");      // (the plan cache holds 8)
-        for (auto &w : work)           // (a later get_plan may have evicted an earlier bucket's plan: every plan of this call must still be cached)
-            { bool ok = false; for (auto &p : e->plans) ok = ok || p.get() == w.first; if (!ok) throw ShapeError("infer_batch_g: more than 8 different geometries in one call"); }
+        for (auto &w : work)
+            { bool ok = false; for (auto &p : e->plans) ok = ok || p.get() == w.first; if (!ok) throw std::logic_error("infer_batch_g: a plan of this call left the cache"); }
         push_call_params(e, 0, pitch_shift);            // per-stream multipliers into the streams' own states (a null array: no shift)
         for (auto &w : work) {
             Plan *pl = w.first; const std::vector<int> &ids = *w.second; const int Bk = (int)ids.size();
@@ -731,7 +794,7 @@ rvc_status rvc_infer_batch_g(rvc_engine *e, const float *const *inputs, const si
         e->last_knn_rows = 0;
         queue_status(e);                                     // the streams' own status words (the plans wrote bucket-local ones)
         HIPCHK(hipStreamSynchronize(e->stream));
-        return check_status(e);
+        return final_status(e);
     });
 }
 
@@ -740,7 +803,7 @@ rvc_status rvc_synchronize(rvc_engine *e)
     return guarded(e, [&]() {
         HIPCHK(hipStreamSynchronize(e->stream));
         if (e->ev0 && e->last_plan) (void)hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1);
-        return check_status(e);
+        return final_status(e);
     });
 }
 
@@ -757,6 +820,28 @@ rvc_status rvc_set_streams(rvc_engine *e, int n_streams)
 }
 
 void rvc_set_use_graph(rvc_engine *e, int on) { if (e) e->use_graph = on != 0; }
+
+// Plan cache: one plan (activation arena, composed weights, launch list) per geometry (mode, n, frame, skip_head, return_length, streams,
+// retrieval on/off, pipeline slot).  Every plugin instance has its own geometry (obs-rvc/src/lib.rs:200-227): a server that serves more
+// geometries than the cache holds rebuilds a plan on every miss.
+rvc_status rvc_set_plan_cache(rvc_engine *e, int n_plans)
+{
+    return guarded(e, [&]() {
+        if (n_plans < 2 || n_plans > 256) throw ShapeError("plan cache size out of range (2..256)");
+        HIPCHK(hipDeviceSynchronize());
+        e->plan_cap = n_plans;
+        while ((int)e->plans.size() > e->plan_cap) { if (e->last_plan == e->plans.front().get()) e->last_plan = nullptr; e->plans.erase(e->plans.begin()); }
+        return RVC_OK;
+    });
+}
+int rvc_plan_cache_info(rvc_engine *e, int *capacity, int *cached, long long *builds)
+{
+    if (!e) return 0;
+    if (capacity) *capacity = e->plan_cap;
+    if (cached) *cached = (int)e->plans.size();
+    if (builds) *builds = e->plan_builds;
+    return 1;
+}
 void rvc_set_pipeline(rvc_engine *e, int on)
 {
     if (!e) return;

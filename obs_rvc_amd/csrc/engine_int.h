@@ -13,6 +13,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
@@ -39,6 +40,8 @@ namespace rvc {
 //     -DRVC_TUNING (tests/tools/build_tuning.py -> librvc_tuning.so) have them, and there both kinds also fall back to the environment
 //     variable of the same name.
 const char *test_opt(const char *name);
+extern std::atomic<unsigned> g_opt_gen;      // generation of the test-hook table (plan.hip)
+extern std::atomic<int> g_knn_test_lose;     // RVC_KNN_LOSE_TICKET (retrieval.hip)
 int test_opt_int(const char *name, int dflt);
 #ifdef RVC_TUNING
 const char *tune_env(const char *name);
@@ -221,6 +224,11 @@ struct Plan {
     float *d_f0 = nullptr;  // [B][Tm]
     float *d_feat = nullptr; // extract_feature output (1,2T+1,C)
     int *d_knn_idx = nullptr; float *d_knn_dist = nullptr;
+    // one-launch retrieval: its ticket counters, and what runs instead when a selector gave up (engine.hip recover_retrieval)
+    unsigned *knn_ticket = nullptr; size_t knn_ticket_bytes = 0;
+    std::vector<Op> knn_fallback;
+    size_t op_phone = 0, op_ret_begin = 0, op_ret_end = 0;      // ops [op_phone, op_ret_begin): phone gather; [op_ret_begin, op_ret_end): the retrieval section
+    unsigned opt_gen = 0;         // test-hook generation the plan was built under
     // profiling
     bool profile = false;
     std::vector<ProfEvent> prof;
@@ -795,6 +803,9 @@ struct rvc_engine {
     // plans (keyed by geometry)
     std::vector<std::unique_ptr<Plan>> plans;
     Plan *last_plan = nullptr;
+    int plan_cap = 8;                 // rvc_set_plan_cache
+    long long knn_recoveries = 0;     // chunks whose retrieval was recomputed after a hand-off time-out (rvc_retrieval_info)
+    long long plan_builds = 0;        // plans built since rvc_create (a miss = arena allocation + composed weights + a device synchronisation)
     int taps_on = 0;               // 0 off, 1 taps on the explicit plan, 2 taps on the production plan (rvc_enable_taps)
     bool profile_on = false, use_graph = false;
     // offline throughput mode: consecutive unsynchronised infer_device calls overlap chunk i+1's two front branches with chunk i's

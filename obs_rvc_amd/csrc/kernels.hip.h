@@ -977,7 +977,7 @@ static __global__ __launch_bounds__(384) void gru_multi_kernel(GruMultiP p)
                 while (!dead) {
                     x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if ((unsigned)(x >> 32) == (unsigned)step) break;
-                    if (++spins > (1u << 22)) { dead = true; p.status[b * p.status_stride] = 7; }
+                    if (++spins > (1u << 22)) { dead = true; atomicOr(&p.status[b * p.status_stride], (int)ST_HANDOFF); }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 hs[tid] = __uint_as_float((unsigned)x);
@@ -1070,7 +1070,7 @@ static __global__ __launch_bounds__(1024) void pitch_post_kernel(PitchP p)
             mx = fmaxf(mx, cache[g * TT + tt]);
         }
         float hz = 0.f;
-        if (start + 8 >= 360) { st->status = 6; }
+        if (start + 8 >= 360) { atomicOr(&st->status, (int)ST_PANIC); }
         else {
             float sv[9];
 #pragma unroll
@@ -1319,6 +1319,13 @@ static __global__ void advance_chunk_kernel(StreamState *st, int B, int *host_st
     if (b < B) { st[b].chunk += 1; if (host_status) host_status[b] = st[b].status; }
 }
 
+// recover_retrieval (engine.hip): the chunk is issued again from the retrieval on, with the counter it had
+static __global__ void rewind_chunk_kernel(StreamState *st, int B)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) st[b].chunk -= 1;
+}
+
 // ------------------------------------------------------------------------------------
 // flat-L2 retrieval (rvc.rs:159 is a TODO; definition in SURVEY.md Appendix A.4).
 // Stage 1: every thread owns one index vector (transposed index [dim][n] -> coalesced) and
@@ -1514,6 +1521,8 @@ struct KnnFusedP {
     const float *cv; int cv_cs; long long cv_bs; int first_raw, nq, q0;
     unsigned long long *lists;         // [B][16][gridDim.x][4] granules: low word = distance bits, high word = index
     unsigned *ticket;                  // [B][2]: arrivals, selectors done; zero between launches
+    unsigned spin_limit;               // polls of the arrival counter before a selector gives up (ST_KNN_TIMEOUT)
+    int test_lose;                     // test hook RVC_KNN_LOSE_TICKET: workgroup 0 of every stream never takes its ticket (a hand-off that cannot complete)
     int skip_head, T, R; float rate;
     float *phone; int ph_cs; long long ph_bs;
     int *out_idx; float *out_dist;
@@ -1693,18 +1702,27 @@ static __global__ __launch_bounds__(256) void knn_scan_select_kernel(KnnFusedP p
     }
     if (wave == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the granules have left (write-through) before the ticket is taken
-        if (tid == 0) s_role = (int)__hip_atomic_fetch_add(p.ticket + b * 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // release: the granule stores above are ordered before the ticket; the selectors' acquire load below pairs with it
+        if (tid == 0) s_role = (p.test_lose && blockIdx.x == 0) ? 0 : (int)__hip_atomic_fetch_add(p.ticket + b * 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     KNN_STAMP(3);
     const int S = nqg < G ? nqg : G;
-    if (s_role < G - S) return;
-    const int sel = s_role - (G - S);
+    if (s_role >= 0 && s_role < G - S) return;
+    // A role outside [0, G): the counters were left behind by a launch that timed out (they are NOT re-armed on that path, so every later launch on
+    // them fails fast here instead of assigning selector roles from stale counts).  The host re-arms them (engine.hip recover_retrieval / plan rebuild).
+    const bool stale = s_role < 0 || s_role >= G;
+    const int sel = stale ? 0 : s_role - (G - S);
     if (tid == 0) {
-        unsigned spins = 0; int dead = 0;
-        while (__hip_atomic_load(p.ticket + b * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G) {
-            if (++spins > (1u << 22)) { dead = 1; p.status[b * p.status_stride] = 7; break; }
+        unsigned spins = 0; int dead = stale ? 1 : 0;
+        while (!dead && __hip_atomic_load(p.ticket + b * 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G) {
+            if (++spins > p.spin_limit) { dead = 1; break; }
             __builtin_amdgcn_s_sleep(2);
+        }
+        if (dead) {
+            atomicOr(&p.status[b * p.status_stride], (int)ST_KNN_TIMEOUT);
+            // poison the arrival counter: whatever is launched on it before the host has re-armed it sees a role beyond G and stops here
+            __hip_atomic_store(p.ticket + b * 2, 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         s_dead = dead;
     }
@@ -1978,8 +1996,8 @@ static __global__ __launch_bounds__(256) void knn_scan_select_kernel(KnnFusedP p
     }
     __syncthreads();
     KNN_STAMP(7);
-    // the last selector to leave re-arms the counters for the next launch
-    if (tid == 0) {
+    // the last selector to leave re-arms the counters for the next launch (never after a time-out: a late workgroup may still take a ticket)
+    if (tid == 0 && !s_dead) {
         const unsigned d = __hip_atomic_fetch_add(p.ticket + b * 2 + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int)d == S - 1) {
             __hip_atomic_store(p.ticket + b * 2 + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -6,7 +6,8 @@
 namespace rvc {
 
 static const char *const kTestHooks[] = {"RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_NO_LN_FUSE", "RVC_NO_CONV0_MULTI", "RVC_KNN_NO_GEMM",
-                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE"};
+                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET"};
+std::atomic<unsigned> g_opt_gen{0};       // bumped by every rvc_debug_option call: plans built under another generation are dropped (engine.hip get_plan)
 static std::mutex g_opt_mu;
 static std::map<std::string, std::string> g_opts;
 static bool is_test_hook(const char *name)
@@ -801,5 +802,7 @@ extern "C" int rvc_debug_option(const char *name, const char *value)
 #endif
     std::lock_guard<std::mutex> lk(g_opt_mu);
     if (value) g_opts[name] = value; else g_opts.erase(name);
+    if (!strcmp(name, "RVC_KNN_LOSE_TICKET")) g_knn_test_lose.store(value && atoi(value) ? 1 : 0);      // (read per launch: kept out of the string table's lock)
+    g_opt_gen.fetch_add(1);
     return 0;
 }

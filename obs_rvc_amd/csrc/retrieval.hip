@@ -6,6 +6,10 @@ namespace rvc {
 
 // The retrieval section of an infer plan: queries from the ContentVec output, one-pass approximate scan (or one implicit GEMM for many streams),
 // exact re-rank + blend into `phone`, exhaustive fallback for streams whose candidate set overflowed.
+std::atomic<int> g_knn_test_lose{0};
+static void build_exhaustive(rvc_engine *e, Plan &pl, int B, int C, int nq, int nblk, int first_raw, uint32_t skip_head, uint32_t R, int T, const T1 &phone, const T1 &cvo,
+                             bool fast, int *d_overflow, float *d_q = nullptr, float *cand_d = nullptr, int *cand_i = nullptr);
+
 void build_retrieval(rvc_engine *e, Plan &pl, int B, int T, int C, uint32_t skip_head, uint32_t R, const T1 &phone)
 {
         if (e->index_dim != (size_t)C) throw std::runtime_error("index dimension does not match the feature dimension");
@@ -38,6 +42,7 @@ void build_retrieval(rvc_engine *e, Plan &pl, int B, int T, int C, uint32_t skip
             unsigned long long *lists = (unsigned long long *)pl.arena.alloc((size_t)ngroups * B * 16 * G * KNN_K * sizeof(unsigned long long));
             unsigned *ticket = (unsigned *)pl.arena.alloc((size_t)ngroups * B * 2 * sizeof(unsigned));
             HIPCHK(hipMemset(ticket, 0, (size_t)ngroups * B * 2 * sizeof(unsigned)));
+            pl.knn_ticket = ticket; pl.knn_ticket_bytes = (size_t)ngroups * B * 2 * sizeof(unsigned);
             for (int gi = 0; gi < ngroups; gi++) {
                 const size_t lds = knn_fused_lds_floats(C, std::min(16, nq - gi * 16), (int)G) * sizeof(float);
                 if (lds > 128 * 1024) throw ShapeError("feature dimension too large for the retrieval kernel");
@@ -47,6 +52,7 @@ void build_retrieval(rvc_engine *e, Plan &pl, int B, int T, int C, uint32_t skip
                 fp.skip_head = (int)skip_head; fp.T = T; fp.R = (int)R; fp.rate = e->index_rate;
                 fp.phone = phone.p; fp.ph_cs = phone.ld; fp.ph_bs = phone.bs; fp.out_idx = pl.d_knn_idx; fp.out_dist = pl.d_knn_dist;
                 fp.status = &e->d_state[0].status; fp.status_stride = (int)(sizeof(StreamState) / sizeof(int));
+                fp.spin_limit = 1u << 22;
                 dim3 grid(G, B);
                 Plan *plp = &pl;
                 const double scan_bytes = (double)e->index_n * C * sizeof(float) * B;     // algorithmic bytes: the index, read once per query group
@@ -56,9 +62,22 @@ void build_retrieval(rvc_engine *e, Plan &pl, int B, int T, int C, uint32_t skip
                         if (plp->prof_used == plp->prof.size()) { ProfEvent ev; HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b)); ev.flops = 0; ev.bytes = 0; plp->prof.push_back(ev); }
                         pe = &plp->prof[plp->prof_used++]; pe->flops = 0; pe->bytes = scan_bytes;
                     }
-                    if (pe) hipExtLaunchKernelGGL(knn_scan_select_kernel, grid, dim3(256), (uint32_t)lds, s, pe->a, pe->b, 0, fp);
+                    if (g_knn_test_lose.load(std::memory_order_relaxed)) {       // test hook (rvc_debug_option RVC_KNN_LOSE_TICKET): a hand-off that cannot complete
+                        KnnFusedP f2 = fp; f2.test_lose = 1; f2.spin_limit = 1u << 12;
+                        hipLaunchKernelGGL(knn_scan_select_kernel, grid, dim3(256), lds, s, f2);
+                    } else if (pe) hipExtLaunchKernelGGL(knn_scan_select_kernel, grid, dim3(256), (uint32_t)lds, s, pe->a, pe->b, 0, fp);
                     else hipLaunchKernelGGL(knn_scan_select_kernel, grid, dim3(256), lds, s, fp);
                 });
+            }
+            // What the engine runs instead when a selector gave up (ST_KNN_TIMEOUT: a workgroup of the launch did not arrive in time, e.g. on a GPU
+            // shared with another process): the exhaustive exact scan over the row-major index + merge + blend, built into a list of its own.
+            // The chunk is then recomputed from `phone` on and the call returns RVC_OK (engine.hip recover_retrieval).
+            if (!pl.bucket) {
+                OpList main_ops = std::move(pl.ops);
+                pl.ops = OpList();
+                build_exhaustive(e, pl, B, C, nq, nblk, first_raw, skip_head, R, T, phone, cvo, false, nullptr);
+                pl.knn_fallback = std::move(pl.ops.v);
+                pl.ops = std::move(main_ops);
             }
             return;
         }
@@ -96,6 +115,20 @@ void build_retrieval(rvc_engine *e, Plan &pl, int B, int T, int C, uint32_t skip
             const size_t slds = (size_t)33 * (C + 4) * sizeof(float);
             if (slds > 128 * 1024) throw ShapeError("feature dimension too large for the retrieval kernel");
             pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(knn_select_blend_kernel, sgrid, dim3(1024), slds, s, sp); });
+        }
+        build_exhaustive(e, pl, B, C, nq, nblk, first_raw, skip_head, R, T, phone, cvo, fast, d_overflow, d_q, cand_d, cand_i);
+}
+
+// The exhaustive exact scan (= the definition) + merge + blend.  d_q == nullptr: the section also gathers its own queries and owns its buffers.
+static void build_exhaustive(rvc_engine *e, Plan &pl, int B, int C, int nq, int nblk, int first_raw, uint32_t skip_head, uint32_t R, int T, const T1 &phone, const T1 &cvo,
+                             bool fast, int *d_overflow, float *d_q, float *cand_d, int *cand_i)
+{
+        if (!d_q) {
+            d_q = pl.arena.floats((size_t)B * nq * C);
+            cand_d = pl.arena.floats((size_t)B * nq * nblk * KNN_K);
+            cand_i = (int *)pl.arena.alloc((size_t)B * nq * nblk * KNN_K * sizeof(int));
+            dim3 grid((nq * C + 255) / 256, B);
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(knn_queries_kernel, grid, dim3(256), 0, s, cvo.p, cvo.ld, cvo.bs, C, first_raw, nq, d_q); });
         }
         for (int q0 = 0; q0 < nq; q0 += KNN_MAXQ) {
             const int qn = std::min(KNN_MAXQ, nq - q0);
@@ -215,7 +248,8 @@ rvc_status rvc_get_knn(rvc_engine *e, int32_t *idx, float *dist, size_t cap_rows
 {
     return guarded(e, [&]() {
         Plan *pl = e->last_plan;
-        if (!pl || !pl->with_index) { if (rows) *rows = 0; return RVC_OK; }
+        // (after rvc_infer_batch_g the last plan is one geometry bucket's, in bucket-local stream order: no rows are reported for such a call)
+        if (!pl || !pl->with_index || !e->last_knn_rows) { if (rows) *rows = 0; return RVC_OK; }
         // stream 0's return_length rows always; the further streams' rows (stream-major) as far as the caller's capacity holds whole streams
         if (cap_rows < pl->R) { if (rows) *rows = pl->R; return RVC_SHAPE; }
         const size_t r = pl->R * std::min((size_t)pl->B, cap_rows / pl->R);
@@ -226,5 +260,8 @@ rvc_status rvc_get_knn(rvc_engine *e, int32_t *idx, float *dist, size_t cap_rows
         return RVC_OK;
     });
 }
+
+// chunks whose retrieval was recomputed through the exhaustive launches after a hand-off time-out of the one-launch form (they returned RVC_OK)
+long long rvc_retrieval_recoveries(rvc_engine *e) { return e ? e->knn_recoveries : 0; }
 
 }  // extern "C"

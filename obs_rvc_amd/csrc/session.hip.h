@@ -176,8 +176,11 @@ rvc_status rvc_session_process(rvc_session *s, const float *input_sample, size_t
                                     (size_t)s->input_buffer_16k_size * 4, (size_t)s->model_return_size * 4, B, hipMemcpyDeviceToDevice, st));
         } else {
             size_t got = 0;
+            // with retrieval on, the chunk is synchronised before the post-processing chain: a hand-off time-out of the one-launch retrieval is
+            // recovered inside infer_common (the SOLA / envelope state behind it must only ever see the recovered chunk)
+            const bool sync_infer = e->d_index && e->index_rate > 0.f;
             rvc_status rc = infer_common(e, ring16, true, (size_t)s->input_buffer_16k_size, (size_t)s->sample_frame_16k, 0, (uint32_t)s->skip_head,
-                                         (uint32_t)s->model_return_length, s->d_model, true, (size_t)s->model_return_size, &got, false, s->pitch_shift.data());
+                                         (uint32_t)s->model_return_length, s->d_model, true, (size_t)s->model_return_size, &got, sync_infer, s->pitch_shift.data());
             if (rc != RVC_OK) return rc;
             if (got != (size_t)s->model_return_size) throw ShapeError("session: the loaded synthesizer's output rate does not match model_output_sample_rate");
         }
@@ -210,7 +213,7 @@ rvc_status rvc_session_process(rvc_session *s, const float *input_sample, size_t
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
         if (sola_offset) for (int b = 0; b < B; b++) sola_offset[b] = (size_t)s->h_off[b];
-        return s->skip_inference ? RVC_OK : check_status(e);
+        return s->skip_inference ? RVC_OK : final_status(e);
     });
 }
 

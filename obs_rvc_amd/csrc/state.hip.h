@@ -18,9 +18,14 @@ struct StreamState {        // one per stream
     float cache_pitchf[1024];   // rvc.rs:42
     uint32_t chunk;
     uint32_t stream_id;
-    int status;             // 0 ok, 6 = the reference would have panicked (rmvpe.rs:124 out-of-bounds), 7 = a hand-off timed out
+    int status;             // 0 ok, else a set of ST_* bits (atomicOr by the kernels, read and cleared by the host: engine.hip check_status)
     float uppower;          // this stream's 2^(pitch_shift / 12), truncating division (rvc.rs:121): every stream is its own caller
 };
+
+// status bits of a stream (several kernels of one chunk may report; a plain store would lose the earlier report)
+enum { ST_PANIC = 1,          // the reference would have panicked (rmvpe.rs:124 out-of-bounds gather)
+       ST_HANDOFF = 2,        // the GRU recurrence's cross-workgroup hand-off timed out: the chunk is lost
+       ST_KNN_TIMEOUT = 4 };  // the one-launch retrieval's selectors gave up waiting for a workgroup: the host recomputes the chunk's retrieval
 
 // Philox4x32-10, the same counter layout as oracle/rvc_oracle.c (ora_philox_normal)
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)

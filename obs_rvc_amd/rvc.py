@@ -207,6 +207,19 @@ class RvcInfer:
         """Offline throughput mode: unsynchronised infer_device calls overlap across chunks (rvc_set_pipeline)."""
         self._L.rvc_set_pipeline(self._h, 1 if on else 0)
 
+    def set_plan_cache(self, n_plans: int):
+        """Plans (one per call geometry) the engine keeps; least recently used evicted first (rvc_set_plan_cache)."""
+        self._chk(self._L.rvc_set_plan_cache(self._h, int(n_plans)))
+
+    def plan_cache_info(self) -> dict:
+        cap, cached, builds = C.c_int(), C.c_int(), C.c_longlong()
+        self._L.rvc_plan_cache_info(self._h, C.byref(cap), C.byref(cached), C.byref(builds))
+        return {"capacity": cap.value, "cached": cached.value, "builds": builds.value}
+
+    def retrieval_recoveries(self) -> int:
+        """Chunks whose retrieval was recomputed through the exhaustive scan after a hand-off time-out (they returned normally)."""
+        return int(self._L.rvc_retrieval_recoveries(self._h))
+
     def synchronize(self):
         self._chk(self._L.rvc_synchronize(self._h))
 

@@ -12,7 +12,11 @@ from common import BASELINE_160MS as g, voice_signal, zoo
 from obs_rvc_amd.rvc import RvcInfer
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 from common import set_opt
-for a in sys.argv[3:]:          # test hooks: NAME=VALUE
+json_out = None
+rest = sys.argv[3:]
+if "--json" in rest:
+    i = rest.index("--json"); json_out = rest[i + 1]; rest = rest[:i] + rest[i + 2:]
+for a in rest:                  # test hooks: NAME=VALUE
     set_opt(*a.split("=", 1))
 z = zoo(sys.argv[2] if len(sys.argv) > 2 else "full")
 eng = RvcInfer(z["data"], device=0); eng.load_contentvec(2); eng.load_f0(1); eng.load_model(z["model"]); eng.set_streams(S); eng.set_noise_seed(1, 0)
@@ -29,12 +33,21 @@ lib.rvc_debug_profile_dump.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.
 buf = ctypes.create_string_buffer(1 << 20)
 n = lib.rvc_debug_profile_dump(eng._h, buf, len(buf))
 tot_us = tot_gf = 0.0
+layers = []
+import re
 for ln in buf.value.decode().splitlines():
     us, gf, desc = ln.split(" ", 2)
     us, gf = float(us), float(gf)
     tot_us += us; tot_gf += gf
     tf = gf / us * 1e3 if us > 0 else 0.0
     print("%8.2f us %8.4f GF %6.1f TF %5.1f%%  %s" % (us, gf, tf, tf / 157.3 * 100, desc))
+    f = dict(re.findall(r"(\w+)=([\w.x]+)", desc))
+    M, N, K, nph = int(f.get("M", 0)), int(f.get("N", 0)), int(f.get("K", 0)), int(f.get("nph", 1))
+    ksum = float(f.get("ksum", K * nph))
+    layers.append({"launch": len(layers), "kernel": desc.split(" ", 1)[0], "M": M, "N": N, "K": K, "phases": nph, "tile": f.get("tile"), "grid": f.get("grid"),
+                   "k_split_waves": int(f.get("ks", 1)), "us": round(us, 2), "gflop": round(gf, 4), "tflops": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / 157.3, 4),
+                   # bytes every launch must move at least once: its weight panel(s) and its output (the input is re-used across taps / phases and not counted)
+                   "weight_bytes": int(4 * M * ksum), "output_bytes": int(4 * M * N * nph), "desc": desc})
 import time
 eng.set_profile(False)
 ts = []
@@ -44,3 +57,13 @@ for _ in range(40):
     ts.append(time.perf_counter() - t0)
 print("wall ms/chunk median %.4f min %.4f" % (np.median(ts[5:]) * 1e3, min(ts) * 1e3))
 print("total %d launches, %.1f us, %.2f GFLOP, %.1f TF/s" % (n, tot_us, tot_gf, tot_gf / tot_us * 1e3))
+if json_out:
+    import json
+    from obs_rvc_amd import _native
+    json.dump({"source": "tests/tools/op_profile.py %d %s: HIP events of the dispatches themselves (hipExtLaunchKernelGGL start / stop), one chunk, the two front "
+                         "branches issued one after the other above 4 streams" % (S, sys.argv[2] if len(sys.argv) > 2 else "full"),
+               "build": _native.binary_hash(), "streams": S, "peak_tflops_fp32_mfma": 157.3, "launches": n, "sum_us": round(tot_us, 1), "gflop": round(tot_gf, 2),
+               "tflops": round(tot_gf / tot_us * 1e3, 2), "wall_ms_per_chunk_median": round(float(np.median(ts[5:]) * 1e3), 4),
+               "kernel_names": {"reg": "igemm2_kernel (register-direct, 16x16x4 MFMA)", "g32": "igemm32_kernel (LDS-staged activations, 32x32x2 MFMA)",
+                                "g32w": "igemm32w_kernel (wide register tiles, 32x32x2 MFMA)", "lds": "igemm_lds_kernel (16x16x4 MFMA)", "ct": "conv_tile_kernel"},
+               "layers": layers}, open(json_out, "w"), indent=1)

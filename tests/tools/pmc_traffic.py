@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (counter_collection.csv) -> profiles/<round>_pmc_traffic.json.
 
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv|-> <out.json> [note]
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv|-> <out.json> [note] [config json] [algorithmic bytes per chunk]
+config json = the configuration the pass was taken on, e.g. {"streams": 64, "index": false, "version": 2, "preset": "full"}: bench.py uses a
+pass only for exactly that configuration (and exactly that build).
 Per the MI355X guide's HBM section: FETCH_SIZE is in KiB and reads exactly half of a wide coalesced stream on gfx950, so
 HBM read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is left uncalibrated.  A chunk ends at advance_chunk_kernel."""
 import csv, json, os, sys, collections
@@ -26,7 +28,7 @@ def per_class(rows):
     n_chunks = len(ends) - 2
     acc = collections.defaultdict(lambda: [0, 0.0])
     for _, name, v, _g in body:
-        key = "igemm_all_instantiations" if ("igemm_kernel" in name or "igemm_lds_kernel" in name or "igemm2_kernel" in name or "igemm32_kernel" in name or "conv_tile_kernel" in name) else ("knn_scan_select_kernel" if "knn_scan_select_kernel" in name else None)
+        key = "igemm_all_instantiations" if ("igemm_kernel" in name or "igemm_lds_kernel" in name or "igemm2_kernel" in name or "igemm32_kernel" in name or "igemm32w_kernel" in name or "conv_tile_kernel" in name) else ("knn_scan_select_kernel" if "knn_scan_select_kernel" in name else None)
         if key:
             acc[key][0] += 1; acc[key][1] += v
     return n_chunks, acc
@@ -54,6 +56,7 @@ out = {"source": (sys.argv[4] if len(sys.argv) > 4 else "") + " rocprofv3 --pmc 
        "chunks_profiled": nf,
        # the library the counters were taken on: bench.py puts these figures into roofline.traffic only when its own library carries the same hash
        "build": _native.binary_hash(),
+       "config": (json.loads(sys.argv[5]) if len(sys.argv) > 5 and sys.argv[5] else None),
        "kernel_class": "igemm_all_instantiations = igemm_kernel + igemm2_kernel + igemm_lds_kernel + igemm32_kernel + conv_tile_kernel (the launches roofline.launches_per_step counts)"}
 for key, (n, kib) in fa.items():
     d = {"launches_per_chunk": n / nf, "fetch_size_kib_per_chunk": kib / nf, "hbm_read_bytes_per_chunk": 2 * 1024 * kib / nf,
@@ -62,6 +65,8 @@ for key, (n, kib) in fa.items():
         d["write_size_kib_per_chunk"] = wa[key][1] / nw
     if key == "igemm_all_instantiations":
         d["algorithmic_weight_bytes_per_chunk"] = 852778176
+        if len(sys.argv) > 6:      # weights once + every layer's input and output once, per step
+            d["algorithmic_bytes_per_chunk_estimate"] = float(sys.argv[6])
     else:
         d["algorithmic_bytes_per_launch"] = 307200000
     out[key] = d

@@ -3,23 +3,34 @@
 # passes (separate runs, --kernel-trace only, as gpurun requires).  Raw traces stay in /tmp on the GPU box (hundreds of MB); the
 # summaries the repository keeps are written to gpurun_out/<tag>/ under their profiles/ names.
 # usage: profile_round.sh <tag> [round]      e.g. profile_round.sh r02d r02
-tag=${1:-r04}; rnd=${2:-r04}; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; raw=/tmp/prof_$tag; mkdir -p $out $raw
+tag=${1:-r05}; rnd=${2:-r05}; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; raw=/tmp/prof_$tag; mkdir -p $out $raw
 cd /tmp; export TMPDIR=/tmp
 prof() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d $raw/ks_$name -- python $R/bench.py --only-headline --no-cpu "$@" > $out/bench_$name.json 2> $out/bench_$name.err
          cp $raw/ks_$name/*/*kernel_stats.csv $out/${rnd}_kernel_stats_bench_$name.csv; }
 prof 1stream --steps 100
 prof index100k --steps 100 --index
 prof 64streams --steps 15 --warmup 3 --streams 64
-# the two front branches issued one after the other: true per-kernel durations at many streams (what roofline.frac of the 64-stream line uses)
-RVC_SERIAL_BRANCHES=1 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/ks_64serial -- python $R/bench.py --only-headline --no-cpu --steps 15 --warmup 3 --streams 64 > $out/bench_64streams_serial.json 2> $out/bench_64streams_serial.err
+# the two front branches issued one after the other (bench.py --serial-branches = the RVC_SERIAL_BRANCHES test hook through rvc_debug_option; the product
+# build reads no such variable from the environment): every kernel's own duration at many streams.  serial_pass.py writes the sidecar that bench.py checks
+# before it prints roofline.frac of a many-stream configuration.
+rocprofv3 --kernel-trace --stats --output-format csv -d $raw/ks_64serial -- python $R/bench.py --only-headline --no-cpu --steps 15 --warmup 3 --streams 64 --serial-branches > $out/bench_64streams_serial.json 2> $out/bench_64streams_serial.err
 cp $raw/ks_64serial/*/*kernel_stats.csv $out/${rnd}_kernel_stats_bench_64streams_serial_branches.csv
+python $R/tests/tools/serial_pass.py $out/${rnd}_kernel_stats_bench_64streams_serial_branches.csv 64 $out/${rnd}_serial_64streams.json ${rnd}_kernel_stats_bench_64streams_serial_branches.csv > /dev/null
 pmc() { name=$1; ctr=$2; shift 2; rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $raw/pmc_${name}_$ctr -- python $R/bench.py --only-headline --no-cpu "$@" > /dev/null 2>&1; }
+pmc 1stream FETCH_SIZE --steps 40
+pmc 1stream WRITE_SIZE --steps 40
 pmc index100k FETCH_SIZE --steps 40 --index
 pmc index100k WRITE_SIZE --steps 40 --index
 pmc 64streams FETCH_SIZE --steps 6 --warmup 2 --streams 64
 pmc 64streams WRITE_SIZE --steps 6 --warmup 2 --streams 64
-python $R/tests/tools/pmc_traffic.py $raw/pmc_index100k_FETCH_SIZE/*/*counter_collection.csv $raw/pmc_index100k_WRITE_SIZE/*/*counter_collection.csv $out/${rnd}_pmc_traffic.json "bench.py --only-headline --index (1 stream + 100k x 768 index):" > /dev/null
-python $R/tests/tools/pmc_traffic.py $raw/pmc_64streams_FETCH_SIZE/*/*counter_collection.csv $raw/pmc_64streams_WRITE_SIZE/*/*counter_collection.csv $out/${rnd}_pmc_traffic_64streams.json "bench.py --only-headline --streams 64:" > /dev/null
+# one file per configuration; bench.py takes roofline.traffic only from the pass of exactly its own configuration and build
+python $R/tests/tools/pmc_traffic.py $raw/pmc_1stream_FETCH_SIZE/*/*counter_collection.csv $raw/pmc_1stream_WRITE_SIZE/*/*counter_collection.csv $out/${rnd}_pmc_traffic_1stream.json "bench.py --only-headline (1 stream, retrieval off):" '{"streams": 1, "index": false, "version": 2, "preset": "full"}' 852778176 > /dev/null
+python $R/tests/tools/pmc_traffic.py $raw/pmc_index100k_FETCH_SIZE/*/*counter_collection.csv $raw/pmc_index100k_WRITE_SIZE/*/*counter_collection.csv $out/${rnd}_pmc_traffic.json "bench.py --only-headline --index (1 stream + 100k x 768 index):" '{"streams": 1, "index": true, "version": 2, "preset": "full"}' 852778176 > /dev/null
+python $R/tests/tools/pmc_traffic.py $raw/pmc_64streams_FETCH_SIZE/*/*counter_collection.csv $raw/pmc_64streams_WRITE_SIZE/*/*counter_collection.csv $out/${rnd}_pmc_traffic_64streams.json "bench.py --only-headline --streams 64:" '{"streams": 64, "index": false, "version": 2, "preset": "full"}' 13.9e9 > /dev/null
+# per-layer roofline table (HIP events of the dispatches themselves, branches serialised): M, N, K, kernel, us, TF/s, fraction of the fp32 MFMA peak
+python $R/tests/tools/op_profile.py 1 full --json $out/${rnd}_layers_1streams.json > $out/op_profile_1.txt 2>&1
+python $R/tests/tools/op_profile.py 8 full --json $out/${rnd}_layers_8streams.json > $out/op_profile_8.txt 2>&1
+python $R/tests/tools/op_profile.py 64 full --json $out/${rnd}_layers_64streams.json > $out/op_profile_64.txt 2>&1
 # SQ / TCC counters per kernel instantiation (two passes each: 8 SQ counters, then TCC + GRBM) -> tests/tools/pmc_summary.py
 SQ="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA"
 pmcs() { name=$1; shift; rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $raw/pmcs_${name}_a -- python $R/bench.py --only-headline --no-cpu "$@" > /dev/null 2>&1

@@ -1,0 +1,24 @@
+#!/usr/bin/env python
+"""rocprofv3 --kernel-trace --stats CSV of `bench.py --only-headline --streams S --serial-branches` -> profiles/<round>_serial_<S>streams.json:
+the sum of implicit-GEMM kernel time per step as rocprofv3 saw it, with the build hash of the library it was taken on.  bench.py prints
+roofline.frac of a many-stream configuration only when this file matches its own library and reproduces its HIP-event sum within 3 %.
+
+usage: serial_pass.py <kernel_stats.csv> <streams> <out.json> [csv name as committed]"""
+import csv, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from obs_rvc_amd import _native
+
+IGEMM = ("igemm_kernel", "igemm2_kernel", "igemm_lds_kernel", "igemm32_kernel", "igemm32w_kernel", "conv_tile_kernel", "splitk_epilogue_kernel")
+rows = list(csv.DictReader(open(sys.argv[1])))
+steps = sum(int(r["Calls"]) for r in rows if "advance_chunk_kernel" in r["Name"])
+if steps < 3:
+    raise SystemExit("no chunks in the trace")
+ig = [r for r in rows if any(k in r["Name"] for k in IGEMM)]
+tot_ns = sum(float(r["TotalDurationNs"]) for r in ig)
+launches = sum(int(r["Calls"]) for r in ig)
+out = {"source": "rocprofv3 --kernel-trace --stats of `bench.py --only-headline --no-cpu --streams %s --serial-branches` (tests/tools/profile_round.sh)" % sys.argv[2],
+       "csv": sys.argv[4] if len(sys.argv) > 4 else os.path.basename(sys.argv[1]), "build": _native.binary_hash(), "streams": int(sys.argv[2]),
+       "steps_in_trace": steps, "igemm_launches_per_step": launches / steps, "sum_igemm_ms_per_step": tot_ns / steps * 1e-6,
+       "kernel_class": ", ".join(IGEMM)}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out, indent=1))
