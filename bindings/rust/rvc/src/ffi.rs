@@ -2,7 +2,7 @@
 //! Names, argument order and integer widths follow the header one to one: `size_t` = `usize`, `int` = `c_int`,
 //! `rvc_status` = `c_int` (0 ok, 1 ModelNotLoaded, 2 ContentvecNotLoaded, 3 F0NotLoaded, 4 Backend, 5 Shape, 6 Panic).
 #![allow(dead_code)]
-use std::os::raw::{c_char, c_double, c_float, c_int, c_void};
+use std::os::raw::{c_char, c_double, c_float, c_int, c_longlong, c_void};
 
 #[repr(C)]
 pub struct RvcEngine {
@@ -73,6 +73,10 @@ extern "C" {
     pub fn rvc_synchronize(e: *mut RvcEngine) -> c_int;
     pub fn rvc_set_use_graph(e: *mut RvcEngine, on: c_int);
     pub fn rvc_set_pipeline(e: *mut RvcEngine, on: c_int);
+    // plan cache (one plan per call geometry; LRU) and the retrieval's recovered hand-off time-outs
+    pub fn rvc_set_plan_cache(e: *mut RvcEngine, n_plans: c_int) -> c_int;
+    pub fn rvc_plan_cache_info(e: *mut RvcEngine, capacity: *mut c_int, cached: *mut c_int, builds: *mut c_longlong) -> c_int;
+    pub fn rvc_retrieval_recoveries(e: *mut RvcEngine) -> c_longlong;
 
     // ---- caller-side steps of the plugin (obs-rvc/src/rt_utils.rs, obs-rvc/src/lib.rs:236-260,659-795)
     pub fn rvc_envelop_mixing(e: *mut RvcEngine, input: *const c_float, output: *mut c_float, output_len: usize, sample_rate: usize,

@@ -1198,8 +1198,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // Epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): a lane owns 16 rows of ONE column, so
 // the column part of the address (stream, row, validity) is computed once per 32-column block.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Wide register tiles (round 5): MT x NT = 4 x 2 (a wave owns 128 x 64 outputs, 128 accumulator registers, two waves per SIMD) and 4 x 4 (128 x 128,
+// 256 accumulator registers in the AGPR half of the file, one wave per SIMD).  An fp32 MFMA hides none of its SIMD's other instructions
+// (tests/tools/mfma_overlap_probe.hip), so what a K step costs beyond its MFMAs is its instruction count: per 32 MFMAs the 2 x 2 tile issues 4
+// weight loads + 8 gathers + 4 ds_read_b128 + 2 ds_write_b128; the 4 x 2 tile 4 + 4 + 2 + 1, the 4 x 4 tile 2 + 4 + 2 + 1.  The K loop is unrolled
+// by two so that the weight registers of consecutive steps alternate instead of being copied.
+template <int MT, int NT> struct G32Occ { static constexpr int W = MT * NT >= 16 ? 1 : (MT * NT >= 8 ? 2 : 3); };
 template <int WM, int WN, int MT, int NT, bool PRE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void igemm32_kernel(IgemmP p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G32Occ<MT, NT>::W, G32Occ<MT, NT>::W))) void igemm32_kernel(IgemmP p)
 {
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
@@ -1263,13 +1269,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     RVC_KP(1);
     const int *kof = s_mem;
     float sb[EPT];
-    f32x4 a_cur[MT][2], a_nxt[MT][2];
+    f32x4 a_ev[MT][2], a_od[MT][2];          // weights of the even / odd K steps (the loop below is unrolled by two: no copies)
 #pragma unroll
     for (int i = 0; i < EPT; i++) sb[i] = *reinterpret_cast<const float *>(xb + (xo_s + (unsigned)kof[kr0 + i]));
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-        for (int u = 0; u < 2; u++) a_cur[mt][u] = *reinterpret_cast<const f32x4 *>(wrow[mt] + u * 128);
+        for (int u = 0; u < 2; u++) a_ev[mt][u] = *reinterpret_cast<const f32x4 *>(wrow[mt] + u * 128);
 #pragma unroll
     for (int i = 0; i < EPT; i += 4) {
         f32x4 v4;
@@ -1281,17 +1287,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     RVC_KP(2);
     // B operand of MFMA (u, j) for column block nt: row k = (2u + ks) * 4 + j of the staged tile
     const float *br = bt + (wn * NT * 32 + c32) * RSK + ks * 4;
-    for (int c = 0; c < nchunks; c++) {
+    // one K step: request the next step's operands (global -> registers), run this step's MFMAs from a_c and the staged tile, stage the next tile
+    auto kstep = [&](const int c, f32x4 (&a_c)[MT][2], f32x4 (&a_n)[MT][2]) {
         const int cn = c + 1 < nchunks ? c + 1 : c;
         const float *bcur = br + (c & 1) * BN * RSK;
         float *bnxt = bt + ((c + 1) & 1) * BN * RSK;
-        // next K step: global -> registers
 #pragma unroll
         for (int i = 0; i < EPT; i++) sb[i] = *reinterpret_cast<const float *>(xb + (xo_s + (unsigned)kof[cn * 16 + kr0 + i]));
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-            for (int u = 0; u < 2; u++) a_nxt[mt][u] = *reinterpret_cast<const f32x4 *>(wrow[mt] + cn * 256 + u * 128);
+            for (int u = 0; u < 2; u++) a_n[mt][u] = *reinterpret_cast<const f32x4 *>(wrow[mt] + cn * 256 + u * 128);
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             f32x4 bv[NT];
@@ -1303,7 +1309,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                     for (int nt = 0; nt < NT; nt++)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][u][j], bv[nt][j], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[mt][u][j], bv[nt][j], acc[mt][nt], 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < EPT; i += 4) {
@@ -1312,11 +1318,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int q = 0; q < 4; q++) v4[q] = PRE ? fmaxf(sb[i + q], sb[i + q] * pre_slope) : sb[i + q];
             *reinterpret_cast<f32x4 *>(bnxt + n_s * RSK + kr0 + i) = v4;
         }
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int u = 0; u < 2; u++) a_cur[mt][u] = a_nxt[mt][u];
         __syncthreads();
+    };
+    {
+        int c = 0;
+        for (; c + 2 <= nchunks; c += 2) { kstep(c, a_ev, a_od); kstep(c + 1, a_od, a_ev); }
+        if (c < nchunks) kstep(c, a_ev, a_od);
     }
     RVC_KP(3);
     const float *resb = p.res ? p.res + (long long)b * p.res_bs : nullptr;

@@ -405,9 +405,21 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         // (round 4, same box: 3072 x 768 / 2304 x 768 at 8 streams 803 / 660 -> 692 / 575 us, 768 x 3072 / 768 x 768 at 32 streams 2761 / 771 -> 2413 / 675 us)
         if (lds_cfg == 7 && wgs < 500 && !tune_env("RVC_NO_G32_SQ64")) lds_cfg = 8;
     }
+    // tuning aid: RVC_G32W = "lc[,min workgroups[,min M]]" forces a wide-register-tile instantiation (9 = 256 x 128, 10 = 256 x 256, 11 / 12 = 128 x 256)
+    // on every layer the 32x32x2 kernel could take
+    if (const char *f = tune_env("RVC_G32W")) {
+        int wl = 0, wmin = 256, mmin = 0;
+        sscanf(f, "%d,%d,%d", &wl, &wmin, &mmin);
+        const bool g32_ok = !ln_fold && !p.glu && nchunks >= 2 && (size_t)nchunks * 64 + 2 * 256 * 20 * 4 <= 60 * 1024;
+        if (wl >= 9 && wl <= 12 && g32_ok) {
+            const int wbm = wl <= 10 ? 256 : 128, wbn = wl == 9 ? 128 : 256;
+            const long long wgs = (long long)((p.M + wbm - 1) / wbm) * ((p.N + wbn - 1) / wbn) * B * p.nphase;
+            if (p.M >= std::max(wbm / 2 + 1, mmin) && wgs >= wmin) lds_cfg = wl;
+        }
+    }
     if (lds_cfg >= 0) {
-        const int bm = lds_cfg == 8 ? 64 : (lds_cfg == 7 ? 128 : (lds_cfg == 6 ? 48 : (lds_cfg % 3 == 0 ? 128 : (lds_cfg % 3 == 1 ? 64 : 32))));
-        const int bn = (lds_cfg == 7 || lds_cfg == 8) ? 64 : ((lds_cfg != 6 && lds_cfg % 3 == 0) ? 128 : 256);
+        const int bm = lds_cfg >= 9 ? (lds_cfg <= 10 ? 256 : 128) : (lds_cfg == 8 ? 64 : (lds_cfg == 7 ? 128 : (lds_cfg == 6 ? 48 : (lds_cfg % 3 == 0 ? 128 : (lds_cfg % 3 == 1 ? 64 : 32)))));
+        const int bn = lds_cfg >= 9 ? (lds_cfg == 9 ? 128 : 256) : ((lds_cfg == 7 || lds_cfg == 8) ? 64 : ((lds_cfg != 6 && lds_cfg % 3 == 0) ? 128 : 256));
         p.ksplit = 1; p.chunks_per_split = nchunks;
         p.ntm = (p.M + bm - 1) / bm; p.ntn = (p.N + bn - 1) / bn;
         // tile order of the tiled kernels when the streams are folded into N: m fastest over XCD-local tile ids (1), or over the raw block index (2)

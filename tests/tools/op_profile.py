@@ -42,12 +42,12 @@ for ln in buf.value.decode().splitlines():
     tf = gf / us * 1e3 if us > 0 else 0.0
     print("%8.2f us %8.4f GF %6.1f TF %5.1f%%  %s" % (us, gf, tf, tf / 157.3 * 100, desc))
     f = dict(re.findall(r"(\w+)=([\w.x]+)", desc))
-    M, N, K, nph = int(f.get("M", 0)), int(f.get("N", 0)), int(f.get("K", 0)), int(f.get("nph", 1))
-    ksum = float(f.get("ksum", K * nph))
-    layers.append({"launch": len(layers), "kernel": desc.split(" ", 1)[0], "M": M, "N": N, "K": K, "phases": nph, "tile": f.get("tile"), "grid": f.get("grid"),
+    lM, lN, lK, nph = int(f.get("M", 0)), int(f.get("N", 0)), int(f.get("K", 0)), int(f.get("nph", 1))
+    ksum = float(f.get("ksum", lK * nph))
+    layers.append({"launch": len(layers), "kernel": desc.split(" ", 1)[0], "M": lM, "N": lN, "K": lK, "phases": nph, "tile": f.get("tile"), "grid": f.get("grid"),
                    "k_split_waves": int(f.get("ks", 1)), "us": round(us, 2), "gflop": round(gf, 4), "tflops": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / 157.3, 4),
                    # bytes every launch must move at least once: its weight panel(s) and its output (the input is re-used across taps / phases and not counted)
-                   "weight_bytes": int(4 * M * ksum), "output_bytes": int(4 * M * N * nph), "desc": desc})
+                   "weight_bytes": int(4 * lM * ksum), "output_bytes": int(4 * lM * lN * nph), "desc": desc})
 import time
 eng.set_profile(False)
 ts = []
