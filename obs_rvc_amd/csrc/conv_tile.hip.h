@@ -159,24 +159,29 @@ __global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_
 #pragma unroll
     for (int nf = 0; nf < NF; nf++) bcur[nf] = *reinterpret_cast<const f32x4 *>(bl + off_b + nf * 16 * cs);
     RVC_CT_ADV()
-    constexpr int T_ = MF * NF * 4, R_ = MF + NF;
+    constexpr int T_ = MF * NF * 4;
 #define RVC_CT_STEP(S, CC)                                                                              \
     {                                                                                                  \
         const int cc_ = (CC);                                                                          \
         const int ob_ = cc_ < last ? off_b : 0;                 /* the surplus request of the last chunk stays inside the tile */ \
         f32x4 bnx_[NF];                                                                                \
-        f32x4 a_old_[MF];                                                                              \
-        _Pragma("unroll") for (int mf = 0; mf < MF; mf++) a_old_[mf] = a_st[S][mf];                    \
         _Pragma("unroll") for (int t = 0; t < T_; t++) {                                               \
             const int j = t / (NF * MF), nf = (t / MF) % NF, mf = t % MF;                              \
-            if (!(RVC_CT_DBG & 8)) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_old_[mf][j], bcur[nf][j], acc[mf][nf], 0, 0, 0); \
-            else acc[mf][nf][0] += a_old_[mf][j] * bcur[nf][j];                                        \
-            _Pragma("unroll") for (int r = t * R_ / T_; r < (t + 1) * R_ / T_; r++) {                  \
-                if (r < NF) { if (!(RVC_CT_DBG & 2)) bnx_[r] = *reinterpret_cast<const f32x4 *>(bl + ob_ + r * 16 * cs); else bnx_[r] = bcur[r]; } \
-                else if (!(RVC_CT_DBG & 1)) a_st[S][r - NF] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(wnext[r - NF]) + lane16); \
+            if (!(RVC_CT_DBG & 8)) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[S][mf][j], bcur[nf][j], acc[mf][nf], 0, 0, 0); \
+            else acc[mf][nf][0] += a_st[S][mf][j] * bcur[nf][j];                                       \
+            /* the next chunk's B fragments are requested between the MFMAs */                         \
+            _Pragma("unroll") for (int r = t * NF / T_; r < (t + 1) * NF / T_; r++) {                  \
+                if (!(RVC_CT_DBG & 2)) bnx_[r] = *reinterpret_cast<const f32x4 *>(bl + ob_ + r * 16 * cs); else bnx_[r] = bcur[r]; \
             }                                                                                          \
             __builtin_amdgcn_sched_barrier(0);                                                         \
         }                                                                                              \
+        /* the weights are reloaded BEHIND their last use (round 5): requested between the MFMAs into the array they were still being read from, the \
+           new value lived in a second register set and the loop-carried copies back (v_mov on registers a load had just been issued into) sat at \
+           the loop head -- every round of DA chunks began by waiting for all weight loads in flight */ \
+        if (!(RVC_CT_DBG & 1)) {                                                                       \
+            _Pragma("unroll") for (int mf = 0; mf < MF; mf++) a_st[S][mf] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(wnext[mf]) + lane16); \
+        }                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
         RVC_CT_ADV()                                                                                   \
         _Pragma("unroll") for (int mf = 0; mf < MF; mf++) wnext[mf] += KS * 256;      /* (requests past the wave's last chunk read the slack behind the panel) */ \
         _Pragma("unroll") for (int nf = 0; nf < NF; nf++) bcur[nf] = bnx_[nf];                         \

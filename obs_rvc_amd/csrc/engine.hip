@@ -508,9 +508,7 @@ void rvc_destroy(rvc_engine *e)
     (void)hipDeviceSynchronize();
     e->plans.clear();
     e->cv.reset(); e->rm.reset(); e->sy.reset();
-    if (e->d_window) (void)hipFree(e->d_window);
-    if (e->d_twiddle) (void)hipFree(e->d_twiddle);
-    if (e->d_basis) (void)hipFree(e->d_basis);
+    wfree(e->d_window); wfree(e->d_twiddle); wfree(e->d_basis);      // (upload_f: slab memory)
     if (e->d_band) (void)hipFree(e->d_band);
     if (e->d_index && e->index_owned) (void)hipFree(e->d_index);
     if (e->d_indexT) (void)hipFree(e->d_indexT);
@@ -1073,7 +1071,7 @@ double rvc_debug_ln_fold_check(rvc_engine *e, int M, int K, int N, float offset)
         }
         worst = err;
         free_conv(c1); free_conv(c2);
-        (void)hipFree(wsum); (void)hipFree(dg); (void)hipFree(dbeta);
+        wfree(wsum); wfree(dg); wfree(dbeta);
         return RVC_OK;
     });
     return worst;

@@ -153,6 +153,7 @@ struct ConvW {
 static inline int round16(int k) { return (k + 15) / 16 * 16; }
 
 
+void *wmalloc(size_t bytes); void wfree(void *p);      // weight memory: slab-allocated (plan.hip)
 float *upload_f(const std::vector<float> &v);
 float *upload_f(const float *p, size_t n);
 float *upload_fragments(const std::vector<float> &panel, int nphase, int M, int Kp);
@@ -250,7 +251,7 @@ struct Plan {
     hipGraphExec_t graph_exec = nullptr;
     ~Plan()
     {
-        for (float *p : owned_dev) (void)hipFree(p);
+        for (float *p : owned_dev) wfree(p);
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (ev_done) (void)hipEventDestroy(ev_done);
         for (auto &e : prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -360,13 +361,13 @@ struct ModelCV {
     {
         for (auto &c : conv) free_conv(c);
         free_conv(proj); free_conv(pos); free_conv(final_proj); free_conv(proj_f);
-        if (proj_wsum) (void)hipFree(proj_wsum);
+        if (proj_wsum) wfree(proj_wsum);
         for (auto &L : layers) {
             free_conv(L.qkv); free_conv(L.o); free_conv(L.ff1); free_conv(L.ff2); free_conv(L.qkv_f); free_conv(L.ff1_f);
-            if (L.qkv_wsum) (void)hipFree(L.qkv_wsum);
-            if (L.ff1_wsum) (void)hipFree(L.ff1_wsum);
+            if (L.qkv_wsum) wfree(L.qkv_wsum);
+            if (L.ff1_wsum) wfree(L.ff1_wsum);
         }
-        for (float *p : owned) (void)hipFree(p);
+        for (float *p : owned) wfree(p);
     }
     int out_frames(size_t L) const
     {
@@ -447,13 +448,13 @@ struct ModelRM {
     }
     ~ModelRM()
     {
-        auto fb = [](std::vector<std::vector<ResBlockW>> &vv) { for (auto &v : vv) for (auto &r : v) { free_conv(r.c1); free_conv(r.c2); free_conv(r.sc); if (r.pair_bias) (void)hipFree(r.pair_bias); } };
+        auto fb = [](std::vector<std::vector<ResBlockW>> &vv) { for (auto &v : vv) for (auto &r : v) { free_conv(r.c1); free_conv(r.c2); free_conv(r.sc); if (r.pair_bias) wfree(r.pair_bias); } };
         fb(enc); fb(inter); fb(dec);
         for (auto &u : up) free_conv(u);
         free_conv(cnn); free_conv(gru_ih); free_conv(fc);
-        if (whhT) (void)hipFree(whhT);
-        if (bhh) (void)hipFree(bhh);
-        if (whh) (void)hipFree(whh);
+        if (whhT) wfree(whhT);
+        if (bhh) wfree(bhh);
+        if (whh) wfree(whh);
     }
 };
 
@@ -757,13 +758,13 @@ struct ModelSY {
     ~ModelSY()
     {
         free_conv(phone); free_conv(proj); free_conv(dec_pre); free_conv(dec_post);
-        for (auto &L : layers) { free_conv(L.qkv); free_conv(L.o); free_conv(L.ff1); free_conv(L.ff2); free_conv(L.qkv_f); if (L.qkv_wsum) (void)hipFree(L.qkv_wsum); }
-        free_conv(proj_f); if (proj_wsum) (void)hipFree(proj_wsum);
+        for (auto &L : layers) { free_conv(L.qkv); free_conv(L.o); free_conv(L.ff1); free_conv(L.ff2); free_conv(L.qkv_f); if (L.qkv_wsum) wfree(L.qkv_wsum); }
+        free_conv(proj_f); if (proj_wsum) wfree(proj_wsum);
         for (auto &F : flows) { free_conv(F.pre); free_conv(F.post); for (auto &c : F.in) free_conv(c); for (auto &c : F.rs) free_conv(c); if (composed) { free_conv(F.pre1); free_conv(F.postc); free_conv(F.posth); for (auto &c : F.inc) free_conv(c); } }
         for (auto &c : ups) free_conv(c);
         for (auto &c : ncs) free_conv(c);
         for (auto &s : rbs) for (auto &ch : s) for (auto &pr : ch) { free_conv(pr.first); free_conv(pr.second); }
-        for (float *p : owned) (void)hipFree(p);
+        for (float *p : owned) wfree(p);
     }
     int upp() const { int u = 1; for (int i = 0; i < n_ups; i++) u *= up_rate[i]; return u; }
 };

@@ -546,6 +546,7 @@ __device__ __forceinline__ Epi2 epi2_from_col(const IgemmP &p, const PhaseD &ph,
     return e;
 }
 __device__ __forceinline__ Epi2 epi2_plain(float bias, int yo) { Epi2 e = {bias, 0.f, 0.f, yo}; return e; }
+__device__ __forceinline__ Epi2 epi2_none() { Epi2 e = {0.f, 0.f, 0.f, -1}; return e; }
 // the same with the bias already in hand (batched epilogues: biases are loaded once per row, before any store)
 __device__ __forceinline__ Epi2 epi2_aux(const IgemmP &p, const PhaseD &ph, const float *resb, const float *yb, const ColOut &c, int m, float bias)
 {
@@ -716,60 +717,47 @@ void igemm2_kernel(IgemmP p)
             }                                                                                          \
     }
 #define RVC_LOAD_STAGE(S, C) { RVC_LOAD_A(S, C) RVC_LOAD_B(S, C) }
-    // 2. first D stages: weights (and, without a table, the activations) leave first
-    if (live) {
-#pragma unroll
-        for (int s = 0; s < D; s++)
-            if (s < nc) { RVC_LOAD_A(s, s) if (LIN) RVC_LOAD_B(s, s) }
-    }
-    // 3b. epilogue operands: requested now, BEHIND the first weight / activation loads (their address arithmetic alone is 0.8 us at a
+    // The K loop has TWO code paths (round 5).  The compiler's s_waitcnt counts at a loop head are the most conservative of all ways into the loop: with
+    // the first D stages requested under `if (s < nc)` there is a path on which only stage 0 was requested, so the head of the steady-state loop (and
+    // every stage of the tail loop) waited with vmcnt(0) -- for the loads issued a few MFMAs earlier, once per round of D chunks: the D-deep register
+    // ring was drained every round and a one-stream wave (12-18 chunks) spent its life in two or three full memory round trips.  Now a wave with at
+    // least D chunks takes a path on which every request of the prologue is unconditional and in stage order, the steady-state loop has that prologue
+    // as its only way in (exact counts: stage s waits until (D - 1) stages' loads are outstanding), and the remainder is two straight-line drain
+    // rounds; a wave with fewer chunks takes the short conditional path.
+    // 3b (both paths). epilogue operands: requested BEHIND the first weight / activation loads (their address arithmetic alone is 0.8 us at a
     //     4-element share per thread; in front of the main loads it delayed every launch by that much)
     Epi2 pre_w[(KS > 1 || !PF) ? 1 : MF][(KS > 1 || !PF) ? 1 : NF][4];
     Epi2 pre_r[PE];
     float pre_ws[LNB ? PE : 1];
-    if (PF && live && !p.glu) {
-        if (KS > 1) {
-#pragma unroll
-            for (int q = 0; q < PE; q++) {
-                const int e = threadIdx.x + q * WAVES * 64;
-                const int l = e & 63, r = (e >> 6) & 3, f = e >> 8, mf = f / NF, nf = f - mf * NF;
-                pre_r[q] = (e < TE) ? epi2_prefetch(p, ph, resb, yb, tm * 16 * MF + mf * 16 + (l >> 4) * 4 + r, tn * 16 * NF + nf * 16 + (l & 15)) : Epi2{0.f, 0.f, 0.f, -1};
-                if (LNB) { const int m_ = tm * 16 * MF + mf * 16 + (l >> 4) * 4 + r; pre_ws[LNB ? q : 0] = (e < TE && m_ < p.M) ? p.ln_wsum[ph.bias_off + m_] : 0.f; }
-            }
-        } else {
-#pragma unroll
-            for (int nf = 0; nf < ((KS > 1 || !PF) ? 1 : NF); nf++) {
-                const ColOut col = col_locate(p, ph, tn * 16 * NF + nf * 16 + li);
-#pragma unroll
-                for (int mf = 0; mf < ((KS > 1 || !PF) ? 1 : MF); mf++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        pre_w[mf][nf][r] = epi2_from_col(p, ph, resb, yb, col, tm * 16 * MF + mf * 16 + kq * 4 + r);
-            }
-        }
+#define RVC_EPI_PREFETCH                                                                               \
+    if (PF && live && !p.glu) {                                                                        \
+        if (KS > 1) {                                                                                  \
+            _Pragma("unroll") for (int q = 0; q < PE; q++) {                                           \
+                const int e = threadIdx.x + q * WAVES * 64;                                            \
+                const int l = e & 63; const int r = (e >> 6) & 3; const int f = e >> 8; const int mf = f / NF; const int nf = f - mf * NF; \
+                pre_r[q] = (e < TE) ? epi2_prefetch(p, ph, resb, yb, tm * 16 * MF + mf * 16 + (l >> 4) * 4 + r, tn * 16 * NF + nf * 16 + (l & 15)) : epi2_none(); \
+                if (LNB) { const int m_ = tm * 16 * MF + mf * 16 + (l >> 4) * 4 + r; pre_ws[LNB ? q : 0] = (e < TE && m_ < p.M) ? p.ln_wsum[ph.bias_off + m_] : 0.f; } \
+            }                                                                                          \
+        } else {                                                                                       \
+            _Pragma("unroll") for (int nf = 0; nf < ((KS > 1 || !PF) ? 1 : NF); nf++) {                \
+                const ColOut col = col_locate(p, ph, tn * 16 * NF + nf * 16 + li);                     \
+                _Pragma("unroll") for (int mf = 0; mf < ((KS > 1 || !PF) ? 1 : MF); mf++)              \
+                    _Pragma("unroll") for (int r = 0; r < 4; r++)                                      \
+                        pre_w[mf][nf][r] = epi2_from_col(p, ph, resb, yb, col, tm * 16 * MF + mf * 16 + kq * 4 + r); \
+            }                                                                                          \
+        }                                                                                              \
     }
-    RVC_KP(11);
-    if (!LIN) {
-        // 4. publish the offset table: registers -> LDS (the rare long tables finish with a plain copy loop)
-#pragma unroll
-        for (int r = 0; r < KR; r++) { const int i = kt_i + r * KT_STRIDE; if (i < kt_n) kdst[i] = kr[r]; }
-        for (int i = kt_i + KR * KT_STRIDE; i < kt_n; i += KT_STRIDE) kdst[i] = ksrc[i];
-        if (KS > 1) __builtin_amdgcn_s_waitcnt(0xC07F);      // wave-private slice: LDS writes done (lgkmcnt(0)), no barrier
-        else lds_only_barrier();
+    // 4 (both paths). publish the offset table: registers -> LDS (the rare long tables finish with a plain copy loop)
+#define RVC_PUBLISH_TABLE                                                                              \
+    if (!LIN) {                                                                                        \
+        _Pragma("unroll") for (int r = 0; r < KR; r++) { const int i = kt_i + r * KT_STRIDE; if (i < kt_n) kdst[i] = kr[r]; } \
+        for (int i = kt_i + KR * KT_STRIDE; i < kt_n; i += KT_STRIDE) kdst[i] = ksrc[i];               \
+        if (KS > 1) __builtin_amdgcn_s_waitcnt(0xC07F);      /* wave-private slice: LDS writes done (lgkmcnt(0)), no barrier */ \
+        else lds_only_barrier();                                                                       \
     }
-    RVC_KP(1);
-    if (!live) { if (KS > 1) { /* whole workgroup is dead: uniform */ } return; }
-    if (!LIN) {
-        ko_nx = nc > 0 ? kol[0] : make_int4(0, 0, 0, 0);
-#pragma unroll
-        for (int s = 0; s < D; s++)
-            if (s < nc) RVC_LOAD_B(s, s)
-    }
-    RVC_KP(2);
-    int c = 0;
-    // steady state: every operand register is reloaded right after its last use, so the loads of the next round are interleaved with
-    // the MFMAs of this one instead of forming a block during which the matrix pipe drains (measured at 64 streams: the 768 x 3072
-    // projection 75 -> 92 TF/s, the 768 x 768 one 61 -> 78 TF/s; no change at one stream)
+    // steady state of the fused form: every operand register is reloaded right after its last use, so the loads of the next round are interleaved
+    // with the MFMAs of this one instead of forming a block during which the matrix pipe drains (measured at 64 streams: the 768 x 3072 projection
+    // 75 -> 92 TF/s, the 768 x 768 one 61 -> 78 TF/s; no change at one stream)
 #define RVC_FUSED_STAGE(S, C)                                                                          \
     {                                                                                                  \
         const int cc_ = (C);                                                                           \
@@ -777,19 +765,22 @@ void igemm2_kernel(IgemmP p)
         if (LIN) { const unsigned kb_ = (unsigned)cc_ * lin16; ko_ = make_int4((int)kb_, (int)(kb_ + lin1), (int)(kb_ + 2u * lin1), (int)(kb_ + 3u * lin1)); } \
         else { ko_ = ko_nx; ko_nx = kol[(cc_ + 1 < nc ? cc_ + 1 : cc_) * 4]; }                         \
         const unsigned kov_[4] = {(unsigned)ko_.x, (unsigned)ko_.y, (unsigned)ko_.z, (unsigned)ko_.w}; \
-        f32x4 a_old_[MF];                                                                              \
-        _Pragma("unroll") for (int mf = 0; mf < MF; mf++) a_old_[mf] = a_st[S][mf];                    \
-        _Pragma("unroll") for (int mf = 0; mf < MF; mf++) a_st[S][mf] = *reinterpret_cast<const f32x4 *>(wrow[mf] + cc_ * 256); \
         _Pragma("unroll") for (int j = 0; j < 4; j++)                                                  \
             _Pragma("unroll") for (int nf = 0; nf < NF; nf++) {                                        \
                 const float bv_ = PRE ? fmaxf(b_st[S][nf][j], b_st[S][nf][j] * pre_slope) : b_st[S][nf][j]; \
                 if (LNB) { const float d_ = bv_ - ln_c[LNB ? nf : 0]; ln_s[LNB ? nf : 0] += d_; ln_ss[LNB ? nf : 0] = fmaf(d_, d_, ln_ss[LNB ? nf : 0]); } \
                 _Pragma("unroll") for (int mf = 0; mf < MF; mf++)                                      \
-                    acc[j % NACC][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_old_[mf][j], bv_, acc[j % NACC][mf][nf], 0, 0, 0); \
+                    acc[j % NACC][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_st[S][mf][j], bv_, acc[j % NACC][mf][nf], 0, 0, 0); \
                 b_st[S][nf][j] = *reinterpret_cast<const float *>(xb + (xo[nf] + kov_[j]));            \
             }                                                                                          \
+        /* the weights are reloaded BEHIND their last use (round 5).  Requested at the top of the stage into the same array, the new value lived in a \
+           second register set next to a copy of the old one, and the loop-carried copies back (v_mov on registers a load had just been issued \
+           into) were placed at the loop head: every round began by waiting for ALL outstanding loads */ \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        _Pragma("unroll") for (int mf = 0; mf < MF; mf++) a_st[S][mf] = *reinterpret_cast<const f32x4 *>(wrow[mf] + cc_ * 256); \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
     }
-    // Not for the lone-fragment tile: with its two alternating accumulators (NACC = 2) this form computes garbage as soon as the loop is
+    // Not for the lone-fragment tile: with its two alternating accumulators (NACC = 2) the fused form computes garbage as soon as the loop is
     // entered (K >= 24 chunks; `test_every_tile_configuration_computes_the_same_convolution` with -DRVC_FUSE_ALL), with or without
     // scheduling barriers between the stages, while the same source with one accumulator per fragment is exact -- a code-generation
     // problem of that instantiation as far as could be determined.  Its 12-deep prefetch hides the load block anyway.
@@ -798,31 +789,76 @@ void igemm2_kernel(IgemmP p)
 #else
     constexpr bool kFuse = NACC == 1;
 #endif
-    if (kFuse) {
-        for (; c + 2 * D <= nc; c += D) {
+    if (live && nc >= D) {
+        // ---- the long path: at least D chunks for this wave (wave-uniform; uniform per workgroup when KS == 1, where all waves share nchunks)
+        // 2. first D stages, unconditional and in stage order: weights (and, without a table, the activations) leave first
 #pragma unroll
-            for (int s = 0; s < D; s++) RVC_FUSED_STAGE(s, c + s + D)
+        for (int s = 0; s < D; s++) { RVC_LOAD_A(s, s) if (LIN) RVC_LOAD_B(s, s) }
+        RVC_EPI_PREFETCH
+        RVC_KP(11);
+        RVC_PUBLISH_TABLE
+        RVC_KP(1);
+        if (!LIN) {
+            ko_nx = kol[0];
+#pragma unroll
+            for (int s = 0; s < D; s++) RVC_LOAD_B(s, s)
         }
-    }
-#undef RVC_FUSED_STAGE
-    for (; c + 2 * D <= nc; c += D) {
+        RVC_KP(2);
+        int c = 0;
+        if (kFuse) {
+            for (; c + 2 * D <= nc; c += D) {
+#pragma unroll
+                for (int s = 0; s < D; s++) RVC_FUSED_STAGE(s, c + s + D)
+            }
+        } else {
+            for (; c + 2 * D <= nc; c += D) {
+#pragma unroll
+                for (int s = 0; s < D; s++) {
+                    RVC_COMPUTE_STAGE(s)
+                    __builtin_amdgcn_sched_barrier(0);
+                    RVC_LOAD_STAGE(s, c + s + D)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // drain: D <= nc - c < 2 D.  Round one computes the D loaded stages and requests the last nc - c - D chunks; round two computes those.
+        const int rem = nc - c - D;
 #pragma unroll
         for (int s = 0; s < D; s++) {
             RVC_COMPUTE_STAGE(s)
-            __builtin_amdgcn_sched_barrier(0);
-            RVC_LOAD_STAGE(s, c + s + D)
-            __builtin_amdgcn_sched_barrier(0);
+            if (s < rem) RVC_LOAD_STAGE(s, c + s + D)
         }
-    }
-    for (; c < nc; c += D) {
 #pragma unroll
         for (int s = 0; s < D; s++) {
-            if (c + s < nc) {
-                RVC_COMPUTE_STAGE(s)
-                if (c + s + D < nc) RVC_LOAD_STAGE(s, c + s + D)
-            }
+            if (s < rem) RVC_COMPUTE_STAGE(s)
+        }
+    } else {
+        // ---- the short path: fewer than D chunks (or a dead tile: nothing but the barrier the workgroup shares)
+        if (live) {
+#pragma unroll
+            for (int s = 0; s < D; s++)
+                if (s < nc) { RVC_LOAD_A(s, s) if (LIN) RVC_LOAD_B(s, s) }
+        }
+        RVC_EPI_PREFETCH
+        RVC_KP(11);
+        RVC_PUBLISH_TABLE
+        RVC_KP(1);
+        if (!live) { if (KS > 1) { /* whole workgroup is dead: uniform */ } return; }
+        if (!LIN) {
+            ko_nx = nc > 0 ? kol[0] : make_int4(0, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < D; s++)
+                if (s < nc) RVC_LOAD_B(s, s)
+        }
+        RVC_KP(2);
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            if (s < nc) RVC_COMPUTE_STAGE(s)
         }
     }
+#undef RVC_FUSED_STAGE
+#undef RVC_EPI_PREFETCH
+#undef RVC_PUBLISH_TABLE
 #undef RVC_COMPUTE_STAGE
 #undef RVC_LOAD_STAGE
 #undef RVC_LOAD_A
@@ -1001,6 +1037,187 @@ void igemm2_kernel(IgemmP p)
         )
     }
     RVC_KP(6);
+}
+
+typedef float f32x16w __attribute__((ext_vector_type(16)));
+// ------------------------------------------------------------------------------------------------------------------------
+// igemm2w_kernel -- register-direct implicit GEMM on v_mfma_f32_32x32x2_f32 for the table-free 1x1 layers (every Linear of the
+// transformers) at a FEW streams (round 5: the regime between the one-stream latency kernels and the many-stream LDS-staged tiles).
+// One wave owns a (32 MT) x (32 NT) output tile; the KS waves of a workgroup split K and meet in a fixed-order LDS reduction
+// (deterministic).  No LDS staging: with the streams folded into N a layer has too few tiles for a workgroup tile to share its
+// activation operand across enough rows, and an in-workgroup K split of a staged tile multiplies the staging per MFMA; here the
+// K split costs nothing but the final reduction.  What the 32x32x2 form buys over igemm2_kernel's 16x16x4 fragments: one activation
+// gather (a dword per lane: 32 consecutive columns of two k rows) feeds a 64-clock MFMA instead of a 32-clock one, and a weight
+// float4 feeds NT * 4 of them -- 20 vector-memory instructions per 32 MFMAs of 64 clocks (2 x 2 blocks) against 10 per 16 of 32
+// clocks: half the instructions per matrix-pipe clock, and an fp32 MFMA hides none of them (tests/tools/mfma_overlap_probe.hip).
+// Operand order inside a 16-deep chunk: MFMA (u, j) takes k = (2u + ks) * 4 + j, ks = lane >> 5 -- the weights come straight from the
+// 16-row fragment packing (lane (row r, k-slot ks) reads the float4 of fragment r >> 4, quad 2u + ks), as in igemm32_kernel.
+template <int MT, int NT, int KS>
+__global__ __launch_bounds__(KS * 64) void igemm2w_kernel(IgemmP p)
+{
+    constexpr int D = MT * NT >= 4 ? 2 : 3;             // chunks in flight per wave
+    constexpr int TE = MT * NT * 1024;                  // elements of the wave tile
+    constexpr int PE = KS > 1 ? (TE + KS * 64 - 1) / (KS * 64) : 1;     // elements a thread finishes after the reduction
+    extern __shared__ __attribute__((aligned(16))) float s_red[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int fast = (int)blockIdx.x, slow = (int)blockIdx.y;
+    const int tm = p.m_fast ? fast : slow, tn = p.m_fast ? slow : fast;
+    if (tm >= p.ntm || tn >= p.ntn) return;             // padding of the XCD-aware order (uniform per workgroup)
+    const PhaseD &ph = p.ph0;
+    const int nchunks = ph.nchunks;
+    int c0 = 0, nc = nchunks;
+    if (KS > 1) {
+        const int cpw = (nchunks + KS - 1) / KS;
+        c0 = wave * cpw;
+        int c1 = c0 + cpw;
+        c1 = c1 < nchunks ? c1 : nchunks;
+        nc = c1 > c0 ? c1 - c0 : 0;
+    }
+    const int c32 = lane & 31, ks = lane >> 5;
+    const float *resb = p.res;
+    float *yb = p.y + ph.y_off;
+    // activations: wave-uniform base + 32-bit byte offset per lane (column of this lane, k rows c0 * 16 + ks * 4 ...)
+    const char *xb = reinterpret_cast<const char *>(p.x + ph.x_off);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xb), 0, 0x7ffff000, 0x00020000);      // raw buffer, 32-bit data format
+    const unsigned lin1 = (unsigned)p.lin_cs4;
+    // (one byte offset per gather of a chunk, fixed for the whole launch: the chunk's position goes into the wave-uniform base pointer, so a gather
+    //  costs no vector ALU instruction)
+    unsigned xo[NT][8];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        int n = (tn * NT + nt) * 32 + c32;
+        n = n < p.N ? n : p.N - 1;
+        int bb = 0;
+        if (p.fold_n) { bb = n / p.fold_n; n -= bb * p.fold_n; }
+        const unsigned o = (unsigned)(bb * (int)p.x_bs + n * p.x_ws) * 4u + (unsigned)(c0 * 16 + ks * 4) * lin1;
+#pragma unroll
+        for (int q = 0; q < 8; q++) xo[nt][q] = o + (unsigned)((q >> 2) * 8 + (q & 3)) * lin1;
+    }
+    // weights: the same addressing (all vector-memory instructions of the loop are buffer loads: one kind of load, so the compiler's
+    // s_waitcnt counts stay exact -- with global loads for the weights next to buffer loads for the activations it waited for the NEWEST
+    // stage's loads before the oldest stage's MFMAs)
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w + ph.w_off), 0, 0x7ffff000, 0x00020000);
+    unsigned wo[MT];
+    const int mtiles = (p.M + 15) >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        int t16 = (tm * MT + mt) * 2 + (c32 >> 4);
+        t16 = t16 < mtiles ? t16 : mtiles - 1;
+        wo[mt] = (unsigned)(((long long)t16 * nchunks + c0) * 256 + (ks * 16 + (c32 & 15)) * 4) * 4u;
+    }
+    f32x16w acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
+    f32x4 a_st[D][MT][2];
+    float b_st[D][NT][8];
+    auto load = [&](f32x4 (&a)[MT][2], float (&b)[NT][8], const int c) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) a[mt][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, (int)wo[mt], c * 1024 + u * 512, 0));
+        // buffer loads: per-lane byte offset in a VGPR that never changes, the chunk's offset in an SGPR -- no vector ALU work per gather
+        const int so = (int)((unsigned)c * 16u * lin1);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) b[nt][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)xo[nt][q], so, 0));
+    };
+    auto compute = [&](const f32x4 (&a)[MT][2], const float (&b)[NT][8]) {
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][u][j], b[nt][u * 4 + j], acc[mt][nt], 0, 0, 0);
+    };
+    // (the first D stages leave unconditionally and in stage order: the compiler's s_waitcnt counts at the loop head are the more conservative of the
+    //  ways into the loop, and with a conditional prologue -- a path on which the second stage was never requested -- every iteration waited for the
+    //  NEWEST stage's loads before computing the oldest)
+#pragma unroll
+    for (int s = 0; s < D; s++) {
+        load(a_st[s], b_st[s], s < nc ? s : (nc > 0 ? nc - 1 : 0));      // unconditional (a stage past the wave's range re-reads its last chunk and is never used)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    int c = 0;
+    for (; c + 2 * D <= nc; c += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            compute(a_st[s], b_st[s]);
+            __builtin_amdgcn_sched_barrier(0);
+            load(a_st[s], b_st[s], c + s + D);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    for (; c < nc; c += D) {
+#pragma unroll
+        for (int s = 0; s < D; s++) {
+            if (c + s < nc) {
+                compute(a_st[s], b_st[s]);
+                if (c + s + D < nc) load(a_st[s], b_st[s], c + s + D);
+            }
+        }
+    }
+    // C / D layout of the 32x32 block: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (KS > 1) {
+        // fixed-order reduction of the KS partial tiles through LDS; every thread then finishes its share of the tile (consecutive
+        // threads = consecutive columns: coalesced stores)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) s_red[wave * TE + ((mt * NT + nt) * 16 + r) * 64 + lane] = acc[mt][nt][r];
+        __syncthreads();
+        // (batches of eight: a whole-share batch of 32 elements took the 64 x 64 tile with two waves to 288 registers)
+        constexpr int EB = PE < 8 ? PE : 8;
+        RVC_ACT_DISPATCH(
+            for (int q0 = 0; q0 < PE; q0 += EB) {
+                float v[EB];
+                Epi2 ep[EB];
+                _Pragma("unroll") for (int qq = 0; qq < EB; qq++) {
+                    const int e = (int)threadIdx.x + (q0 + qq) * KS * 64;
+                    const bool in = q0 + qq < PE && e < TE;
+                    float sum = 0.f;
+                    if (in) {
+                        _Pragma("unroll") for (int w = 0; w < KS; w++) sum += s_red[w * TE + e];
+                    }
+                    v[qq] = sum;
+                    const int l = e & 63; const int r = (e >> 6) & 15; const int f = e >> 10; const int mt = f / NT; const int nt = f - mt * NT;
+                    ep[qq] = in ? epi2_prefetch(p, ph, resb, yb, (tm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), (tn * NT + nt) * 32 + (l & 31)) : epi2_none();
+                }
+                _Pragma("unroll") for (int qq = 0; qq < EB; qq++) epi2_finish<A_>(p, yb, v[qq], ep[qq]);
+            }
+        )
+        return;
+    }
+    ColOut cols[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) cols[nt] = col_locate(p, ph, (tn * NT + nt) * 32 + c32);
+    RVC_ACT_DISPATCH(
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) {
+            float bias_r[16];
+            _Pragma("unroll") for (int r = 0; r < 16; r++) {
+                const int m = (tm * MT + mt) * 32 + ks * 4 + (r & 3) + 8 * (r >> 2);
+                bias_r[r] = (p.bias && m < p.M) ? p.bias[ph.bias_off + m] : 0.f;
+            }
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {
+                _Pragma("unroll") for (int h = 0; h < 16; h += 8) {
+                    Epi2 e_[8];
+                    _Pragma("unroll") for (int r = 0; r < 8; r++)
+                        e_[r] = epi2_aux(p, ph, resb, yb, cols[nt], (tm * MT + mt) * 32 + ks * 4 + ((h + r) & 3) + 8 * ((h + r) >> 2), bias_r[h + r]);
+                    _Pragma("unroll") for (int r = 0; r < 8; r++) epi2_finish<A_>(p, yb, acc[mt][nt][h + r], e_[r]);
+                }
+            }
+        }
+    )
 }
 
 // Throughput-mode implicit GEMM (many streams batched: N = B*T is large).  Classic CDNA anatomy: a 256-thread

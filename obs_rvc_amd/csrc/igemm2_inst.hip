@@ -43,7 +43,7 @@ void RVC_FN(int ks, bool pre, bool lin, const IgemmP &p, dim3 grid, size_t lds, 
         switch (ks) {
         case 4: launch_k(igemm2_kernel<MF, NF, D, 4, false, true, true>, p, grid, dim3(256), lds, s, ea, eb); return;
         case 8: launch_k(igemm2_kernel<MF, NF, D, 8, false, true, true>, p, grid, dim3(512), lds, s, ea, eb); return;
-        default: launch_k(igemm2_kernel<MF, NF, D16, 16, false, true, true>, p, grid, dim3(1024), lds, s, ea, eb); return;
+        default: launch_k(igemm2_kernel<MF, NF, (D16 > 4 ? 4 : D16), 16, false, true, true>, p, grid, dim3(1024), lds, s, ea, eb); return;      // (128 registers at 16 waves: a shallower ring instead of spills)
         }
     }
 #define RVC_KS2(PRE, LIN)                                                                                              \

@@ -1,0 +1,60 @@
+// igemm2w_inst.hip (-DRVC_G2W_PART=0..2: one unit per wave tile, compiled in parallel) -- instantiations of igemm2w_kernel, the register-direct
+// 32x32x2 kernel of the table-free 1x1 layers at a few streams (igemm.hip.h): wave tiles 32 x 32, 64 x 32, 64 x 64, each with 1 / 2 / 3 / 4 / 6 / 8
+// waves per workgroup splitting K.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include "igemm_launch.h"
+
+#ifndef RVC_G2W_PART
+#define RVC_G2W_PART 0
+#endif
+
+namespace rvc {
+
+#if RVC_G2W_PART == 0
+#define G2W_MT 1
+#define G2W_NT 1
+#define G2W_FN launch_igemm2w_t0
+#elif RVC_G2W_PART == 1
+#define G2W_MT 2
+#define G2W_NT 1
+#define G2W_FN launch_igemm2w_t1
+#else
+#define G2W_MT 2
+#define G2W_NT 2
+#define G2W_FN launch_igemm2w_t2
+#endif
+
+template <int KS> static void g2w_attr()
+{
+    // the K-split reduction keeps KS partial tiles in LDS: up to 128 KB (64 x 64 tile, 8 waves)
+    (void)hipFuncSetAttribute((const void *)igemm2w_kernel<G2W_MT, G2W_NT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+}
+void G2W_FN(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
+{
+    if (ks < 0) { g2w_attr<2>(); g2w_attr<3>(); g2w_attr<4>(); g2w_attr<6>(); g2w_attr<8>(); return; }      // once per device (igemm2w_prepare_device)
+    switch (ks) {
+    case 1: launch_k(igemm2w_kernel<G2W_MT, G2W_NT, 1>, p, grid, dim3(64), lds, s, ea, eb); return;
+    case 2: launch_k(igemm2w_kernel<G2W_MT, G2W_NT, 2>, p, grid, dim3(128), lds, s, ea, eb); return;
+    case 3: launch_k(igemm2w_kernel<G2W_MT, G2W_NT, 3>, p, grid, dim3(192), lds, s, ea, eb); return;
+    case 4: launch_k(igemm2w_kernel<G2W_MT, G2W_NT, 4>, p, grid, dim3(256), lds, s, ea, eb); return;
+    case 6: launch_k(igemm2w_kernel<G2W_MT, G2W_NT, 6>, p, grid, dim3(384), lds, s, ea, eb); return;
+    default: launch_k(igemm2w_kernel<G2W_MT, G2W_NT, 8>, p, grid, dim3(512), lds, s, ea, eb); return;
+    }
+}
+
+#if RVC_G2W_PART == 0
+void launch_igemm2w(int tile, int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
+{
+    if (tile == 0) launch_igemm2w_t0(ks, p, grid, lds, s, ea, eb);
+    else if (tile == 1) launch_igemm2w_t1(ks, p, grid, lds, s, ea, eb);
+    else launch_igemm2w_t2(ks, p, grid, lds, s, ea, eb);
+}
+void igemm2w_prepare_device()
+{
+    IgemmP p{};
+    for (int t = 0; t < 3; t++) launch_igemm2w(t, -1, p, dim3(1), 0, nullptr, nullptr, nullptr);
+}
+#endif
+
+}  // namespace rvc

@@ -34,6 +34,14 @@ static const int kTileBM[3] = {128, 64, 32}, kTileBN[3] = {16, 32, 64}, kTileWF[
 void conv_tile_prepare_device();
 void launch_conv_tile(int tile, int kshares, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
 
+// igemm2w_kernel (register-direct 32x32x2, table-free 1x1 layers at a few streams): tile 0 = 32 x 32 per wave, 1 = 64 x 32, 2 = 64 x 64; ks waves split K
+static const int kG2wMT[3] = {1, 2, 2}, kG2wNT[3] = {1, 1, 2};
+void igemm2w_prepare_device();
+void launch_igemm2w(int tile, int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
+void launch_igemm2w_t0(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+void launch_igemm2w_t1(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+void launch_igemm2w_t2(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+
 template <typename K> static inline void launch_k(K kern, const IgemmP &p, dim3 grid, dim3 block, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
 {
     if (ea) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, s, ea, eb, 0, p);

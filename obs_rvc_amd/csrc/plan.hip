@@ -6,7 +6,7 @@
 namespace rvc {
 
 static const char *const kTestHooks[] = {"RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_NO_LN_FUSE", "RVC_NO_CONV0_MULTI", "RVC_KNN_NO_GEMM",
-                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET"};
+                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W"};
 std::atomic<unsigned> g_opt_gen{0};       // bumped by every rvc_debug_option call: plans built under another generation are dropped (engine.hip get_plan)
 static std::mutex g_opt_mu;
 static std::map<std::string, std::string> g_opts;
@@ -32,10 +32,55 @@ const char *test_opt(const char *name) { return opt_lookup(name); }
 #endif
 int test_opt_int(const char *name, int dflt) { const char *v = test_opt(name); return v ? atoi(v) : dflt; }
 
+// Weight memory.  A model is ~1 200 tensors from a few bytes to 9 MB; one hipMalloc each gave every tensor its own mapping, placed wherever the
+// driver's VRAM manager had a hole: the weights of an engine that is created after others have come and gone end up in small scattered page
+// fragments, and the one-stream f0 branch -- 361 MB of weights streamed once per chunk through the 32 CUs of one XCD behind one L2 TLB -- ran up
+// to 18 % slower for the sixth engine of a process than for the first (tests/tools/late_engine.py).  Weights are now
+// bump-allocated from 256 MB slabs, each ONE hipMalloc (contiguous, maximal page fragments), reference-counted: a slab is returned to the driver
+// when its last tensor is freed.
+namespace {
+struct WSlab { char *base; size_t size, used; long live; };
+std::mutex g_wslab_mu;
+std::vector<WSlab> g_wslabs;
+const size_t kWSlabBytes = (size_t)256 << 20;
+}
+void *wmalloc(size_t bytes)
+{
+    bytes = (std::max<size_t>(bytes, 16) + 255) / 256 * 256;
+    std::lock_guard<std::mutex> lk(g_wslab_mu);
+    int dev = 0; HIPCHK(hipGetDevice(&dev));
+    if (bytes <= kWSlabBytes / 4 && !g_wslabs.empty()) {
+        WSlab &b = g_wslabs.back();         // (slabs are per device in practice: one process drives one GPU; a pointer from another device's slab is never handed out
+        hipPointerAttribute_t at;           //  because the bump slab is abandoned when the current device differs)
+        if (b.size == kWSlabBytes && b.used + bytes <= b.size && hipPointerGetAttributes(&at, b.base) == hipSuccess && at.device == dev) {
+            void *r = b.base + b.used; b.used += bytes; b.live++;
+            return r;
+        }
+        (void)hipGetLastError();
+    }
+    const size_t sz = bytes <= kWSlabBytes / 4 ? kWSlabBytes : bytes;
+    void *c;
+    HIPCHK(hipMalloc(&c, sz));
+    g_wslabs.push_back(WSlab{(char *)c, sz, bytes, 1});
+    return c;
+}
+void wfree(void *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_wslab_mu);
+    for (size_t i = 0; i < g_wslabs.size(); i++) {
+        WSlab &b = g_wslabs[i];
+        if ((char *)p >= b.base && (char *)p < b.base + b.size) {
+            if (--b.live == 0) { (void)hipFree(b.base); g_wslabs.erase(g_wslabs.begin() + i); }
+            return;
+        }
+    }
+    (void)hipFree(p);          // not from a slab
+}
+
 float *upload_f(const std::vector<float> &v)
 {
-    float *d;
-    HIPCHK(hipMalloc(&d, std::max<size_t>(v.size(), 4) * sizeof(float)));
+    float *d = (float *)wmalloc(std::max<size_t>(v.size(), 4) * sizeof(float));
     if (!v.empty()) HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
     return d;
 }
@@ -119,8 +164,8 @@ ConvW prep_convT2d(const float *w, const float *bias, int Cin, int Cout)
 void free_conv(ConvW &c)
 {
     if (c.owns) {
-        if (c.w) (void)hipFree(c.w);
-        if (c.bias) (void)hipFree(c.bias);
+        if (c.w) wfree(c.w);
+        if (c.bias) wfree(c.bias);
     }
     c.w = c.bias = nullptr;
 }
@@ -131,14 +176,14 @@ void merge_convs(const std::vector<ConvW *> &cs)
     size_t tw = 0, tb = 0;
     for (ConvW *c : cs) { if (!c->owns || !c->bias) throw std::runtime_error("merge_convs: unexpected conv"); tw += (size_t)c->nphase * phase_stride(*c); tb += (size_t)c->Cout; }
     float *W, *Bv;
-    HIPCHK(hipMalloc(&W, tw * sizeof(float))); HIPCHK(hipMalloc(&Bv, std::max<size_t>(tb, 4) * sizeof(float)));
+    W = (float *)wmalloc(tw * sizeof(float)); Bv = (float *)wmalloc(std::max<size_t>(tb, 4) * sizeof(float));
     size_t ow = 0, ob = 0;
     for (size_t i = 0; i < cs.size(); i++) {
         ConvW *c = cs[i];
         const size_t nw = (size_t)c->nphase * phase_stride(*c);
         HIPCHK(hipMemcpy(W + ow, c->w, nw * sizeof(float), hipMemcpyDeviceToDevice));
         HIPCHK(hipMemcpy(Bv + ob, c->bias, (size_t)c->Cout * sizeof(float), hipMemcpyDeviceToDevice));
-        (void)hipFree(c->w); (void)hipFree(c->bias);
+        wfree(c->w); wfree(c->bias);
         c->w = W + ow; c->bias = Bv + ob; c->owns = i == 0;
         ow += nw; ob += c->Cout;
     }
@@ -273,6 +318,14 @@ static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &
 }
 
 // generic: the caller fills geometry (N, NW, strides, koff, phases); this picks the tile + split-K and queues the op
+// Which table-free 1x1 layers take igemm2w_kernel, and with what tile / K split (filled in from per-layer measurements: tests/tools/g2w_sweep.py).
+// gt < 0: not this kernel.
+static void g2w_rule(const IgemmP &p, int nchunks, int &gt, int &gk)
+{
+    (void)p; (void)nchunks;
+    gt = -1; gk = 1;
+}
+
 void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases, bool final_out)
 {
     p.probe = g_kprobe;
@@ -405,6 +458,47 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         // (round 4, same box: 3072 x 768 / 2304 x 768 at 8 streams 803 / 660 -> 692 / 575 us, 768 x 3072 / 768 x 768 at 32 streams 2761 / 771 -> 2413 / 675 us)
         if (lds_cfg == 7 && wgs < 500 && !tune_env("RVC_NO_G32_SQ64")) lds_cfg = 8;
     }
+    // igemm2w_kernel: register-direct 32x32x2 tiles for the table-free 1x1 layers at a few streams (igemm.hip.h).  Test hook RVC_FORCE_G2W = "tile,ks"
+    // (tile 0 = 32 x 32 per wave, 1 = 64 x 32, 2 = 64 x 64; ks = 1 / 2 / 3 / 4 / 6 / 8 waves splitting K) forces it wherever it is eligible.
+    {
+        const bool g2w_ok = p.lin_cs4 != 0 && p.nphase == 1 && !pre && !p.glu && !ln_fold && B == 1 && nchunks >= 1;
+        int gt = -1, gk = 1;
+        if (const char *f = test_opt("RVC_FORCE_G2W")) { if (sscanf(f, "%d,%d", &gt, &gk) < 1) gt = -1; }
+        else g2w_rule(p, nchunks, gt, gk);
+        if (g2w_ok && gt >= 0 && gt <= 2) {
+            if (gk != 1 && gk != 2 && gk != 3 && gk != 4 && gk != 6 && gk != 8) gk = gk > 8 ? 8 : 4;
+            while (gk > 1 && nchunks < gk) gk = gk == 8 ? 6 : (gk == 6 ? 4 : gk - 1);
+            const int bm = 32 * kG2wMT[gt], bn = 32 * kG2wNT[gt];
+            p.ksplit = 1; p.chunks_per_split = nchunks;
+            p.ntm = (p.M + bm - 1) / bm; p.ntn = (p.N + bn - 1) / bn;
+            const bool wh = p.ntm >= 2;           // all column tiles of one weight-row block on one XCD (its L2 is private)
+            p.m_fast = wh ? (p.ntm + 7) / 8 * 8 : 0;
+            unsigned gx = (unsigned)(wh ? p.ntm : p.ntn);
+            if (wh && gx >= 8) gx = (gx + 7) / 8 * 8;
+            const dim3 grid(gx, (unsigned)(wh ? p.ntn : p.ntm), 1);
+            if (grid.y > 65535) throw ShapeError("implicit GEMM grid too large");
+            p.nbatch = 1;
+            const size_t lds = gk > 1 ? (size_t)gk * kG2wMT[gt] * kG2wNT[gt] * 1024 * sizeof(float) : 0;
+            g_last_wgs = (int)(grid.x * grid.y); g_last_waves = gk;
+            const double flops = 2.0 * p.M * (double)p.N * ksum;
+            pl.igemm_flops += flops; pl.n_igemm++;
+            Plan *plp = &pl;
+            { char d[176]; snprintf(d, sizeof d, "g2w M=%d N=%d K=%d B=1 nph=1 tile=%dx%d ks=%d grid=%ux%u", p.M, p.N, p.K, bm, bn, gk, grid.x, grid.y); pl.descs.push_back(d); }
+            const int desc_id = (int)pl.descs.size() - 1;
+            if (final_out) pl.final_out_honoured = true;
+            pl.ops.push_back([=](hipStream_t s) {
+                ProfEvent *pe = nullptr;
+                if (plp->profile) {
+                    if (plp->prof_used == plp->prof.size()) { ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; e.bytes = 0; plp->prof.push_back(e); }
+                    pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
+                }
+                hipEvent_t ea = pe ? pe->a : nullptr, eb = pe ? pe->b : nullptr;
+                if (final_out && plp->cur_out) { IgemmP q = p; q.y = plp->cur_out; q.y_bs = plp->cur_out_bs; launch_igemm2w(gt, gk, q, grid, lds, s, ea, eb); }
+                else launch_igemm2w(gt, gk, p, grid, lds, s, ea, eb);
+            });
+            return;
+        }
+    }
     // tuning aid: RVC_G32W = "lc[,min workgroups[,min M]]" forces a wide-register-tile instantiation (9 = 256 x 128, 10 = 256 x 256, 11 / 12 = 128 x 256)
     // on every layer the 32x32x2 kernel could take
     if (const char *f = tune_env("RVC_G32W")) {
@@ -415,7 +509,9 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
             const int wbm = wl <= 10 ? 256 : 128, wbn = wl == 9 ? 128 : 256;
             const long long wgs = (long long)((p.M + wbm - 1) / wbm) * ((p.N + wbn - 1) / wbn) * B * p.nphase;
             if (p.M >= std::max(wbm / 2 + 1, mmin) && wgs >= wmin) lds_cfg = wl;
-        }
+        } else if (g32_ok && (wl == 3 || wl == 4 || wl == 5 || wl == 7 || wl == 8)) lds_cfg = wl;      // any of the older 32x32x2 tiles
+        else if (wl == -1) lds_cfg = -1;                                                                  // the register-direct kernel (then RVC_FORCE_CFG picks its tile)
+
     }
     if (lds_cfg >= 0) {
         const int bm = lds_cfg >= 9 ? (lds_cfg <= 10 ? 256 : 128) : (lds_cfg == 8 ? 64 : (lds_cfg == 7 ? 128 : (lds_cfg == 6 ? 48 : (lds_cfg % 3 == 0 ? 128 : (lds_cfg % 3 == 1 ? 64 : 32)))));
@@ -799,6 +895,7 @@ void plan_kernel_attrs()
 {
     HIPCHK(hipFuncSetAttribute((const void *)layernorm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));   // + 1.3 KB static
     conv_tile_prepare_device();
+    igemm2w_prepare_device();
 }
 
 }  // namespace rvc

@@ -212,7 +212,7 @@ static rvc_status resampler_create_n(rvc_engine *e, size_t rate_in, size_t rate_
         HIPCHK(hipMalloc(&r->d_x, (size_t)nb * fi * 4)); HIPCHK(hipMalloc(&r->d_out, (size_t)nb * fo * 4));
         HIPCHK(hipStreamSynchronize(e->stream));
         HIPCHK(hipGetLastError());
-        (void)hipFree(d_h); (void)hipFree(d_Fr); (void)hipFree(d_Fi);
+        wfree(d_h); (void)hipFree(d_Fr); (void)hipFree(d_Fi);
         HIPCHK(hipFuncSetAttribute((const void *)resample_polyphase_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         *out = r.release();
         return RVC_OK;

@@ -733,6 +733,16 @@ def test_every_tile_configuration_computes_the_same_convolution():
                     e1 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, 1, pre)
                     assert 0 <= e1 < 2e-5, (cfg, ks, M, Cin, KW, dil, N, pre, e1)
         set_opt("RVC_FORCE_CFG", None)
+        # igemm2w_kernel (round 5: register-direct 32x32x2 tiles for the table-free 1x1 layers at a few streams): every wave tile x K split, one stream
+        # and streams folded into N, ragged M / N, K shorter and longer than the register ring, K splits that leave waves without a chunk
+        for tile in range(3):
+            for ks in (1, 2, 3, 4, 6, 8):
+                set_opt("RVC_FORCE_G2W", "%d,%d" % (tile, ks))
+                for streams in (1, 3, 8):
+                    for (M, Cin, N) in [(48, 48, 111), (144, 48, 111), (96, 384, 37), (768, 256, 111), (100, 1040, 70), (64, 16, 33)]:
+                        e5 = L.rvc_debug_conv_check(h, M, Cin, 1, 1, N, streams, 0)
+                        assert 0 <= e5 < 2e-5, ("igemm2w", tile, ks, streams, M, Cin, N, e5)
+        set_opt("RVC_FORCE_G2W", None)
         # conv_tile_kernel (one stream, stride-1 1-D convolutions whose input channels come in 16s: input tile staged once per workgroup, K walked
         # tap-major from repacked weights): every tile shape, with one and two K shares, forced onto short and long layers alike
         for tile128 in ("0",):
@@ -755,7 +765,7 @@ def test_every_tile_configuration_computes_the_same_convolution():
                 e4 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, streams, pre)
                 assert 0 <= e4 < 2e-5, ("tall", streams, M, Cin, KW, dil, N, pre, e4)
     finally:
-        for k in ("RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS"):
+        for k in ("RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_FORCE_G2W"):
             set_opt(k, None)
         L.rvc_destroy(h)
 

@@ -215,3 +215,25 @@ def test_full_size_end_to_end_at_the_stream_counts_the_bench_times(S):
         yo = _oracle(z, 6, 200 + s).infer(xin[s], g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
         assert rms(ye[s] - yo) < PCM_TOL, (s, rms(ye[s] - yo))
     eng.close()
+
+
+@pytest.mark.parametrize("force,streams", [("2,4", 3), ("1,3", 2), ("0,2", 5), ("2,1", 3), ("2,8", 1)])
+def test_forced_igemm2w_end_to_end(force, streams):
+    # igemm2w_kernel (register-direct 32x32x2 tiles, K split over the waves of a workgroup) forced onto every table-free 1x1 layer it can take --
+    # the transformer projections with their GELU / residual epilogues, the text encoder's 1x1 layers -- through the whole model against the oracle
+    # (the kernel-level test covers the tile arithmetic; this one the epilogue operands in a real plan).
+    z = zoo("tiny")
+    set_opt("RVC_FORCE_G2W", force)
+    try:
+        eng = _engine(z, streams, (3, 60))
+        xin = np.stack([voice_signal(g.input_buffer_16k_size, seed=20 + s) for s in range(streams)])
+        for tick in range(2):
+            ye = eng.infer_batch(xin, g.sample_frame_16k, 12, g.skip_head, g.model_return_length) if streams > 1 else eng.infer(xin[0], g.sample_frame_16k, 12, g.skip_head, g.model_return_length)[None]
+            if tick == 0:
+                oras = [_oracle(z, 3, 60 + s) for s in range(streams)]
+            for s in range(streams):
+                yo = oras[s].infer(xin[s], g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+                assert rms(ye[s] - yo) < PCM_TOL, (force, tick, s, rms(ye[s] - yo))
+        eng.close()
+    finally:
+        set_opt("RVC_FORCE_G2W", None)
