@@ -40,7 +40,7 @@ _INT_DEPS = ("engine_int.h", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "
 _ENGINE_DEPS = ("engine.hip", "resample.hip.h", "session.hip.h", "rccl_bcast.hip.h") + _INT_DEPS
 UNITS = [("engine.hip", [], _ENGINE_DEPS)] + [(u, [], (u,) + _INT_DEPS) for u in ("plan.hip", "model_cv.hip", "model_rmvpe.hip", "model_synth.hip", "retrieval.hip")] + \
         [("igemm2_inst.hip", ["-DRVC_IGEMM2_CFG=%d" % c], ("igemm2_inst.hip",) + _IGEMM_DEPS) for c in range(5)] + \
-        [("igemm_tiled_inst.hip", ["-DRVC_TILED_PART=%d" % c], ("igemm_tiled_inst.hip",) + _IGEMM_DEPS) for c in range(6)] + \
+        [("igemm_tiled_inst.hip", ["-DRVC_TILED_PART=%d" % c], ("igemm_tiled_inst.hip",) + _IGEMM_DEPS) for c in range(4)] + \
         [("igemm2w_inst.hip", ["-DRVC_G2W_PART=%d" % c], ("igemm2w_inst.hip",) + _IGEMM_DEPS) for c in range(3)] + \
         [("conv_tile_inst.hip", [], ("conv_tile_inst.hip", "conv_tile.hip.h") + _IGEMM_DEPS)]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]

@@ -1415,11 +1415,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // Epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): a lane owns 16 rows of ONE column, so
 // the column part of the address (stream, row, validity) is computed once per 32-column block.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-// Wide register tiles (round 5): MT x NT = 4 x 2 (a wave owns 128 x 64 outputs, 128 accumulator registers, two waves per SIMD) and 4 x 4 (128 x 128,
-// 256 accumulator registers in the AGPR half of the file, one wave per SIMD).  An fp32 MFMA hides none of its SIMD's other instructions
-// (tests/tools/mfma_overlap_probe.hip), so what a K step costs beyond its MFMAs is its instruction count: per 32 MFMAs the 2 x 2 tile issues 4
-// weight loads + 8 gathers + 4 ds_read_b128 + 2 ds_write_b128; the 4 x 2 tile 4 + 4 + 2 + 1, the 4 x 4 tile 2 + 4 + 2 + 1.  The K loop is unrolled
-// by two so that the weight registers of consecutive steps alternate instead of being copied.
+// Wide register tiles were measured in round 5 and are not instantiated: MT x NT = 4 x 2 (a wave owns 128 x 64 outputs, 222 registers, two waves per
+// SIMD) runs the 64-stream layers at the speed of the 2 x 2 tile (+-1 %; +5 % on the one layer whose grid it rounds better), 4 x 4 (256 accumulator
+// registers) spills -- DESIGN.md section 7 round 5.  The occupancy rule and the loop below stay general.  The K loop is unrolled by two so that the weight
+// registers of consecutive steps alternate instead of being copied.
 template <int MT, int NT> struct G32Occ { static constexpr int W = MT * NT >= 16 ? 1 : (MT * NT >= 8 ? 2 : 3); };
 template <int WM, int WN, int MT, int NT, bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G32Occ<MT, NT>::W, G32Occ<MT, NT>::W))) void igemm32_kernel(IgemmP p)

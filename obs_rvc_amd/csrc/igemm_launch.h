@@ -25,8 +25,6 @@ void launch_igemm_tiled_p0(int lc, bool pre, const IgemmP &p, dim3 grid, size_t 
 void launch_igemm_tiled_p1(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 void launch_igemm_tiled_p2(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 void launch_igemm_tiled_p3(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
-void launch_igemm_tiled_p4(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
-void launch_igemm_tiled_p5(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 
 // conv_tile_kernel (conv_tile.hip.h) tiles: 0 = 128 x 16 (four waves stacked in M), 1 = 64 x 32, 2 = 32 x 64 (2 x 2 waves), each with one or two K shares.
 // WF = waves per K share x MF x NF.

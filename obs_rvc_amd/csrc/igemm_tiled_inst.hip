@@ -34,8 +34,6 @@ void launch_igemm_tiled(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds
     if (lc == 0 || lc == 1) launch_igemm_tiled_p0(lc, pre, p, grid, lds, s, ea, eb);
     else if (lc == 2 || lc == 6 || lc == 8) launch_igemm_tiled_p1(lc, pre, p, grid, lds, s, ea, eb);
     else if (lc == 3 || lc == 4) launch_igemm_tiled_p2(lc, pre, p, grid, lds, s, ea, eb);
-    else if (lc >= 9 && lc <= 10) launch_igemm_tiled_p4(lc, pre, p, grid, lds, s, ea, eb);
-    else if (lc >= 11 && lc <= 12) launch_igemm_tiled_p5(lc, pre, p, grid, lds, s, ea, eb);
     else launch_igemm_tiled_p3(lc, pre, p, grid, lds, s, ea, eb);
 }
 #endif
@@ -53,13 +51,6 @@ void launch_igemm_tiled_p2(int lc, bool pre, const IgemmP &p, dim3 grid, size_t 
 #endif
 #if RVC_TILED_PART == 3 || defined(RVC_UNITY)
 void launch_igemm_tiled_p3(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb) { if (lc == 7) RVC_LG32(4, 1, 1, 2) else RVC_LG32(1, 4, 1, 2) }
-#endif
-// wide register tiles: 9 = 256 x 128 (waves 2 x 2, each 128 x 64), 10 = 256 x 256 (each 128 x 128), 11 = 128 x 256 (each 64 x 128), 12 = 128 x 256 (waves 1 x 4, each 128 x 64)
-#if RVC_TILED_PART == 4 || defined(RVC_UNITY)
-void launch_igemm_tiled_p4(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb) { if (lc == 9) RVC_LG32(2, 2, 4, 2) else RVC_LG32(2, 2, 4, 4) }
-#endif
-#if RVC_TILED_PART == 5 || defined(RVC_UNITY)
-void launch_igemm_tiled_p5(int lc, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb) { if (lc == 11) RVC_LG32(2, 2, 2, 4) else RVC_LG32(1, 4, 4, 2) }
 #endif
 #undef RVC_LG32
 #undef RVC_LG

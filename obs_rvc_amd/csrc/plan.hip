@@ -320,10 +320,26 @@ static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &
 // generic: the caller fills geometry (N, NW, strides, koff, phases); this picks the tile + split-K and queues the op
 // Which table-free 1x1 layers take igemm2w_kernel, and with what tile / K split (filled in from per-layer measurements: tests/tools/g2w_sweep.py).
 // gt < 0: not this kernel.
+// Round 5, tests/tools/g2w_sweep.py (isolated launches, one box; us, planner's previous choice -> this kernel):
+//   streams            2              4              8              16             32
+//   3072 x  768   20.4 -> 14.7   43.1 -> 27.0   57.5 -> 48.8   94.7 (-> 95.4)  182.6 (-> 173.6)
+//   2304 x  768   14.4 -> 11.0   28.8 -> 19.9   43.3 -> 36.2   67.9 -> 64.6    124.3 (-> 129.5)
+//    768 x 3072   22.1 -> 16.5   40.7 -> 29.8   59.8 -> 45.2  114.2 -> 86.5    209.8 -> 162.2
+//    768 x  768    8.9 ->  7.1   13.7 -> 10.4   20.7 -> 15.2   42.4 -> 28.1     57.0 -> 49.2
+//    768 x  512    7.5 ->  6.1   11.3 ->  8.7   16.7 -> 11.9   34.0 -> 20.9     39.4 -> 36.3
+// The 32 x 32 wave tile wins everywhere (64 x 32 / 64 x 64 leave too few waves); the K split that wins puts ~4 000-5 000 waves into the launch
+// (six waves per workgroup -- 2, 2, 1, 1 over the SIMDs -- always loses to four or eight).  One stream keeps its own kernels (folded LayerNorm,
+// latency-tuned splits: 13.5 -> 15.0 us for the 768 x 3072 projection); the tall panels from 16 streams on stay on the LDS-staged 32x32x2 tiles.
 static void g2w_rule(const IgemmP &p, int nchunks, int &gt, int &gk)
 {
-    (void)p; (void)nchunks;
     gt = -1; gk = 1;
+    if (!p.fold_n || p.M < 256 || nchunks < 16) return;
+    if (p.M > 1024 ? p.N > 1000 : p.N > 4000) return;
+    const long long tiles = (long long)((p.M + 31) / 32) * ((p.N + 31) / 32);
+    const long long want = (4800 + tiles / 2) / tiles;
+    int ks = want <= 1 ? 1 : (want == 2 ? 2 : (want == 3 ? 3 : (want <= 4 ? 4 : 8)));
+    while (ks > 1 && nchunks / ks < 4) ks = ks == 8 ? 4 : ks - 1;
+    gt = 0; gk = ks;
 }
 
 void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases, bool final_out)
@@ -499,23 +515,17 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
             return;
         }
     }
-    // tuning aid: RVC_G32W = "lc[,min workgroups[,min M]]" forces a wide-register-tile instantiation (9 = 256 x 128, 10 = 256 x 256, 11 / 12 = 128 x 256)
-    // on every layer the 32x32x2 kernel could take
+    // tuning aid: RVC_G32W = "lc" forces one of the 32x32x2 tiles (3 4 5 7 8) on every layer that kernel can take, "-1" the register-direct kernel
+    // (then RVC_FORCE_CFG picks its tile): tests/tools/tile_sweep.py
     if (const char *f = tune_env("RVC_G32W")) {
-        int wl = 0, wmin = 256, mmin = 0;
-        sscanf(f, "%d,%d,%d", &wl, &wmin, &mmin);
+        const int wl = atoi(f);
         const bool g32_ok = !ln_fold && !p.glu && nchunks >= 2 && (size_t)nchunks * 64 + 2 * 256 * 20 * 4 <= 60 * 1024;
-        if (wl >= 9 && wl <= 12 && g32_ok) {
-            const int wbm = wl <= 10 ? 256 : 128, wbn = wl == 9 ? 128 : 256;
-            const long long wgs = (long long)((p.M + wbm - 1) / wbm) * ((p.N + wbn - 1) / wbn) * B * p.nphase;
-            if (p.M >= std::max(wbm / 2 + 1, mmin) && wgs >= wmin) lds_cfg = wl;
-        } else if (g32_ok && (wl == 3 || wl == 4 || wl == 5 || wl == 7 || wl == 8)) lds_cfg = wl;      // any of the older 32x32x2 tiles
-        else if (wl == -1) lds_cfg = -1;                                                                  // the register-direct kernel (then RVC_FORCE_CFG picks its tile)
-
+        if (g32_ok && (wl == 3 || wl == 4 || wl == 5 || wl == 7 || wl == 8)) lds_cfg = wl;
+        else if (wl == -1) lds_cfg = -1;
     }
     if (lds_cfg >= 0) {
-        const int bm = lds_cfg >= 9 ? (lds_cfg <= 10 ? 256 : 128) : (lds_cfg == 8 ? 64 : (lds_cfg == 7 ? 128 : (lds_cfg == 6 ? 48 : (lds_cfg % 3 == 0 ? 128 : (lds_cfg % 3 == 1 ? 64 : 32)))));
-        const int bn = lds_cfg >= 9 ? (lds_cfg == 9 ? 128 : 256) : ((lds_cfg == 7 || lds_cfg == 8) ? 64 : ((lds_cfg != 6 && lds_cfg % 3 == 0) ? 128 : 256));
+        const int bm = lds_cfg == 8 ? 64 : (lds_cfg == 7 ? 128 : (lds_cfg == 6 ? 48 : (lds_cfg % 3 == 0 ? 128 : (lds_cfg % 3 == 1 ? 64 : 32))));
+        const int bn = (lds_cfg == 7 || lds_cfg == 8) ? 64 : ((lds_cfg != 6 && lds_cfg % 3 == 0) ? 128 : 256);
         p.ksplit = 1; p.chunks_per_split = nchunks;
         p.ntm = (p.M + bm - 1) / bm; p.ntn = (p.N + bn - 1) / bn;
         // tile order of the tiled kernels when the streams are folded into N: m fastest over XCD-local tile ids (1), or over the raw block index (2)
