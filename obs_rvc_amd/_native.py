@@ -213,10 +213,11 @@ def lib():
     L.rvc_synchronize.argtypes = [vp]
     L.rvc_set_use_graph.argtypes = [vp, C.c_int]
     L.rvc_set_use_graph.restype = None
-    L.rvc_set_plan_cache.argtypes = [vp, C.c_int]
-    L.rvc_plan_cache_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
-    L.rvc_retrieval_recoveries.argtypes = [vp]
-    L.rvc_retrieval_recoveries.restype = C.c_longlong
+    if hasattr(L, "rvc_set_plan_cache") or not override:      # (an older build loaded for an A/B timing lacks the newer entry points)
+        L.rvc_set_plan_cache.argtypes = [vp, C.c_int]
+        L.rvc_plan_cache_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
+        L.rvc_retrieval_recoveries.argtypes = [vp]
+        L.rvc_retrieval_recoveries.restype = C.c_longlong
     L.rvc_set_pipeline.argtypes = [vp, C.c_int]
     L.rvc_set_pipeline.restype = None
     L.rvc_last_gpu_ms.argtypes = [vp]

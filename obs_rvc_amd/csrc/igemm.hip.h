@@ -586,8 +586,15 @@ __device__ __forceinline__ void glu_from_col_b(const IgemmP &p, const PhaseD &ph
     default: { constexpr int A_ = ACT_NONE; STMT } break;                        \
     }
 
+// Minimum waves per SIMD the register allocation has to leave room for.  LNB: 264 registers otherwise -- one wave per SIMD.  The two others are the
+// instantiations that round 5's two-path K loop pushed over an occupancy step (132 registers for the lone fragment with four K shares: three waves
+// per SIMD instead of four, and RMVPE's 128-workgroup launches on the 32-CU partition took a second round: 81 -> 116 us per chunk; 172 for the 2 x 4
+// tile with the fused input activation).
+template <int MF, int NF, int KS, bool PRE, bool LIN, bool LNB> struct Ig2Occ {
+    static constexpr int W = LNB ? 2 : ((MF * NF == 1 && KS == 4 && !PRE && !LIN) ? 4 : ((MF * NF == 8 && KS == 1 && PRE) ? 3 : 1));
+};
 template <int MF, int NF, int D, int KS, bool PRE, bool LIN, bool LNB = false>
-__global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) __attribute__((amdgpu_waves_per_eu(LNB ? 2 : 1)))      // (LNB: 264 registers otherwise -- one wave per SIMD)
+__global__ __launch_bounds__((KS > 1 ? KS : 4) * 64) __attribute__((amdgpu_waves_per_eu(Ig2Occ<MF, NF, KS, PRE, LIN, LNB>::W)))
 void igemm2_kernel(IgemmP p)
 {
     static_assert(!LNB || (LIN && !PRE && KS > 1), "LayerNorm-consumer instantiations: table-free 1x1 layers with the in-workgroup K split");
