@@ -76,7 +76,7 @@ static void reset_state(rvc_engine *e)
 }
 
 // CU partition for the two concurrent branches of a chunk at low stream counts: the f0 branch (RMVPE: ~140 short weight-streaming
-// kernels) gets two XCDs (a quarter of the CUs; one XCD until round 5), ContentVec the rest.  Sharing CUs slows the f0 branch by ~35 % (measured).  With
+// kernels) gets 1/8 of the CUs (one XCD), ContentVec the rest.  Sharing CUs slows the f0 branch by ~35 % (measured).  With
 // many streams every kernel fills the chip and the streams are plain.
 //
 // CU-masked streams are never destroyed: the runtime recycles the hardware queue of a destroyed stream, mask included, for the next
@@ -134,11 +134,12 @@ static void release_stream_set(StreamSet *m)
 static void configure_aux_streams(rvc_engine *e)
 {
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, e->device));
-    // The f0 branch gets two whole XCDs (a quarter of the CUs), ContentVec the other six.  Round 2 measured one XCD (1/8) as the optimum; with ContentVec's
-    // GEMMs faster since (round 5: K loops that no longer drain) the f0 branch had become the longer one.  Same box, tuning build, ms per chunk at
-    // 1 / 2 / 4 streams: 32 CUs 2.253 / 3.166 / 4.986, 64 CUs 2.167 / 3.095 / 4.614; partitions that cut an XCD in two lose badly (56: 2.244, 72: 2.469,
-    // 80: 2.484), three XCDs starve ContentVec (96: 2.469).
-    int ncu = prop.multiProcessorCount, nf0 = ncu / 4;
+    // The f0 branch gets ONE whole XCD (an eighth of the CUs), ContentVec the other seven.  Round 5 tried two XCDs after ContentVec's GEMMs had become
+    // faster.  The tuning build (per-wave probe stamps compiled in) said 2.253 -> 2.167 ms at one stream and 4.99 -> 4.61 at four; the PRODUCT build on
+    // the same pool says the opposite: 2.044-2.048 -> 2.06-2.08 at one stream, 2.87 -> 3.03 at two, 4.21 -> 4.46 at four (only the v1 model, whose
+    // ContentVec stops at layer 9, gains: 2.075 -> 1.994).  Partitions that cut an XCD in two lose badly either way (56: 2.244, 72: 2.469, 80: 2.484).
+    // Lesson kept here: partition sizes are tuned on the product build only.
+    int ncu = prop.multiProcessorCount, nf0 = ncu / 8;
     g_ncu = ncu > 0 ? ncu : 256;
     if (const char *f = tune_env("RVC_F0_CUS")) { const int v = atoi(f); if (v >= 8 && v < ncu) nf0 = v; }   // tuning aid
     if (!e->sset) {
