@@ -308,7 +308,7 @@ def roofline_of(eng, step, S, reps=5, with_index=False, version=2, preset="full"
     return roof
 
 
-def run_config(job, z, g, S, with_index, steps, warmup, graph, index_vecs, want_roofline=True, version=2, soak=0, preset="full"):
+def run_config(job, z, g, S, with_index, steps, warmup, graph, index_vecs, want_roofline=True, version=2, soak=0, preset="full", gemm_precision=0):
     """One configuration on every rank: S streams per GPU, retrieval on/off.  soak > 0: that many more synchronised chunks after the
     timed region for the latency distribution (p99.9 needs >= 1000 samples).  -> record (rank 0) / None"""
     from obs_rvc_amd import dist as rdist
@@ -317,6 +317,8 @@ def run_config(job, z, g, S, with_index, steps, warmup, graph, index_vecs, want_
     eng = RvcInfer(z["data"], device=job.local_rank)
     eng.load_contentvec(version); eng.load_f0(1); eng.load_model(z["model"])
     eng.set_streams(S)
+    if gemm_precision:
+        eng.set_gemm_precision(gemm_precision)
     # stream s of this rank is stream (s * world + rank) of the job: round-robin sharding
     stream_ids = [s * job.world + job.rank for s in range(S)]
     eng.set_noise_seed(1234, job.rank * S)
@@ -616,6 +618,17 @@ def main(argv=None):
             if rec:
                 rec["config"] = "BASELINE configs[1] read literally: ContentVec-256 (v1: layer 9 + final_proj, enums.rs:10-23) + RMVPE + v1 NSF-HiFiGAN 48k"
             return rec
+        def streams64_bf16x3():
+            # EXPLORATORY sub-configuration, never `value`: the 1-D layers with >= 128 output rows as three bf16 matrix-core products per fp32 product
+            # (rvc_set_gemm_precision(e, 1)); everything else, and every other record of this line, computes in f32 like the reference
+            k64 = max(10, min(args.steps, 20))
+            rec, e7, _, d7 = run_config(job, z, g, 64, False, k64, 8, graph, index_vecs, want_roofline=False, soak=sub_soak, gemm_precision=1)
+            del e7, d7
+            if rec:
+                rec["steps"] = k64
+                rec["dtype"] = "bf16x3 in the 1-D layers with >= 128 output rows (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16, f32 accumulate: ~2^-16 relative per product); f32 everywhere else"
+                rec["exploratory"] = "not the reference's arithmetic: reported next to streams64 (f32), never as value; parity of the mode: tests/test_gpu_round5.py::test_split_bf16_gemms_exploratory_mode"
+            return rec
         leg("index100k", index100k)
         leg("streams64", streams64)
         if job.world == 1:
@@ -623,6 +636,8 @@ def main(argv=None):
         for S2 in (2, 4, 8, 16, 32):
             leg("streams%d" % S2, sweep(S2))
         leg("v1_256", v1_256)
+        if job.world == 1:
+            leg("streams64_bf16x3", streams64_bf16x3)
 
     if job.rank == 0:
         if args.serial_branches:

@@ -77,6 +77,7 @@ extern "C" {
     pub fn rvc_set_plan_cache(e: *mut RvcEngine, n_plans: c_int) -> c_int;
     pub fn rvc_plan_cache_info(e: *mut RvcEngine, capacity: *mut c_int, cached: *mut c_int, builds: *mut c_longlong) -> c_int;
     pub fn rvc_retrieval_recoveries(e: *mut RvcEngine) -> c_longlong;
+    pub fn rvc_set_gemm_precision(e: *mut RvcEngine, mode: c_int) -> c_int;
 
     // ---- caller-side steps of the plugin (obs-rvc/src/rt_utils.rs, obs-rvc/src/lib.rs:236-260,659-795)
     pub fn rvc_envelop_mixing(e: *mut RvcEngine, input: *const c_float, output: *mut c_float, output_len: usize, sample_rate: usize,

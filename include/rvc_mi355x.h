@@ -143,6 +143,10 @@ void rvc_set_use_graph(rvc_engine *e, int on);    /* replay the per-chunk launch
  * tens of milliseconds; a server that rotates through more geometries than the cache holds pays that on every call.  rvc_plan_cache_info reports
  * capacity, plans currently cached and plans built since rvc_create (-> 1 on a valid engine). */
 rvc_status rvc_set_plan_cache(rvc_engine *e, int n_plans);
+/* EXPLORATORY (no counterpart in the reference, off by default, never used for the headline figure): mode 1 = the 1-D layers with >= 128 output rows (ContentVec's projections and stem, the decoder's wide stages) run every
+ * fp32 product as three bf16 matrix-core products (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulate) in launches of >= 250 workgroups of 128 x 128 (many
+ * streams); ~2^-16 relative per product instead of fp32 rounding.  mode 0 = fp32 everywhere, the reference's arithmetic. */
+rvc_status rvc_set_gemm_precision(rvc_engine *e, int mode);
 int rvc_plan_cache_info(rvc_engine *e, int *capacity, int *cached, long long *builds);
 /* Offline throughput mode (no counterpart in the reference, whose protocol is one request at a time): with on != 0, consecutive
  * rvc_infer_device(..., sync = 0) calls overlap chunk i+1's ContentVec / f0 branches with chunk i's synthesizer (two plan slots).

@@ -23,12 +23,12 @@ SYMBOLS = [
     "rvc_resampler_create", "rvc_resampler_destroy", "rvc_resampler_input_frames_next", "rvc_resampler_output_frames_max",
     "rvc_resampler_reset", "rvc_resampler_process", "rvc_resampler_process_device",
     "rvc_rccl_unique_id", "rvc_index_broadcast", "rvc_rccl_available", "rvc_index_broadcast_info",
-    "rvc_set_plan_cache", "rvc_plan_cache_info", "rvc_retrieval_recoveries",
+    "rvc_set_plan_cache", "rvc_plan_cache_info", "rvc_retrieval_recoveries", "rvc_set_gemm_precision",
     "rvc_session_create", "rvc_session_destroy", "rvc_session_process", "rvc_session_frame_size", "rvc_session_set_params", "rvc_session_set_params_stream", "rvc_session_geometry",
 ]
 
 
-SOURCES = ("engine.hip", "engine_int.h", "plan.hip", "model_cv.hip", "model_rmvpe.hip", "model_synth.hip", "retrieval.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "igemm2_inst.hip", "igemm_tiled_inst.hip", "igemm2w_inst.hip", "conv_tile.hip.h", "conv_tile_inst.hip", "version.cpp",
+SOURCES = ("engine.hip", "engine_int.h", "plan.hip", "model_cv.hip", "model_rmvpe.hip", "model_synth.hip", "retrieval.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "igemm2_inst.hip", "igemm_tiled_inst.hip", "igemm2w_inst.hip", "igemm_bf3_inst.hip", "conv_tile.hip.h", "conv_tile_inst.hip", "version.cpp",
            "state.hip.h",
            "resample.hip.h", "session.hip.h", "rccl_bcast.hip.h", "blob.h", "rvc_rpc.cpp")
 
@@ -42,6 +42,7 @@ UNITS = [("engine.hip", [], _ENGINE_DEPS)] + [(u, [], (u,) + _INT_DEPS) for u in
         [("igemm2_inst.hip", ["-DRVC_IGEMM2_CFG=%d" % c], ("igemm2_inst.hip",) + _IGEMM_DEPS) for c in range(5)] + \
         [("igemm_tiled_inst.hip", ["-DRVC_TILED_PART=%d" % c], ("igemm_tiled_inst.hip",) + _IGEMM_DEPS) for c in range(4)] + \
         [("igemm2w_inst.hip", ["-DRVC_G2W_PART=%d" % c], ("igemm2w_inst.hip",) + _IGEMM_DEPS) for c in range(3)] + \
+        [("igemm_bf3_inst.hip", [], ("igemm_bf3_inst.hip",) + _IGEMM_DEPS)] + \
         [("conv_tile_inst.hip", [], ("conv_tile_inst.hip", "conv_tile.hip.h") + _IGEMM_DEPS)]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # Object cache: content-addressed (sources + flags).  It lives under the repository's build/ directory (git- and gpurun-ignored), is
@@ -218,6 +219,8 @@ def lib():
         L.rvc_plan_cache_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
         L.rvc_retrieval_recoveries.argtypes = [vp]
         L.rvc_retrieval_recoveries.restype = C.c_longlong
+    if hasattr(L, "rvc_set_gemm_precision") or not override:
+        L.rvc_set_gemm_precision.argtypes = [vp, C.c_int]
     L.rvc_set_pipeline.argtypes = [vp, C.c_int]
     L.rvc_set_pipeline.restype = None
     L.rvc_last_gpu_ms.argtypes = [vp]

@@ -193,7 +193,7 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         } else i++;
     for (auto &p : e->plans)
         if (p->mode == mode && p->L == L && p->frame16k == frame16k && p->skip_head == skip_head && p->R == R && p->B == B &&
-            p->with_index == with_index && p->with_taps == (e->taps_on != 0) && p->plain_plan == (e->taps_on == 1) && p->slot == slot && p->bucket == (bucket_B > 0)) {
+            p->with_index == with_index && p->bf3 == (e->gemm_precision == 1) && p->with_taps == (e->taps_on != 0) && p->plain_plan == (e->taps_on == 1) && p->slot == slot && p->bucket == (bucket_B > 0)) {
             // least recently used first: a hit moves to the back, so eviction (front) never takes a plan the current call has just fetched
             Plan *hit = p.get();
             std::rotate(&p, &p + 1, e->plans.data() + e->plans.size());
@@ -203,7 +203,7 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
     std::unique_ptr<Plan> up(new Plan());
     Plan &pl = *up;
     pl.mode = mode; pl.L = L; pl.frame16k = frame16k; pl.skip_head = skip_head; pl.R = R; pl.B = B; pl.with_index = with_index; pl.with_taps = e->taps_on != 0; pl.plain_plan = e->taps_on == 1; pl.bucket = bucket_B > 0;
-    pl.slot = slot; pl.opt_gen = gen;
+    pl.slot = slot; pl.opt_gen = gen; pl.bf3 = e->gemm_precision == 1;
     pl.d_in = pl.arena.floats((size_t)B * L + 64);
     T1 sal0, src0; float *d_pitchf0 = nullptr; int *d_pitch0 = nullptr;
     size_t rm_begin = 0, rm_end = 0;
@@ -823,6 +823,19 @@ rvc_status rvc_set_streams(rvc_engine *e, int n_streams)
 }
 
 void rvc_set_use_graph(rvc_engine *e, int on) { if (e) e->use_graph = on != 0; }
+
+// EXPLORATORY, off by default and never part of the headline figure: mode 1 runs the 1-D layers with >= 128 output rows (ContentVec's projections and convolution stem, the decoder's
+// 128- / 256-channel stages) as three bf16 MFMAs per fp32 product (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulation; igemm_bf3_kernel) wherever a launch has >= 250 workgroups of 128 x 128
+// (at 64 streams 2.5 of the 3.6 TFLOP of a step).  gfx950's fp32 MFMA runs at 1/16 of its bf16 rate and there is no xf32.  Results differ from the fp32 path by ~2^-16 relative
+// per product (tests/test_gpu_round5.py measures it against the oracle); mode 0 is the reference's arithmetic.
+rvc_status rvc_set_gemm_precision(rvc_engine *e, int mode)
+{
+    return guarded(e, [&]() {
+        if (mode != 0 && mode != 1) throw ShapeError("gemm precision: 0 (fp32) or 1 (split bf16, exploratory)");
+        e->gemm_precision = mode;
+        return RVC_OK;
+    });
+}
 
 // Plan cache: one plan (activation arena, composed weights, launch list) per geometry (mode, n, frame, skip_head, return_length, streams,
 // retrieval on/off, pipeline slot).  Every plugin instance has its own geometry (obs-rvc/src/lib.rs:200-227): a server that serves more

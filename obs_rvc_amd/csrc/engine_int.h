@@ -179,6 +179,7 @@ struct ConvOpts {
     int m_off = 0, m_cnt = -1;   // output-row sub-range of the weight panel
     bool no_bias = false;
     bool glu = false;            // GLU-packed weight rows, gate fused into the epilogue (ModelSY flows)
+    bool bf3 = false;            // exploratory: this 1x1 layer may run its products as three bf16 MFMAs (rvc_set_gemm_precision; igemm_bf3_kernel)
     bool final_out = false;      // the chunk's last convolution: writes the caller's device buffer when the call provides one (Plan::cur_out)
     // LayerNorm folded into its neighbours (IgemmP::ln_*): this layer consumes a not-yet-normalised tensor (weights pre-scaled, wsum
     // per output row, optional (mean, rstd) output) / this layer's residual is LayerNorm(stored tensor) with published statistics
@@ -217,6 +218,7 @@ struct Plan {
     int T = 0, Tm = 0, C = 0; size_t N = 0;
     bool with_index = false, with_taps = false;
     bool bucket = false;          // a plan of rvc_infer_batch_g: built for a subset of the streams on the gathered state block (rvc_engine::d_state_bucket)
+    bool bf3 = false;             // built under rvc_set_gemm_precision(e, 1): ContentVec's 1x1 GEMMs on the split-bf16 kernel (exploratory)
     bool plain_plan = false;      // taps level 1: the explicit plan (LayerNorm launches, WaveNets layer by layer); level 2 taps the production plan
     int mode = 0;   // 0 infer, 1 hubert only, 2 pitch only
     // I/O tensors
@@ -804,6 +806,7 @@ struct rvc_engine {
     // plans (keyed by geometry)
     std::vector<std::unique_ptr<Plan>> plans;
     Plan *last_plan = nullptr;
+    int gemm_precision = 0;           // 0 = fp32 everywhere (the product), 1 = split-bf16 for ContentVec's 1x1 GEMMs at many streams (exploratory)
     int plan_cap = 8;                 // rvc_set_plan_cache
     long long knn_recoveries = 0;     // chunks whose retrieval was recomputed after a hand-off time-out (rvc_retrieval_info)
     long long plan_builds = 0;        // plans built since rvc_create (a miss = arena allocation + composed weights + a device synchronisation)

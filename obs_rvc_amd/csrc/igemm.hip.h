@@ -82,6 +82,7 @@ struct IgemmP {
     int nbatch;              // igemm2: streams in the launch (grid z = batch * nphase + phase)
     int fold_n;              // > 0: the streams of the launch are folded into the N axis: position n = stream (n / fold_n), local position
                              // (n % fold_n); N = streams * fold_n and the launch has one batch (tiles may straddle streams, nothing is padded per stream)
+    int bf3;                 // exploratory (igemm_bf3_kernel): w points at the split-bf16 panels of this layer, the products run as three bf16 MFMAs
     int lin_cs4;             // igemm2 LIN layers (1x1 conv on a 1-D tensor): input channel stride in BYTES, k-th operand row = k * lin_cs4
     // LayerNorm folded into its neighbours (one stream, ContentVec's post-LN layers):
     //  * consumer of a not-yet-normalised tensor y (igemm2 LNB instantiations): the weights carry the LayerNorm scale, the bias its
@@ -1612,6 +1613,179 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G32Occ<MT, 
         }
     )
     RVC_KP(6);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// igemm_bf3_kernel -- EXPLORATORY, off by default (rvc_set_gemm_precision), never part of the headline figure: the table-free 1x1 layers of ContentVec
+// at many streams with every fp32 product replaced by three bf16 products, a * b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi (a_hi = bf16(a), a_lo = bf16(a - a_hi):
+// 16 of the 24 mantissa bits of each operand; the dropped a_lo b_lo term is 2^-16 relative), accumulated in fp32.  Why: gfx950 has no xf32, its fp32 MFMA
+// runs at 1/16 of the bf16 rate (v_mfma_f32_32x32x2_f32: 4 096 flops in 64 clocks; v_mfma_f32_32x32x16_bf16: 32 768 in 32), so three bf16 MFMAs per
+// 16-deep chunk cost 96 clocks where the fp32 form costs 512.  The kernel is igemm32_kernel's anatomy (128 x 128 workgroup tile, 2 x 2 waves of 64 x 64,
+// activation tile staged through LDS once per workgroup, one barrier per K step of 16):
+//   * weights: split at plan time (bf3_pack_kernel) into panels [32-row block][chunk][hi | lo][lane][8 bf16] -- a lane's 16 bytes are its row's eight
+//     k values (k = (lane >> 5) * 8 + i) of one half, a wave instruction reads 1 KB contiguous;
+//   * activations: a staging thread gathers the eight k rows of one k group for its column (8 dword loads), splits them (v_cvt_pk_bf16_f32) and writes
+//     two 16-byte pieces; LDS holds [hi | lo][column][k group 0 | k group 1 | pad] at 48 bytes per column (16 lanes x 16 bytes on disjoint banks);
+//   * A and B use the SAME (lane >> 5, i) -> k assignment, which is all the instruction's sum over k needs.
+// C / D layout = the 32x32x2 form's (dtype-independent on gfx950).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void bf3_split(const float (&v)[8], bf16x8 &hi, bf16x8 &lo)
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++) { hi[i] = (__bf16)v[i]; lo[i] = (__bf16)(v[i] - (float)hi[i]); }
+}
+static __global__ void bf3_pack_kernel(const float *wfrag, int M, int nchunks, bf16x8 *out, long long total)
+{
+    // out element (blk32, chunk, half, lane): eight bf16 of row blk32 * 32 + (lane & 31), k = chunk * 16 + (lane >> 5) * 8 + i, from the fp32
+    // fragment packing [m_tile16][chunk][lane16x4][4]
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int lane = (int)(e & 63), half = (int)((e >> 6) & 1);
+    const long long bc = e >> 7;
+    const int chunk = (int)(bc % nchunks), blk = (int)(bc / nchunks);
+    const int m = blk * 32 + (lane & 31), mt16 = (M + 15) >> 4;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int kk = (lane >> 5) * 8 + i;
+        v[i] = (m >> 4) < mt16 ? wfrag[((((long long)(m >> 4) * nchunks + chunk) * 64) + (kk >> 2) * 16 + (m & 15)) * 4 + (kk & 3)] : 0.f;
+    }
+    bf16x8 hi, lo;
+    bf3_split(v, hi, lo);
+    out[e] = half ? lo : hi;
+}
+template <int WM, int WN, int MT, int NT, bool LIN, bool PRE>
+__global__ __launch_bounds__(256) void igemm_bf3_kernel(IgemmP p)
+{
+    static_assert(WM * WN == 4, "four waves per workgroup");
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    static_assert(BN == 128, "two staging threads per column: one per k group");
+    constexpr int CSB = 48;                         // bytes per column and half
+    constexpr int HALF = BN * CSB, BUF = 2 * HALF;  // one half, one buffer (hi + lo)
+    extern __shared__ __attribute__((aligned(16))) char s_raw[];     // [offset table: nchunks * 16 ints, unless LIN][2][hi | lo][BN][48]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tid_x = p.m_fast == 1 ? xcd_tile_id((int)blockIdx.x, (int)gridDim.x, (int)(blockIdx.y * gridDim.x)) : (int)blockIdx.x;
+    const int tn = p.m_fast ? tid_x / p.ntm : tid_x % p.ntn, tm = p.m_fast ? tid_x % p.ntm : tid_x / p.ntn;
+    const int phase = (int)blockIdx.y;              // (streams are folded into N: one batch)
+    const PhaseD ph = p.nphase == 1 ? p.ph0 : p.ph[phase];
+    const int nchunks = ph.nchunks;
+    const int *kof = reinterpret_cast<const int *>(s_raw);
+    char *s_bt = s_raw + (LIN ? 0 : nchunks * 64);
+    if (!LIN) {
+        const int4 *src = reinterpret_cast<const int4 *>(p.koff + ph.koff_off);
+        int4 *dst = reinterpret_cast<int4 *>(s_raw);
+        for (int i = threadIdx.x; i < nchunks * 4; i += 256) dst[i] = src[i];
+        __syncthreads();
+    }
+    const int c32 = lane & 31, ks = lane >> 5;
+    const char *xb = reinterpret_cast<const char *>(p.x + ph.x_off) - (LIN ? 0 : p.koff_bias);
+    const unsigned lin1 = (unsigned)p.lin_cs4;
+    const float pre_slope = p.pre_slope;
+    const int n_s = threadIdx.x % BN, g_s = threadIdx.x / BN;
+    unsigned xo_s;
+    {
+        int n = tn * BN + n_s;
+        n = n < p.N ? n : p.N - 1;
+        int bb = 0;
+        if (p.fold_n) { bb = n / p.fold_n; n -= bb * p.fold_n; }
+        xo_s = (unsigned)(bb * (int)p.x_bs + n * p.x_ws) * 4u + (LIN ? (unsigned)(g_s * 8) * lin1 : 0u);
+    }
+    const char *wb = reinterpret_cast<const char *>(p.w + ph.w_off);
+    const int nblk = (p.M + 31) >> 5;
+    long long wo[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        int blk = (tm * WM + wm) * MT + mt;
+        blk = blk < nblk ? blk : nblk - 1;
+        wo[mt] = (long long)blk * nchunks * 2048 + lane * 16;
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
+    float sb[8];
+    bf16x8 a_ev[MT][2], a_od[MT][2];            // [mt][hi | lo] of the even / odd K steps
+    auto gather = [&](const int c) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            sb[i] = *reinterpret_cast<const float *>(xb + (xo_s + (LIN ? (unsigned)(c * 16 + i) * lin1 : (unsigned)kof[c * 16 + g_s * 8 + i])));
+    };
+    auto stage = [&](char *buf) {
+        if (PRE) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) sb[i] = fmaxf(sb[i], sb[i] * pre_slope);      // fused input LeakyReLU, once per staged element
+        }
+        bf16x8 hi, lo;
+        bf3_split(sb, hi, lo);
+        *reinterpret_cast<bf16x8 *>(buf + n_s * CSB + g_s * 16) = hi;
+        *reinterpret_cast<bf16x8 *>(buf + HALF + n_s * CSB + g_s * 16) = lo;
+    };
+    auto wload = [&](bf16x8 (&a)[MT][2], const int c) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) a[mt][h] = *reinterpret_cast<const bf16x8 *>(wb + wo[mt] + (long long)c * 2048 + h * 1024);
+    };
+    gather(0);
+    wload(a_ev, 0);
+    stage(s_bt);
+    __syncthreads();
+    const char *br = s_bt + (wn * NT * 32 + c32) * CSB + ks * 16;
+    auto kstep = [&](const int c, bf16x8 (&a_c)[MT][2], bf16x8 (&a_n)[MT][2]) {
+        const int cn = c + 1 < nchunks ? c + 1 : c;
+        const char *bcur = br + (c & 1) * BUF;
+        gather(cn);
+        wload(a_n, cn);
+        bf16x8 bh[NT], bl[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            bh[nt] = *reinterpret_cast<const bf16x8 *>(bcur + nt * 32 * CSB);
+            bl[nt] = *reinterpret_cast<const bf16x8 *>(bcur + HALF + nt * 32 * CSB);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                // the two small terms first, the leading term last
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_c[mt][1], bh[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_c[mt][0], bl[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_c[mt][0], bh[nt], acc[mt][nt], 0, 0, 0);
+            }
+        stage(s_bt + ((c + 1) & 1) * BUF);
+        __syncthreads();
+    };
+    {
+        int c = 0;
+        for (; c + 2 <= nchunks; c += 2) { kstep(c, a_ev, a_od); kstep(c + 1, a_od, a_ev); }
+        if (c < nchunks) kstep(c, a_ev, a_od);
+    }
+    const float *resb = p.res;
+    float *yb = p.y + ph.y_off;
+    ColOut cols[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) cols[nt] = col_locate(p, ph, tn * BN + (wn * NT + nt) * 32 + c32);
+    const int row0 = (tm * WM + wm) * MT * 32 + ks * 4;
+    RVC_ACT_DISPATCH(
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) {
+            float bias_r[16];
+            _Pragma("unroll") for (int r = 0; r < 16; r++) {
+                const int m = row0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+                bias_r[r] = (p.bias && m < p.M) ? p.bias[ph.bias_off + m] : 0.f;
+            }
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {
+                _Pragma("unroll") for (int h = 0; h < 16; h += 8) {
+                    Epi2 e_[8];
+                    _Pragma("unroll") for (int r = 0; r < 8; r++)
+                        e_[r] = epi2_aux(p, ph, resb, yb, cols[nt], row0 + mt * 32 + ((h + r) & 3) + 8 * ((h + r) >> 2), bias_r[h + r]);
+                    _Pragma("unroll") for (int r = 0; r < 8; r++) epi2_finish<A_>(p, yb, acc[mt][nt][h + r], e_[r]);
+                }
+            }
+        }
+    )
 }
 
 }  // namespace rvc

@@ -40,6 +40,10 @@ void launch_igemm2w_t0(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream
 void launch_igemm2w_t1(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 void launch_igemm2w_t2(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 
+// exploratory split-bf16 GEMM (igemm_bf3_kernel): 128 x 128 workgroup tile; bf3_pack builds the weight panels it reads
+void launch_igemm_bf3(bool lin, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
+void bf3_pack(const float *wfrag, int M, int nchunks, void *out, hipStream_t s);
+
 template <typename K> static inline void launch_k(K kern, const IgemmP &p, dim3 grid, dim3 block, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
 {
     if (ea) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, s, ea, eb, 0, p);

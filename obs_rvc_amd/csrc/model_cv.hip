@@ -88,7 +88,7 @@ T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
             if (raw) { ConvOpts o; o.ln_wsum = Ly.qkv_wsum; o.ln_stats_out = st_a; o.ln_rows = E; add_conv1d(pl, Ly.qkv_f, h2, qkv, 1, 0, 1, o); raw_st = st_a; }
             else add_conv1d(pl, Ly.qkv, h2, qkv, 1, 0, 1);
         } else
-        add_conv1d(pl, Ly.qkv, h2, qkv, 1, 0, 1);
+        { ConvOpts o; o.bf3 = pl.bf3; add_conv1d(pl, Ly.qkv, h2, qkv, 1, 0, 1, o); }
         AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = E; ap.T = T; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;
         ap.scale = 1.0f / sqrtf((float)hd); ap.rel_k = nullptr; ap.rel_v = nullptr; ap.window = 0;
         dim3 ag(m.heads * ((T + 15) / 16), B);
@@ -114,10 +114,10 @@ T1 build_contentvec(rvc_engine *e, Plan &pl, int B, size_t L)
             if (l + 1 < m.run_layers) { raw = true; raw_g = Ly.ln2_g; raw_b = Ly.ln2_b; }
             else { add_layernorm(pl, h2, Ly.ln2_g, Ly.ln2_b); raw = false; }
         } else {
-        { ConvOpts o; o.res = h2.p; o.res_cs = h2.ld; o.res_bs = h2.bs; add_conv1d(pl, Ly.o, att, h2, 1, 0, 1, o); }
+        { ConvOpts o; o.bf3 = pl.bf3; o.res = h2.p; o.res_cs = h2.ld; o.res_bs = h2.bs; add_conv1d(pl, Ly.o, att, h2, 1, 0, 1, o); }
         add_layernorm(pl, h2, Ly.ln1_g, Ly.ln1_b);
-        { ConvOpts o; o.act = ACT_GELU; add_conv1d(pl, Ly.ff1, h2, ff, 1, 0, 1, o); }
-        { ConvOpts o; o.res = h2.p; o.res_cs = h2.ld; o.res_bs = h2.bs; add_conv1d(pl, Ly.ff2, ff, h2, 1, 0, 1, o); }
+        { ConvOpts o; o.bf3 = pl.bf3; o.act = ACT_GELU; add_conv1d(pl, Ly.ff1, h2, ff, 1, 0, 1, o); }
+        { ConvOpts o; o.bf3 = pl.bf3; o.res = h2.p; o.res_cs = h2.ld; o.res_bs = h2.bs; add_conv1d(pl, Ly.ff2, ff, h2, 1, 0, 1, o); }
         add_layernorm(pl, h2, Ly.ln2_g, Ly.ln2_b);
         }
         if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, raw ? "cv.l%d.raw" : "cv.l%d", l); add_tap(pl, nm, h2); } else if (l % 4 == 3) add_stamp(pl, "cv.l4");

@@ -474,6 +474,48 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         // (round 4, same box: 3072 x 768 / 2304 x 768 at 8 streams 803 / 660 -> 692 / 575 us, 768 x 3072 / 768 x 768 at 32 streams 2761 / 771 -> 2413 / 675 us)
         if (lds_cfg == 7 && wgs < 500 && !tune_env("RVC_NO_G32_SQ64")) lds_cfg = 8;
     }
+    // exploratory split-bf16 GEMM (rvc_set_gemm_precision(e, 1); never the default): every 1-D layer the 32x32x2 kernel could take with >= 128 rows and
+    // >= 250 workgroups of 128 x 128 (below that the fp32 kernels with their finer tiles win -- 16 streams, 768-row panels, 84 workgroups: 162 vs 86 us)
+    if ((p.bf3 || pl.bf3) && !p.glu && !ln_fold && B == 1 && p.x_hs == 0 && p.y_hm == 0 && p.M >= 128 && nchunks >= 2 && !p.accumulate &&
+        (size_t)nchunks * 64 + 2 * 2 * 128 * 48 <= 60 * 1024 &&
+        (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nphase >= 250) {
+        const bool lin = p.lin_cs4 != 0 && p.nphase == 1 && !pre;
+        const int nblk = (p.M + 31) / 32;
+        // every phase's fp32 fragment panel -> its split panels ([32-row block][chunk][hi | lo][lane][8 bf16]); phases keep their own K
+        size_t tot = 0;
+        std::vector<size_t> off(phv.size());
+        for (size_t f = 0; f < phv.size(); f++) { off[f] = tot; tot += (size_t)nblk * phv[f].nchunks * 2048; }
+        float *wsplit = (float *)wmalloc(tot);
+        for (size_t f = 0; f < phv.size(); f++) bf3_pack(p.w + phv[f].w_off, p.M, phv[f].nchunks, (char *)wsplit + off[f], nullptr);
+        HIPCHK(hipDeviceSynchronize());
+        pl.owned_dev.push_back(wsplit);
+        std::vector<PhaseD> ph3(phv);
+        for (size_t f = 0; f < ph3.size(); f++) ph3[f].w_off = (long long)(off[f] / 4);
+        p.w = wsplit; p.ph = pl.arena.upload(ph3); p.ph0 = ph3[0];
+        p.ksplit = 1; p.chunks_per_split = nchunks;
+        p.ntm = (p.M + 127) / 128; p.ntn = (p.N + 127) / 128;
+        p.m_fast = p.fold_n ? 1 : 0;
+        const dim3 grid((unsigned)(p.ntm * p.ntn), (unsigned)p.nphase);
+        const size_t lds = (lin ? 0 : (size_t)nchunks * 64) + (size_t)2 * 2 * 128 * 48;
+        g_last_wgs = (int)(grid.x * grid.y); g_last_waves = 4;
+        const double flops = 2.0 * p.M * (double)p.N * ksum;
+        pl.igemm_flops += flops; pl.n_igemm++;
+        Plan *plp = &pl;
+        { char d[176]; snprintf(d, sizeof d, "bf3 M=%d N=%d K=%d B=1 nph=%d tile=128x128 grid=%ux%u lin=%d pre=%d", p.M, p.N, p.K, p.nphase, grid.x, grid.y, (int)lin, (int)pre); pl.descs.push_back(d); }
+        const int desc_id = (int)pl.descs.size() - 1;
+        if (final_out) pl.final_out_honoured = true;
+        pl.ops.push_back([=](hipStream_t s) {
+            ProfEvent *pe = nullptr;
+            if (plp->profile) {
+                if (plp->prof_used == plp->prof.size()) { ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; e.bytes = 0; plp->prof.push_back(e); }
+                pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
+            }
+            hipEvent_t ea = pe ? pe->a : nullptr, eb = pe ? pe->b : nullptr;
+            if (final_out && plp->cur_out) { IgemmP q = p; q.y = plp->cur_out; q.y_bs = plp->cur_out_bs; launch_igemm_bf3(lin, pre, q, grid, lds, s, ea, eb); }
+            else launch_igemm_bf3(lin, pre, p, grid, lds, s, ea, eb);
+        });
+        return;
+    }
     // igemm2w_kernel: register-direct 32x32x2 tiles for the table-free 1x1 layers at a few streams (igemm.hip.h).  Test hook RVC_FORCE_G2W = "tile,ks"
     // (tile 0 = 32 x 32 per wave, 1 = 64 x 32, 2 = 64 x 64; ks = 1 / 2 / 3 / 4 / 6 / 8 waves splitting K) forces it wherever it is eligible.
     {
@@ -672,6 +714,7 @@ void add_conv1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int stride,
     p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.ld; p.y_rs = 0;
     p.x_ld = x.ld; p.x_lo = -x.halo; p.x_lim = x.T - 1 + x.halo;
     fill_epilogue(p, cw, o);
+    p.bf3 = o.bf3 ? 1 : 0;
     // 1x1 convolution with a whole number of 16-row chunks: operand row k sits at k * channel stride, no offset table (igemm2 LIN)
     if (KW == 1 && cw.groups == 1 && pad == 0 && cw.K == cw.Kp) p.lin_cs4 = x.ld * 4;
     if (cw.groups > 1 && (o.m_off != 0 || o.m_cnt >= 0)) throw std::runtime_error("row sub-range on grouped conv");

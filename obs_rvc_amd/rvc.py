@@ -207,6 +207,10 @@ class RvcInfer:
         """Offline throughput mode: unsynchronised infer_device calls overlap across chunks (rvc_set_pipeline)."""
         self._L.rvc_set_pipeline(self._h, 1 if on else 0)
 
+    def set_gemm_precision(self, mode: int):
+        """EXPLORATORY: 1 = the wide 1-D layers as three bf16 matrix-core products per fp32 product at many streams; 0 = fp32 (default)."""
+        self._chk(self._L.rvc_set_gemm_precision(self._h, int(mode)))
+
     def set_plan_cache(self, n_plans: int):
         """Plans (one per call geometry) the engine keeps; least recently used evicted first (rvc_set_plan_cache)."""
         self._chk(self._L.rvc_set_plan_cache(self._h, int(n_plans)))

@@ -16,10 +16,14 @@ json_out = None
 rest = sys.argv[3:]
 if "--json" in rest:
     i = rest.index("--json"); json_out = rest[i + 1]; rest = rest[:i] + rest[i + 2:]
+bf3 = "--bf3" in rest            # exploratory split-bf16 mode (rvc_set_gemm_precision(e, 1))
+rest = [a for a in rest if a != "--bf3"]
 for a in rest:                  # test hooks: NAME=VALUE
     set_opt(*a.split("=", 1))
 z = zoo(sys.argv[2] if len(sys.argv) > 2 else "full")
 eng = RvcInfer(z["data"], device=0); eng.load_contentvec(2); eng.load_f0(1); eng.load_model(z["model"]); eng.set_streams(S); eng.set_noise_seed(1, 0)
+if bf3:
+    eng.set_gemm_precision(1)
 L, chunk, N = g.input_buffer_16k_size, g.sample_frame_16k, g.model_return_size
 x = torch.from_numpy(np.stack([voice_signal(L, seed=1 + s) for s in range(S)])).cuda(); out = torch.empty((S, N), device="cuda")
 for _ in range(3):
@@ -65,5 +69,6 @@ if json_out:
                "build": _native.binary_hash(), "streams": S, "peak_tflops_fp32_mfma": 157.3, "launches": n, "sum_us": round(tot_us, 1), "gflop": round(tot_gf, 2),
                "tflops": round(tot_gf / tot_us * 1e3, 2), "wall_ms_per_chunk_median": round(float(np.median(ts[5:]) * 1e3), 4),
                "kernel_names": {"reg": "igemm2_kernel (register-direct, 16x16x4 MFMA)", "g32": "igemm32_kernel (LDS-staged activations, 32x32x2 MFMA)",
-                                "g32w": "igemm32w_kernel (wide register tiles, 32x32x2 MFMA)", "lds": "igemm_lds_kernel (16x16x4 MFMA)", "ct": "conv_tile_kernel"},
+                                "g32w": "igemm32w_kernel (wide register tiles, 32x32x2 MFMA)", "lds": "igemm_lds_kernel (16x16x4 MFMA)", "ct": "conv_tile_kernel", "g2w": "igemm2w_kernel (register-direct 32x32x2 MFMA, K split in the workgroup)",
+                                "bf3": "igemm_bf3_kernel (exploratory: three bf16 MFMAs per fp32 product)"},
                "layers": layers}, open(json_out, "w"), indent=1)
