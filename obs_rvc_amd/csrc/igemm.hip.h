@@ -1522,6 +1522,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G32Occ<MT, 
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int u = 0; u < 2; u++) a_n[mt][u] = *reinterpret_cast<const f32x4 *>(wrow[mt] + cn * 256 + u * 128);
+        __builtin_amdgcn_sched_barrier(0);      // (the next step's requests stay in FRONT of this step's MFMAs: left to itself the scheduler sinks them behind most of them)
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             f32x4 bv[NT];
@@ -1740,6 +1741,7 @@ __global__ __launch_bounds__(256) void igemm_bf3_kernel(IgemmP p)
         const char *bcur = br + (c & 1) * BUF;
         gather(cn);
         wload(a_n, cn);
+        __builtin_amdgcn_sched_barrier(0);      // (requests in front of the MFMAs, as in igemm32_kernel)
         bf16x8 bh[NT], bl[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
