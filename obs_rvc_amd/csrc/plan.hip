@@ -472,7 +472,9 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         if (wgs >= g32_narrow_min) lds_cfg = 7;
         // between one and two workgroups per CU the 128 x 64 tile leaves half of the slots empty: 64 x 64 tiles (one 32 x 32 accumulator per wave) double them
         // (round 4, same box: 3072 x 768 / 2304 x 768 at 8 streams 803 / 660 -> 692 / 575 us, 768 x 3072 / 768 x 768 at 32 streams 2761 / 771 -> 2413 / 675 us)
-        if (lds_cfg == 7 && wgs < 500 && !tune_env("RVC_NO_G32_SQ64")) lds_cfg = 8;
+        // (round 5: only the table-free 1x1 layers, where that was measured.  The 512-row stem convolutions with ~7 160 columns -- 448 workgroups of
+        //  128 x 64 -- run 119-120 us on the 128 x 64 tile against 148-152 on 64 x 64, isolated, at 4 and 16 streams: tests/tools/tile_sweep.py)
+        if (lds_cfg == 7 && wgs < 500 && p.lin_cs4 != 0 && !tune_env("RVC_NO_G32_SQ64")) lds_cfg = 8;
     }
     // exploratory split-bf16 GEMM (rvc_set_gemm_precision(e, 1); never the default): every 1-D layer the 32x32x2 kernel could take with >= 128 rows and
     // >= 250 workgroups of 128 x 128 (below that the fp32 kernels with their finer tiles win -- 16 streams, 768-row panels, 84 workgroups: 162 vs 86 us)
