@@ -89,7 +89,7 @@ static void reset_state(rvc_engine *e)
 // streams 3.35 -> 4.79 ms per chunk for engines created after several others had come and gone).  So ALL streams of an engine come
 // from a per-device pool of complete sets (main + three plain auxiliaries + the masked pair), created together -- six consecutive
 // hardware queues -- and never destroyed; an engine borrows a set and hands it back.
-struct StreamSet { int device; hipStream_t main, plain[3], f0, cv; bool masked_ok, in_use; };
+struct StreamSet { int device; hipStream_t main, plain[3], f0, cv; bool masked_ok, in_use; int nf0; };      // nf0: CUs of the masked f0 stream (sets differ only in this)
 static std::mutex g_pool_mu;
 static std::vector<StreamSet *> g_pool;
 
@@ -97,8 +97,8 @@ static StreamSet *acquire_stream_set(int device, int ncu, int nf0, bool want_mas
 {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (StreamSet *m : g_pool)
-        if (m->device == device && !m->in_use) { m->in_use = true; return m; }
-    StreamSet *m = new StreamSet{device, nullptr, {nullptr, nullptr, nullptr}, nullptr, nullptr, false, true};
+        if (m->device == device && !m->in_use && m->nf0 == nf0) { m->in_use = true; return m; }
+    StreamSet *m = new StreamSet{device, nullptr, {nullptr, nullptr, nullptr}, nullptr, nullptr, false, true, nf0};
     // creation order = the order a lone engine always used: main, the masked pair, the side stream (the first bench run of this
     // pool created all plain streams first: 2.17 -> 2.80 ms per chunk -- queue assignment follows creation order); the two plain
     // streams that stand in for the masked pair at more than 4 streams are created when such an engine first borrows the set
@@ -139,9 +139,19 @@ static void configure_aux_streams(rvc_engine *e)
     // the same pool says the opposite: 2.044-2.048 -> 2.06-2.08 at one stream, 2.87 -> 3.03 at two, 4.21 -> 4.46 at four (only the v1 model, whose
     // ContentVec stops at layer 9, gains: 2.075 -> 1.994).  Partitions that cut an XCD in two lose badly either way (56: 2.244, 72: 2.469, 80: 2.484).
     // Lesson kept here: partition sizes are tuned on the product build only.
-    int ncu = prop.multiProcessorCount, nf0 = ncu / 8;
+    // The one exception is measured on the product build too (tests/tools/f0_xcds.py, same box, two alternating runs): the v1 model (ContentVec stops at
+    // layer 9: the chunk waits for the f0 branch) with two XCDs for f0 runs 1.98-2.02 -> 1.92-1.93 ms at one stream, 2.72-2.77 -> 2.68 at two,
+    // 3.45 -> 3.43 at three (and 3.87 -> 3.95 at four: one XCD there; v2 loses at every count: 1.98-2.02 -> 2.04-2.06, 2.77 -> 2.96, 3.65 -> 3.79, 4.09 -> 4.36).
+    // Sets with that partition are separate members of the pool (masks are fixed at creation).
+    int ncu = prop.multiProcessorCount;
+    int xcds = e->cv && e->cv->run_layers <= 9 && e->n_streams <= 3 ? 2 : 1;
+    if (const char *f = test_opt("RVC_F0_XCDS")) { const int v = atoi(f); if (v >= 1 && v <= 4) xcds = v; }     // test hook: both partitions are covered by the parity tests
+    int nf0 = xcds * (ncu / 8);
     g_ncu = ncu > 0 ? ncu : 256;
     if (const char *f = tune_env("RVC_F0_CUS")) { const int v = atoi(f); if (v >= 8 && v < ncu) nf0 = v; }   // tuning aid
+    if (e->sset && e->sset->nf0 != nf0 && e->sset->masked_ok) {      // (callers have synchronised the device and dropped the plans)
+        release_stream_set(e->sset); e->sset = nullptr;
+    }
     if (!e->sset) {
         e->sset = acquire_stream_set(e->device, ncu, nf0, e->partition_ok && ncu >= 64 && ncu <= 1024);
         e->stream = e->sset->main;
@@ -553,6 +563,7 @@ rvc_status rvc_load_contentvec(rvc_engine *e, int model_version)
         HIPCHK(hipDeviceSynchronize());      // unsynchronised calls may still be running on the plans freed below
         e->plans.clear(); e->last_plan = nullptr;
         e->cv.reset(new ModelCV(b));
+        configure_aux_streams(e);       // (the f0 partition depends on the ContentVec depth)
         return RVC_OK;
     });
 }

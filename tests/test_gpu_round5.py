@@ -274,3 +274,40 @@ def test_split_bf16_gemms_exploratory_mode():
         print("stream %d: PCM rms error vs oracle: fp32 path %.3e, split-bf16 path %.3e; between the two paths %.3e" % (s, e32, e3, rms(outs[1][s] - outs[0][s])))
         assert e32 < PCM_TOL and e3 < PCM_TOL, (s, e32, e3)
     assert worst < PCM_TOL
+
+
+def test_v1_engine_takes_the_two_xcd_f0_partition_beside_a_v2_engine():
+    # A one-stream engine of the v1 model (ContentVec stops at layer 9) runs its f0 branch on two XCDs instead of one (engine.hip configure_aux_streams;
+    # stream sets with different partitions are separate members of the per-device pool).  Both engines alive in one process, interleaved, each against
+    # its own oracle; then the same v1 engine forced back to one XCD (test hook RVC_F0_XCDS) -- the partition must change nothing but the timing.
+    from obs_rvc_amd.rvc import RvcInfer
+    from oracle import oracle as O
+    z1, z2 = zoo("tiny", 1), zoo("tiny", 2)
+    e2 = _engine(z2, 1, (5, 50))
+    o2 = _oracle(z2, 5, 50)
+
+    def v1_engine():
+        e = RvcInfer(z1["data"]); e.load_contentvec(1); e.load_f0(); e.load_model(z1["model"]); e.set_noise_seed(6, 60)
+        return e
+
+    def v1_oracle():
+        o = O.OracleRvcInfer(z1["data"]); o.load_contentvec(1); o.load_f0(1); o.load_model(z1["model"]); o.set_noise_seed(6, 60)
+        return o
+
+    x = voice_signal(g.input_buffer_16k_size, seed=31)
+    a = (g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+    e1, o1 = v1_engine(), v1_oracle()
+    for tick in range(3):
+        y1, y2 = e1.infer(x, *a), e2.infer(x, *a)
+        assert rms(y1 - o1.infer(x, *a)) < PCM_TOL and rms(y2 - o2.infer(x, *a)) < PCM_TOL, tick
+    e1.close()
+    set_opt("RVC_F0_XCDS", "1")
+    try:
+        e1, o1 = v1_engine(), v1_oracle()
+        for tick in range(2):
+            assert rms(e1.infer(x, *a) - o1.infer(x, *a)) < PCM_TOL
+            assert rms(e2.infer(x, *a) - o2.infer(x, *a)) < PCM_TOL
+        e1.close()
+    finally:
+        set_opt("RVC_F0_XCDS", None)
+    e2.close()
