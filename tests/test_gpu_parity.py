@@ -500,6 +500,7 @@ def test_graph_replay_equals_eager_and_device_api():
     x = voice_signal(g.input_buffer_16k_size, seed=8)
     d_in = torch.from_numpy(x).cuda()
     d_out = torch.zeros(g.model_return_length * 48, device="cuda")
+    torch.cuda.synchronize()         # (the fill runs on torch's stream, the engine on its own)
     for i in range(4):
         ya = eng.infer(x, 2560, 12 if i < 2 else -12, 200, 21)
         n = eng2.infer_device(d_in.data_ptr(), len(x), 2560, 12 if i < 2 else -12, 200, 21, d_out.data_ptr(), d_out.numel(), sync=True)
@@ -701,6 +702,7 @@ def test_pipelined_chunks_equal_serial_chunks():
         eng = RvcInfer(z["data"]); eng.load_contentvec(2); eng.load_f0(); eng.load_model(z["model"]); eng.set_noise_seed(11, 0)
         eng.set_pipeline(pipelined)
         outs = torch.zeros((8, N), device="cuda")
+        torch.cuda.synchronize()     # (the fill runs on torch's stream, the engine on its own)
         for i in range(8):
             eng.infer_device(rings[i].data_ptr(), L, chunk, 12, g.skip_head, g.model_return_length, outs[i].data_ptr(), N, sync=not pipelined)
         eng.synchronize()

@@ -101,6 +101,7 @@ def test_gpu_resampler_device_api_and_tone():
     gpu = FftFixedInOut(eng, 48000, 16000, 8640)
     x = np.sin(2 * np.pi * 440.0 * np.arange(8640 * 3) / 48000).astype(np.float32)
     dx, dy = torch.from_numpy(x).cuda(), torch.zeros(3, 2880, device="cuda")
+    torch.cuda.synchronize()         # (the fill runs on torch's stream, the engine on its own: the caller orders the two)
     for i in range(3):
         gpu.process_device(dx[i * 8640:].data_ptr(), dy[i].data_ptr(), sync=True)
     y = dy.cpu().numpy().reshape(-1)
