@@ -14,7 +14,7 @@ L.rvc_debug_option.argtypes = [C.c_char_p, C.c_char_p]
 h = C.c_void_p()
 assert L.rvc_create(b"/tmp", 0, C.byref(h)) == 0
 SHAPES = [("ffn1 3072x768", 3072, 768, 1, 1, 111, 3), ("qkv 2304x768", 2304, 768, 1, 1, 111, 0), ("ffn2 768x3072", 768, 3072, 1, 1, 111, 0),
-          ("out 768x768", 768, 768, 1, 1, 111, 0), ("conv2 512k3 N=1791", 512, 512, 3, 1, 1791, 3), ("conv4 512k3 N=447", 512, 512, 3, 1, 447, 3),
+          ("out 768x768", 768, 768, 1, 1, 111, 0), ("conv1 512k3 N=3583", 512, 512, 3, 1, 3583, 3), ("conv2 512k3 N=1791", 512, 512, 3, 1, 1791, 3), ("conv3 512k3 N=895", 512, 512, 3, 1, 895, 3), ("conv4 512k3 N=447", 512, 512, 3, 1, 447, 3),
           ("dec 256k11 N=210", 256, 256, 11, 1, 210, 0), ("dec 128k11 N=2520", 128, 128, 11, 1, 2520, 0)]
 G32 = [("128x128", "3"), ("64x256", "4"), ("32x256", "5"), ("128x64", "7"), ("64x64", "8")]
 REG = [("r32x64k%d" % k, "4,%d" % k) for k in (1, 4, 8)] + [("r32x32k%d" % k, "3,%d" % k) for k in (1, 4, 8)] + [("r16x64k4", "2,4"), ("r16x16k8", "0,8")]
