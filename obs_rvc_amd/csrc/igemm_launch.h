@@ -40,6 +40,15 @@ void launch_igemm2w_t0(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream
 void launch_igemm2w_t1(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 void launch_igemm2w_t2(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 
+// conv32s_kernel (conv32s.hip.h: stride-1 1-D convolutions at many streams, input staged once per workgroup and 32-channel block, 32x32x2 MFMAs).
+// Workgroup tiles BM x BN (every wave 32 x 64): 0 = 32 x 256, 1 = 64 x 128, 2 = 128 x 64
+static const int kC32sBM[3] = {32, 64, 128}, kC32sBN[3] = {256, 128, 64};
+static const int kC32sCB = 32, kC32sCS = 36;        // channels staged per block, LDS column stride (floats)
+void launch_conv32s(int tile, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
+void launch_conv32s_p0(const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+void launch_conv32s_p1(const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+void launch_conv32s_p2(const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+
 // exploratory split-bf16 GEMM (igemm_bf3_kernel): 128 x 128 workgroup tile; bf3_pack builds the weight panels it reads
 void launch_igemm_bf3(bool lin, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
 void bf3_pack(const float *wfrag, int M, int nchunks, void *out, hipStream_t s);

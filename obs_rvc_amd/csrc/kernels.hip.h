@@ -1171,12 +1171,14 @@ static __global__ void prior_sample_kernel(const float *stats, int s_cs, long lo
 }
 
 // channel flip (Flip flow): y[c] = x[C-1-c]
-static __global__ void flip_channels_kernel(const float *x, float *y, int C, int T, int cs, long long bs)
+static __global__ void flip_channels_kernel(const float *x, int x_cs, long long x_bs, float *y, int y_cs, long long y_bs, int C, int T)
 {
+    // (source and destination have their own strides: with composed WaveNets the latent is a row range of a wider tensor -- a shared stride put every
+    //  stream but the first in the wrong place: found in round 5 by the first multi-stream test of an odd flow count)
     int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= C * T) return;
     int c = i / T, t = i - c * T;
-    y[(long long)b * bs + (long long)c * cs + t] = x[(long long)b * bs + (long long)(C - 1 - c) * cs + t];
+    y[(long long)b * y_bs + (long long)c * y_cs + t] = x[(long long)b * x_bs + (long long)(C - 1 - c) * x_cs + t];
 }
 
 // WaveNet gate: acts[c] = tanh(a[c]) * sigmoid(a[H + c])   (conditioning already folded into the conv bias)

@@ -153,7 +153,7 @@ void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T1 &src,
         if (m.flow_n & 1) {
             // odd number of flips: materialise the last one
             T1 zi = z, zo = zf; dim3 grid((I * R + 255) / 256, B);
-            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(flip_channels_kernel, grid, dim3(256), 0, s, zi.p, zo.p, I, R, zi.ld, zi.bs); });
+            pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(flip_channels_kernel, grid, dim3(256), 0, s, zi.p, zi.ld, zi.bs, zo.p, zo.ld, zo.bs, I, R); });
             std::swap(z, zf);
         }
     }

@@ -6,7 +6,7 @@
 namespace rvc {
 
 static const char *const kTestHooks[] = {"RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_NO_LN_FUSE", "RVC_NO_CONV0_MULTI", "RVC_KNN_NO_GEMM",
-                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS"};
+                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_C32S_DBG"};
 std::atomic<unsigned> g_opt_gen{0};       // bumped by every rvc_debug_option call: plans built under another generation are dropped (engine.hip get_plan)
 static std::mutex g_opt_mu;
 static std::map<std::string, std::string> g_opts;
@@ -317,6 +317,101 @@ static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &
     return true;
 }
 
+// More than 4 streams, stride-1 1-D convolution whose input channels come in 32s: conv32s_kernel (conv32s.hip.h) stages the input rows of a 32-channel
+// block once per workgroup and walks the taps from LDS (32x32x2 MFMAs); igemm32_kernel re-gathers the activation tile for every 16-deep K step, i.e.
+// once per tap.  The streams stay a grid dimension (tiles never straddle streams).  Test hook RVC_CONV32S: 0 = off, 2 = wherever eligible (any stream
+// count, any size), "RVC_CONV32S_TILE" forces a tile (0..2).  false = not eligible.
+static bool queue_conv32s(Plan &pl, IgemmP &p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phv, double ksum, bool final_out)
+{
+    const int mode = test_opt_int("RVC_CONV32S", 1);
+    if (!mode || p.fold_n || p.x_ld <= 0 || p.x_hs || p.x_ws != 1 || p.y_hm || p.y_ws != 1 || p.glu || p.ln_wsum || p.ln_stats_in || p.ln_stats_out || p.part || p.bf3 || pl.bf3) return false;
+    if (mode < 2 && (B <= 4 || p.N < 200 || p.M < 32)) return false;
+    for (const PhaseD &q : phv) if (q.act_p1 != 0 || q.y_off != 0 || q.y_pos != 0) return false;
+    // tile by the height of the weight panel; every wave owns 32 x 64 outputs (round 5 sweep of six tiles per layer at 8 / 16 / 32 / 64 streams, gpurun_out
+    // of tests/tools/c32s_layers.py: 2 x 2 accumulator blocks per wave -- 128 x 128, 64 x 256 -- lose to these at every count but 64, where they tie)
+    auto wgs_of = [&](int t) { return (long long)((p.M + kC32sBM[t] - 1) / kC32sBM[t]) * ((p.N + kC32sBN[t] - 1) / kC32sBN[t]) * (long long)phv.size() * B; };
+    int tile = p.M <= 32 ? 0 : (p.M <= 64 ? 1 : 2);
+    const int forced = test_opt_int("RVC_CONV32S_TILE", -1);
+    if (forced >= 0 && forced <= 2) tile = forced;
+    // under two workgroups per CU the register-direct kernels with their K split win (256-row stage at 32 streams: 684 vs 720 us)
+    if (mode < 2 && wgs_of(tile) < 2 * g_ncu) return false;
+    const int BM = kC32sBM[tile], BN = kC32sBN[tile], CB = kC32sCB;
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    if ((long long)phv.size() * B > 65535) return false;
+    std::vector<PhaseD> phs(phv);
+    std::vector<float> wnew;
+    size_t lds_max = 0;
+    const int mt = (p.M + 15) / 16;
+    for (PhaseD &q : phs) {
+        const int K = q.nchunks * 16;
+        int cin = 1;
+        for (int k = 0; k < K; k++) cin = std::max(cin, (int)std::floor((double)koff[q.koff_off + k] / p.x_ld + 0.5) + 1);
+        if (cin % CB != 0 || K % cin != 0) return false;
+        const int KW = K / cin;
+        if (KW > 255) return false;
+        const int dmin = koff[q.koff_off];
+        const int dil = KW > 1 ? koff[q.koff_off + 1] - koff[q.koff_off] : 1;
+        if (dil < 1 || dil > 255 || dmin > 0 || dmin < p.x_lo) return false;
+        for (int k = 0; k < K; k++) if (koff[q.koff_off + k] != (k / KW) * p.x_ld + dmin + (k % KW) * dil) return false;
+        if ((KW - 1) * dil > 64) return false;          // (the kernel's staging grid covers BN + 64 columns)
+        q.t_tab = KW | (dil << 8); q.t_cin = cin; q.t_rs = 0; q.t_dmin = dmin;
+        lds_max = std::max(lds_max, (size_t)(BN + (KW - 1) * dil) * kC32sCS * 4);
+        // K order of the kernel: chunk (block * KW + tap) * 2 + group, slot kk of a chunk <- source k = (block * 32 + group * 16 + kk) * KW + tap
+        std::vector<float> wold((size_t)mt * q.nchunks * 256);
+        HIPCHK(hipMemcpy(wold.data(), p.w + q.w_off, wold.size() * 4, hipMemcpyDeviceToHost));
+        const size_t base = wnew.size();
+        wnew.resize(base + wold.size());
+        const int GB = CB / 16, nblk = cin / CB;
+        for (int t = 0; t < mt; t++)
+            for (int blk = 0; blk < nblk; blk++)
+                for (int tap = 0; tap < KW; tap++)
+                    for (int g = 0; g < GB; g++)
+                        for (int l = 0; l < 64; l++)
+                            for (int j = 0; j < 4; j++) {
+                                const int k = (blk * CB + g * 16 + (l >> 4) * 4 + j) * KW + tap;          // the source's k
+                                wnew[base + (((size_t)t * q.nchunks + (blk * KW + tap) * GB + g) * 64 + l) * 4 + j] =
+                                    wold[(((size_t)t * q.nchunks + k / 16) * 64 + (((k % 16) / 4) << 4 | (l & 15))) * 4 + (k % 4)];
+                            }
+        q.w_off = (long long)base;
+    }
+    if (lds_max > 60 * 1024) return false;
+    // three-tap layers of the 64- / 128- / 256-row panels at 24 streams and more stay on igemm32_kernel: a channel block is only six chunks there, shorter than
+    // the latency of the next block's staging loads that the first weight wait behind them has to sit out (32 / 64 streams: 546 vs 496, 998 vs 919 us for the
+    // six 128-row layers, 351 vs 331, 592 vs 564 for the 64-row ones; at 16 streams this kernel wins them too: 294 vs 301, 182 vs 207)
+    {
+        int kw_max = 0;
+        for (const PhaseD &q : phs) kw_max = std::max(kw_max, q.t_tab & 0xff);
+        if (mode < 2 && kw_max <= 3 && p.M >= 64 && B >= 24) return false;
+    }
+    p.w = pl.arena.upload(wnew);
+    p.koff = nullptr; p.items = nullptr; p.ttab = nullptr;
+    p.ph = pl.arena.upload(phs);
+    p.nphase = (int)phs.size();
+    p.ph0 = phs[0];
+    p.ntm = ntm; p.ntn = ntn; p.ksplit = 1; p.nbatch = B; p.m_fast = 0;
+    p.pad2_ = test_opt_int("RVC_C32S_DBG", 0);
+    const dim3 grid((unsigned)(ntm * ntn), (unsigned)(p.nphase * B));
+    g_last_wgs = (int)(grid.x * grid.y); g_last_waves = 4;
+    const double flops = 2.0 * p.M * (double)p.N * ksum * B;
+    pl.igemm_flops += flops; pl.n_igemm++;
+    Plan *plp = &pl;
+    { char d[200]; snprintf(d, sizeof d, "c32s M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%u lds=%zu pre=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, BM, BN, grid.x, grid.y, lds_max, (int)(p.pre_act != ACT_NONE), ksum); pl.descs.push_back(d); }
+    const int desc_id = (int)pl.descs.size() - 1;
+    const IgemmP pc = p;
+    if (final_out) pl.final_out_honoured = true;
+    pl.ops.push_back([=](hipStream_t s) {
+        ProfEvent *pe = nullptr;
+        if (plp->profile) {
+            if (plp->prof_used == plp->prof.size()) { ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; e.bytes = 0; plp->prof.push_back(e); }
+            pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
+        }
+        hipEvent_t ea = pe ? pe->a : nullptr, eb = pe ? pe->b : nullptr;
+        if (final_out && plp->cur_out) { IgemmP q = pc; q.y = plp->cur_out; q.y_bs = plp->cur_out_bs; launch_conv32s(tile, q, grid, lds_max, s, ea, eb); }
+        else launch_conv32s(tile, pc, grid, lds_max, s, ea, eb);
+    });
+    return true;
+}
+
 // generic: the caller fills geometry (N, NW, strides, koff, phases); this picks the tile + split-K and queues the op
 // Which table-free 1x1 layers take igemm2w_kernel, and with what tile / K split (filled in from per-layer measurements: tests/tools/g2w_sweep.py).
 // gt < 0: not this kernel.
@@ -357,6 +452,16 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         std::stable_sort(phq.begin(), phq.end(), [](const PhaseD &a, const PhaseD &b) { return a.nchunks > b.nchunks; });
         IgemmP pt = p;
         if (queue_conv_tile(pl, pt, B, koff, phq, ks0, final_out)) return;
+        // five streams and more: the staged 32x32x2 convolution (streams as a grid dimension: also before the fold)
+        pt = p;
+        if (queue_conv32s(pl, pt, B, koff, phq, ks0, final_out)) return;
+    }
+    if (B == 1 && test_opt_int("RVC_CONV32S", 1) == 2) {           // test hook: the kernel forced onto one stream
+        std::vector<PhaseD> phq(phases);
+        double ks0 = 0;
+        for (PhaseD &q : phq) { if (q.nchunks == 0) q.nchunks = p.K / 16; ks0 += q.nchunks * 16.0; }
+        IgemmP pt = p;
+        if (queue_conv32s(pl, pt, B, koff, phq, ks0, final_out)) return;
     }
     if (B > 1 && !tune_env("RVC_NO_FOLD")) {
         const long long lim = (1LL << 29);

@@ -542,6 +542,15 @@ def test_five_stage_synthesizer_with_odd_flow_count():
     for _ in range(2):
         yo, ye = ora.infer(x, 2560, 3, 200, 21), eng.infer(x, 2560, 3, 200, 21)
         assert ye.shape == yo.shape == (21 * 64,) and rms(ye - yo) < PCM_TOL, rms(ye - yo)
+    # ... and with three streams (round 5: the materialised flip of an odd flow count read and wrote with ONE batch stride; with composed WaveNets the
+    # latent is a row range of a wider tensor, so every stream but the first came out wrong -- 0.19 RMS -- and no test ran this family with streams)
+    eng3 = RvcInfer(z["data"]); eng3.load_contentvec(2); eng3.load_f0(); eng3.load_model(z["model"]); eng3.set_streams(3); eng3.set_noise_seed(4, 30)
+    xin = np.stack([voice_signal(g.input_buffer_16k_size, seed=40 + s) for s in range(3)])
+    y3 = eng3.infer_batch(xin, 2560, 3, 200, 21)
+    for s in range(3):
+        o = O.OracleRvcInfer(z["data"]); o.load_contentvec(2); o.load_f0(1); o.load_model(z["model"]); o.set_noise_seed(4, 30 + s)
+        assert rms(y3[s] - o.infer(xin[s], 2560, 3, 200, 21)) < PCM_TOL, s
+    eng3.close()
 
 
 def test_plain_c_client_links_and_runs(tmp_path):
@@ -756,6 +765,19 @@ def test_every_tile_configuration_computes_the_same_convolution():
                     assert 0 <= e3 < 2e-5, ("conv_tile", tile128, ks, M, Cin, KW, dil, N, pre, e3)
         for k in ("RVC_CONV_TILE", "RVC_CONV_TILE_KS"):
             set_opt(k, None)
+        # conv32s_kernel (round 5: stride-1 1-D convolutions at five streams and more -- input rows of a 32-channel block staged once per workgroup,
+        # taps walked from LDS, 32x32x2 MFMAs, K walked (block, tap, group)-major from repacked weights): every tile forced onto one, three and eight
+        # streams; ragged M / N, one to eight channel blocks, reach of the taps from 0 to 50 columns, N shorter than a tile
+        set_opt("RVC_CONV32S", "2")
+        for tile in range(3):
+            set_opt("RVC_CONV32S_TILE", str(tile))
+            for streams in (1, 3, 8):
+                for (M, Cin, KW, dil, N, pre) in [(32, 32, 11, 1, 1000, 1), (64, 64, 7, 3, 520, 0), (128, 128, 11, 5, 700, 1), (40, 32, 7, 3, 300, 1), (256, 64, 3, 1, 97, 1),
+                                                  (100, 96, 5, 2, 333, 0), (32, 32, 1, 1, 256, 0), (256, 256, 3, 1, 252, 1)]:
+                    e6 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, streams, pre)
+                    assert 0 <= e6 < 2e-5, ("conv32s", tile, streams, M, Cin, KW, dil, N, pre, e6)
+        for k in ("RVC_CONV32S", "RVC_CONV32S_TILE"):
+            set_opt(k, None)
         for streams in (3, 20):                            # folded streams; 20 streams reach the workgroup-tiled kernels on the wide layers
             # (+ a 48-row panel wide enough for the 48 x 256 workgroup tile, a 32-row and a 64-row panel for the narrow 32x32x2 tiles)
             for (M, Cin, KW, dil, N, pre) in shapes + [(128, 128, 7, 3, 2520, 1), (768, 256, 1, 1, 111, 0), (48, 48, 15, 1, 5000, 0), (32, 32, 11, 1, 10080, 1), (64, 64, 7, 1, 5040, 0)]:
@@ -767,7 +789,7 @@ def test_every_tile_configuration_computes_the_same_convolution():
                 e4 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, streams, pre)
                 assert 0 <= e4 < 2e-5, ("tall", streams, M, Cin, KW, dil, N, pre, e4)
     finally:
-        for k in ("RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_FORCE_G2W"):
+        for k in ("RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_FORCE_G2W", "RVC_CONV32S", "RVC_CONV32S_TILE"):
             set_opt(k, None)
         L.rvc_destroy(h)
 
