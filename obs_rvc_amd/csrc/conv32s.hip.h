@@ -33,8 +33,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C32sOcc<MT,
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wm = wave / WN, wn = wave % WN;
     const int c32 = lane & 31, ks = lane >> 5;
-    const int tn = (int)blockIdx.x % p.ntn, tm = (int)blockIdx.x / p.ntn;
-    const int phase = (int)blockIdx.y / p.nbatch, b = (int)blockIdx.y % p.nbatch;      // long phases first (the planner sorts them), every stream of a phase together
+    // grid = (n-tiles x m-tiles, streams, phases): no division for the common one-m-tile layers (the four runtime divisions of a flat index were ~160 of the
+    // prologue's ~900 instructions, and a 32-row layer's wave has only 96-352 MFMAs to set them against); long phases first (the planner sorts them)
+    const int tm = p.ntm == 1 ? 0 : (int)blockIdx.x / p.ntn, tn = p.ntm == 1 ? (int)blockIdx.x : (int)blockIdx.x - tm * p.ntn;
+    const int phase = (int)blockIdx.z, b = (int)blockIdx.y;
     const PhaseD ph = p.nphase == 1 ? p.ph0 : p.ph[phase];
     const int nchunks = ph.nchunks;
     const int kw = ph.t_tab & 0xff, dil = ph.t_tab >> 8;

@@ -337,7 +337,7 @@ static bool queue_conv32s(Plan &pl, IgemmP &p, int B, const std::vector<int> &ko
     if (mode < 2 && wgs_of(tile) < 2 * g_ncu) return false;
     const int BM = kC32sBM[tile], BN = kC32sBN[tile], CB = kC32sCB;
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-    if ((long long)phv.size() * B > 65535) return false;
+    if (phv.size() > 65535 || B > 65535) return false;
     std::vector<PhaseD> phs(phv);
     std::vector<float> wnew;
     size_t lds_max = 0;
@@ -382,6 +382,8 @@ static bool queue_conv32s(Plan &pl, IgemmP &p, int B, const std::vector<int> &ko
         int kw_max = 0;
         for (const PhaseD &q : phs) kw_max = std::max(kw_max, q.t_tab & 0xff);
         if (mode < 2 && kw_max <= 3 && p.M >= 64 && B >= 24) return false;
+        // ... and the 128-row fused launches of 5-11 streams (8 streams, same box, twice: 843 / 846 vs 827 / 825 us for the six launches of the stage)
+        if (mode < 2 && p.M > 64 && B < 12) return false;
     }
     p.w = pl.arena.upload(wnew);
     p.koff = nullptr; p.items = nullptr; p.ttab = nullptr;
@@ -390,12 +392,12 @@ static bool queue_conv32s(Plan &pl, IgemmP &p, int B, const std::vector<int> &ko
     p.ph0 = phs[0];
     p.ntm = ntm; p.ntn = ntn; p.ksplit = 1; p.nbatch = B; p.m_fast = 0;
     p.pad2_ = test_opt_int("RVC_C32S_DBG", 0);
-    const dim3 grid((unsigned)(ntm * ntn), (unsigned)(p.nphase * B));
-    g_last_wgs = (int)(grid.x * grid.y); g_last_waves = 4;
+    const dim3 grid((unsigned)(ntm * ntn), (unsigned)B, (unsigned)p.nphase);
+    g_last_wgs = (int)(grid.x * grid.y * grid.z); g_last_waves = 4;
     const double flops = 2.0 * p.M * (double)p.N * ksum * B;
     pl.igemm_flops += flops; pl.n_igemm++;
     Plan *plp = &pl;
-    { char d[200]; snprintf(d, sizeof d, "c32s M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%u lds=%zu pre=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, BM, BN, grid.x, grid.y, lds_max, (int)(p.pre_act != ACT_NONE), ksum); pl.descs.push_back(d); }
+    { char d[200]; snprintf(d, sizeof d, "c32s M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%ux%u lds=%zu pre=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, BM, BN, grid.x, grid.y, grid.z, lds_max, (int)(p.pre_act != ACT_NONE), ksum); pl.descs.push_back(d); }
     const int desc_id = (int)pl.descs.size() - 1;
     const IgemmP pc = p;
     if (final_out) pl.final_out_honoured = true;

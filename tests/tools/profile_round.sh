@@ -16,6 +16,13 @@ prof 64streams --steps 15 --warmup 3 --streams 64
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/ks_64serial -- python $R/bench.py --only-headline --no-cpu --steps 15 --warmup 3 --streams 64 --serial-branches > $out/bench_64streams_serial.json 2> $out/bench_64streams_serial.err
 cp $raw/ks_64serial/*/*kernel_stats.csv $out/${rnd}_kernel_stats_bench_64streams_serial_branches.csv
 python $R/tests/tools/serial_pass.py $out/${rnd}_kernel_stats_bench_64streams_serial_branches.csv 64 $out/${rnd}_serial_64streams.json ${rnd}_kernel_stats_bench_64streams_serial_branches.csv > /dev/null
+# the same pass at the stream counts between the two regimes (bench.py prints their roofline.frac only with a matching pass of the same build); RVC_PROFILE_ONLY_SERIAL=1 stops here
+for S in 8 16 32; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d $raw/ks_${S}serial -- python $R/bench.py --only-headline --no-cpu --steps 20 --warmup 3 --streams $S --serial-branches > $out/bench_${S}streams_serial.json 2> $out/bench_${S}streams_serial.err
+    cp $raw/ks_${S}serial/*/*kernel_stats.csv $out/${rnd}_kernel_stats_bench_${S}streams_serial_branches.csv
+    python $R/tests/tools/serial_pass.py $out/${rnd}_kernel_stats_bench_${S}streams_serial_branches.csv $S $out/${rnd}_serial_${S}streams.json ${rnd}_kernel_stats_bench_${S}streams_serial_branches.csv > /dev/null
+done
+if [ -n "$RVC_PROFILE_ONLY_SERIAL" ]; then ls -la $out; exit 0; fi
 pmc() { name=$1; ctr=$2; shift 2; rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $raw/pmc_${name}_$ctr -- python $R/bench.py --only-headline --no-cpu "$@" > /dev/null 2>&1; }
 pmc 1stream FETCH_SIZE --steps 40
 pmc 1stream WRITE_SIZE --steps 40
