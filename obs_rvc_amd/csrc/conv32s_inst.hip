@@ -10,7 +10,7 @@ namespace rvc {
 #error "compile with -DRVC_C32S_PART=0..2"
 #endif
 
-// tile 0 = 32 x 256 (four waves side by side), 1 = 64 x 128 (2 x 2 waves), 2 = 128 x 64 (four waves stacked in M); every wave owns 32 x 64 outputs
+// tile 0 = 32 x 256 (four waves side by side), 1 = 64 x 128 (2 x 2 waves), 2 = 128 x 64 (four waves stacked in M; conv32s_buf_kernel); every wave owns 32 x 64 outputs
 #if RVC_C32S_PART == 0
 void launch_conv32s_p0(const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb) { launch_k(conv32s_kernel<1, 4, 1, 2>, p, grid, dim3(256), lds, s, ea, eb); }
 void launch_conv32s(int tile, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
@@ -22,7 +22,7 @@ void launch_conv32s(int tile, const IgemmP &p, dim3 grid, size_t lds, hipStream_
 #elif RVC_C32S_PART == 1
 void launch_conv32s_p1(const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb) { launch_k(conv32s_kernel<2, 2, 1, 2>, p, grid, dim3(256), lds, s, ea, eb); }
 #else
-void launch_conv32s_p2(const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb) { launch_k(conv32s_kernel<4, 1, 1, 2>, p, grid, dim3(256), lds, s, ea, eb); }
+void launch_conv32s_p2(const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb) { launch_k(conv32s_buf_kernel<4, 1, 1, 2>, p, grid, dim3(256), lds, s, ea, eb); }
 #endif
 
 }  // namespace rvc

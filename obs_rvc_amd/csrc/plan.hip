@@ -382,8 +382,6 @@ static bool queue_conv32s(Plan &pl, IgemmP &p, int B, const std::vector<int> &ko
         int kw_max = 0;
         for (const PhaseD &q : phs) kw_max = std::max(kw_max, q.t_tab & 0xff);
         if (mode < 2 && kw_max <= 3 && p.M >= 64 && B >= 24) return false;
-        // ... and the 128-row fused launches of 5-11 streams (8 streams, same box, twice: 843 / 846 vs 827 / 825 us for the six launches of the stage)
-        if (mode < 2 && p.M > 64 && B < 12) return false;
     }
     p.w = pl.arena.upload(wnew);
     p.koff = nullptr; p.items = nullptr; p.ttab = nullptr;

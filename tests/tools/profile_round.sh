@@ -7,6 +7,7 @@ tag=${1:-r05}; rnd=${2:-r05}; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; raw=/t
 cd /tmp; export TMPDIR=/tmp
 prof() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d $raw/ks_$name -- python $R/bench.py --only-headline --no-cpu "$@" > $out/bench_$name.json 2> $out/bench_$name.err
          cp $raw/ks_$name/*/*kernel_stats.csv $out/${rnd}_kernel_stats_bench_$name.csv; }
+if [ -z "$RVC_PROFILE_ONLY_SERIAL" ]; then
 prof 1stream --steps 100
 prof index100k --steps 100 --index
 prof 64streams --steps 15 --warmup 3 --streams 64
@@ -16,6 +17,7 @@ prof 64streams --steps 15 --warmup 3 --streams 64
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/ks_64serial -- python $R/bench.py --only-headline --no-cpu --steps 15 --warmup 3 --streams 64 --serial-branches > $out/bench_64streams_serial.json 2> $out/bench_64streams_serial.err
 cp $raw/ks_64serial/*/*kernel_stats.csv $out/${rnd}_kernel_stats_bench_64streams_serial_branches.csv
 python $R/tests/tools/serial_pass.py $out/${rnd}_kernel_stats_bench_64streams_serial_branches.csv 64 $out/${rnd}_serial_64streams.json ${rnd}_kernel_stats_bench_64streams_serial_branches.csv > /dev/null
+fi
 # the same pass at the stream counts between the two regimes (bench.py prints their roofline.frac only with a matching pass of the same build); RVC_PROFILE_ONLY_SERIAL=1 stops here
 for S in 8 16 32; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $raw/ks_${S}serial -- python $R/bench.py --only-headline --no-cpu --steps 20 --warmup 3 --streams $S --serial-branches > $out/bench_${S}streams_serial.json 2> $out/bench_${S}streams_serial.err
