@@ -595,7 +595,7 @@ def main(argv=None):
         def sweep(S2):
             def fn():
                 k = max(10, min(args.steps, 30))
-                rec, e4, _, d4 = run_config(job, z, g, S2, False, k, 3, graph, index_vecs, want_roofline=False, soak=sub_soak)
+                rec, e4, _, d4 = run_config(job, z, g, S2, False, k, 3, graph, index_vecs, want_roofline=S2 >= 8, soak=sub_soak)      # (8 / 16 / 32 streams have committed serial-branch passes: profiles/r05_serial_<S>streams.json)
                 del e4, d4
                 if rec:
                     rec["steps"] = k
