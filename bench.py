@@ -283,7 +283,7 @@ def roofline_of(eng, step, S, reps=5, with_index=False, version=2, preset="full"
     t_launch, t_knn, t_src = committed_traffic(S, with_index, version, preset)
     roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": t_launch, "traffic_unit": "HBM read bytes per launch (class average)",
-            "kernel": "rvc::igemm2_kernel / igemm2w_kernel / conv_tile_kernel / igemm32_kernel / conv32s_kernel / conv32s_buf_kernel / igemm_lds_kernel (all instantiations)", "launches_per_step": n_l // reps,
+            "kernel": "rvc::igemm2_kernel / igemm2w_kernel / conv_tile_kernel / igemm32_kernel / igemm32l_kernel / conv32s_kernel / conv32s_buf_kernel / igemm_lds_kernel (all instantiations)", "launches_per_step": n_l // reps,
             "avg_launch_us": round(tot_ms * 1e3 / max(n_l, 1), 3), "flops_per_step": tot_fl / reps,
             "sum_kernel_ms": round(tot_ms / reps, 4),
             "note": ("achieved = flops / SUM of per-launch durations; the ContentVec and f0 branches overlap on disjoint CU sets, so the sum "

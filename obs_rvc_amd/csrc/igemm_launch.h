@@ -40,6 +40,11 @@ void launch_igemm2w_t0(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream
 void launch_igemm2w_t1(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 void launch_igemm2w_t2(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 
+// igemm32l_kernel (igemm32l.hip.h): igemm32_kernel's tiles 3 / 7 / 8 for table-free 1x1 layers, buffer loads with scalar row offsets
+void launch_igemm32l(int lc, int mode, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);      // mode 0 table-free, 1 table, 2 table + fused input LeakyReLU
+void launch_igemm32l_p0(int mode, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+void launch_igemm32l_p1(int lc, int mode, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+
 // conv32s_kernel (conv32s.hip.h: stride-1 1-D convolutions at many streams, input staged once per workgroup and 32-channel block, 32x32x2 MFMAs).
 // Workgroup tiles BM x BN (every wave 32 x 64): 0 = 32 x 256, 1 = 64 x 128, 2 = 128 x 64
 static const int kC32sBM[3] = {32, 64, 128}, kC32sBN[3] = {256, 128, 64};

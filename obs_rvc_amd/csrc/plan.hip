@@ -6,7 +6,7 @@
 namespace rvc {
 
 static const char *const kTestHooks[] = {"RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_NO_LN_FUSE", "RVC_NO_CONV0_MULTI", "RVC_KNN_NO_GEMM",
-                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_C32S_DBG"};
+                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_C32S_DBG", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB"};
 std::atomic<unsigned> g_opt_gen{0};       // bumped by every rvc_debug_option call: plans built under another generation are dropped (engine.hip get_plan)
 static std::mutex g_opt_mu;
 static std::map<std::string, std::string> g_opts;
@@ -672,6 +672,9 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         if (g32_ok && (wl == 3 || wl == 4 || wl == 5 || wl == 7 || wl == 8)) lds_cfg = wl;
         else if (wl == -1) lds_cfg = -1;
     }
+    // igemm32l_kernel (table-free 1x1 layers, buffer loads): its 128 x 64 tile beats igemm32_kernel's 128 x 128 on the 3072-row projection (test hook RVC_G32L_TALL = 0: keep 128 x 128)
+    const bool g32l_on = p.lin_cs4 != 0 && p.nphase == 1 && !pre && !p.bf3 && !pl.bf3 && test_opt_int("RVC_G32L", 1) != 0;
+    if (g32l_on && lds_cfg == 3 && p.fold_n && ((p.M + 127) / 128) % 8 == 0 && (size_t)p.M * (size_t)ksum * sizeof(float) > ((size_t)4 << 20) && test_opt_int("RVC_G32L_TALL", 1) != 0) lds_cfg = 7;
     if (lds_cfg >= 0) {
         const int bm = lds_cfg == 8 ? 64 : (lds_cfg == 7 ? 128 : (lds_cfg == 6 ? 48 : (lds_cfg % 3 == 0 ? 128 : (lds_cfg % 3 == 1 ? 64 : 32))));
         const int bn = (lds_cfg == 7 || lds_cfg == 8) ? 64 : ((lds_cfg != 6 && lds_cfg % 3 == 0) ? 128 : 256);
@@ -688,7 +691,16 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         pl.igemm_flops += flops; pl.n_igemm++;
         Plan *plp = &pl;
         const int lc = lds_cfg;
-        { char d[160]; snprintf(d, sizeof d, "%s M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%u", (lds_cfg >= 3 && lds_cfg != 6) ? "g32" : "lds", p.M, p.N, p.K, B, p.nphase, bm, bn, grid.x, grid.y); pl.descs.push_back(d); }
+        // table-free 1x1 layers on tiles 3 / 7 / 8: igemm32l_kernel (buffer loads with scalar row offsets, no offset table in LDS); test hook RVC_G32L = 0: off
+        // ... and the one-phase 1-D layers WITH a table (the strided stem of ContentVec, three-tap decoder layers): the same kernel with the table entries as
+        // scalar loads (test hook RVC_G32L_TAB = 0: off)
+        const bool g32t = (lc == 3 || lc == 7 || lc == 8) && !g32l_on && p.lin_cs4 == 0 && p.nphase == 1 && B == 1 && p.x_hs == 0 && p.y_hm == 0 && !p.bf3 && !pl.bf3 && !p.glu &&
+                          !(lc == 3 && pre) &&         // (the decoder's three-tap 128-row layers with the fused input activation: 167 vs 152 us on the 128 x 128 tile)
+                          test_opt_int("RVC_G32L", 1) != 0 && test_opt_int("RVC_G32L_TAB", 1) != 0;
+        const bool g32l = ((lc == 3 || lc == 7 || lc == 8) && g32l_on && !(lc == 3 && p.m_fast == 2)) || g32t;
+        const int g32l_mode = g32t ? (pre ? 2 : 1) : 0;
+        const size_t lds_l = (size_t)2 * bn * 20 * 4;
+        { char d[160]; snprintf(d, sizeof d, "%s M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%u", g32t ? "g32t" : g32l ? "g32l" : (lds_cfg >= 3 && lds_cfg != 6) ? "g32" : "lds", p.M, p.N, p.K, B, p.nphase, bm, bn, grid.x, grid.y); pl.descs.push_back(d); }
         const int desc_id = (int)pl.descs.size() - 1;
         if (final_out) pl.final_out_honoured = true;
         pl.ops.push_back([=](hipStream_t s) {
@@ -698,6 +710,11 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
                 pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
             }
             hipEvent_t ea = pe ? pe->a : nullptr, eb = pe ? pe->b : nullptr;
+            if (g32l) {
+                if (final_out && plp->cur_out) { IgemmP q = p; q.y = plp->cur_out; q.y_bs = plp->cur_out_bs; launch_igemm32l(lc, g32l_mode, q, grid, lds_l, s, ea, eb); }
+                else launch_igemm32l(lc, g32l_mode, p, grid, lds_l, s, ea, eb);
+                return;
+            }
             if (final_out && plp->cur_out) { IgemmP q = p; q.y = plp->cur_out; q.y_bs = plp->cur_out_bs; launch_igemm_tiled(lc, pre, q, grid, lds, s, ea, eb); }
             else launch_igemm_tiled(lc, pre, p, grid, lds, s, ea, eb);
         });

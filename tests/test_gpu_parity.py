@@ -788,8 +788,25 @@ def test_every_tile_configuration_computes_the_same_convolution():
             for (M, Cin, KW, dil, N, pre) in [(3072, 32, 1, 1, 111, 0), (2304, 48, 1, 1, 111, 1), (600, 32, 3, 1, 500, 0)]:
                 e4 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, streams, pre)
                 assert 0 <= e4 < 2e-5, ("tall", streams, M, Cin, KW, dil, N, pre, e4)
+        # igemm32l_kernel (round 5: igemm32_kernel's 128 x 128 / 128 x 64 / 64 x 64 tiles for table-free 1x1 layers, buffer loads with scalar row offsets, no
+        # offset table): the planner sends the tall panels above to its 64-column tiles; here a 2304-row panel wide enough for the 128 x 128 tile and a 3072-row
+        # panel (eight-fold m-tile count: moved to the 128 x 64 tile) at 64 streams, ragged M, and the old kernel on the same shapes (test hook RVC_G32L = 0)
+        for g32l in ("1", "0"):
+            set_opt("RVC_G32L", g32l)
+            for (M, Cin, N) in [(2304, 48, 111), (3072, 32, 111), (2300, 64, 111)]:
+                e7 = L.rvc_debug_conv_check(h, M, Cin, 1, 1, N, 64, 0)
+                assert 0 <= e7 < 2e-5, ("igemm32l", g32l, M, Cin, N, e7)
+        set_opt("RVC_G32L", None)
+        # ... and its table variant (one-phase 1-D layers WITH an offset table: table entries as scalar loads): the strided-stem shape class (three taps, 512 rows)
+        # and a dilated layer with the fused input activation on the 64-column tiles, hook on and off
+        for tab in ("1", "0"):
+            set_opt("RVC_G32L_TAB", tab)
+            for (M, Cin, KW, dil, N, pre, streams) in [(512, 64, 3, 1, 700, 0, 16), (600, 32, 3, 1, 500, 0, 8), (256, 64, 3, 2, 252, 1, 64), (512, 32, 5, 1, 3000, 0, 6)]:
+                e8 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, streams, pre)
+                assert 0 <= e8 < 2e-5, ("igemm32l table", tab, M, Cin, KW, dil, N, pre, streams, e8)
+        set_opt("RVC_G32L_TAB", None)
     finally:
-        for k in ("RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_FORCE_G2W", "RVC_CONV32S", "RVC_CONV32S_TILE"):
+        for k in ("RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_FORCE_G2W", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_G32L", "RVC_G32L_TAB"):
             set_opt(k, None)
         L.rvc_destroy(h)
 
