@@ -429,7 +429,9 @@ static void g2w_rule(const IgemmP &p, int nchunks, int &gt, int &gk)
 {
     gt = -1; gk = 1;
     if (!p.fold_n || p.M < 256 || nchunks < 16) return;
-    if (p.M > 1024 ? p.N > 1000 : p.N > 4000) return;
+    // (round 5, after igemm32l_kernel: from 24 streams -- 2 664 columns -- the 768-row panels run faster on its 64 x 64 / 128 x 64 tiles: step time with this kernel
+    //  / without, same process: 20 streams 14.73 / 14.91, 24 streams 16.19 / 15.81, 32 streams 20.16 / 19.70 ms; at 16 streams 11.34 / 11.47-11.60)
+    if (p.M > 1024 ? p.N > 1000 : p.N > 2400) return;
     const long long tiles = (long long)((p.M + 31) / 32) * ((p.N + 31) / 32);
     const long long want = (4800 + tiles / 2) / tiles;
     int ks = want <= 1 ? 1 : (want == 2 ? 2 : (want == 3 ? 3 : (want <= 4 ? 4 : 8)));
@@ -672,9 +674,13 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         if (g32_ok && (wl == 3 || wl == 4 || wl == 5 || wl == 7 || wl == 8)) lds_cfg = wl;
         else if (wl == -1) lds_cfg = -1;
     }
-    // igemm32l_kernel (table-free 1x1 layers, buffer loads): its 128 x 64 tile beats igemm32_kernel's 128 x 128 on the 3072-row projection (test hook RVC_G32L_TALL = 0: keep 128 x 128)
+    // igemm32l_kernel (one-phase 1-D layers, buffer loads with scalar offsets): its 128 x 64 tile beats the 128 x 128 tile of either kernel on every layer it can
+    // take -- the 3072-row projection (64 streams 36.12 -> 35.81 ms), the 2304-row one (35.31 -> 35.05), the strided stem (35.28 -> 35.05; 16 / 32 streams
+    // 11.35 / 19.70 -> 11.23 / 19.50) -- so those layers move there (test hook RVC_G32L_TALL = 0: keep the 128 x 128 tile)
     const bool g32l_on = p.lin_cs4 != 0 && p.nphase == 1 && !pre && !p.bf3 && !pl.bf3 && test_opt_int("RVC_G32L", 1) != 0;
-    if (g32l_on && lds_cfg == 3 && p.fold_n && ((p.M + 127) / 128) % 8 == 0 && (size_t)p.M * (size_t)ksum * sizeof(float) > ((size_t)4 << 20) && test_opt_int("RVC_G32L_TALL", 1) != 0) lds_cfg = 7;
+    const bool g32t_on = !g32l_on && p.lin_cs4 == 0 && p.nphase == 1 && B == 1 && p.x_hs == 0 && p.y_hm == 0 && !p.bf3 && !pl.bf3 && !p.glu &&
+                         test_opt_int("RVC_G32L", 1) != 0 && test_opt_int("RVC_G32L_TAB", 1) != 0;
+    if ((g32l_on || (g32t_on && !pre)) && lds_cfg == 3 && test_opt_int("RVC_G32L_TALL", 1) != 0) lds_cfg = 7;
     if (lds_cfg >= 0) {
         const int bm = lds_cfg == 8 ? 64 : (lds_cfg == 7 ? 128 : (lds_cfg == 6 ? 48 : (lds_cfg % 3 == 0 ? 128 : (lds_cfg % 3 == 1 ? 64 : 32))));
         const int bn = (lds_cfg == 7 || lds_cfg == 8) ? 64 : ((lds_cfg != 6 && lds_cfg % 3 == 0) ? 128 : 256);
@@ -694,9 +700,8 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         // table-free 1x1 layers on tiles 3 / 7 / 8: igemm32l_kernel (buffer loads with scalar row offsets, no offset table in LDS); test hook RVC_G32L = 0: off
         // ... and the one-phase 1-D layers WITH a table (the strided stem of ContentVec, three-tap decoder layers): the same kernel with the table entries as
         // scalar loads (test hook RVC_G32L_TAB = 0: off)
-        const bool g32t = (lc == 3 || lc == 7 || lc == 8) && !g32l_on && p.lin_cs4 == 0 && p.nphase == 1 && B == 1 && p.x_hs == 0 && p.y_hm == 0 && !p.bf3 && !pl.bf3 && !p.glu &&
-                          !(lc == 3 && pre) &&         // (the decoder's three-tap 128-row layers with the fused input activation: 167 vs 152 us on the 128 x 128 tile)
-                          test_opt_int("RVC_G32L", 1) != 0 && test_opt_int("RVC_G32L_TAB", 1) != 0;
+        const bool g32t = (lc == 3 || lc == 7 || lc == 8) && g32t_on &&
+                          !(lc == 3 && pre);           // (the decoder's three-tap 128-row layers with the fused input activation: 167 vs 152 us on the 128 x 128 tile)
         const bool g32l = ((lc == 3 || lc == 7 || lc == 8) && g32l_on && !(lc == 3 && p.m_fast == 2)) || g32t;
         const int g32l_mode = g32t ? (pre ? 2 : 1) : 0;
         const size_t lds_l = (size_t)2 * bn * 20 * 4;
