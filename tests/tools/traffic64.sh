@@ -1,3 +1,6 @@
+#!/bin/bash
+# One-off of round 5: re-take ONLY the 64-stream FETCH_SIZE / WRITE_SIZE passes (after a kernel class list changed) and the default bench line; the full
+# evidence set is tests/tools/profile_round.sh.
 R=$GRAFT_REPO_ROOT; raw=/tmp/prof_t64; out=$R/gpurun_out/r05j; mkdir -p $raw $out; cd /tmp; export TMPDIR=/tmp
 pmc() { name=$1; ctr=$2; shift 2; rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $raw/pmc_${name}_$ctr -- python $R/bench.py --only-headline --no-cpu "$@" > /dev/null 2>&1; }
 pmc 64streams FETCH_SIZE --steps 6 --warmup 2 --streams 64
