@@ -51,7 +51,7 @@ static const int kC32sBM[3] = {32, 64, 128}, kC32sBN[3] = {256, 128, 64};
 static const int kC32sCB = 32, kC32sCS = 36;        // channels staged per block, LDS column stride (floats)
 void launch_conv32s(int tile, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
 void launch_conv32s_p0(const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
-void launch_conv32s_p1(const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
+void launch_conv32s_p1(int tile, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 void launch_conv32s_p2(const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 
 // exploratory split-bf16 GEMM (igemm_bf3_kernel): 128 x 128 workgroup tile; bf3_pack builds the weight panels it reads

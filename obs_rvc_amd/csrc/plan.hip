@@ -6,7 +6,7 @@
 namespace rvc {
 
 static const char *const kTestHooks[] = {"RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_NO_LN_FUSE", "RVC_NO_CONV0_MULTI", "RVC_KNN_NO_GEMM",
-                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_C32S_DBG", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB"};
+                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_C32S_DBG", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB", "RVC_CONV32S_BUF"};
 std::atomic<unsigned> g_opt_gen{0};       // bumped by every rvc_debug_option call: plans built under another generation are dropped (engine.hip get_plan)
 static std::mutex g_opt_mu;
 static std::map<std::string, std::string> g_opts;
@@ -390,6 +390,10 @@ static bool queue_conv32s(Plan &pl, IgemmP &p, int B, const std::vector<int> &ko
     p.ph0 = phs[0];
     p.ntm = ntm; p.ntn = ntn; p.ksplit = 1; p.nbatch = B; p.m_fast = 0;
     p.pad2_ = test_opt_int("RVC_C32S_DBG", 0);
+    // the 64 x 128 tile takes the buffer-load kernel below 24 streams (us per six launches, all-buffer build against this one: 8 streams 437 vs 474, 16 streams 461 vs 479,
+    // 32 streams 842 vs 775, 64 streams 1 543 vs 1 510-1 533); test hook RVC_CONV32S_BUF: 0 never, 2 always
+    const int buf_opt = test_opt_int("RVC_CONV32S_BUF", 1);
+    const int ltile = tile | ((tile == 1 && (buf_opt == 2 || (buf_opt == 1 && B < 24))) ? 4 : 0);
     const dim3 grid((unsigned)(ntm * ntn), (unsigned)B, (unsigned)p.nphase);
     g_last_wgs = (int)(grid.x * grid.y * grid.z); g_last_waves = 4;
     const double flops = 2.0 * p.M * (double)p.N * ksum * B;
@@ -406,8 +410,8 @@ static bool queue_conv32s(Plan &pl, IgemmP &p, int B, const std::vector<int> &ko
             pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
         }
         hipEvent_t ea = pe ? pe->a : nullptr, eb = pe ? pe->b : nullptr;
-        if (final_out && plp->cur_out) { IgemmP q = pc; q.y = plp->cur_out; q.y_bs = plp->cur_out_bs; launch_conv32s(tile, q, grid, lds_max, s, ea, eb); }
-        else launch_conv32s(tile, pc, grid, lds_max, s, ea, eb);
+        if (final_out && plp->cur_out) { IgemmP q = pc; q.y = plp->cur_out; q.y_bs = plp->cur_out_bs; launch_conv32s(ltile, q, grid, lds_max, s, ea, eb); }
+        else launch_conv32s(ltile, pc, grid, lds_max, s, ea, eb);
     });
     return true;
 }

@@ -776,7 +776,14 @@ def test_every_tile_configuration_computes_the_same_convolution():
                                                   (100, 96, 5, 2, 333, 0), (32, 32, 1, 1, 256, 0), (256, 256, 3, 1, 252, 1)]:
                     e6 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, streams, pre)
                     assert 0 <= e6 < 2e-5, ("conv32s", tile, streams, M, Cin, KW, dil, N, pre, e6)
-        for k in ("RVC_CONV32S", "RVC_CONV32S_TILE"):
+        # (the 64 x 128 tile exists in both kernels -- conv32s_buf_kernel below 24 streams, conv32s_kernel from there: each forced with the other's stream counts)
+        set_opt("RVC_CONV32S_TILE", "1")
+        for buf in ("0", "2"):
+            set_opt("RVC_CONV32S_BUF", buf)
+            for (M, Cin, KW, dil, N, pre, streams) in [(64, 64, 7, 3, 520, 1, 3), (64, 64, 11, 5, 700, 0, 8), (40, 32, 3, 1, 300, 1, 1)]:
+                e9 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, streams, pre)
+                assert 0 <= e9 < 2e-5, ("conv32s 64x128", buf, M, Cin, KW, dil, N, pre, streams, e9)
+        for k in ("RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_CONV32S_BUF"):
             set_opt(k, None)
         for streams in (3, 20):                            # folded streams; 20 streams reach the workgroup-tiled kernels on the wide layers
             # (+ a 48-row panel wide enough for the 48 x 256 workgroup tile, a 32-row and a 64-row panel for the narrow 32x32x2 tiles)
@@ -806,7 +813,7 @@ def test_every_tile_configuration_computes_the_same_convolution():
                 assert 0 <= e8 < 2e-5, ("igemm32l table", tab, M, Cin, KW, dil, N, pre, streams, e8)
         set_opt("RVC_G32L_TAB", None)
     finally:
-        for k in ("RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_FORCE_G2W", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_G32L", "RVC_G32L_TAB"):
+        for k in ("RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_FORCE_G2W", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_CONV32S_BUF", "RVC_G32L", "RVC_G32L_TAB"):
             set_opt(k, None)
         L.rvc_destroy(h)
 
