@@ -16,6 +16,17 @@ pub struct RvcResampler {
 pub struct RvcSession {
     _private: [u8; 0],
 }
+/// rvc_calibration (include/rvc_mi355x.h)
+#[repr(C)]
+pub struct RvcCalibration {
+    pub mfma_f32_tflops: c_double,
+    pub mfma_sclk_mhz: c_double,
+    pub mfma_ms: c_double,
+    pub hbm_read_tbs: c_double,
+    pub hbm_sclk_mhz: c_double,
+    pub ms_total: c_double,
+    pub compute_units: c_int,
+}
 
 pub const RVC_OK: c_int = 0;
 pub const RVC_MODEL_NOT_LOADED: c_int = 1;
@@ -78,6 +89,10 @@ extern "C" {
     pub fn rvc_plan_cache_info(e: *mut RvcEngine, capacity: *mut c_int, cached: *mut c_int, builds: *mut c_longlong) -> c_int;
     pub fn rvc_retrieval_recoveries(e: *mut RvcEngine) -> c_longlong;
     pub fn rvc_set_gemm_precision(e: *mut RvcEngine, mode: c_int) -> c_int;
+    // what this GPU sustains, measured in-run (bare fp32-MFMA stream, HBM read stream), and the effective shader clock while other work runs
+    pub fn rvc_calibrate(device: c_int, out: *mut RvcCalibration) -> c_int;
+    pub fn rvc_clock_monitor_start(device: c_int) -> c_int;
+    pub fn rvc_clock_monitor_stop(device: c_int, sclk_mhz_mean: *mut c_double, sclk_mhz_min: *mut c_double, seconds: *mut c_double) -> c_int;
 
     // ---- caller-side steps of the plugin (obs-rvc/src/rt_utils.rs, obs-rvc/src/lib.rs:236-260,659-795)
     pub fn rvc_envelop_mixing(e: *mut RvcEngine, input: *const c_float, output: *mut c_float, output_len: usize, sample_rate: usize,

@@ -194,6 +194,22 @@ rvc_status rvc_session_set_params_stream(rvc_session *s, int stream, int32_t pit
 void rvc_session_geometry(rvc_session *s, int32_t out[10]);   /* the derived sizes of lib.rs:200-227 (see session.hip.h) */
 rvc_status rvc_session_process(rvc_session *s, const float *input_sample, size_t n, float *output, size_t cap, size_t *sola_offset);
 
+/* ---- what THIS GPU sustains, measured in-run (bench.py; boxes of one pool differ by ~10 % on matrix-core-bound work) ---- */
+/* rvc_calibrate: ~50 ms of device time.  A bare v_mfma_f32_32x32x2_f32 stream on every SIMD (four waves per SIMD, non-zero operands) -> fp32 matrix-core
+ * TFLOP/s actually reached and the shader clock it ran at (s_memtime cycles per s_memrealtime tick); a float4 read stream over 1 GiB -> HBM TB/s. */
+typedef struct {
+    double mfma_f32_tflops, mfma_sclk_mhz, mfma_ms;
+    double hbm_read_tbs, hbm_sclk_mhz;
+    double ms_total;
+    int compute_units;
+} rvc_calibration;
+rvc_status rvc_calibrate(int device, rvc_calibration *out);
+/* Effective shader clock WHILE other work runs: start leaves eight sleeping one-wave workgroups (one per XCD) on a stream of their own that count shader
+ * cycles against the 100 MHz real-time counter; stop ends them and reports the mean / minimum over the XCDs and the seconds observed.  The waves leave
+ * by themselves after 20 s (do not run it under a profiler that serialises dispatches).  One monitor per device. */
+rvc_status rvc_clock_monitor_start(int device);
+rvc_status rvc_clock_monitor_stop(int device, double *sclk_mhz_mean, double *sclk_mhz_min, double *seconds);
+
 /* ---- measurement / debugging ---- */
 /* total milliseconds of the last infer measured with HIP events on the engine's stream */
 float rvc_last_gpu_ms(rvc_engine *e);

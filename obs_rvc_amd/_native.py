@@ -24,11 +24,12 @@ SYMBOLS = [
     "rvc_resampler_reset", "rvc_resampler_process", "rvc_resampler_process_device",
     "rvc_rccl_unique_id", "rvc_index_broadcast", "rvc_rccl_available", "rvc_index_broadcast_info",
     "rvc_set_plan_cache", "rvc_plan_cache_info", "rvc_retrieval_recoveries", "rvc_set_gemm_precision",
+    "rvc_calibrate", "rvc_clock_monitor_start", "rvc_clock_monitor_stop",
     "rvc_session_create", "rvc_session_destroy", "rvc_session_process", "rvc_session_frame_size", "rvc_session_set_params", "rvc_session_set_params_stream", "rvc_session_geometry",
 ]
 
 
-SOURCES = ("engine.hip", "engine_int.h", "plan.hip", "model_cv.hip", "model_rmvpe.hip", "model_synth.hip", "retrieval.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "igemm2_inst.hip", "igemm_tiled_inst.hip", "igemm2w_inst.hip", "igemm_bf3_inst.hip", "conv_tile.hip.h", "conv_tile_inst.hip", "conv32s.hip.h", "conv32s_inst.hip", "igemm32l.hip.h", "igemm32l_inst.hip", "version.cpp",
+SOURCES = ("engine.hip", "engine_int.h", "plan.hip", "model_cv.hip", "model_rmvpe.hip", "model_synth.hip", "retrieval.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "igemm2_inst.hip", "igemm_tiled_inst.hip", "igemm2w_inst.hip", "igemm_bf3_inst.hip", "conv_tile.hip.h", "conv_tile_inst.hip", "conv32s.hip.h", "conv32s_inst.hip", "igemm32l.hip.h", "igemm32l_inst.hip", "version.cpp", "calib.hip", "exports.map",
            "state.hip.h",
            "resample.hip.h", "session.hip.h", "rccl_bcast.hip.h", "blob.h", "rvc_rpc.cpp")
 
@@ -38,7 +39,7 @@ SOURCES = ("engine.hip", "engine_int.h", "plan.hip", "model_cv.hip", "model_rmvp
 _IGEMM_DEPS = ("igemm.hip.h", "igemm_launch.h")
 _INT_DEPS = ("engine_int.h", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "blob.h", "state.hip.h")
 _ENGINE_DEPS = ("engine.hip", "resample.hip.h", "session.hip.h", "rccl_bcast.hip.h") + _INT_DEPS
-UNITS = [("engine.hip", [], _ENGINE_DEPS)] + [(u, [], (u,) + _INT_DEPS) for u in ("plan.hip", "model_cv.hip", "model_rmvpe.hip", "model_synth.hip", "retrieval.hip")] + \
+UNITS = [("engine.hip", [], _ENGINE_DEPS), ("calib.hip", [], ("calib.hip",))] + [(u, [], (u,) + _INT_DEPS) for u in ("plan.hip", "model_cv.hip", "model_rmvpe.hip", "model_synth.hip", "retrieval.hip")] + \
         [("igemm2_inst.hip", ["-DRVC_IGEMM2_CFG=%d" % c], ("igemm2_inst.hip",) + _IGEMM_DEPS) for c in range(5)] + \
         [("igemm_tiled_inst.hip", ["-DRVC_TILED_PART=%d" % c], ("igemm_tiled_inst.hip",) + _IGEMM_DEPS) for c in range(4)] + \
         [("igemm2w_inst.hip", ["-DRVC_G2W_PART=%d" % c], ("igemm2w_inst.hip",) + _IGEMM_DEPS) for c in range(3)] + \
@@ -138,7 +139,8 @@ def link_library(objs, out, want_hash, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + [ver, "-o", tmp_out, "-ldl"]
+        # exports.map: only the C ABI (rvc_*) is visible; the planner's C++ internals and the kernels' host stubs stay local
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + [ver, "-o", tmp_out, "-ldl", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -268,5 +270,36 @@ def lib():
     L.rvc_session_set_params_stream.argtypes = [vp, C.c_int, i32, C.c_double]
     L.rvc_session_geometry.argtypes = [vp, C.POINTER(i32)]
     L.rvc_session_geometry.restype = None
+    if hasattr(L, "rvc_calibrate") or not override:
+        L.rvc_calibrate.argtypes = [C.c_int, C.POINTER(Calibration)]
+        L.rvc_clock_monitor_start.argtypes = [C.c_int]
+        L.rvc_clock_monitor_stop.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     _LIB = L
     return L
+
+
+class Calibration(C.Structure):
+    """rvc_calibration (include/rvc_mi355x.h)"""
+    _fields_ = [("mfma_f32_tflops", C.c_double), ("mfma_sclk_mhz", C.c_double), ("mfma_ms", C.c_double),
+                ("hbm_read_tbs", C.c_double), ("hbm_sclk_mhz", C.c_double), ("ms_total", C.c_double), ("compute_units", C.c_int)]
+
+
+def calibrate(device: int = 0) -> dict:
+    """rvc_calibrate: what this GPU sustains right now (bare fp32-MFMA stream, HBM read stream) -> dict"""
+    c = Calibration()
+    rc = lib().rvc_calibrate(device, C.byref(c))
+    if rc != 0:
+        raise RuntimeError("rvc_calibrate failed (%d)" % rc)
+    return {k: getattr(c, k) for k, _ in Calibration._fields_}
+
+
+def clock_monitor_start(device: int = 0) -> None:
+    if lib().rvc_clock_monitor_start(device) != 0:
+        raise RuntimeError("rvc_clock_monitor_start failed")
+
+
+def clock_monitor_stop(device: int = 0) -> dict:
+    mean, mn, secs = C.c_double(), C.c_double(), C.c_double()
+    if lib().rvc_clock_monitor_stop(device, C.byref(mean), C.byref(mn), C.byref(secs)) != 0:
+        raise RuntimeError("rvc_clock_monitor_stop failed")
+    return {"sclk_mhz_mean": mean.value, "sclk_mhz_min": mn.value, "seconds": secs.value}

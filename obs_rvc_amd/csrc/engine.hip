@@ -1201,6 +1201,90 @@ double rvc_debug_conv_check(rvc_engine *e, int M, int Cin, int KW, int dil, int 
     return worst;
 }
 
+// test aid: one Conv2d(Cin -> M, 3x3, pad 1, bias, ReLU) [kind 0] or ConvTranspose2d(Cin -> M, 3x3, stride 2, pad 1, output_pad 1, bias, ReLU) [kind 1] on
+// `streams` images of H x W (RMVPE's layers, rvc/src/f0/rmvpe.rs:235-238), residual 0 = none, 1 = + a residual tensor, 2 = accumulate into the
+// output; deterministic data, whatever kernel the planner (or a hook) picks, against a double-precision host evaluation.
+// Returns the largest |gpu - host| / (rms(host) + 1e-12); negative on failure.
+double rvc_debug_conv2d_check(rvc_engine *e, int M, int Cin, int H, int W, int streams, int kind, int residual)
+{
+    double worst = -1.0;
+    (void)guarded(e, [&]() {
+        if (kind == 1 && residual) throw ShapeError("transposed test layer takes no residual");
+        std::vector<float> w((size_t)M * Cin * 9), bias(M);
+        for (size_t i = 0; i < w.size(); i++) w[i] = (float)((i * 2654435761u) % 1000) / 1000.0f - 0.5f;
+        for (int m = 0; m < M; m++) bias[m] = 0.01f * (float)(m % 7) - 0.02f;
+        // Conv2d: w [M][Cin][3][3]; ConvTranspose2d: w [Cin][M][3][3]
+        ConvW cw = kind == 0 ? prep_conv(w.data(), bias.data(), M, Cin, 9, 1) : prep_convT2d(w.data(), bias.data(), Cin, M);
+        Plan pl; pl.B = streams;
+        const int OH = kind ? 2 * H : H, OW = kind ? 2 * W : W;
+        T2 x = make_t2(pl.arena, streams, Cin, H, W), y = make_t2(pl.arena, streams, M, OH, OW), r = make_t2(pl.arena, streams, M, OH, OW);
+        std::vector<float> hx((size_t)streams * Cin * H * W), hr((size_t)streams * M * OH * OW);
+        for (size_t i = 0; i < hx.size(); i++) hx[i] = (float)(((i * 40503u) ^ (i >> 3)) % 2001) / 1000.0f - 1.0f;
+        for (size_t i = 0; i < hr.size(); i++) hr[i] = (float)(((i * 9973u) ^ (i >> 2)) % 1001) / 1000.0f - 0.5f;
+        for (int b = 0; b < streams; b++)
+            for (int c = 0; c < Cin; c++)
+                HIPCHK(hipMemcpy2D(x.p + (long long)b * x.bs + (long long)c * x.cs, (size_t)x.ld * 4, &hx[(((size_t)b * Cin + c) * H) * W], (size_t)W * 4, (size_t)W * 4, H, hipMemcpyHostToDevice));
+        for (int b = 0; b < streams; b++)
+            for (int c = 0; c < M; c++) {
+                T2 &dst = residual == 2 ? y : r;
+                HIPCHK(hipMemcpy2D(dst.p + (long long)b * dst.bs + (long long)c * dst.cs, (size_t)dst.ld * 4, &hr[(((size_t)b * M + c) * OH) * OW], (size_t)OW * 4, (size_t)OW * 4, OH, hipMemcpyHostToDevice));
+            }
+        ConvOpts o; o.act = ACT_RELU;
+        if (residual == 1) { o.res = r.p; o.res_cs = r.cs; o.res_bs = r.bs; o.res_rs = r.ld; }
+        if (residual == 2) o.accumulate = true;
+        if (kind == 0) add_conv2d(pl, cw, x, y, o); else add_convT2d(pl, cw, x, y, o);
+        HIPCHK(hipDeviceSynchronize());
+        for (auto &op : pl.ops.v) op(e->stream);
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipGetLastError());
+        std::vector<float> hy((size_t)OH * OW);
+        std::vector<double> ref((size_t)OH * OW);
+        double err = 0.0, ss = 0.0; size_t cnt = 0;
+        for (int b = 0; b < streams; b++)
+            for (int m = 0; m < M; m++) {
+                HIPCHK(hipMemcpy2D(hy.data(), (size_t)OW * 4, y.p + (long long)b * y.bs + (long long)m * y.cs, (size_t)y.ld * 4, (size_t)OW * 4, OH, hipMemcpyDeviceToHost));
+                for (int oh = 0; oh < OH; oh++)
+                    for (int ow = 0; ow < OW; ow++) {
+                        double a = bias[m];
+                        for (int c = 0; c < Cin; c++) {
+                            const float *xc = &hx[(((size_t)b * Cin + c) * H) * W];
+                            for (int kh = 0; kh < 3; kh++)
+                                for (int kw = 0; kw < 3; kw++) {
+                                    if (kind == 0) {
+                                        const int ih = oh + kh - 1, iw = ow + kw - 1;
+                                        if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+                                        a += (double)w[(((size_t)m * Cin + c) * 3 + kh) * 3 + kw] * xc[(size_t)ih * W + iw];
+                                    } else {
+                                        // out[oh] += w[kh] * in[ih] with oh = 2 ih - 1 + kh
+                                        const int th = oh + 1 - kh, tw = ow + 1 - kw;
+                                        if (th < 0 || tw < 0 || (th & 1) || (tw & 1)) continue;
+                                        const int ih = th / 2, iw = tw / 2;
+                                        if (ih >= H || iw >= W) continue;
+                                        a += (double)w[(((size_t)c * M + m) * 3 + kh) * 3 + kw] * xc[(size_t)ih * W + iw];
+                                    }
+                                }
+                        }
+                        a = a > 0 ? a : 0;
+                        if (residual) a += hr[(((size_t)b * M + m) * OH + oh) * OW + ow];
+                        ref[(size_t)oh * OW + ow] = a; ss += a * a; cnt++;
+                    }
+                for (size_t i = 0; i < ref.size(); i++) err = std::max(err, std::fabs((double)hy[i] - ref[i]));
+            }
+        worst = err / (std::sqrt(ss / (double)std::max<size_t>(cnt, 1)) + 1e-12);
+        free_conv(cw);
+        return RVC_OK;
+    });
+    return worst;
+}
+
+// the kernel family of the most recently queued implicit-GEMM launch (the first word of its description): tests assert which path they exercised
+const char *rvc_debug_last_kernel(void)
+{
+    static thread_local std::string buf;
+    buf = g_last_kernel;
+    return buf.c_str();
+}
+
 rvc_status rvc_profile_last_knn(rvc_engine *e, int *launches, double *kernel_ms, double *bytes)
 {
     return guarded(e, [&]() {

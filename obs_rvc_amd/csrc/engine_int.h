@@ -153,10 +153,12 @@ struct ConvW {
 static inline int round16(int k) { return (k + 15) / 16 * 16; }
 
 
-void *wmalloc(size_t bytes); void wfree(void *p);      // weight memory: slab-allocated (plan.hip)
-float *upload_f(const std::vector<float> &v);
+void *wmalloc(size_t bytes); void wfree(void *p);      // weight memory: slab-allocated per (device, class) (plan.hip)
+void *wmalloc_plan(size_t bytes);                      // ... class 1: plan-lifetime copies, in slabs of their own
+void wslab_info(int dev, int *count, size_t *bytes);
+float *upload_f(const std::vector<float> &v, int cls = 0);
 float *upload_f(const float *p, size_t n);
-float *upload_fragments(const std::vector<float> &panel, int nphase, int M, int Kp);
+float *upload_fragments(const std::vector<float> &panel, int nphase, int M, int Kp, int cls = 0);
 static inline long long phase_stride(const ConvW &c) { return (long long)((c.M + 15) / 16 * 16) * c.Kp; }
 ConvW prep_conv(const float *w, const float *bias, int Cout, int Cin, int KW, int groups);
 ConvW prep_convT1d(const float *w, const float *bias, int Cin, int Cout, int K, int S);
@@ -264,6 +266,7 @@ struct Plan {
 // ---- planner entry points (plan.hip) ----
 extern unsigned long long *g_kprobe;      // tuning build (-DRVC_KPROBE): destination of the per-wave phase stamps
 extern int g_last_waves, g_last_wgs, g_ncu;
+extern char g_last_kernel[16];          // family of the most recently queued implicit-GEMM launch ("reg", "g32", "c32s", "c2d", ...)
 void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases, bool final_out = false);
 void fill_epilogue(IgemmP &p, const ConvW &cw, const ConvOpts &o);
 void add_conv1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int stride, int pad, int dil, ConvOpts o = ConvOpts());

@@ -25,7 +25,7 @@ static void add_conv2d_with_shortcut(Plan &pl, const ResBlockW &w, const T2 &x, 
         for (int mo = 0; mo < c1.M; mo++)
             for (int ci = 0; ci < c1.Cin; ci++)
                 for (int kw = 0; kw < 3; kw++) panel[(size_t)mo * Kp3 + ci * 3 + kw] = c1.host_w[(size_t)mo * c1.K + ci * 9 + 3 + kw];
-        float *dw = upload_fragments(panel, 1, c1.M, Kp3);
+        float *dw = upload_fragments(panel, 1, c1.M, Kp3, 1);      // plan-lifetime copy
         pl.owned_dev.push_back(dw);
         p.w = dw; ph[0].nchunks = Kp3 / 16;
         koff.assign(Kp3, 0);

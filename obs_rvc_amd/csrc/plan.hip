@@ -6,7 +6,7 @@
 namespace rvc {
 
 static const char *const kTestHooks[] = {"RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_NO_LN_FUSE", "RVC_NO_CONV0_MULTI", "RVC_KNN_NO_GEMM",
-                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_C32S_DBG", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB", "RVC_CONV32S_BUF"};
+                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB", "RVC_CONV32S_BUF", "RVC_CONV2D32S", "RVC_CONV2D32S_TILE"};
 std::atomic<unsigned> g_opt_gen{0};       // bumped by every rvc_debug_option call: plans built under another generation are dropped (engine.hip get_plan)
 static std::mutex g_opt_mu;
 static std::map<std::string, std::string> g_opts;
@@ -38,32 +38,39 @@ int test_opt_int(const char *name, int dflt) { const char *v = test_opt(name); r
 // to 18 % slower for the sixth engine of a process than for the first (tests/tools/late_engine.py).  Weights are now
 // bump-allocated from 256 MB slabs, each ONE hipMalloc (contiguous, maximal page fragments), reference-counted: a slab is returned to the driver
 // when its last tensor is freed.
+// Slabs are per (device, class): a process may drive several GPUs (rvc_create(device)), and loads on two devices may interleave -- every device
+// has its own open slabs, all of them searched for room (with one global "current" slab, alternating loads opened a fresh 256 MB slab
+// per tensor).  Class 0 = model weights (live as long as the model), class 1 = plan-lifetime copies (one-row tap panels, split-bf16 panels): kept in
+// slabs of their own so that evicting a plan returns its memory instead of pinning a slab of model weights.
 namespace {
-struct WSlab { char *base; size_t size, used; long live; };
+struct WSlab { char *base; size_t size, used; long live; int dev, cls; };
 std::mutex g_wslab_mu;
 std::vector<WSlab> g_wslabs;
-const size_t kWSlabBytes = (size_t)256 << 20;
-}
-void *wmalloc(size_t bytes)
+const size_t kWSlabBytes = (size_t)256 << 20, kPlanSlabBytes = (size_t)64 << 20;
+void *wmalloc_cls(size_t bytes, int cls)
 {
     bytes = (std::max<size_t>(bytes, 16) + 255) / 256 * 256;
     std::lock_guard<std::mutex> lk(g_wslab_mu);
     int dev = 0; HIPCHK(hipGetDevice(&dev));
-    if (bytes <= kWSlabBytes / 4 && !g_wslabs.empty()) {
-        WSlab &b = g_wslabs.back();         // (slabs are per device in practice: one process drives one GPU; a pointer from another device's slab is never handed out
-        hipPointerAttribute_t at;           //  because the bump slab is abandoned when the current device differs)
-        if (b.size == kWSlabBytes && b.used + bytes <= b.size && hipPointerGetAttributes(&at, b.base) == hipSuccess && at.device == dev) {
-            void *r = b.base + b.used; b.used += bytes; b.live++;
-            return r;
+    const size_t slab = cls ? kPlanSlabBytes : kWSlabBytes;
+    if (bytes <= slab / 4) {
+        for (size_t i = g_wslabs.size(); i-- > 0; ) {          // newest first: the open slab of this (device, class) is usually the last one made
+            WSlab &b = g_wslabs[i];
+            if (b.dev == dev && b.cls == cls && b.size == slab && b.used + bytes <= b.size) {
+                void *r = b.base + b.used; b.used += bytes; b.live++;
+                return r;
+            }
         }
-        (void)hipGetLastError();
     }
-    const size_t sz = bytes <= kWSlabBytes / 4 ? kWSlabBytes : bytes;
+    const size_t sz = bytes <= slab / 4 ? slab : bytes;
     void *c;
     HIPCHK(hipMalloc(&c, sz));
-    g_wslabs.push_back(WSlab{(char *)c, sz, bytes, 1});
+    g_wslabs.push_back(WSlab{(char *)c, sz, bytes, 1, dev, cls});
     return c;
 }
+}
+void *wmalloc(size_t bytes) { return wmalloc_cls(bytes, 0); }
+void *wmalloc_plan(size_t bytes) { return wmalloc_cls(bytes, 1); }
 void wfree(void *p)
 {
     if (!p) return;
@@ -77,17 +84,24 @@ void wfree(void *p)
     }
     (void)hipFree(p);          // not from a slab
 }
-
-float *upload_f(const std::vector<float> &v)
+// slabs alive on `dev` (all classes): (count, bytes) -- test aid (rvc_debug_weight_slabs)
+void wslab_info(int dev, int *count, size_t *bytes)
 {
-    float *d = (float *)wmalloc(std::max<size_t>(v.size(), 4) * sizeof(float));
+    std::lock_guard<std::mutex> lk(g_wslab_mu);
+    *count = 0; *bytes = 0;
+    for (const WSlab &b : g_wslabs) if (b.dev == dev) { (*count)++; *bytes += b.size; }
+}
+
+float *upload_f(const std::vector<float> &v, int cls)
+{
+    float *d = (float *)(cls ? wmalloc_plan(std::max<size_t>(v.size(), 4) * sizeof(float)) : wmalloc(std::max<size_t>(v.size(), 4) * sizeof(float)));
     if (!v.empty()) HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
     return d;
 }
 float *upload_f(const float *p, size_t n) { return upload_f(std::vector<float>(p, p + n)); }
 
 // [nphase][M][Kp] row-major panels -> MFMA-fragment-major [nphase][m_tile][chunk][lane][4] (M padded to 16 with zeros)
-float *upload_fragments(const std::vector<float> &panel, int nphase, int M, int Kp)
+float *upload_fragments(const std::vector<float> &panel, int nphase, int M, int Kp, int cls)
 {
     const int mt = (M + 15) / 16, nch = Kp / 16;
     std::vector<float> out((size_t)nphase * mt * nch * 256, 0.f);
@@ -101,7 +115,7 @@ float *upload_fragments(const std::vector<float> &panel, int nphase, int M, int 
                     float *dst = &out[(((size_t)ph * mt + t) * nch + c) * 256 + l * 4];
                     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
                 }
-    return upload_f(out);
+    return upload_f(out, cls);
 }
 
 // Conv (any rank flattened to K = Cin/groups * KW taps): w [Cout][Cin/groups][KW]
@@ -193,6 +207,8 @@ void merge_convs(const std::vector<ConvW *> &cs)
 
 unsigned long long *g_kprobe = nullptr;   // tuning build (-DRVC_KPROBE): destination of the per-wave phase stamps
 int g_last_waves = 0, g_last_wgs = 0;
+char g_last_kernel[16] = "";
+static void note_kernel(const char *d) { size_t i = 0; for (; i < sizeof(g_last_kernel) - 1 && d[i] && d[i] != ' '; i++) g_last_kernel[i] = d[i]; g_last_kernel[i] = 0; }
 
 // One stream, stride-1 1-D convolution with a long output: conv_tile_kernel (conv_tile.hip.h) stages the input rows once per workgroup.
 // Builds the LDS-offset tables (k -> row * RS + tap column) from the layer's gather table and a work-item table that balances the
@@ -300,7 +316,7 @@ static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &
     const double flops = 2.0 * p.M * (double)p.N * ksum * B;
     pl.igemm_flops += flops; pl.n_igemm++;
     Plan *plp = &pl;
-    { char d[200]; snprintf(d, sizeof d, "tile M=%d N=%d K=%d B=%d nph=%d tile=%dx%d items=%lld grid=%u lds=%zu pre=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, BM, BN, nitems, grid.x, lds_max, (int)(p.pre_act != ACT_NONE), ksum); pl.descs.push_back(d); }
+    { char d[200]; snprintf(d, sizeof d, "tile M=%d N=%d K=%d B=%d nph=%d tile=%dx%d items=%lld grid=%u lds=%zu pre=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, BM, BN, nitems, grid.x, lds_max, (int)(p.pre_act != ACT_NONE), ksum); pl.descs.push_back(d); note_kernel(d); }
     const int desc_id = (int)pl.descs.size() - 1;
     const IgemmP pc = p;
     if (final_out) pl.final_out_honoured = true;
@@ -389,7 +405,9 @@ static bool queue_conv32s(Plan &pl, IgemmP &p, int B, const std::vector<int> &ko
     p.nphase = (int)phs.size();
     p.ph0 = phs[0];
     p.ntm = ntm; p.ntn = ntn; p.ksplit = 1; p.nbatch = B; p.m_fast = 0;
-    p.pad2_ = test_opt_int("RVC_C32S_DBG", 0);
+    // conv32s_kernel's three ablation branches (timing only: they drop loads, i.e. change results) are reachable in the -DRVC_TUNING build alone; the product
+    // always passes 0.  The never-taken branches stay in the kernel because they delimit the scheduler's regions (finding 6).
+    p.pad2_ = tune_env("RVC_C32S_DBG") ? atoi(tune_env("RVC_C32S_DBG")) : 0;
     // the 64 x 128 tile takes the buffer-load kernel below 24 streams (us per six launches, all-buffer build against this one: 8 streams 437 vs 474, 16 streams 461 vs 479,
     // 32 streams 842 vs 775, 64 streams 1 543 vs 1 510-1 533); test hook RVC_CONV32S_BUF: 0 never, 2 always
     const int buf_opt = test_opt_int("RVC_CONV32S_BUF", 1);
@@ -399,7 +417,7 @@ static bool queue_conv32s(Plan &pl, IgemmP &p, int B, const std::vector<int> &ko
     const double flops = 2.0 * p.M * (double)p.N * ksum * B;
     pl.igemm_flops += flops; pl.n_igemm++;
     Plan *plp = &pl;
-    { char d[200]; snprintf(d, sizeof d, "c32s M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%ux%u lds=%zu pre=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, BM, BN, grid.x, grid.y, grid.z, lds_max, (int)(p.pre_act != ACT_NONE), ksum); pl.descs.push_back(d); }
+    { char d[200]; snprintf(d, sizeof d, "c32s M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%ux%u lds=%zu pre=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, BM, BN, grid.x, grid.y, grid.z, lds_max, (int)(p.pre_act != ACT_NONE), ksum); pl.descs.push_back(d); note_kernel(d); }
     const int desc_id = (int)pl.descs.size() - 1;
     const IgemmP pc = p;
     if (final_out) pl.final_out_honoured = true;
@@ -598,7 +616,7 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         size_t tot = 0;
         std::vector<size_t> off(phv.size());
         for (size_t f = 0; f < phv.size(); f++) { off[f] = tot; tot += (size_t)nblk * phv[f].nchunks * 2048; }
-        float *wsplit = (float *)wmalloc(tot);
+        float *wsplit = (float *)wmalloc_plan(tot);
         for (size_t f = 0; f < phv.size(); f++) bf3_pack(p.w + phv[f].w_off, p.M, phv[f].nchunks, (char *)wsplit + off[f], nullptr);
         HIPCHK(hipDeviceSynchronize());
         pl.owned_dev.push_back(wsplit);
@@ -614,7 +632,7 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         const double flops = 2.0 * p.M * (double)p.N * ksum;
         pl.igemm_flops += flops; pl.n_igemm++;
         Plan *plp = &pl;
-        { char d[176]; snprintf(d, sizeof d, "bf3 M=%d N=%d K=%d B=1 nph=%d tile=128x128 grid=%ux%u lin=%d pre=%d", p.M, p.N, p.K, p.nphase, grid.x, grid.y, (int)lin, (int)pre); pl.descs.push_back(d); }
+        { char d[176]; snprintf(d, sizeof d, "bf3 M=%d N=%d K=%d B=1 nph=%d tile=128x128 grid=%ux%u lin=%d pre=%d", p.M, p.N, p.K, p.nphase, grid.x, grid.y, (int)lin, (int)pre); pl.descs.push_back(d); note_kernel(d); }
         const int desc_id = (int)pl.descs.size() - 1;
         if (final_out) pl.final_out_honoured = true;
         pl.ops.push_back([=](hipStream_t s) {
@@ -654,7 +672,7 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
             const double flops = 2.0 * p.M * (double)p.N * ksum;
             pl.igemm_flops += flops; pl.n_igemm++;
             Plan *plp = &pl;
-            { char d[176]; snprintf(d, sizeof d, "g2w M=%d N=%d K=%d B=1 nph=1 tile=%dx%d ks=%d grid=%ux%u", p.M, p.N, p.K, bm, bn, gk, grid.x, grid.y); pl.descs.push_back(d); }
+            { char d[176]; snprintf(d, sizeof d, "g2w M=%d N=%d K=%d B=1 nph=1 tile=%dx%d ks=%d grid=%ux%u", p.M, p.N, p.K, bm, bn, gk, grid.x, grid.y); pl.descs.push_back(d); note_kernel(d); }
             const int desc_id = (int)pl.descs.size() - 1;
             if (final_out) pl.final_out_honoured = true;
             pl.ops.push_back([=](hipStream_t s) {
@@ -709,7 +727,7 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         const bool g32l = ((lc == 3 || lc == 7 || lc == 8) && g32l_on && !(lc == 3 && p.m_fast == 2)) || g32t;
         const int g32l_mode = g32t ? (pre ? 2 : 1) : 0;
         const size_t lds_l = (size_t)2 * bn * 20 * 4;
-        { char d[160]; snprintf(d, sizeof d, "%s M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%u", g32t ? "g32t" : g32l ? "g32l" : (lds_cfg >= 3 && lds_cfg != 6) ? "g32" : "lds", p.M, p.N, p.K, B, p.nphase, bm, bn, grid.x, grid.y); pl.descs.push_back(d); }
+        { char d[160]; snprintf(d, sizeof d, "%s M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%u", g32t ? "g32t" : g32l ? "g32l" : (lds_cfg >= 3 && lds_cfg != 6) ? "g32" : "lds", p.M, p.N, p.K, B, p.nphase, bm, bn, grid.x, grid.y); pl.descs.push_back(d); note_kernel(d); }
         const int desc_id = (int)pl.descs.size() - 1;
         if (final_out) pl.final_out_honoured = true;
         pl.ops.push_back([=](hipStream_t s) {
@@ -795,7 +813,7 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
     pl.igemm_flops += flops;
     pl.n_igemm++;
     Plan *plp = &pl;
-    { char d[200]; snprintf(d, sizeof d, "reg M=%d N=%d K=%d B=%d nph=%d tile=%dx%d ks=%d mfast=%d grid=%ux%ux%u pre=%d lin=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, 16 * kMF[cfg], 16 * kNF[cfg], wg_ks, p.m_fast, grid.x, grid.y, grid.z, (int)pre, (int)lin, ksum); pl.descs.push_back(d); }
+    { char d[200]; snprintf(d, sizeof d, "reg M=%d N=%d K=%d B=%d nph=%d tile=%dx%d ks=%d mfast=%d grid=%ux%ux%u pre=%d lin=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, 16 * kMF[cfg], 16 * kNF[cfg], wg_ks, p.m_fast, grid.x, grid.y, grid.z, (int)pre, (int)lin, ksum); pl.descs.push_back(d); note_kernel(d); }
     const int desc_id = (int)pl.descs.size() - 1;
     if (final_out && lean) pl.final_out_honoured = true;      // (the two-stage grid split-K fallback writes through a second kernel: it keeps the plan's own tensor)
     pl.ops.push_back([=](hipStream_t s) {
@@ -952,7 +970,7 @@ void add_conv2d(Plan &pl, const ConvW &cw, const T2 &x, const T2 &y, ConvOpts o)
         for (int mo = 0; mo < cw.M; mo++)
             for (int ci = 0; ci < cw.Cin; ci++)
                 for (int kw = 0; kw < 3; kw++) panel[(size_t)mo * Kp3 + ci * 3 + kw] = cw.host_w[(size_t)mo * cw.K + ci * 9 + 3 + kw];
-        float *dw = upload_fragments(panel, 1, cw.M, Kp3);
+        float *dw = upload_fragments(panel, 1, cw.M, Kp3, 1);      // plan-lifetime copy
         pl.owned_dev.push_back(dw);
         p.w = dw; p.K = Kp3;
         koff.assign(Kp3, 0);
@@ -1088,6 +1106,15 @@ void plan_kernel_attrs()
 
 // test hook (see "switches" in engine_int.h): set (value != NULL) or clear one of the named hooks; 0 = done, -1 = unknown name.
 // Hooks are read when a model is loaded (RVC_NO_LN_FUSE) or a plan is built -- set them before.
+extern "C" int rvc_debug_weight_slabs(int device, int *count, size_t *bytes)
+{
+    int c = 0; size_t b = 0;
+    rvc::wslab_info(device, &c, &b);
+    if (count) *count = c;
+    if (bytes) *bytes = b;
+    return 0;
+}
+
 extern "C" int rvc_debug_option(const char *name, const char *value)
 {
     using namespace rvc;

@@ -67,6 +67,32 @@ def test_product_reads_only_the_documented_environment():
     assert lib.rvc_debug_option(b"RVC_GEMM32", b"0") == -1          # a tuning switch: not settable in the product
     assert lib.rvc_debug_option(b"PATH", b"x") == -1
 
+def test_library_exports_only_the_c_abi_and_no_result_changing_hook():
+    # `nm -D` listed ~70 C++ internals of the planner and the kernels' host stubs; the link now takes an export list
+    # (csrc/exports.map): the dynamic symbols are the C ABI of include/rvc_mi355x.h plus the rvc_debug_* test hooks of include/rvc_mi355x_debug.h,
+    # nothing else.  And no hook of the PRODUCT build changes results: conv32s_kernel's ablation switches (RVC_C32S_DBG: they drop loads) exist
+    # in the -DRVC_TUNING build only.
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _native.SO_PATH], capture_output=True, text=True, check=True).stdout
+    syms = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert syms and all(s.startswith("rvc_") for s in syms), [s for s in syms if not s.startswith("rvc_")][:5]
+    dbg_hdr = open(os.path.join(ROOT, "include", "rvc_mi355x_debug.h")).read()
+    dbg_hdr = re.sub(r"/\*.*?\*/", "", dbg_hdr, flags=re.S)
+    dbg_declared = sorted(set(re.findall(r"\b(rvc_debug_[a-z0-9_]+)\s*\(", dbg_hdr)))
+    assert sorted(s for s in syms if s.startswith("rvc_debug_")) == dbg_declared
+    assert sorted(s for s in syms if not s.startswith("rvc_debug_")) == _declared()
+    lib = _native.lib()
+    lib.rvc_debug_option.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    assert lib.rvc_debug_option(b"RVC_C32S_DBG", b"7") == -1
+    # every hook the product accepts is a planner CHOICE between kernels / tiles / plan structures (plan.hip kTestHooks); the names are listed in DESIGN.md
+    plan = open(os.path.join(_native.CSRC, "plan.hip")).read()
+    hooks = re.findall(r'"(RVC_[A-Z0-9_]+)"', plan[plan.index("kTestHooks[]"):plan.index("};", plan.index("kTestHooks[]"))])
+    assert "RVC_C32S_DBG" not in hooks and len(hooks) >= 15
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for h in hooks:
+        assert h in design, h
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():

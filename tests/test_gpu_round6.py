@@ -1,0 +1,218 @@
+"""Round-6 GPU tests (through the C ABI, against the oracle / fp64 host evaluations): the full-size stream counts the bench times but no oracle test ran
+(2 and 4 streams, v1 at 2 streams), one rank of BASELINE configs[4] (64 streams + the 100k x 768 index), the staged 2-D convolution of RMVPE at many
+streams, the in-run calibration, the weight slabs -- SURVEY.md section 8 rows a6, a12, a16, d."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from common import BASELINE_160MS as g, rms, set_opt, voice_signal, zoo
+from obs_rvc_amd import _native, weights as W
+
+pytestmark = pytest.mark.gpu
+PCM_TOL = 1e-3          # north_star: +-1e-3 RMS on the float PCM output
+
+
+def _engine(z, streams=1, seed=(1234, 0), version=2):
+    from obs_rvc_amd.rvc import RvcInfer
+    eng = RvcInfer(z["data"]); eng.load_contentvec(version); eng.load_f0(); eng.load_model(z["model"])
+    if streams > 1:
+        eng.set_streams(streams)
+    eng.set_noise_seed(*seed)
+    return eng
+
+
+def _oracle(z, seed, stream, version=2):
+    from oracle import oracle as O
+    o = O.OracleRvcInfer(z["data"]); o.load_contentvec(version); o.load_f0(1); o.load_model(z["model"]); o.set_noise_seed(seed, stream)
+    return o
+
+
+@pytest.mark.parametrize("S,version", [(2, 2), (4, 2), (2, 1)])
+def test_full_size_end_to_end_at_few_streams(S, version):
+    # VERDICT r5 weak #1a: the bench times streams2 / streams4 (igemm2w_kernel from 2 streams, conv_tile_kernel with the streams in its item table at
+    # 2-4, the v1 two-XCD f0 partition at <= 3 streams); end to end those plans were oracle-checked only on the tiny zoo.  Full-size models, the
+    # planner's own choices, two chunks (the second one exercises the pitch cache carried per stream), EVERY stream against its oracle.
+    z = zoo("full", version)
+    eng = _engine(z, S, (6, 300), version)
+    oras = [_oracle(z, 6, 300 + s, version) for s in range(S)]
+    for tick in range(2):
+        xin = np.stack([voice_signal(g.input_buffer_16k_size, seed=80 + 10 * tick + s) for s in range(S)])
+        ye = eng.infer_batch(xin, g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+        assert ye.shape == (S, g.model_return_size) and np.isfinite(ye).all()
+        for s in range(S):
+            yo = oras[s].infer(xin[s], g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+            assert rms(ye[s] - yo) < PCM_TOL, (S, version, tick, s, rms(ye[s] - yo))
+    for s in range(S):
+        assert np.allclose(eng.pitch_cache(s), oras[s].pitch_cache(), rtol=1e-5, atol=1e-3), s
+    eng.close()
+
+
+def test_sixty_four_streams_with_the_100k_index_is_one_rank_of_config4():
+    # VERDICT r5 weak #1b: `streams64_index100k` -- the per-rank workload of BASELINE configs[4] -- had no oracle test at 64 streams (the GEMM retrieval was
+    # checked at 16 streams, stream 0 only).  64 full-size streams + the 100k x 768 index: kNN hits bit-exact (np.array_equal) and PCM within 1e-3 for
+    # streams 0 / 31 / 63.
+    z = zoo("full")
+    S, R = 64, g.model_return_length
+    index = W.make_index(100000, 768, seed=7)
+    eng = _engine(z, S, (11, 0))
+    eng.load_index(index); eng.set_index_rate(0.75)
+    xin = np.stack([voice_signal(g.input_buffer_16k_size, seed=900 + s) for s in range(S)])
+    ye = eng.infer_batch(xin, g.sample_frame_16k, 12, g.skip_head, R)
+    ie, de = eng.knn(rows_cap=S * R)
+    assert ie.shape[0] == S * R and np.isfinite(ye).all()
+    for s in (0, 31, 63):
+        o = _oracle(z, 11, s); o.load_index(index); o.set_index_rate(0.75)
+        yo = o.infer(xin[s], g.sample_frame_16k, 12, g.skip_head, R)
+        io, do = o.knn()
+        assert np.array_equal(ie[s * R:(s + 1) * R], io), s
+        assert np.allclose(de[s * R:(s + 1) * R], do, rtol=1e-4), s
+        assert rms(ye[s] - yo) < PCM_TOL, (s, rms(ye[s] - yo))
+    assert eng.retrieval_recoveries() == 0
+    eng.close()
+
+
+def _conv2d_check():
+    L = _native.lib()
+    L.rvc_debug_conv2d_check.restype = C.c_double
+    L.rvc_debug_conv2d_check.argtypes = [C.c_void_p] + [C.c_int] * 7
+    L.rvc_debug_last_kernel.restype = C.c_char_p
+    return L
+
+
+# RMVPE's shapes at Tm = 32 (rvc/src/f0/rmvpe.rs:225-241: E2E(4, 1, (2, 2)), levels 16 .. 256 channels, images 32 x 128 .. 2 x 8) and ragged ones
+C2D_SHAPES = [(16, 16, 32, 128), (32, 32, 16, 64), (64, 64, 8, 32), (128, 128, 4, 16), (256, 256, 2, 8), (32, 16, 16, 64), (64, 128, 8, 32),
+              (48, 32, 5, 19), (32, 64, 3, 7), (16, 1, 32, 128), (3, 16, 32, 128)]
+
+
+@pytest.mark.parametrize("streams", [1, 3, 8, 20])
+@pytest.mark.parametrize("residual", [0, 1, 2])
+def test_conv2d_3x3_every_planner_choice_against_fp64(streams, residual):
+    # Conv2d 3x3 (pad 1) + bias + ReLU (+ residual / accumulate) through whatever kernel the planner picks at that stream count -- the register-direct
+    # 16x16x4 kernel at few streams, the staged 2-D convolution (conv2d32s_kernel) at many -- against a double-precision host evaluation.
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("tiny")
+    eng = RvcInfer(z["data"])
+    L = _conv2d_check()
+    seen = set()
+    for (M, Cin, H, Wd) in C2D_SHAPES:
+        err = L.rvc_debug_conv2d_check(eng._h, M, Cin, H, Wd, streams, 0, residual)
+        seen.add(L.rvc_debug_last_kernel().decode())
+        assert 0 <= err < 2e-5, (M, Cin, H, Wd, streams, residual, err)
+    eng.close()
+    assert seen, seen
+
+
+@pytest.mark.parametrize("force", ["0", "2"])
+@pytest.mark.parametrize("streams", [1, 5, 16])
+def test_conv2d_staged_kernel_forced_and_off(force, streams):
+    # test hook RVC_CONV2D32S: 0 = the staged 2-D convolution never, 2 = wherever it is eligible (any stream count) -- both against fp64, and with the hook
+    # at 2 the kernel must really have run on the 32-channel-block shapes
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("tiny")
+    set_opt("RVC_CONV2D32S", force)
+    try:
+        eng = RvcInfer(z["data"])
+        L = _conv2d_check()
+        kinds = {}
+        for (M, Cin, H, Wd) in C2D_SHAPES:
+            for residual in (0, 1, 2):
+                err = L.rvc_debug_conv2d_check(eng._h, M, Cin, H, Wd, streams, 0, residual)
+                kinds[(M, Cin, H, Wd)] = L.rvc_debug_last_kernel().decode()
+                assert 0 <= err < 2e-5, (force, M, Cin, H, Wd, streams, residual, err)
+        eng.close()
+    finally:
+        set_opt("RVC_CONV2D32S", None)
+    if force == "2":
+        assert kinds[(64, 64, 8, 32)] == "c2d" and kinds[(128, 128, 4, 16)] == "c2d" and kinds[(32, 32, 16, 64)] == "c2d", kinds
+    else:
+        assert "c2d" not in kinds.values(), kinds
+
+
+@pytest.mark.parametrize("streams", [1, 4, 16])
+def test_conv_transpose2d_against_fp64(streams):
+    # ConvTranspose2d 3x3 stride 2 (four polyphase sub-convolutions of 2x2 taps) + bias + ReLU: RMVPE's decoder upsampling
+    from obs_rvc_amd.rvc import RvcInfer
+    z = zoo("tiny")
+    eng = RvcInfer(z["data"])
+    L = _conv2d_check()
+    for (M, Cin, H, Wd) in [(16, 32, 16, 64), (32, 64, 8, 32), (64, 128, 4, 16), (128, 256, 2, 8), (256, 512, 1, 4), (24, 16, 3, 5)]:
+        err = L.rvc_debug_conv2d_check(eng._h, M, Cin, H, Wd, streams, 1, 0)
+        assert 0 <= err < 2e-5, (M, Cin, H, Wd, streams, err)
+    eng.close()
+
+
+@pytest.mark.parametrize("S", [8, 64])
+def test_rmvpe_taps_at_many_streams_on_the_production_plan(S):
+    # the nine rm.* taps at 8 and 64 streams on the plan that really runs (the staged 2-D convolution takes RMVPE's 3x3 layers there).
+    # Taps are stream 0's tensors; the oracle runs stream 0.
+    z = zoo("full")
+    eng = _engine(z, S, (6, 0))
+    eng.enable_taps(2)
+    xin = np.stack([voice_signal(g.input_buffer_16k_size, seed=70 + s) for s in range(S)])
+    ye = eng.infer_batch(xin, g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+    o = _oracle(z, 6, 0); o.enable_taps(True)
+    yo = o.infer(xin[0], g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+    from common import rel_rms
+    checked = 0
+    for name in ("rm.mel", "rm.enc0", "rm.enc4", "rm.int", "rm.dec0", "rm.dec4"):
+        a, b = o.tap(name), eng.tap(name)
+        assert a.size == b.size, name
+        assert rel_rms(b, a) < 1e-4, (name, rel_rms(b, a))
+        checked += 1
+    Tm = 32
+    for oname, ename in (("rm.cnn", "rm.cnn_ct"), ("rm.gru", "rm.gru_ct"), ("rm.sal", "rm.sal_ct")):
+        a = o.tap(oname); b = eng.tap(ename).reshape(-1, Tm).T.reshape(-1)
+        assert a.size == b.size and rel_rms(b, a) < 1e-4, (oname, rel_rms(b, a))
+        checked += 1
+    assert checked == 9
+    assert rms(ye[0] - yo) < PCM_TOL
+    eng.close()
+
+
+def test_calibration_measures_this_box():
+    # rvc_calibrate (bench.py's peak_measured): a bare fp32-MFMA stream and an HBM read stream, timed on this GPU.  Sanity windows around the guide's
+    # figures (157.3 TF/s at 2.4 GHz; 8 TB/s nominal, ~6.3 TB/s measured for a copy); the clock monitor sees a clock between idle and the maximum.
+    c = _native.calibrate(0)
+    assert 90.0 < c["mfma_f32_tflops"] < 165.0, c
+    assert 1200.0 < c["mfma_sclk_mhz"] < 2500.0, c
+    assert abs(c["mfma_f32_tflops"] / (157.3 * c["mfma_sclk_mhz"] / 2400.0) - 1.0) < 0.06, c      # the loop runs at the matrix pipe's rate at the clock it measured
+    assert 2.5 < c["hbm_read_tbs"] < 8.2, c
+    assert c["compute_units"] == 256 and c["ms_total"] < 2000.0, c
+    _native.clock_monitor_start(0)
+    c2 = _native.calibrate(0)          # some load while the monitor counts
+    m = _native.clock_monitor_stop(0)
+    assert 100.0 < m["sclk_mhz_min"] <= m["sclk_mhz_mean"] < 2500.0 and m["seconds"] > 0.01, m
+    assert c2["mfma_f32_tflops"] > 90.0
+    with pytest.raises(RuntimeError):
+        _native.clock_monitor_stop(0)          # not running any more
+
+
+def test_weight_slabs_are_per_device_and_plan_copies_have_their_own():
+    # the slab allocator bump-allocated from the most recent slab only and abandoned it when the device differed or a large tensor came in
+    # between.  Slabs are now per (device, class) and all of a device's open slabs are searched: a second engine on the same device fills the first
+    # engine's open slab before a new one is made, and plan-lifetime copies (class 1) live in slabs that go away with their plans.
+    from obs_rvc_amd.rvc import RvcInfer
+    L = _native.lib()
+    L.rvc_debug_weight_slabs.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+
+    def slabs():
+        n, b = C.c_int(), C.c_size_t()
+        L.rvc_debug_weight_slabs(0, C.byref(n), C.byref(b))
+        return n.value, b.value
+    z = zoo("tiny")
+    n0, b0 = slabs()
+    e1 = RvcInfer(z["data"]); e1.load_contentvec(2); e1.load_f0(); e1.load_model(z["model"])
+    n1, b1 = slabs()
+    e2 = RvcInfer(z["data"]); e2.load_contentvec(2); e2.load_f0(); e2.load_model(z["model"])
+    n2, b2 = slabs()
+    assert n1 >= n0 + 1
+    assert n2 == n1 and b2 == b1, (n1, n2)          # the tiny zoo's second copy fits the open 256 MB slab: no slab per tensor, none per engine
+    x = voice_signal(g.input_buffer_16k_size, seed=3)
+    e1.set_noise_seed(7, 0)
+    y = e1.infer(x, g.sample_frame_16k, 12, g.skip_head, g.model_return_length)      # builds a plan (plan-time copies: class 1)
+    n3, _ = slabs()
+    assert np.isfinite(y).all() and n3 <= n2 + 1
+    e1.close(); e2.close()
+    n4, _ = slabs()
+    assert n4 == n0, (n0, n4)          # everything returned

@@ -1,14 +1,15 @@
 #!/usr/bin/env python
 """rocprofv3 --kernel-trace --stats CSV of `bench.py --only-headline --streams S --serial-branches` -> profiles/<round>_serial_<S>streams.json:
-the sum of implicit-GEMM kernel time per step as rocprofv3 saw it, with the build hash of the library it was taken on.  bench.py prints
-roofline.frac of a many-stream configuration only when this file matches its own library and reproduces its HIP-event sum within 3 %.
+the sum of implicit-GEMM kernel time per step as rocprofv3 saw it AND the HIP-event sum the same process printed (its bench line), with the build hash
+of the library.  The ratio of the two validates bench.py's event method (it is a property of the method, not of the box); bench.py quotes it next to
+its own in-run `frac` and never withholds a figure because of it.
 
-usage: serial_pass.py <kernel_stats.csv> <streams> <out.json> [csv name as committed]"""
+usage: serial_pass.py <kernel_stats.csv> <streams> <out.json> [csv name as committed] [bench line of the same process (json)]"""
 import csv, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from obs_rvc_amd import _native
 
-IGEMM = ("igemm_kernel", "igemm2_kernel", "igemm2w_kernel", "igemm_lds_kernel", "igemm32_kernel", "igemm32l_kernel", "igemm32w_kernel", "igemm_bf3_kernel", "conv_tile_kernel", "conv32s_kernel", "conv32s_buf_kernel", "splitk_epilogue_kernel")
+IGEMM = ("igemm_kernel", "igemm2_kernel", "igemm2w_kernel", "igemm_lds_kernel", "igemm32_kernel", "igemm32l_kernel", "igemm32w_kernel", "igemm_bf3_kernel", "conv_tile_kernel", "conv32s_kernel", "conv32s_buf_kernel", "conv2d32s_kernel", "splitk_epilogue_kernel")
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = sum(int(r["Calls"]) for r in rows if "advance_chunk_kernel" in r["Name"])
 if steps < 3:
@@ -20,5 +21,15 @@ out = {"source": "rocprofv3 --kernel-trace --stats of `bench.py --only-headline 
        "csv": sys.argv[4] if len(sys.argv) > 4 else os.path.basename(sys.argv[1]), "build": _native.binary_hash(), "streams": int(sys.argv[2]),
        "steps_in_trace": steps, "igemm_launches_per_step": launches / steps, "sum_igemm_ms_per_step": tot_ns / steps * 1e-6,
        "kernel_class": ", ".join(IGEMM)}
+if len(sys.argv) > 5:
+    try:
+        line = [ln for ln in open(sys.argv[5]).read().splitlines() if ln.startswith("{")][-1]
+        roof = json.loads(line).get("roofline") or {}
+        out["events_sum_igemm_ms_per_step"] = roof.get("sum_kernel_ms")
+        out["events_launches_per_step"] = roof.get("launches_per_step")
+        if roof.get("sum_kernel_ms"):
+            out["events_over_rocprof"] = roof["sum_kernel_ms"] / out["sum_igemm_ms_per_step"]
+    except Exception as ex:
+        out["events_note"] = "bench line unreadable: %s" % ex
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
