@@ -111,64 +111,101 @@ def pct(lat, q):
 
 # ------------------------------------------------------------------------------------------------------------ the box
 class BoxProbe:
-    """Clocks / socket power / temperature of one GPU from sysfs (amdgpu: pp_dpm_sclk, pp_dpm_mclk, hwmon power1_average | power1_input,
-    temp*_input).  Everything is optional: a missing file is a missing key, never an error.  `sample()` is cheap (a few small reads);
-    `Sampler` polls it from a thread while a leg's probe steps run (the calls block inside the library with the GIL released)."""
+    """Socket power / temperature / clock of THIS rank's GPU while a leg runs.  First choice: the amdsmi Python binding of the ROCm image (the same SMU
+    metrics rocm-smi prints: current socket power, gfx clock, hotspot temperature, power cap), device matched by PCI bus id.  Fallback: sysfs hwmon of
+    the card with that bus id (power1_input "PPT", freq1_input, temp2_input).  NB sysfs lists every GPU of the NODE even when the container sees one --
+    card0 is not "the" GPU (tests/tools/power_series.py, box_probe.sh) -- hence the bus-id match.  Everything is optional: a missing source is a missing
+    key, never an error.  The leg's CLOCK of record is the in-kernel monitor's (rvc_clock_monitor_*), these are the box's own view next to it."""
 
-    def __init__(self, local_rank=0):
-        import glob
-        cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
-        self.dev = cards[local_rank] if local_rank < len(cards) else (cards[0] if cards else None)
-        self.hwmon = None
-        if self.dev:
-            hw = sorted(glob.glob(os.path.join(self.dev, "hwmon", "hwmon*")))
-            self.hwmon = hw[0] if hw else None
+    def __init__(self, local_rank=0, bdf=None):
+        self.smi = self.h = self.hwmon = None
+        self.bdf = (bdf or "").lower()
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            pick = None
+            for h in hs:
+                try:
+                    if self.bdf and amdsmi.amdsmi_get_gpu_device_bdf(h).lower().endswith(self.bdf[-7:]):
+                        pick = h
+                except Exception:
+                    pass
+            if pick is None and hs:
+                pick = hs[local_rank] if local_rank < len(hs) else hs[0]
+            if pick is not None:
+                self.smi, self.h = amdsmi, pick
+        except Exception:
+            pass
+        if self.smi is None:
+            import glob
+            for hw in sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*")):
+                dev = os.path.basename(os.path.realpath(os.path.dirname(os.path.dirname(hw))))
+                if self.bdf and dev.lower().endswith(self.bdf[-7:]):
+                    self.hwmon = hw
+        self.source = "amdsmi" if self.smi else ("sysfs " + self.hwmon if self.hwmon else None)
 
     @staticmethod
-    def _read(path):
+    def _int(path):
         try:
             with open(path) as fh:
-                return fh.read()
+                return int(fh.read().strip())
         except Exception:
             return None
 
-    def _dpm(self, name):
-        t = self._read(os.path.join(self.dev, name)) if self.dev else None
-        if not t:
-            return None
-        cur = [ln for ln in t.splitlines() if ln.strip().endswith("*")]
-        import re
-        m = re.search(r"(\d+)\s*[Mm][Hh]z", cur[0] if cur else t.splitlines()[-1])
-        return int(m.group(1)) if m else None
-
     def sample(self):
         out = {}
-        if not self.dev:
+        if self.smi is not None:
+            A, h = self.smi, self.h
+            try:
+                pi = A.amdsmi_get_power_info(h)
+                v = pi.get("current_socket_power")
+                if not isinstance(v, (int, float)):
+                    v = pi.get("average_socket_power")
+                if isinstance(v, (int, float)):
+                    out["power_w"] = float(v)
+            except Exception:
+                pass
+            try:
+                ci = A.amdsmi_get_clock_info(h, A.AmdSmiClkType.GFX)
+                v = ci.get("clk", ci.get("cur_clk"))
+                if isinstance(v, (int, float)):
+                    out["sclk_mhz"] = float(v)
+            except Exception:
+                pass
+            for tt in ("HOTSPOT", "JUNCTION", "EDGE"):
+                try:
+                    v = A.amdsmi_get_temp_metric(h, getattr(A.AmdSmiTemperatureType, tt), A.AmdSmiTemperatureMetric.CURRENT)
+                    if isinstance(v, (int, float)):
+                        out["temp_c"] = float(v)
+                        break
+                except Exception:
+                    pass
+            try:
+                pc = A.amdsmi_get_power_cap_info(h).get("power_cap")
+                if isinstance(pc, (int, float)) and pc > 0:
+                    out["power_cap_w"] = round(pc / 1e6) if pc > 1e5 else round(pc)
+            except Exception:
+                pass
             return out
-        for k, f in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
-            v = self._dpm(f)
-            if v is not None:
-                out[k] = v
         if self.hwmon:
-            for f in ("power1_average", "power1_input"):
-                t = self._read(os.path.join(self.hwmon, f))
-                if t and t.strip().isdigit():
-                    out["power_w"] = round(int(t) / 1e6, 1)
-                    break
-            temps = []
-            for i in range(1, 9):
-                t = self._read(os.path.join(self.hwmon, "temp%d_input" % i))
-                if t and t.strip().lstrip("-").isdigit():
-                    temps.append(int(t) / 1000.0)
-            if temps:
-                out["temp_c"] = round(max(temps), 1)
+            for k, f, scale, nd in (("sclk_mhz", "freq1_input", 1e-6, 0), ("temp_c", "temp2_input", 1e-3, 1)):
+                v = self._int(os.path.join(self.hwmon, f))
+                if v is not None:
+                    out[k] = round(v * scale, nd)
+            v = self._int(os.path.join(self.hwmon, "power1_input"))
+            if v is not None:
+                out["power_w"] = round(v / 1e6, 1)
+            cap = self._int(os.path.join(self.hwmon, "power1_cap"))
+            if cap:
+                out["power_cap_w"] = round(cap / 1e6)
         return out
 
 
 class Sampler:
     """polls BoxProbe.sample() every `period` seconds from a thread -> mean / max of what it saw"""
 
-    def __init__(self, probe, period=0.05):
+    def __init__(self, probe, period=0.1):
         import threading
         self.probe, self.period, self.rows, self._stop = probe, period, [], threading.Event()
         self._t = threading.Thread(target=self._run, daemon=True)
@@ -189,12 +226,14 @@ class Sampler:
 
     def summary(self):
         out = {}
-        for k in ("sclk_mhz", "mclk_mhz", "power_w", "temp_c"):
+        for k in ("sclk_mhz", "power_w", "temp_c"):
             v = [r[k] for r in self.rows if k in r]
             if v:
                 out[k] = round(float(np.mean(v)), 1)
                 if k in ("power_w", "temp_c"):
                     out[k + "_max"] = round(float(np.max(v)), 1)
+        if self.rows and "power_cap_w" in self.rows[0]:
+            out["power_cap_w"] = self.rows[0]["power_cap_w"]
         out["samples"] = len(self.rows)
         return out
 
@@ -212,7 +251,7 @@ def calibrate(job, when):
 
 def clock_probe(job, step, ms_per_step, box):
     """The leg's own load for >= 0.6 s with (a) the in-kernel clock monitor of the library (eight sleeping waves, one per XCD, counting shader cycles
-    against the 100 MHz real-time counter: rvc_clock_monitor_*) and (b) the sysfs sampler running.  Outside the timed region and the latency soak."""
+    against the 100 MHz real-time counter: rvc_clock_monitor_*) and (b) the box sensors (amdsmi / hwmon) sampled from a thread.  Outside the timed region and the latency soak."""
     from obs_rvc_amd import _native
     n = int(min(400, max(8, np.ceil(600.0 / max(ms_per_step, 1e-3)))))
     rec = {"steps": n}
@@ -232,7 +271,7 @@ def clock_probe(job, step, ms_per_step, box):
             rec["sclk_mhz"] = round(m["sclk_mhz_mean"], 1); rec["sclk_mhz_min_xcd"] = round(m["sclk_mhz_min"], 1)
         except Exception as ex:
             rec["monitor_error"] = str(ex)
-    rec["sysfs"] = sm.summary()
+    rec["sensors"] = sm.summary()
     return rec
 
 
@@ -551,11 +590,13 @@ def compact_sub(rec):
     b = rec.get("box_under_load") or {}
     if b.get("sclk_mhz"):
         o["sclk"] = round(b["sclk_mhz"])
-    sysfs = b.get("sysfs") or {}
+    sysfs = b.get("sensors") or {}
     if sysfs.get("power_w") is not None:
         o["W"] = round(sysfs["power_w"])
     if sysfs.get("temp_c_max") is not None:
         o["C"] = round(sysfs["temp_c_max"])
+    if sysfs.get("power_cap_w") is not None and sysfs.get("power_w_max") is not None:
+        o["W_max"] = round(sysfs["power_w_max"])
     r = rec.get("roofline") or {}
     for k_in, k_out in (("frac", "frac"), ("frac_by_wall", "frac_wall"), ("frac_vs_measured_peak", "frac_meas"), ("frac_at_leg_clock", "frac_clk")):
         if r.get(k_in) is not None:
@@ -722,12 +763,18 @@ def main(argv=None):
         set_opt("RVC_SERIAL_BRANCHES", "1")
     index_vecs = W.make_index() if (job.rank == 0 and full) else None      # only rank 0 ever holds the host copy
 
-    # ---- the box: sysfs probe + in-run calibration (what this GPU's matrix cores and HBM sustain right now; every rank calibrates its own GPU)
+    # ---- the box: sensor probe + in-run calibration (what this GPU's matrix cores and HBM sustain right now; every rank calibrates its own GPU)
     # (under rocprofv3 the in-kernel clock monitor is left out: counter collection serialises dispatches, and a monitor that waits for a host flag would
     #  hold every later kernel back until its own time-out)
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ)
     CTX["calib"] = not args.no_calibration and not under_profiler
-    CTX["box"] = BoxProbe(job.local_rank)
+    bdf = None
+    try:
+        pr = job.torch.cuda.get_device_properties(job.local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        pass
+    CTX["box"] = BoxProbe(job.local_rank, bdf)
     box_idle = CTX["box"].sample()
     calib = []
     if CTX["calib"]:
@@ -856,7 +903,7 @@ def main(argv=None):
             gpu_name = job.torch.cuda.get_device_name(job.local_rank)
         except Exception:
             pass
-        box = {"gpu": gpu_name, "host_cpus": os.cpu_count(), "idle": box_idle, "headline_under_load": head.get("box_under_load")}
+        box = {"gpu": gpu_name, "pci": bdf, "sensor_source": CTX["box"].source, "host_cpus": os.cpu_count(), "idle": box_idle, "headline_under_load": head.get("box_under_load")}
         # ---- the verbose record: everything, with notes and sources (file + optionally stderr)
         full_rec = {
             "metric": "audio frames/sec (10 ms hops of new input, 160 ms chunks @16 kHz)", "value": head["frames_per_s"], "unit": "frames/s",
@@ -875,7 +922,7 @@ def main(argv=None):
                 "frac": "roofline.frac = algorithmic flops of the implicit-GEMM class / SUM of its launches' own HIP-event durations of THIS run (above 4 streams with the two front branches issued serially), against the nominal 157.3 TF/s fp32 matrix-core peak",
                 "frac_vs_measured_peak": "the same achieved figure against peak_measured[0].mfma_f32_tflops: a bare v_mfma_f32_32x32x2_f32 stream timed on this GPU at the start of this run (rvc_calibrate)",
                 "frac_at_leg_clock": "against 157.3 TF/s x (effective shader clock while the leg ran / 2400 MHz); the clock is counted by sleeping waves inside the GPU (s_memtime cycles per s_memrealtime tick, rvc_clock_monitor_*) during >= 0.6 s of the leg's own load, outside the timed region",
-                "box": "sclk / W / C per leg: shader clock from that monitor, socket power and hottest sensor from sysfs (hwmon) sampled every 50 ms during the same probe steps",
+                "box": "sclk / W / C per leg: shader clock from that monitor; socket power (W, against power_cap_w) and hotspot temperature from the SMU (amdsmi, device matched by PCI bus id) sampled every 100 ms during the same probe steps",
                 "serial_pass": "profiles/<round>_serial_<S>streams.json: rocprofv3 kernel-trace sum and HIP-event sum of one serial-branch process on the builder's box; their ratio validates the event method and is box-independent",
             },
         }
@@ -911,7 +958,7 @@ def main(argv=None):
         out["cpu_baseline"] = cpu
         out["peak_measured"] = [{k: c[k] for k in ("when", "mfma_f32_tflops", "mfma_sclk_mhz", "hbm_read_tbs", "error") if k in c} for c in calib] or None
         hl = head.get("box_under_load") or {}
-        out["box"] = {"gpu": gpu_name, "idle": box_idle, "headline": {"sclk": hl.get("sclk_mhz"), "sclk_min_xcd": hl.get("sclk_mhz_min_xcd"), **{k: v for k, v in (hl.get("sysfs") or {}).items() if k != "samples"}}}
+        out["box"] = {"gpu": gpu_name, "pci": bdf, "sensors": CTX["box"].source, "idle": box_idle, "headline": {"sclk": hl.get("sclk_mhz"), "sclk_min_xcd": hl.get("sclk_mhz_min_xcd"), **{k: v for k, v in (hl.get("sensors") or {}).items() if k != "samples"}}}
         out["sub_configs"] = {k: compact_sub(v) for k, v in sub.items()} or None
         if job.world > 1 and sub.get("streams64"):
             c4 = sub["streams64"]

@@ -17,6 +17,66 @@
 
 namespace rvc {
 
+// The epilogue of the family (one body for conv32s_kernel, conv32s_buf_kernel and conv2d32s_kernel): igemm32_kernel's C / D layout -- col = lane & 31,
+// row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) --, bias -> activation -> residual -> scale (-> accumulate); full tiles without accumulation take the
+// straight-line path (operands in store-free batches, one predicate per column block), everything else the general one.
+template <int WM, int WN, int MT, int NT>
+__device__ __forceinline__ void c32s_epilogue(const IgemmP &p, const PhaseD &ph, f32x16 (&acc)[MT][NT], const int tm, const int tn, const int wm, const int wn, const int c32,
+                                              const int ks, const int b)
+{
+    constexpr int BN = WN * NT * 32;
+    const float *resb = p.res ? p.res + (long long)b * p.res_bs : nullptr;
+    float *yb = p.y + (long long)b * p.y_bs;
+    ColOut cols[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) cols[nt] = col_locate(p, ph, tn * BN + (wn * NT + nt) * 32 + c32);
+    const int row0 = (tm * WM + wm) * MT * 32 + ks * 4;
+    const bool full_m = row0 - ks * 4 + MT * 32 <= p.M;
+    if (!p.accumulate && full_m) {
+        const float slope = p.slope, scale = p.scale;
+        const long long cs = p.y_cs, rcs = p.res_cs;
+        RVC_ACT_DISPATCH(
+            _Pragma("unroll") for (int mt = 0; mt < MT; mt++) {
+                const int m0 = row0 + mt * 32;
+                float bias_r[16];
+                _Pragma("unroll") for (int r = 0; r < 16; r++)
+                    bias_r[r] = p.bias ? p.bias[ph.bias_off + m0 + (r & 3) + 8 * (r >> 2)] : 0.f;
+                _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {
+                    if (cols[nt].yo >= 0) {
+                        float rr[16];
+                        _Pragma("unroll") for (int r = 0; r < 16; r++) rr[r] = 0.f;
+                        if (resb) {
+                            const float *rp = resb + cols[nt].ro + (long long)(p.res_nogroup ? m0 : m0 + ph.y_c0) * rcs;
+                            _Pragma("unroll") for (int r = 0; r < 16; r++) rr[r] = rp[((r & 3) + 8 * (r >> 2)) * rcs];
+                        }
+                        float *yc = yb + cols[nt].yo + (long long)(m0 + ph.y_c0) * cs;
+                        _Pragma("unroll") for (int r = 0; r < 16; r++)
+                            yc[((r & 3) + 8 * (r >> 2)) * cs] = epi2_value<A_>(acc[mt][nt][r], bias_r[r], rr[r], 0.f, slope, scale);
+                    }
+                }
+            }
+        )
+        return;
+    }
+    RVC_ACT_DISPATCH(
+        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) {
+            float bias_r[16];
+            _Pragma("unroll") for (int r = 0; r < 16; r++) {
+                const int m = row0 + mt * 32 + (r & 3) + 8 * (r >> 2);
+                bias_r[r] = (p.bias && m < p.M) ? p.bias[ph.bias_off + m] : 0.f;
+            }
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {
+                _Pragma("unroll") for (int h = 0; h < 16; h += 8) {
+                    Epi2 e_[8];
+                    _Pragma("unroll") for (int r = 0; r < 8; r++)
+                        e_[r] = epi2_aux(p, ph, resb, yb, cols[nt], row0 + mt * 32 + ((h + r) & 3) + 8 * ((h + r) >> 2), bias_r[h + r]);
+                    _Pragma("unroll") for (int r = 0; r < 8; r++) epi2_finish<A_>(p, yb, acc[mt][nt][h + r], e_[r]);
+                }
+            }
+        }
+    )
+}
+
 // (2 x 2 accumulator blocks per wave + the staging registers of the next block pass 170 registers: two waves per SIMD there, three for the 1 x 2 tiles
 //  -- the only ones instantiated: conv32s_inst.hip)
 template <int MT, int NT> struct C32sOcc { static constexpr int W = MT * NT >= 4 ? 2 : 3; };
@@ -154,57 +214,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C32sOcc<MT,
             bt += dil * CS;
         }
     }
-    // epilogue: igemm32_kernel's (C / D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
-    const float *resb = p.res ? p.res + (long long)b * p.res_bs : nullptr;
-    float *yb = p.y + (long long)b * p.y_bs;
-    ColOut cols[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) cols[nt] = col_locate(p, ph, tn * BN + (wn * NT + nt) * 32 + c32);
-    const int row0 = (tm * WM + wm) * MT * 32 + ks * 4;
-    const bool full_m = row0 - ks * 4 + MT * 32 <= p.M;
-    if (!p.accumulate && full_m) {
-        const float slope = p.slope, scale = p.scale;
-        const long long cs = p.y_cs, rcs = p.res_cs;
-        RVC_ACT_DISPATCH(
-            _Pragma("unroll") for (int mt = 0; mt < MT; mt++) {
-                const int m0 = row0 + mt * 32;
-                float bias_r[16];
-                _Pragma("unroll") for (int r = 0; r < 16; r++)
-                    bias_r[r] = p.bias ? p.bias[ph.bias_off + m0 + (r & 3) + 8 * (r >> 2)] : 0.f;
-                _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {
-                    if (cols[nt].yo >= 0) {
-                        float rr[16];
-                        _Pragma("unroll") for (int r = 0; r < 16; r++) rr[r] = 0.f;
-                        if (resb) {
-                            const float *rp = resb + cols[nt].ro + (long long)(p.res_nogroup ? m0 : m0 + ph.y_c0) * rcs;
-                            _Pragma("unroll") for (int r = 0; r < 16; r++) rr[r] = rp[((r & 3) + 8 * (r >> 2)) * rcs];
-                        }
-                        float *yc = yb + cols[nt].yo + (long long)(m0 + ph.y_c0) * cs;
-                        _Pragma("unroll") for (int r = 0; r < 16; r++)
-                            yc[((r & 3) + 8 * (r >> 2)) * cs] = epi2_value<A_>(acc[mt][nt][r], bias_r[r], rr[r], 0.f, slope, scale);
-                    }
-                }
-            }
-        )
-        return;
-    }
-    RVC_ACT_DISPATCH(
-        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) {
-            float bias_r[16];
-            _Pragma("unroll") for (int r = 0; r < 16; r++) {
-                const int m = row0 + mt * 32 + (r & 3) + 8 * (r >> 2);
-                bias_r[r] = (p.bias && m < p.M) ? p.bias[ph.bias_off + m] : 0.f;
-            }
-            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {
-                _Pragma("unroll") for (int h = 0; h < 16; h += 8) {
-                    Epi2 e_[8];
-                    _Pragma("unroll") for (int r = 0; r < 8; r++)
-                        e_[r] = epi2_aux(p, ph, resb, yb, cols[nt], row0 + mt * 32 + ((h + r) & 3) + 8 * ((h + r) >> 2), bias_r[h + r]);
-                    _Pragma("unroll") for (int r = 0; r < 8; r++) epi2_finish<A_>(p, yb, acc[mt][nt][h + r], e_[r]);
-                }
-            }
-        }
-    )
+    c32s_epilogue<WM, WN, MT, NT>(p, ph, acc, tm, tn, wm, wn, c32, ks, b);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -344,57 +354,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C32sOcc<MT,
             bt += dil * CS;
         }
     }
-    // epilogue: igemm32_kernel's (C / D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
-    const float *resb = p.res ? p.res + (long long)b * p.res_bs : nullptr;
-    float *yb = p.y + (long long)b * p.y_bs;
-    ColOut cols[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) cols[nt] = col_locate(p, ph, tn * BN + (wn * NT + nt) * 32 + c32);
-    const int row0 = (tm * WM + wm) * MT * 32 + ks * 4;
-    const bool full_m = row0 - ks * 4 + MT * 32 <= p.M;
-    if (!p.accumulate && full_m) {
-        const float slope = p.slope, scale = p.scale;
-        const long long cs = p.y_cs, rcs = p.res_cs;
-        RVC_ACT_DISPATCH(
-            _Pragma("unroll") for (int mt = 0; mt < MT; mt++) {
-                const int m0 = row0 + mt * 32;
-                float bias_r[16];
-                _Pragma("unroll") for (int r = 0; r < 16; r++)
-                    bias_r[r] = p.bias ? p.bias[ph.bias_off + m0 + (r & 3) + 8 * (r >> 2)] : 0.f;
-                _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {
-                    if (cols[nt].yo >= 0) {
-                        float rr[16];
-                        _Pragma("unroll") for (int r = 0; r < 16; r++) rr[r] = 0.f;
-                        if (resb) {
-                            const float *rp = resb + cols[nt].ro + (long long)(p.res_nogroup ? m0 : m0 + ph.y_c0) * rcs;
-                            _Pragma("unroll") for (int r = 0; r < 16; r++) rr[r] = rp[((r & 3) + 8 * (r >> 2)) * rcs];
-                        }
-                        float *yc = yb + cols[nt].yo + (long long)(m0 + ph.y_c0) * cs;
-                        _Pragma("unroll") for (int r = 0; r < 16; r++)
-                            yc[((r & 3) + 8 * (r >> 2)) * cs] = epi2_value<A_>(acc[mt][nt][r], bias_r[r], rr[r], 0.f, slope, scale);
-                    }
-                }
-            }
-        )
-        return;
-    }
-    RVC_ACT_DISPATCH(
-        _Pragma("unroll") for (int mt = 0; mt < MT; mt++) {
-            float bias_r[16];
-            _Pragma("unroll") for (int r = 0; r < 16; r++) {
-                const int m = row0 + mt * 32 + (r & 3) + 8 * (r >> 2);
-                bias_r[r] = (p.bias && m < p.M) ? p.bias[ph.bias_off + m] : 0.f;
-            }
-            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {
-                _Pragma("unroll") for (int h = 0; h < 16; h += 8) {
-                    Epi2 e_[8];
-                    _Pragma("unroll") for (int r = 0; r < 8; r++)
-                        e_[r] = epi2_aux(p, ph, resb, yb, cols[nt], row0 + mt * 32 + ((h + r) & 3) + 8 * ((h + r) >> 2), bias_r[h + r]);
-                    _Pragma("unroll") for (int r = 0; r < 8; r++) epi2_finish<A_>(p, yb, acc[mt][nt][h + r], e_[r]);
-                }
-            }
-        }
-    )
+    c32s_epilogue<WM, WN, MT, NT>(p, ph, acc, tm, tn, wm, wn, c32, ks, b);
 }
 
 }  // namespace rvc
