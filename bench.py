@@ -432,7 +432,7 @@ def committed_serial_pass(S, sum_kernel_ms):
     return rec
 
 
-KERNEL_CLASS = "implicit-GEMM class: rvc::igemm2 / igemm2w / conv_tile / igemm32 / igemm32l / conv32s(_buf) / conv2d32s / igemm_lds kernels, all instantiations"
+KERNEL_CLASS = "implicit-GEMM class: rvc::igemm2 / igemm2w / conv_tile / igemm32 / igemm32l / conv32s(_buf) / igemm_lds kernels, all instantiations"
 
 
 def roofline_of(eng, step, S, reps=5, with_index=False, version=2, preset="full"):
@@ -573,7 +573,7 @@ def compact_roofline(r):
             "peak_measured", "frac_vs_measured_peak", "leg_sclk_mhz", "frac_at_leg_clock", "traffic_bytes_per_step", "algorithmic_weight_bytes_per_step",
             "algorithmic_bytes_per_step_estimate", "events_over_rocprof_builder_box", "this_run_events_over_committed_rocprof", "serial_pass_same_build")
     out = {k: r[k] for k in keep if r.get(k) is not None or k in ("frac", "traffic")}
-    out["kernel"] = "implicit-GEMM class (igemm2/2w/32/32l, conv_tile, conv32s, conv2d32s), all launches"
+    out["kernel"] = "implicit-GEMM class (igemm2/2w/32/32l, conv_tile, conv32s), all launches"
     if r.get("traffic_source"):
         out["traffic_source"] = r["traffic_source"].split(" ")[0]
     if r.get("retrieval_scan"):

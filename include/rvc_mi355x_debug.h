@@ -29,7 +29,7 @@ double rvc_debug_conv2d_check(rvc_engine *e, int M, int Cin, int H, int W, int s
 double rvc_debug_ln_fold_check(rvc_engine *e, int M, int K, int N, float offset);
 /* weight slabs alive on a device: count and bytes (obs_rvc_amd/csrc/plan.hip, wmalloc) */
 int rvc_debug_weight_slabs(int device, int *count, size_t *bytes);
-/* the kernel the planner chose for the last rvc_debug_conv*_check launch ("c2d", "reg", "g32", ...) */
+/* the kernel the planner chose for the last rvc_debug_conv*_check launch ("reg", "g32", "c32s", ...) */
 const char *rvc_debug_last_kernel(void);
 
 #ifdef __cplusplus

@@ -29,7 +29,7 @@ SYMBOLS = [
 ]
 
 
-SOURCES = ("engine.hip", "engine_int.h", "plan.hip", "model_cv.hip", "model_rmvpe.hip", "model_synth.hip", "retrieval.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "igemm2_inst.hip", "igemm_tiled_inst.hip", "igemm2w_inst.hip", "igemm_bf3_inst.hip", "conv_tile.hip.h", "conv_tile_inst.hip", "conv32s.hip.h", "conv32s_inst.hip", "igemm32l.hip.h", "igemm32l_inst.hip", "conv2d32s.hip.h", "conv2d32s_inst.hip", "version.cpp", "calib.hip", "exports.map",
+SOURCES = ("engine.hip", "engine_int.h", "plan.hip", "model_cv.hip", "model_rmvpe.hip", "model_synth.hip", "retrieval.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "igemm2_inst.hip", "igemm_tiled_inst.hip", "igemm2w_inst.hip", "igemm_bf3_inst.hip", "conv_tile.hip.h", "conv_tile_inst.hip", "conv32s.hip.h", "conv32s_inst.hip", "igemm32l.hip.h", "igemm32l_inst.hip", "version.cpp", "calib.hip", "exports.map",
            "state.hip.h",
            "resample.hip.h", "session.hip.h", "rccl_bcast.hip.h", "blob.h", "rvc_rpc.cpp")
 
@@ -46,8 +46,7 @@ UNITS = [("engine.hip", [], _ENGINE_DEPS), ("calib.hip", [], ("calib.hip",))] + 
         [("igemm_bf3_inst.hip", [], ("igemm_bf3_inst.hip",) + _IGEMM_DEPS)] + \
         [("conv_tile_inst.hip", [], ("conv_tile_inst.hip", "conv_tile.hip.h") + _IGEMM_DEPS)] + \
         [("conv32s_inst.hip", ["-DRVC_C32S_PART=%d" % c], ("conv32s_inst.hip", "conv32s.hip.h") + _IGEMM_DEPS) for c in range(3)] + \
-        [("igemm32l_inst.hip", ["-DRVC_G32L_PART=%d" % c], ("igemm32l_inst.hip", "igemm32l.hip.h") + _IGEMM_DEPS) for c in range(2)] + \
-        [("conv2d32s_inst.hip", ["-DRVC_C2D_PART=%d" % c], ("conv2d32s_inst.hip", "conv2d32s.hip.h", "conv32s.hip.h") + _IGEMM_DEPS) for c in range(2)]
+        [("igemm32l_inst.hip", ["-DRVC_G32L_PART=%d" % c], ("igemm32l_inst.hip", "igemm32l.hip.h") + _IGEMM_DEPS) for c in range(2)]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # Object cache: content-addressed (sources + flags).  It lives under the repository's build/ directory (git- and gpurun-ignored), is
 # created 0700, and a directory that is not ours (other owner, or writable by group / others) is refused: objects are linked straight

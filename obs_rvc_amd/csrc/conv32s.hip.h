@@ -17,7 +17,7 @@
 
 namespace rvc {
 
-// The epilogue of the family (one body for conv32s_kernel, conv32s_buf_kernel and conv2d32s_kernel): igemm32_kernel's C / D layout -- col = lane & 31,
+// The epilogue of the family (one body for conv32s_kernel and conv32s_buf_kernel): igemm32_kernel's C / D layout -- col = lane & 31,
 // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) --, bias -> activation -> residual -> scale (-> accumulate); full tiles without accumulation take the
 // straight-line path (operands in store-free batches, one predicate per column block), everything else the general one.
 template <int WM, int WN, int MT, int NT>

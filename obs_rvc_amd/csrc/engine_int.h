@@ -266,7 +266,7 @@ struct Plan {
 // ---- planner entry points (plan.hip) ----
 extern unsigned long long *g_kprobe;      // tuning build (-DRVC_KPROBE): destination of the per-wave phase stamps
 extern int g_last_waves, g_last_wgs, g_ncu;
-extern char g_last_kernel[16];          // family of the most recently queued implicit-GEMM launch ("reg", "g32", "c32s", "c2d", ...)
+extern char g_last_kernel[16];          // family of the most recently queued implicit-GEMM launch ("reg", "g32", "c32s", ...)
 void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases, bool final_out = false);
 void fill_epilogue(IgemmP &p, const ConvW &cw, const ConvOpts &o);
 void add_conv1d(Plan &pl, const ConvW &cw, const T1 &x, const T1 &y, int stride, int pad, int dil, ConvOpts o = ConvOpts());

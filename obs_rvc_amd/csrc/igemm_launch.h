@@ -53,13 +53,6 @@ void launch_conv32s(int tile, const IgemmP &p, dim3 grid, size_t lds, hipStream_
 void launch_conv32s_p0(const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 void launch_conv32s_p1(int tile, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 void launch_conv32s_p2(const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
-// conv2d32s_kernel (conv2d32s.hip.h: RMVPE's Conv2d 3x3 layers at many streams as flat 1-D convolutions over the zero-haloed planes, staged like conv32s).
-// tile 0 = 32 x 256, 1 = 64 x 128, 2 = 128 x 64, 3 = 32 x 128; kC2dHalo staged columns beyond the tile
-static const int kC2dBM[4] = {32, 64, 128, 32}, kC2dBN[4] = {256, 128, 64, 128};
-static const int kC2dHalo = 192;
-void launch_conv2d32s(int tile, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
-void launch_conv2d32s_a(int tile, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
-void launch_conv2d32s_b(int tile, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 
 // exploratory split-bf16 GEMM (igemm_bf3_kernel): 128 x 128 workgroup tile; bf3_pack builds the weight panels it reads
 void launch_igemm_bf3(bool lin, bool pre, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);

@@ -6,7 +6,7 @@
 namespace rvc {
 
 static const char *const kTestHooks[] = {"RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_NO_LN_FUSE", "RVC_NO_CONV0_MULTI", "RVC_KNN_NO_GEMM",
-                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB", "RVC_CONV32S_BUF", "RVC_CONV2D32S", "RVC_CONV2D32S_TILE"};
+                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB", "RVC_CONV32S_BUF"};
 std::atomic<unsigned> g_opt_gen{0};       // bumped by every rvc_debug_option call: plans built under another generation are dropped (engine.hip get_plan)
 static std::mutex g_opt_mu;
 static std::map<std::string, std::string> g_opts;
@@ -434,112 +434,6 @@ static bool queue_conv32s(Plan &pl, IgemmP &p, int B, const std::vector<int> &ko
     return true;
 }
 
-// More than 4 streams, Conv2d 3x3 (stride 1, pad 1) on zero-haloed images whose input channels come in 32s (RMVPE's encoder / decoder levels from 32
-// channels up): conv2d32s_kernel (conv2d32s.hip.h) treats the padded plane of a channel as ONE flat row and the convolution as nine taps at the flat offsets
-// (kh - 1) ld + (kw - 1) -- conv32s's staged structure; the two halo columns of every image row are computed and masked.  The layer arrives in the 2-D
-// parameterisation of add_conv2d (N = H W, NW = W, x_hs = ld) and is re-expressed on the flat axis here (N = (H - 1) ld + W, NW = ld).  Test hook
-// RVC_CONV2D32S: 0 = off, 2 = wherever eligible (any stream count, any size); RVC_CONV2D32S_TILE forces a tile (0..3).  false = not eligible.
-static bool queue_conv2d32s(Plan &pl, IgemmP &p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phv, double ksum)
-{
-    const int mode = test_opt_int("RVC_CONV2D32S", 1);
-    if (!mode || p.fold_n || p.x_hs <= 0 || p.x_ws != 1 || p.y_hm != 1 || p.y_ws != 1 || p.glu || p.ln_wsum || p.ln_stats_in || p.ln_stats_out || p.part || p.bf3 || pl.bf3) return false;
-    if (p.y_rs != p.x_hs || (p.res && p.res_rs != p.x_hs)) return false;          // input, output and residual planes share one row stride (all are [H + 2][W + 2])
-    if (mode < 2 && (B <= 4 || p.M < 32)) return false;
-    for (const PhaseD &q : phv) if (q.act_p1 != 0 || q.y_off != 0 || q.y_pos != 0 || q.y_h0 != 0) return false;
-    const int W = p.NW, H = p.N / p.NW, ld = p.x_hs;
-    if (H * W != p.N || H < 1) return false;
-    const int CB = kC32sCB;
-    // per phase: channels, taps per row, row step from the gather table (entries ci * cs + (kh - 1) ld + (kw - 1), k = ci * 9 + kh * 3 + kw)
-    std::vector<PhaseD> phs(phv);
-    int cs = 0, reach = 0;
-    for (PhaseD &q : phs) {
-        const int K = q.nchunks * 16;
-        if (K < 18 || K % 9 != 0) return false;
-        const int cin = K / 9;
-        if (cin % CB != 0) return false;
-        const int cs_q = koff[q.koff_off + 9] - koff[q.koff_off];
-        if (cs && cs_q != cs) return false;
-        cs = cs_q;
-        const int dmin = koff[q.koff_off];
-        if (dmin != -(ld + 1) || cs < (H + 2) * ld) return false;
-        for (int k = 0; k < K; k++) if (koff[q.koff_off + k] != (k / 9) * cs + dmin + ((k % 9) / 3) * ld + (k % 3)) return false;
-        q.t_tab = 9 | (1 << 8); q.pad_ = 3 | (ld << 8); q.t_cin = cin; q.t_rs = 0; q.t_dmin = dmin;
-        reach = 2 * ld + 2;
-    }
-    if (reach > kC2dHalo) return false;
-    const int Nf = (H - 1) * ld + W;          // flat output positions of one stream: (0, 0) .. (H - 1, W - 1) inclusive of the halo columns in between
-    // tile: the candidate with the least padded MFMA work among those that give every CU a workgroup (a 32 x 32 wave tile reloads its weights twice as often
-    // as a 32 x 64 one: charged 15 %); under one workgroup per CU, or with less than ~0.6 of the tiles' work useful (images of a few rows: a tile is mostly halo
-    // and padding), the register-direct kernel with its K split stays
-    auto ntn_of = [&](int t) { return (Nf + kC2dBN[t] - 1) / kC2dBN[t]; };
-    auto ntm_of = [&](int t) { return (p.M + kC2dBM[t] - 1) / kC2dBM[t]; };
-    int tile = -1; double best = 0;
-    for (int t = 0; t < 4; t++) {
-        if (kC2dBM[t] > 32 && kC2dBM[t] > (p.M + 31) / 32 * 32) continue;          // taller than the panel: rows of padding
-        const long long w = (long long)ntm_of(t) * ntn_of(t) * (long long)phs.size() * B;
-        if (mode < 2 && w < g_ncu) continue;
-        const double cost = (double)ntm_of(t) * kC2dBM[t] * ntn_of(t) * kC2dBN[t] * (t == 3 ? 1.15 : 1.0);
-        if (tile < 0 || cost < best) { tile = t; best = cost; }
-    }
-    const int forced = test_opt_int("RVC_CONV2D32S_TILE", -1);
-    if (forced >= 0 && forced <= 3) tile = forced;
-    if (tile < 0) return false;
-    const int BM = kC2dBM[tile], BN = kC2dBN[tile];
-    const int ntm = ntm_of(tile), ntn = ntn_of(tile);
-    const double useful = (double)H * W * p.M / ((double)ntn * BN * ntm * BM);
-    if (mode < 2 && useful < 0.6) return false;
-    if (phs.size() > 65535 || B > 65535) return false;
-    const size_t lds = (size_t)(BN + reach) * kC32sCS * 4;
-    if (lds > 64 * 1024) return false;
-    // weights: K order (block, tap, group)-major, as for conv32s_kernel
-    std::vector<float> wnew;
-    const int mt = (p.M + 15) / 16;
-    for (PhaseD &q : phs) {
-        const int KW = 9, cin = q.t_cin, GB = CB / 16, nblk = cin / CB;
-        std::vector<float> wold((size_t)mt * q.nchunks * 256);
-        HIPCHK(hipMemcpy(wold.data(), p.w + q.w_off, wold.size() * 4, hipMemcpyDeviceToHost));
-        const size_t base = wnew.size();
-        wnew.resize(base + wold.size());
-        for (int t = 0; t < mt; t++)
-            for (int blk = 0; blk < nblk; blk++)
-                for (int tap = 0; tap < KW; tap++)
-                    for (int g = 0; g < GB; g++)
-                        for (int l = 0; l < 64; l++)
-                            for (int j = 0; j < 4; j++) {
-                                const int k = (blk * CB + g * 16 + (l >> 4) * 4 + j) * KW + tap;          // the source's k
-                                wnew[base + (((size_t)t * q.nchunks + (blk * KW + tap) * GB + g) * 64 + l) * 4 + j] =
-                                    wold[(((size_t)t * q.nchunks + k / 16) * 64 + (((k % 16) / 4) << 4 | (l & 15))) * 4 + (k % 4)];
-                            }
-        q.w_off = (long long)base;
-    }
-    p.w = pl.arena.upload(wnew);
-    p.koff = nullptr; p.items = nullptr; p.ttab = nullptr;
-    p.ph = pl.arena.upload(phs);
-    p.nphase = (int)phs.size();
-    p.ph0 = phs[0];
-    // the flat axis
-    p.N = Nf; p.NW = ld; p.x_hs = 0;
-    p.x_ld = cs; p.x_lo = -(ld + 1); p.x_lim = H * ld + W;
-    p.ntm = ntm; p.ntn = ntn; p.ksplit = 1; p.nbatch = B; p.m_fast = 0; p.pad2_ = 0;
-    const dim3 grid((unsigned)(ntm * ntn), (unsigned)B, (unsigned)p.nphase);
-    g_last_wgs = (int)(grid.x * grid.y * grid.z); g_last_waves = 4;
-    const double flops = 2.0 * p.M * (double)H * W * ksum * B;          // the layer's own flops (halo columns and tile padding are overhead, not work)
-    pl.igemm_flops += flops; pl.n_igemm++;
-    Plan *plp = &pl;
-    { char d[200]; snprintf(d, sizeof d, "c2d M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%ux%u lds=%zu img=%dx%d useful=%.2f ksum=%.0f", p.M, H * W, p.K, B, p.nphase, BM, BN, grid.x, grid.y, grid.z, lds, H, W, useful, ksum); pl.descs.push_back(d); note_kernel(d); }
-    const int desc_id = (int)pl.descs.size() - 1;
-    const IgemmP pc = p;
-    pl.ops.push_back([=](hipStream_t s) {
-        ProfEvent *pe = nullptr;
-        if (plp->profile) {
-            if (plp->prof_used == plp->prof.size()) { ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; e.bytes = 0; plp->prof.push_back(e); }
-            pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
-        }
-        launch_conv2d32s(tile, pc, grid, lds, s, pe ? pe->a : nullptr, pe ? pe->b : nullptr);
-    });
-    return true;
-}
-
 // generic: the caller fills geometry (N, NW, strides, koff, phases); this picks the tile + split-K and queues the op
 // Which table-free 1x1 layers take igemm2w_kernel, and with what tile / K split (filled in from per-layer measurements: tests/tools/g2w_sweep.py).
 // gt < 0: not this kernel.
@@ -585,16 +479,9 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         // five streams and more: the staged 32x32x2 convolution (streams as a grid dimension: also before the fold)
         pt = p;
         if (queue_conv32s(pl, pt, B, koff, phq, ks0, final_out)) return;
-        // ... and its 2-D form for RMVPE's 3x3 layers
-        pt = p;
-        if (!final_out && queue_conv2d32s(pl, pt, B, koff, phq, ks0)) return;
-    }
-    if (B == 1 && test_opt_int("RVC_CONV2D32S", 1) == 2 && !final_out) {           // test hook: the 2-D kernel forced onto one stream
-        std::vector<PhaseD> phq(phases);
-        double ks0 = 0;
-        for (PhaseD &q : phq) { if (q.nchunks == 0) q.nchunks = p.K / 16; ks0 += q.nchunks * 16.0; }
-        IgemmP pt = p;
-        if (queue_conv2d32s(pl, pt, B, koff, phq, ks0)) return;
+        // (round 6: the same structure for RMVPE's Conv2d 3x3 layers -- conv2d32s_kernel, the padded planes as flat 1-D rows -- was built, parity-green and
+        //  SLOWER than the register-direct kernel at 16 / 64 / 128 streams, 41-54 against 60-67 TF/s: the layers are 0.6-1.2 GFLOP with K = 288-576, a tile's
+        //  K loop is 18-36 chunks behind a 50 KB staging prologue.  Not in the tree; DESIGN.md section 7 round 6, profiles/r06_conv2d32s_*.txt)
     }
     if (B == 1 && test_opt_int("RVC_CONV32S", 1) == 2) {           // test hook: the kernel forced onto one stream
         std::vector<PhaseD> phq(phases);

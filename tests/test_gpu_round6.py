@@ -1,12 +1,11 @@
 """Round-6 GPU tests (through the C ABI, against the oracle / fp64 host evaluations): the full-size stream counts the bench times but no oracle test ran
-(2 and 4 streams, v1 at 2 streams), one rank of BASELINE configs[4] (64 streams + the 100k x 768 index), the staged 2-D convolution of RMVPE at many
-streams, the in-run calibration, the weight slabs -- SURVEY.md section 8 rows a6, a12, a16, d."""
+(2 and 4 streams, v1 at 2 streams), one rank of BASELINE configs[4] (64 streams + the 100k x 768 index), RMVPE's 2-D layers at many streams (every planner choice vs fp64, the nine rm.* taps), the in-run calibration, the weight slabs -- SURVEY.md section 8 rows a6, a12, a16, d."""
 import ctypes as C
 
 import numpy as np
 import pytest
 
-from common import BASELINE_160MS as g, rms, set_opt, voice_signal, zoo
+from common import BASELINE_160MS as g, rms, voice_signal, zoo
 from obs_rvc_amd import _native, weights as W
 
 pytestmark = pytest.mark.gpu
@@ -88,8 +87,9 @@ C2D_SHAPES = [(16, 16, 32, 128), (32, 32, 16, 64), (64, 64, 8, 32), (128, 128, 4
 @pytest.mark.parametrize("streams", [1, 3, 8, 20])
 @pytest.mark.parametrize("residual", [0, 1, 2])
 def test_conv2d_3x3_every_planner_choice_against_fp64(streams, residual):
-    # Conv2d 3x3 (pad 1) + bias + ReLU (+ residual / accumulate) through whatever kernel the planner picks at that stream count -- the register-direct
-    # 16x16x4 kernel at few streams, the staged 2-D convolution (conv2d32s_kernel) at many -- against a double-precision host evaluation.
+    # Conv2d 3x3 (pad 1) + bias + ReLU (+ residual / accumulate) through whatever kernel and tile the planner picks at that stream count (RMVPE's layers
+    # run on the register-direct 16x16x4 kernel with streams folded into N; the staged 2-D form of round 6 lost to it and is not in the tree) against a
+    # double-precision host evaluation.
     from obs_rvc_amd.rvc import RvcInfer
     z = zoo("tiny")
     eng = RvcInfer(z["data"])
@@ -101,32 +101,6 @@ def test_conv2d_3x3_every_planner_choice_against_fp64(streams, residual):
         assert 0 <= err < 2e-5, (M, Cin, H, Wd, streams, residual, err)
     eng.close()
     assert seen, seen
-
-
-@pytest.mark.parametrize("force", ["0", "2"])
-@pytest.mark.parametrize("streams", [1, 5, 16])
-def test_conv2d_staged_kernel_forced_and_off(force, streams):
-    # test hook RVC_CONV2D32S: 0 = the staged 2-D convolution never, 2 = wherever it is eligible (any stream count) -- both against fp64, and with the hook
-    # at 2 the kernel must really have run on the 32-channel-block shapes
-    from obs_rvc_amd.rvc import RvcInfer
-    z = zoo("tiny")
-    set_opt("RVC_CONV2D32S", force)
-    try:
-        eng = RvcInfer(z["data"])
-        L = _conv2d_check()
-        kinds = {}
-        for (M, Cin, H, Wd) in C2D_SHAPES:
-            for residual in (0, 1, 2):
-                err = L.rvc_debug_conv2d_check(eng._h, M, Cin, H, Wd, streams, 0, residual)
-                kinds[(M, Cin, H, Wd)] = L.rvc_debug_last_kernel().decode()
-                assert 0 <= err < 2e-5, (force, M, Cin, H, Wd, streams, residual, err)
-        eng.close()
-    finally:
-        set_opt("RVC_CONV2D32S", None)
-    if force == "2":
-        assert kinds[(64, 64, 8, 32)] == "c2d" and kinds[(128, 128, 4, 16)] == "c2d" and kinds[(32, 32, 16, 64)] == "c2d", kinds
-    else:
-        assert "c2d" not in kinds.values(), kinds
 
 
 @pytest.mark.parametrize("streams", [1, 4, 16])
@@ -144,7 +118,7 @@ def test_conv_transpose2d_against_fp64(streams):
 
 @pytest.mark.parametrize("S", [8, 64])
 def test_rmvpe_taps_at_many_streams_on_the_production_plan(S):
-    # the nine rm.* taps at 8 and 64 streams on the plan that really runs (the staged 2-D convolution takes RMVPE's 3x3 layers there).
+    # the nine rm.* taps at 8 and 64 streams on the plan that really runs (streams folded into N, three-level decomposition of the 2-D images).
     # Taps are stream 0's tensors; the oracle runs stream 0.
     z = zoo("full")
     eng = _engine(z, S, (6, 0))

@@ -9,7 +9,7 @@ import csv, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from obs_rvc_amd import _native
 
-IGEMM = ("igemm_kernel", "igemm2_kernel", "igemm2w_kernel", "igemm_lds_kernel", "igemm32_kernel", "igemm32l_kernel", "igemm32w_kernel", "igemm_bf3_kernel", "conv_tile_kernel", "conv32s_kernel", "conv32s_buf_kernel", "conv2d32s_kernel", "splitk_epilogue_kernel")
+IGEMM = ("igemm_kernel", "igemm2_kernel", "igemm2w_kernel", "igemm_lds_kernel", "igemm32_kernel", "igemm32l_kernel", "igemm32w_kernel", "igemm_bf3_kernel", "conv_tile_kernel", "conv32s_kernel", "conv32s_buf_kernel", "splitk_epilogue_kernel")
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = sum(int(r["Calls"]) for r in rows if "advance_chunk_kernel" in r["Name"])
 if steps < 3:
