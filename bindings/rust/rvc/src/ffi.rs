@@ -89,6 +89,10 @@ extern "C" {
     pub fn rvc_plan_cache_info(e: *mut RvcEngine, capacity: *mut c_int, cached: *mut c_int, builds: *mut c_longlong) -> c_int;
     pub fn rvc_retrieval_recoveries(e: *mut RvcEngine) -> c_longlong;
     pub fn rvc_set_gemm_precision(e: *mut RvcEngine, mode: c_int) -> c_int;
+    // plan-time selection among eligible kernels / tiles by measurement (default on above 4 streams)
+    pub fn rvc_set_plan_autotune(e: *mut RvcEngine, on: c_int) -> c_int;
+    pub fn rvc_plan_autotune_info(e: *mut RvcEngine, tuned: *mut c_int, changed: *mut c_int, cache_hits: *mut c_int, tune_ms: *mut c_double,
+                                  build_ms: *mut c_double) -> c_int;
     // what this GPU sustains, measured in-run (bare fp32-MFMA stream, HBM read stream), and the effective shader clock while other work runs
     pub fn rvc_calibrate(device: c_int, out: *mut RvcCalibration) -> c_int;
     pub fn rvc_clock_monitor_start(device: c_int) -> c_int;

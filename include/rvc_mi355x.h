@@ -143,6 +143,15 @@ void rvc_set_use_graph(rvc_engine *e, int on);    /* replay the per-chunk launch
  * tens of milliseconds; a server that rotates through more geometries than the cache holds pays that on every call.  rvc_plan_cache_info reports
  * capacity, plans currently cached and plans built since rvc_create (-> 1 on a valid engine). */
 rvc_status rvc_set_plan_cache(rvc_engine *e, int n_plans);
+/* Plan-time selection by measurement.  The planner's kernel / tile rules are thresholds measured on one box at a handful of stream counts and one geometry;
+ * every plugin instance has its own geometry (obs-rvc/src/lib.rs:200-227) and GPUs of one pool differ.  With on = 1 (the default) a plan of MORE THAN 4 STREAMS
+ * times, while it is built and on the engine's own device, the eligible kernels / tiles of every layer that has more than one (the rule-based choice and its
+ * neighbours across the nearest thresholds: a warm-up and 1-3 timed launches each) and keeps the fastest; results are cached per process by (device, layer
+ * signature, stream count).  All candidates are parity-tested kernels: the choice affects fp32 summation order only.  A first plan build at 64 streams takes
+ * ~0.1-0.3 s longer, later builds of the same layers nothing.  on = 0: the rules only (results then do not depend on timing).  rvc_plan_autotune_info reports
+ * the engine's LAST plan build: layers tuned by trials, layers whose choice differs from the rules, layers served from the cache, ms in trials, ms in all. */
+rvc_status rvc_set_plan_autotune(rvc_engine *e, int on);
+rvc_status rvc_plan_autotune_info(rvc_engine *e, int *tuned, int *changed, int *cache_hits, double *tune_ms, double *build_ms);
 /* EXPLORATORY (no counterpart in the reference, off by default, never used for the headline figure): mode 1 = the 1-D layers with >= 128 output rows (ContentVec's projections and stem, the decoder's wide stages) run every
  * fp32 product as three bf16 matrix-core products (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulate) in launches of >= 250 workgroups of 128 x 128 (many
  * streams); ~2^-16 relative per product instead of fp32 rounding.  mode 0 = fp32 everywhere, the reference's arithmetic. */

@@ -27,6 +27,10 @@ int rvc_debug_profile_dump(rvc_engine *e, char *buf, size_t cap);
 double rvc_debug_conv_check(rvc_engine *e, int M, int Cin, int KW, int dil, int N, int streams, int pre_act);
 double rvc_debug_conv2d_check(rvc_engine *e, int M, int Cin, int H, int W, int streams, int kind, int residual);
 double rvc_debug_ln_fold_check(rvc_engine *e, int M, int K, int N, float offset);
+/* the autotuner's decisions of this process, one line each ("<layer signature> -> [choice] <kernel description> | <us> (<candidates>)"); returns the number of
+ * entries.  reset forgets them (the next plan build measures again). */
+int rvc_debug_autotune_dump(char *buf, size_t cap);
+void rvc_debug_autotune_reset(void);
 /* weight slabs alive on a device: count and bytes (obs_rvc_amd/csrc/plan.hip, wmalloc) */
 int rvc_debug_weight_slabs(int device, int *count, size_t *bytes);
 /* the kernel the planner chose for the last rvc_debug_conv*_check launch ("reg", "g32", "c32s", ...) */

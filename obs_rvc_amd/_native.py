@@ -23,7 +23,7 @@ SYMBOLS = [
     "rvc_resampler_create", "rvc_resampler_destroy", "rvc_resampler_input_frames_next", "rvc_resampler_output_frames_max",
     "rvc_resampler_reset", "rvc_resampler_process", "rvc_resampler_process_device",
     "rvc_rccl_unique_id", "rvc_index_broadcast", "rvc_rccl_available", "rvc_index_broadcast_info",
-    "rvc_set_plan_cache", "rvc_plan_cache_info", "rvc_retrieval_recoveries", "rvc_set_gemm_precision",
+    "rvc_set_plan_cache", "rvc_plan_cache_info", "rvc_set_plan_autotune", "rvc_plan_autotune_info", "rvc_retrieval_recoveries", "rvc_set_gemm_precision",
     "rvc_calibrate", "rvc_clock_monitor_start", "rvc_clock_monitor_stop",
     "rvc_session_create", "rvc_session_destroy", "rvc_session_process", "rvc_session_frame_size", "rvc_session_set_params", "rvc_session_set_params_stream", "rvc_session_geometry",
 ]
@@ -270,6 +270,9 @@ def lib():
     L.rvc_session_set_params_stream.argtypes = [vp, C.c_int, i32, C.c_double]
     L.rvc_session_geometry.argtypes = [vp, C.POINTER(i32)]
     L.rvc_session_geometry.restype = None
+    if hasattr(L, "rvc_set_plan_autotune") or not override:
+        L.rvc_set_plan_autotune.argtypes = [vp, C.c_int]
+        L.rvc_plan_autotune_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if hasattr(L, "rvc_calibrate") or not override:
         L.rvc_calibrate.argtypes = [C.c_int, C.POINTER(Calibration)]
         L.rvc_clock_monitor_start.argtypes = [C.c_int]

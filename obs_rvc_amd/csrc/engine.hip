@@ -5,6 +5,7 @@
 // All compute is launched as hand-written gfx950 kernels (kernels.hip.h); nothing here falls
 // back to a CPU path: without a HIP device every entry point returns RVC_BACKEND.
 #include "engine_int.h"
+#include <chrono>
 
 // The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The engine runs four
 // streams concurrently per chunk; a second engine in the process, or the streams an RCCL communicator leaves behind, then share
@@ -210,8 +211,10 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
             return hit;
         }
     e->plan_builds++;
+    const auto build_t0 = std::chrono::steady_clock::now();
     std::unique_ptr<Plan> up(new Plan());
     Plan &pl = *up;
+    pl.autotune = e->autotune != 0 && B > 4;          // (queue_igemm: trials on this device while the plan is built; plans of <= 4 streams keep the latency-tuned rules)
     pl.mode = mode; pl.L = L; pl.frame16k = frame16k; pl.skip_head = skip_head; pl.R = R; pl.B = B; pl.with_index = with_index; pl.with_taps = e->taps_on != 0; pl.plain_plan = e->taps_on == 1; pl.bucket = bucket_B > 0;
     pl.slot = slot; pl.opt_gen = gen; pl.bf3 = e->gemm_precision == 1;
     pl.d_in = pl.arena.floats((size_t)B * L + 64);
@@ -303,6 +306,8 @@ static Plan *get_plan(rvc_engine *e, int mode, size_t L, size_t frame16k, uint32
         pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(advance_chunk_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, B, hst); });
     }
     HIPCHK(hipDeviceSynchronize());
+    e->last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - build_t0).count();
+    e->last_tuned = pl.tuned_layers; e->last_changed = pl.tune_changed; e->last_hits = pl.tune_hits; e->last_tune_ms = pl.tune_ms;
     // bounded plan cache (each geometry owns its activation arena and graph; rvc_set_plan_cache): evict the least recently used
     while ((int)e->plans.size() >= e->plan_cap) { if (e->last_plan == e->plans.front().get()) e->last_plan = nullptr; e->plans.erase(e->plans.begin()); }
     e->plans.push_back(std::move(up));
@@ -851,6 +856,34 @@ rvc_status rvc_set_gemm_precision(rvc_engine *e, int mode)
 // Plan cache: one plan (activation arena, composed weights, launch list) per geometry (mode, n, frame, skip_head, return_length, streams,
 // retrieval on/off, pipeline slot).  Every plugin instance has its own geometry (obs-rvc/src/lib.rs:200-227): a server that serves more
 // geometries than the cache holds rebuilds a plan on every miss.
+// Plan-time selection by measurement (plan.hip, queue_igemm): on = 1 (default) lets plans of more than 4 streams time the eligible kernels / tiles of every
+// layer on this device while the plan is built and keep the fastest; on = 0: the planner's rules only.  Cached plans are dropped when the setting changes.
+rvc_status rvc_set_plan_autotune(rvc_engine *e, int on)
+{
+    return guarded(e, [&]() {
+        const int v = on ? 1 : 0;
+        if (v != e->autotune) {
+            HIPCHK(hipDeviceSynchronize());
+            e->plans.clear(); e->last_plan = nullptr;
+            e->autotune = v;
+        }
+        return RVC_OK;
+    });
+}
+// the engine's LAST plan build: layers tuned by trials in it, layers whose choice differs from the rules, layers taken from the process-wide cache of earlier
+// trials, milliseconds spent in trials, milliseconds of the whole build
+rvc_status rvc_plan_autotune_info(rvc_engine *e, int *tuned, int *changed, int *cache_hits, double *tune_ms, double *build_ms)
+{
+    return guarded(e, [&]() {
+        if (tuned) *tuned = e->last_tuned;
+        if (changed) *changed = e->last_changed;
+        if (cache_hits) *cache_hits = e->last_hits;
+        if (tune_ms) *tune_ms = e->last_tune_ms;
+        if (build_ms) *build_ms = e->last_build_ms;
+        return RVC_OK;
+    });
+}
+
 rvc_status rvc_set_plan_cache(rvc_engine *e, int n_plans)
 {
     return guarded(e, [&]() {

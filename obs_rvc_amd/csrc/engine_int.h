@@ -68,10 +68,11 @@ public:
     {
         bytes = (bytes + 255) / 256 * 256;
         if (bytes > left_) {
-            size_t sz = std::max(bytes, (size_t)64 << 20);
+            size_t sz = std::max(bytes, chunk_min_);
             void *c;
             HIPCHK(hipMalloc(&c, sz));
             HIPCHK(hipMemset(c, 0, sz));
+            if (chunks_.empty()) first_size_ = sz;
             chunks_.push_back(c);
             cur_ = (char *)c;
             left_ = sz;
@@ -90,8 +91,17 @@ public:
         return d;
     }
     size_t total() const { return total_; }
+    void set_chunk_min(size_t b) { chunk_min_ = b; }          // (trial plans of the autotuner hold one layer's tables: small chunks)
+    // start over in the first chunk, keeping the memory (the autotuner's scratch plan: hundreds of trials per plan build, no hipMalloc / hipFree per trial);
+    // later chunks are returned.  The memory is NOT zeroed again: only for arenas that hold tables, never activation tensors with halos.
+    void rewind()
+    {
+        while (chunks_.size() > 1) { (void)hipFree(chunks_.back()); chunks_.pop_back(); }
+        if (!chunks_.empty()) { cur_ = (char *)chunks_[0]; left_ = first_size_; total_ = first_size_; }
+    }
 
 private:
+    size_t chunk_min_ = (size_t)64 << 20, first_size_ = 0;
     std::vector<void *> chunks_;
     char *cur_ = nullptr;
     size_t left_ = 0, total_ = 0;
@@ -164,6 +174,9 @@ ConvW prep_conv(const float *w, const float *bias, int Cout, int Cin, int KW, in
 ConvW prep_convT1d(const float *w, const float *bias, int Cin, int Cout, int K, int S);
 ConvW prep_convT2d(const float *w, const float *bias, int Cin, int Cout);
 void free_conv(ConvW &c);
+// conv32s_kernel's K order of a phase's fragment panel ((channel block, tap, channel group)-major): built ONCE per source panel by a device kernel and
+// shared by every plan (and every trial of the autotuner); forgotten when the source conv is freed (plan.hip)
+const float *c32s_panel(const float *src_frag, int M, int nchunks, int cin, int KW);
 void merge_convs(const std::vector<ConvW *> &cs);
 
 // ---------------------------------------------------------------------------------------
@@ -221,6 +234,8 @@ struct Plan {
     bool with_index = false, with_taps = false;
     bool bucket = false;          // a plan of rvc_infer_batch_g: built for a subset of the streams on the gathered state block (rvc_engine::d_state_bucket)
     bool bf3 = false;             // built under rvc_set_gemm_precision(e, 1): ContentVec's 1x1 GEMMs on the split-bf16 kernel (exploratory)
+    bool autotune = false;        // rvc_set_plan_autotune: layers with several eligible kernels / tiles are chosen by timing them at plan build (plan.hip queue_igemm)
+    double tune_ms = 0; int tuned_layers = 0, tune_changed = 0, tune_hits = 0;      // time spent in trials, layers tuned here / changed against the rules / taken from the process cache
     bool plain_plan = false;      // taps level 1: the explicit plan (LayerNorm launches, WaveNets layer by layer); level 2 taps the production plan
     int mode = 0;   // 0 infer, 1 hubert only, 2 pitch only
     // I/O tensors
@@ -811,6 +826,9 @@ struct rvc_engine {
     Plan *last_plan = nullptr;
     int gemm_precision = 0;           // 0 = fp32 everywhere (the product), 1 = split-bf16 for ContentVec's 1x1 GEMMs at many streams (exploratory)
     int plan_cap = 8;                 // rvc_set_plan_cache
+    int autotune = 1;                 // rvc_set_plan_autotune: 1 = plans of more than 4 streams pick among eligible kernels by timing them at plan build, 0 = the rules only
+    double last_build_ms = 0;         // wall time of the last plan build (rvc_plan_autotune_info)
+    int last_tuned = 0, last_changed = 0, last_hits = 0; double last_tune_ms = 0;
     long long knn_recoveries = 0;     // chunks whose retrieval was recomputed after a hand-off time-out (rvc_retrieval_info)
     long long plan_builds = 0;        // plans built since rvc_create (a miss = arena allocation + composed weights + a device synchronisation)
     int taps_on = 0;               // 0 off, 1 taps on the explicit plan, 2 taps on the production plan (rvc_enable_taps)

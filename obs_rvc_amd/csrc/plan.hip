@@ -2,6 +2,7 @@
 // order), and the translation of a layer (Conv1d / ConvT1d / Conv2d / ConvT2d / Linear, fused variants) into implicit-GEMM launches: tile
 // choice, in-workgroup K split, streams folded into N, staged-tile convolution, 32x32x2 throughput kernels.
 #include "engine_int.h"
+#include <chrono>
 
 namespace rvc {
 
@@ -175,8 +176,55 @@ ConvW prep_convT2d(const float *w, const float *bias, int Cin, int Cout)
     if (bias) c.bias = upload_f(bias, Cout);
     return c;
 }
+// ---- conv32s_kernel's weight order, built on the device and cached per source panel (every plan build copied every eligible decoder panel to
+// the host, repacked it in a six-deep CPU loop and uploaded a private copy -- once per layer, per plan, per trial) ----
+static __global__ void c32s_repack_kernel(const float *src, float *dst, int mt, int nchunks, int KW, int nblk)
+{
+    // dst[((t * nchunks + (blk * KW + tap) * 2 + g) * 64 + l) * 4 + j]  <-  source k = (blk * 32 + g * 16 + (l >> 4) * 4 + j) * KW + tap of the 16-row fragment packing
+    const long long total = (long long)mt * nchunks * 256;
+    for (long long d = (long long)blockIdx.x * blockDim.x + threadIdx.x; d < total; d += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(d & 3), l = (int)((d >> 2) & 63);
+        const long long tc = d >> 8;
+        const int c = (int)(tc % nchunks), t = (int)(tc / nchunks);
+        const int g = c & 1, bt = c >> 1, tap = bt % KW, blk = bt / KW;
+        if (blk >= nblk) { dst[d] = 0.f; continue; }
+        const int k = (blk * 32 + g * 16 + (l >> 4) * 4 + j) * KW + tap;
+        dst[d] = src[(((long long)t * nchunks + k / 16) * 64 + ((((k % 16) / 4) << 4) | (l & 15))) * 4 + (k % 4)];
+    }
+}
+namespace {
+struct PanelKey { const float *src; int M, nchunks, cin, KW; bool operator<(const PanelKey &o) const { return std::tie(src, M, nchunks, cin, KW) < std::tie(o.src, o.M, o.nchunks, o.cin, o.KW); } };
+std::mutex g_panel_mu;
+std::map<PanelKey, float *> g_panels;
+}
+const float *c32s_panel(const float *src_frag, int M, int nchunks, int cin, int KW)
+{
+    std::lock_guard<std::mutex> lk(g_panel_mu);
+    const PanelKey key{src_frag, M, nchunks, cin, KW};
+    auto it = g_panels.find(key);
+    if (it != g_panels.end()) return it->second;
+    const int mt = (M + 15) / 16;
+    const size_t n = (size_t)mt * nchunks * 256 + (size_t)16 * 256;      // (+ slack: a wave's weight requests run one chunk past its last)
+    float *dst = (float *)wmalloc(n * sizeof(float));
+    HIPCHK(hipMemsetAsync(dst + (size_t)mt * nchunks * 256, 0, (size_t)16 * 256 * sizeof(float), nullptr));
+    hipLaunchKernelGGL(c32s_repack_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, nullptr, src_frag, dst, mt, nchunks, KW, cin / 32);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(nullptr));
+    g_panels[key] = dst;
+    return dst;
+}
+static void c32s_forget(const float *base, size_t elems)
+{
+    std::lock_guard<std::mutex> lk(g_panel_mu);
+    for (auto it = g_panels.begin(); it != g_panels.end();) {
+        if (it->first.src >= base && it->first.src < base + elems) { wfree(it->second); it = g_panels.erase(it); }
+        else ++it;
+    }
+}
+
 void free_conv(ConvW &c)
 {
+    if (c.w) c32s_forget(c.w, (size_t)c.nphase * (size_t)phase_stride(c));
     if (c.owns) {
         if (c.w) wfree(c.w);
         if (c.bias) wfree(c.bias);
@@ -214,9 +262,20 @@ static void note_kernel(const char *d) { size_t i = 0; for (; i < sizeof(g_last_
 // Builds the LDS-offset tables (k -> row * RS + tap column) from the layer's gather table and a work-item table that balances the
 // unequal phases of a fused launch over the CUs (workgroup b lands on CU b % ncu: tests/tools/place_probe.hip).  false = not eligible.
 int g_ncu = 256;
+
+// Plan-time selection by measurement (rvc_set_plan_autotune, queue_igemm below): a trial build of a layer runs under a forced Choice -- the same switch points
+// the test hooks RVC_CONV32S_TILE / RVC_FORCE_G2W / RVC_FORCE_CFG use, per layer and thread-local instead of process-wide.  A choice the layer is not eligible
+// for falls through to the rules (the trial then reports the same kernel description as the rule-based build and is not timed twice).
+struct Choice {
+    int kind = 0;      // 0 = the rules; 1 = conv32s_kernel (a = tile | 4 for the buffer-load variant of tile 1); 2 = igemm2w_kernel (tile a, K split b);
+    int a = 0, b = 0;  // 3 = workgroup-tiled kernels (lds_cfg a: 3 4 5 7 8); 4 = register-direct kernel (tile a, K split b)
+    bool operator==(const Choice &o) const { return kind == o.kind && a == o.a && b == o.b; }
+};
+static thread_local Choice t_choice;
+
 static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phv, double ksum, bool final_out)
 {
-    const int mode = test_opt_int("RVC_CONV_TILE", 1);       // test hook: 0 = off, 2 = wherever eligible; read per plan
+    const int mode = t_choice.kind ? 0 : test_opt_int("RVC_CONV_TILE", 1);       // test hook: 0 = off, 2 = wherever eligible; read per plan
     auto no = [&](int why) { (void)why; return false; };
     // streams: one always; two to four with the same narrow tiles and the streams in the item table (measured -1 % / -2 % at 2 / 4 streams, nothing at
     // 8; wider tiles for many streams measured slower than the 32x32x2 kernels and are gone)
@@ -339,7 +398,9 @@ static bool queue_conv_tile(Plan &pl, IgemmP &p, int B, const std::vector<int> &
 // count, any size), "RVC_CONV32S_TILE" forces a tile (0..2).  false = not eligible.
 static bool queue_conv32s(Plan &pl, IgemmP &p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phv, double ksum, bool final_out)
 {
-    const int mode = test_opt_int("RVC_CONV32S", 1);
+    if (t_choice.kind != 0 && t_choice.kind != 1) return false;          // (a trial of another kernel family)
+    const bool chosen = t_choice.kind == 1;                               // (a trial of THIS family: the size rules below are what is being measured)
+    const int mode = chosen ? 2 : test_opt_int("RVC_CONV32S", 1);
     if (!mode || p.fold_n || p.x_ld <= 0 || p.x_hs || p.x_ws != 1 || p.y_hm || p.y_ws != 1 || p.glu || p.ln_wsum || p.ln_stats_in || p.ln_stats_out || p.part || p.bf3 || pl.bf3) return false;
     if (mode < 2 && (B <= 4 || p.N < 200 || p.M < 32)) return false;
     for (const PhaseD &q : phv) if (q.act_p1 != 0 || q.y_off != 0 || q.y_pos != 0) return false;
@@ -347,7 +408,7 @@ static bool queue_conv32s(Plan &pl, IgemmP &p, int B, const std::vector<int> &ko
     // of tests/tools/c32s_layers.py: 2 x 2 accumulator blocks per wave -- 128 x 128, 64 x 256 -- lose to these at every count but 64, where they tie)
     auto wgs_of = [&](int t) { return (long long)((p.M + kC32sBM[t] - 1) / kC32sBM[t]) * ((p.N + kC32sBN[t] - 1) / kC32sBN[t]) * (long long)phv.size() * B; };
     int tile = p.M <= 32 ? 0 : (p.M <= 64 ? 1 : 2);
-    const int forced = test_opt_int("RVC_CONV32S_TILE", -1);
+    const int forced = chosen ? (t_choice.a & 3) : test_opt_int("RVC_CONV32S_TILE", -1);
     if (forced >= 0 && forced <= 2) tile = forced;
     // under two workgroups per CU the register-direct kernels with their K split win (256-row stage at 32 streams: 684 vs 720 us)
     if (mode < 2 && wgs_of(tile) < 2 * g_ncu) return false;
@@ -355,9 +416,7 @@ static bool queue_conv32s(Plan &pl, IgemmP &p, int B, const std::vector<int> &ko
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     if (phv.size() > 65535 || B > 65535) return false;
     std::vector<PhaseD> phs(phv);
-    std::vector<float> wnew;
     size_t lds_max = 0;
-    const int mt = (p.M + 15) / 16;
     for (PhaseD &q : phs) {
         const int K = q.nchunks * 16;
         int cin = 1;
@@ -372,23 +431,9 @@ static bool queue_conv32s(Plan &pl, IgemmP &p, int B, const std::vector<int> &ko
         if ((KW - 1) * dil > 64) return false;          // (the kernel's staging grid covers BN + 64 columns)
         q.t_tab = KW | (dil << 8); q.t_cin = cin; q.t_rs = 0; q.t_dmin = dmin;
         lds_max = std::max(lds_max, (size_t)(BN + (KW - 1) * dil) * kC32sCS * 4);
-        // K order of the kernel: chunk (block * KW + tap) * 2 + group, slot kk of a chunk <- source k = (block * 32 + group * 16 + kk) * KW + tap
-        std::vector<float> wold((size_t)mt * q.nchunks * 256);
-        HIPCHK(hipMemcpy(wold.data(), p.w + q.w_off, wold.size() * 4, hipMemcpyDeviceToHost));
-        const size_t base = wnew.size();
-        wnew.resize(base + wold.size());
-        const int GB = CB / 16, nblk = cin / CB;
-        for (int t = 0; t < mt; t++)
-            for (int blk = 0; blk < nblk; blk++)
-                for (int tap = 0; tap < KW; tap++)
-                    for (int g = 0; g < GB; g++)
-                        for (int l = 0; l < 64; l++)
-                            for (int j = 0; j < 4; j++) {
-                                const int k = (blk * CB + g * 16 + (l >> 4) * 4 + j) * KW + tap;          // the source's k
-                                wnew[base + (((size_t)t * q.nchunks + (blk * KW + tap) * GB + g) * 64 + l) * 4 + j] =
-                                    wold[(((size_t)t * q.nchunks + k / 16) * 64 + (((k % 16) / 4) << 4 | (l & 15))) * 4 + (k % 4)];
-                            }
-        q.w_off = (long long)base;
+        // K order of the kernel: chunk (block * KW + tap) * 2 + group, slot kk of a chunk <- source k = (block * 32 + group * 16 + kk) * KW + tap: the phase's
+        // panel in that order comes from the per-model cache (c32s_panel: built once on the device, shared by all plans)
+        q.t_rs = KW;          // (scratch until the panels are fetched below: the staged kernel does not read t_rs)
     }
     if (lds_max > 60 * 1024) return false;
     // three-tap layers of the 64- / 128- / 256-row panels at 24 streams and more stay on igemm32_kernel: a channel block is only six chunks there, shorter than
@@ -399,7 +444,16 @@ static bool queue_conv32s(Plan &pl, IgemmP &p, int B, const std::vector<int> &ko
         for (const PhaseD &q : phs) kw_max = std::max(kw_max, q.t_tab & 0xff);
         if (mode < 2 && kw_max <= 3 && p.M >= 64 && B >= 24) return false;
     }
-    p.w = pl.arena.upload(wnew);
+    {
+        const float *w0 = nullptr;
+        for (PhaseD &q : phs) {
+            const float *panel = c32s_panel(p.w + q.w_off, p.M, q.nchunks, q.t_cin, q.t_rs);
+            if (!w0) w0 = panel;
+            q.w_off = panel - w0;          // (device pointers of one flat address space)
+            q.t_rs = 0;
+        }
+        p.w = w0;
+    }
     p.koff = nullptr; p.items = nullptr; p.ttab = nullptr;
     p.ph = pl.arena.upload(phs);
     p.nphase = (int)phs.size();
@@ -410,14 +464,14 @@ static bool queue_conv32s(Plan &pl, IgemmP &p, int B, const std::vector<int> &ko
     p.pad2_ = tune_env("RVC_C32S_DBG") ? atoi(tune_env("RVC_C32S_DBG")) : 0;
     // the 64 x 128 tile takes the buffer-load kernel below 24 streams (us per six launches, all-buffer build against this one: 8 streams 437 vs 474, 16 streams 461 vs 479,
     // 32 streams 842 vs 775, 64 streams 1 543 vs 1 510-1 533); test hook RVC_CONV32S_BUF: 0 never, 2 always
-    const int buf_opt = test_opt_int("RVC_CONV32S_BUF", 1);
+    const int buf_opt = chosen ? ((t_choice.a & 4) ? 2 : 0) : test_opt_int("RVC_CONV32S_BUF", 1);
     const int ltile = tile | ((tile == 1 && (buf_opt == 2 || (buf_opt == 1 && B < 24))) ? 4 : 0);
     const dim3 grid((unsigned)(ntm * ntn), (unsigned)B, (unsigned)p.nphase);
     g_last_wgs = (int)(grid.x * grid.y * grid.z); g_last_waves = 4;
     const double flops = 2.0 * p.M * (double)p.N * ksum * B;
     pl.igemm_flops += flops; pl.n_igemm++;
     Plan *plp = &pl;
-    { char d[200]; snprintf(d, sizeof d, "c32s M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%ux%u lds=%zu pre=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, BM, BN, grid.x, grid.y, grid.z, lds_max, (int)(p.pre_act != ACT_NONE), ksum); pl.descs.push_back(d); note_kernel(d); }
+    { char d[200]; snprintf(d, sizeof d, "c32s M=%d N=%d K=%d B=%d nph=%d tile=%dx%d%s grid=%ux%ux%u lds=%zu pre=%d ksum=%.0f", p.M, p.N, p.K, B, p.nphase, BM, BN, (ltile & 4) ? "b" : "", grid.x, grid.y, grid.z, lds_max, (int)(p.pre_act != ACT_NONE), ksum); pl.descs.push_back(d); note_kernel(d); }
     const int desc_id = (int)pl.descs.size() - 1;
     const IgemmP pc = p;
     if (final_out) pl.final_out_honoured = true;
@@ -461,7 +515,7 @@ static void g2w_rule(const IgemmP &p, int nchunks, int &gt, int &gk)
     gt = 0; gk = ks;
 }
 
-void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases, bool final_out)
+static void queue_igemm_impl(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases, bool final_out)
 {
     p.probe = g_kprobe;
     // many streams: fold them into the N axis (one launch-wide column index instead of a grid dimension), so that tiles are cut from
@@ -655,7 +709,9 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
     {
         const bool g2w_ok = p.lin_cs4 != 0 && p.nphase == 1 && !pre && !p.glu && !ln_fold && B == 1 && nchunks >= 1;
         int gt = -1, gk = 1;
-        if (const char *f = test_opt("RVC_FORCE_G2W")) { if (sscanf(f, "%d,%d", &gt, &gk) < 1) gt = -1; }
+        if (t_choice.kind == 2) { gt = t_choice.a; gk = t_choice.b; }
+        else if (t_choice.kind != 0) gt = -1;
+        else if (const char *f = test_opt("RVC_FORCE_G2W")) { if (sscanf(f, "%d,%d", &gt, &gk) < 1) gt = -1; }
         else g2w_rule(p, nchunks, gt, gk);
         if (g2w_ok && gt >= 0 && gt <= 2) {
             if (gk != 1 && gk != 2 && gk != 3 && gk != 4 && gk != 6 && gk != 8) gk = gk > 8 ? 8 : 4;
@@ -699,13 +755,19 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         if (g32_ok && (wl == 3 || wl == 4 || wl == 5 || wl == 7 || wl == 8)) lds_cfg = wl;
         else if (wl == -1) lds_cfg = -1;
     }
+    if (t_choice.kind == 3) {
+        const int wl = t_choice.a;
+        const bool g32_ok = !ln_fold && !p.glu && nchunks >= 2 && (size_t)nchunks * 64 + 2 * 256 * 20 * 4 <= 60 * 1024;
+        const int need_m = (wl == 3 || wl == 7) ? 96 : ((wl == 4 || wl == 8) ? 48 : 17);
+        if (g32_ok && (wl == 3 || wl == 4 || wl == 5 || wl == 7 || wl == 8) && p.M >= need_m) lds_cfg = wl;
+    } else if (t_choice.kind == 4) lds_cfg = -1;
     // igemm32l_kernel (one-phase 1-D layers, buffer loads with scalar offsets): its 128 x 64 tile beats the 128 x 128 tile of either kernel on every layer it can
     // take -- the 3072-row projection (64 streams 36.12 -> 35.81 ms), the 2304-row one (35.31 -> 35.05), the strided stem (35.28 -> 35.05; 16 / 32 streams
     // 11.35 / 19.70 -> 11.23 / 19.50) -- so those layers move there (test hook RVC_G32L_TALL = 0: keep the 128 x 128 tile)
     const bool g32l_on = p.lin_cs4 != 0 && p.nphase == 1 && !pre && !p.bf3 && !pl.bf3 && test_opt_int("RVC_G32L", 1) != 0;
     const bool g32t_on = !g32l_on && p.lin_cs4 == 0 && p.nphase == 1 && B == 1 && p.x_hs == 0 && p.y_hm == 0 && !p.bf3 && !pl.bf3 && !p.glu &&
                          test_opt_int("RVC_G32L", 1) != 0 && test_opt_int("RVC_G32L_TAB", 1) != 0;
-    if ((g32l_on || (g32t_on && !pre)) && lds_cfg == 3 && test_opt_int("RVC_G32L_TALL", 1) != 0) lds_cfg = 7;
+    if ((g32l_on || (g32t_on && !pre)) && lds_cfg == 3 && t_choice.kind != 3 && test_opt_int("RVC_G32L_TALL", 1) != 0) lds_cfg = 7;
     if (lds_cfg >= 0) {
         const int bm = lds_cfg == 8 ? 64 : (lds_cfg == 7 ? 128 : (lds_cfg == 6 ? 48 : (lds_cfg % 3 == 0 ? 128 : (lds_cfg % 3 == 1 ? 64 : 32))));
         const int bn = (lds_cfg == 7 || lds_cfg == 8) ? 64 : ((lds_cfg != 6 && lds_cfg % 3 == 0) ? 128 : 256);
@@ -763,6 +825,12 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
     }
     if (const char *f = test_opt("RVC_FORCE_CFG")) {   // tuning aid: "cfg,ks[,mfast]"
         int fc = 0, fk = 1; if (sscanf(f, "%d,%d", &fc, &fk) >= 1) { cfg = fc; wg_ks = fk; }
+    }
+    if (t_choice.kind == 4 && !(p.ln_wsum || p.ln_stats_in)) {
+        const int fc = t_choice.a, fk = t_choice.b;
+        const bool ok = fc >= 0 && fc <= 4 && (fk == 1 || ((fk == 4 || fk == 8 || fk == 16) && nchunks / fk >= 4 && fk * kMF[fc] * kNF[fc] <= 32)) &&
+                        (size_t)nchunks * 64 + (fk > 1 ? (size_t)fk * kMF[fc] * kNF[fc] * 1024 : 0) <= 60 * 1024;
+        if (ok) { cfg = fc; wg_ks = fk; }
     }
     if (p.ln_wsum || p.ln_stats_in) {
         // folded LayerNorm: one stream or a few folded into N (statistics are per launch column), in-workgroup K split (the statistics / the
@@ -835,6 +903,201 @@ void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const 
         if (ksplit > 1) hipLaunchKernelGGL(splitk_epilogue_kernel, egrid, dim3(256), 0, s, p);
         if (pe && ksplit > 1) HIPCHK(hipEventRecord(pe->b, s));
     });
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Plan-time selection by measurement (the rules above are thresholds fitted on one box at the bench's stream counts and geometry; every
+// plugin instance has its own geometry, obs-rvc/src/lib.rs:200-227, and boxes of one pool differ by 10 %).  With Plan::autotune (rvc_set_plan_autotune,
+// default on above 4 streams) every layer that has more than one eligible kernel / tile is built as the rule-based choice AND as its neighbours across the
+// nearest thresholds -- each in a scratch plan, launched on the engine's device: one warm-up, then the best of two timed launches (three when two candidates
+// are within 8 %) -- and the fastest is queued.  Results are cached per process by (device, layer signature, streams), so the twelve identical transformer
+// layers, the second plan slot and later engines cost nothing, and two engines of one process always agree.  Every candidate is a kernel the parity tests
+// cover; the choice changes fp32 summation order at most.  A plan built while a planner test hook is set is never tuned (the hook IS the choice).
+namespace {
+struct TuneRec { Choice c; std::string desc; double us; int ncand; };
+std::mutex g_tune_mu;
+std::map<std::string, TuneRec> g_tune;
+std::atomic<long long> g_tune_trials{0};
+hipStream_t tune_stream()
+{
+    static thread_local std::map<int, hipStream_t> st;
+    int dev = 0; HIPCHK(hipGetDevice(&dev));
+    auto it = st.find(dev);
+    if (it != st.end()) return it->second;
+    hipStream_t s; HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    st[dev] = s;
+    return s;
+}
+bool planner_hook_set()
+{
+    static const char *const names[] = {"RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_FORCE_G2W", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB", "RVC_CONV32S_BUF"};
+    for (const char *n : names) if (test_opt(n)) return true;
+    return false;
+}
+}
+
+// one candidate in a scratch plan: -> microseconds per launch (best of `reps`), < 0 if it cannot be built; *desc = the kernel it really became
+static double tune_trial(const Plan &pl, const IgemmP &p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases, const Choice &c, int reps, std::string *desc)
+{
+    // one scratch plan per thread, rewound between trials (its arena holds a layer's tables only)
+    static thread_local std::unique_ptr<Plan> scratch;
+    static thread_local int scratch_dev = -1;
+    int dev = 0; HIPCHK(hipGetDevice(&dev));
+    if (!scratch || scratch_dev != dev) { scratch.reset(new Plan()); scratch->arena.set_chunk_min((size_t)8 << 20); scratch_dev = dev; }
+    Plan &tp = *scratch;
+    HIPCHK(hipStreamSynchronize(tune_stream()));          // (the previous trial's launches still read the tables that are about to be overwritten)
+    tp.ops = OpList(); tp.descs.clear(); tp.arena.rewind();
+    tp.B = pl.B; tp.bf3 = pl.bf3; tp.autotune = false; tp.profile = false; tp.igemm_flops = 0; tp.n_igemm = 0;
+    const Choice saved = t_choice;
+    t_choice = c;
+    try { queue_igemm_impl(tp, p, B, koff, phases, false); }
+    catch (...) { t_choice = saved; return -1.0; }
+    t_choice = saved;
+    if (tp.ops.v.empty() || tp.descs.empty()) return -1.0;
+    *desc = tp.descs.back();
+    hipStream_t st = tune_stream();
+    static thread_local hipEvent_t ea = nullptr, eb = nullptr;
+    if (!ea) { HIPCHK(hipEventCreate(&ea)); HIPCHK(hipEventCreate(&eb)); }
+    Op &op = tp.ops.v.back();
+    // the first launch is a warm-up (code object, tables and weights into the caches) -- and, timed, already the answer for a long kernel, whose cold-start
+    // share is below the 1.5 % a candidate must win by
+    double best = 1e30;
+    for (int r = 0; r <= reps; r++) {
+        HIPCHK(hipEventRecord(ea, st));
+        op(st);
+        HIPCHK(hipEventRecord(eb, st));
+        HIPCHK(hipEventSynchronize(eb));
+        float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, ea, eb));
+        if (r == 0 && ms < 0.4f) continue;          // short kernels: the warm-up does not count
+        best = std::min(best, (double)ms * 1e3);
+        if (ms >= 0.4f && r + 1 >= reps) break;          // long kernels: one launch fewer
+    }
+    HIPCHK(hipGetLastError());
+    g_tune_trials.fetch_add(1);
+    return best;
+}
+
+void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases, bool final_out)
+{
+    if (!pl.autotune || B <= 4 || pl.bf3 || p.bf3 || p.ln_wsum || p.ln_stats_in || p.ln_stats_out || planner_hook_set() || t_choice.kind != 0) return queue_igemm_impl(pl, p, B, koff, phases, final_out);
+    // layer signature: everything the kernels' speed depends on (shape, strides, taps, epilogue class), not the tensors
+    std::string key;
+    {
+        int dev = 0; HIPCHK(hipGetDevice(&dev));
+        unsigned long long h = 1469598103934665603ull;
+        auto mix = [&](long long v) { h ^= (unsigned long long)v; h *= 1099511628211ull; };
+        for (size_t i = 0; i < koff.size(); i += std::max<size_t>(1, koff.size() / 97)) mix(koff[i]);
+        mix((long long)koff.size());
+        for (const PhaseD &q : phases) { mix(q.nchunks); mix(q.y_pos); mix(q.y_h0); mix(q.act_p1); mix(q.y_off != 0); mix(q.x_off); }
+        char k[256];
+        snprintf(k, sizeof k, "d%d B%d M%d N%d K%d ph%zu NW%d xs%d,%d ys%d,%d ld%d lin%d pre%d act%d res%d acc%d glu%d fo%d h%llx", dev, B, p.M, p.N, p.K, phases.size(), p.NW, p.x_hs, p.x_ws, p.y_hm, p.y_ws,
+                 p.x_ld, p.lin_cs4 != 0, p.pre_act != ACT_NONE, p.act, p.res != nullptr, p.accumulate, p.glu, (int)final_out, h);
+        key = k;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        auto it = g_tune.find(key);
+        if (it != g_tune.end()) {
+            const Choice c = it->second.c;
+            t_choice = c;
+            try { queue_igemm_impl(pl, p, B, koff, phases, final_out); } catch (...) { t_choice = Choice(); throw; }
+            t_choice = Choice();
+            pl.tune_hits++;
+            return;
+        }
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    // the rule-based build first: its family decides which neighbours are worth a trial
+    std::string d0;
+    const double us0 = tune_trial(pl, p, B, koff, phases, Choice(), 2, &d0);
+    if (us0 < 0) return queue_igemm_impl(pl, p, B, koff, phases, final_out);
+    const std::string fam = d0.substr(0, d0.find(' '));
+    std::vector<Choice> cands;
+    auto add = [&](int kind, int a, int b) { Choice c; c.kind = kind; c.a = a; c.b = b; for (const Choice &o : cands) if (o == c) return; cands.push_back(c); };
+    const bool one_d = p.x_ld > 0 && p.x_hs == 0 && p.x_ws == 1 && p.y_hm == 0 && p.y_ws == 1 && !p.glu;      // conv32s_kernel's domain (it checks the rest itself)
+    const bool lin = p.lin_cs4 != 0 && phases.size() == 1 && p.pre_act == ACT_NONE && !p.glu;
+    const int t32 = p.M <= 32 ? 0 : (p.M <= 64 ? 1 : 2);                                              // conv32s tile by panel height
+    const int lc_m = p.M >= 96 ? 7 : (p.M >= 48 ? 8 : 5);                                             // a 32x32x2 workgroup tile by panel height
+    int nchunks = p.K / 16;
+    auto g2w_ks = [&](int &ks) {          // g2w_rule's K split on the folded column count (the rule itself sees the layer after the fold)
+        const long long tiles = (long long)((p.M + 31) / 32) * (((long long)B * p.N + 31) / 32), want = (4800 + tiles / 2) / std::max<long long>(tiles, 1);
+        ks = want <= 1 ? 1 : (want == 2 ? 2 : (want == 3 ? 3 : (want <= 4 ? 4 : 8)));
+        while (ks > 1 && nchunks / ks < 4) ks = ks == 8 ? 4 : ks - 1;
+    };
+    if (fam == "c32s") {
+        add(1, t32 == 2 ? 1 : t32 + 1, 0); if (t32 > 0) add(1, t32 - 1, 0);
+        if (t32 == 1) { add(1, 1 | 4, 0); add(1, 1, 0); }            // both load variants of the 64 x 128 tile
+        add(3, lc_m, 0);
+    } else if (fam == "g2w") {
+        int ks; g2w_ks(ks);
+        add(2, 0, ks == 1 ? 2 : ks / 2); if (ks < 8) add(2, 0, ks == 3 ? 4 : ks * 2);
+        add(3, p.M >= 96 ? 8 : lc_m, 0); add(4, 3, 4);
+    } else if (fam == "g32l" || fam == "g32t" || fam == "g32" || fam == "lds") {
+        // the neighbouring workgroup tiles, the staged convolution / the register-direct 32x32x2 kernel where the layer is in their domain, the register-direct 16x16x4 kernel
+        if (p.M >= 96) { add(3, 7, 0); add(3, 3, 0); add(3, 8, 0); } else if (p.M >= 48) { add(3, 4, 0); add(3, 8, 0); add(3, 5, 0); } else add(3, 5, 0);
+        if (one_d && !lin) add(1, t32, 0);
+        if (lin && p.M >= 256) { int ks; g2w_ks(ks); add(2, 0, ks); }
+        add(4, p.M > 16 ? 3 : 1, nchunks >= 16 ? 4 : 1);
+    } else if (fam == "reg") {
+        if (one_d && !lin) add(1, t32, 0);
+        if (lin && p.M >= 256) { int ks; g2w_ks(ks); add(2, 0, ks); }
+        if (p.M > 16) add(3, lc_m, 0);
+        // the other K split of the same tile (the rule wants >= 1024 waves; with streams folded into N a wave count between the steps goes either way)
+        {
+            int ks = 1; const char *q = strstr(d0.c_str(), " ks="); if (q) ks = atoi(q + 4);
+            int cf = 0; const char *t = strstr(d0.c_str(), " tile="); int bm = 16, bn = 16; if (t && sscanf(t + 6, "%dx%d", &bm, &bn) == 2) { for (int c = 0; c < 5; c++) if (16 * kMF[c] == bm && 16 * kNF[c] == bn) cf = c; }
+            add(4, cf, ks == 1 ? 4 : (ks == 4 ? 8 : 4));
+            if (cf == 4 || cf == 3) add(4, cf == 4 ? 3 : 0, ks);
+        }
+    }
+    struct Res { Choice c; std::string d; double us; };
+    std::vector<Res> res;
+    res.push_back({Choice(), d0, us0});
+    for (const Choice &c : cands) {
+        std::string d;
+        // skip what cannot beat the leader by a wide margin: a single timed launch first
+        double us = tune_trial(pl, p, B, koff, phases, c, 1, &d);
+        if (us < 0) continue;
+        bool dup = false;
+        for (const Res &r : res) dup = dup || r.d == d;
+        if (dup) continue;
+        double lead = 1e30; for (const Res &r : res) lead = std::min(lead, r.us);
+        if (us < lead * 1.08) us = std::min(us, tune_trial(pl, p, B, koff, phases, c, 2, &d));
+        res.push_back({c, d, us});
+    }
+    size_t bi = 0;
+    for (size_t i = 1; i < res.size(); i++) if (res[i].us < res[bi].us) bi = i;
+    // the rules keep a tie: a candidate must win by more than the noise of two launches
+    if (bi != 0 && res[bi].us > res[0].us * 0.985) bi = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        g_tune[key] = TuneRec{res[bi].c, res[bi].d, res[bi].us, (int)res.size()};
+    }
+    pl.tune_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    pl.tuned_layers++;
+    if (bi != 0) pl.tune_changed++;
+    t_choice = res[bi].c;
+    try { queue_igemm_impl(pl, p, B, koff, phases, final_out); } catch (...) { t_choice = Choice(); throw; }
+    t_choice = Choice();
+}
+
+// the autotuner's decisions of this process, one line each: "<key> -> <kernel description> <us> (<candidates>)"; returns the number of entries (test / tool aid)
+extern "C" int rvc_debug_autotune_dump(char *buf, size_t cap)
+{
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    std::string out;
+    for (const auto &kv : g_tune) {
+        char ln[640];
+        snprintf(ln, sizeof ln, "%s -> [%d,%d,%d] %s | %.1f us (%d candidates)\n", kv.first.c_str(), kv.second.c.kind, kv.second.c.a, kv.second.c.b, kv.second.desc.c_str(), kv.second.us, kv.second.ncand);
+        out += ln;
+    }
+    if (buf && out.size() + 1 <= cap) memcpy(buf, out.c_str(), out.size() + 1);
+    return (int)g_tune.size();
+}
+extern "C" void rvc_debug_autotune_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tune.clear();
 }
 
 void fill_epilogue(IgemmP &p, const ConvW &cw, const ConvOpts &o)

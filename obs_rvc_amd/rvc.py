@@ -215,6 +215,17 @@ class RvcInfer:
         """Plans (one per call geometry) the engine keeps; least recently used evicted first (rvc_set_plan_cache)."""
         self._chk(self._L.rvc_set_plan_cache(self._h, int(n_plans)))
 
+    def set_plan_autotune(self, on: bool = True):
+        """plans of more than 4 streams pick among the eligible kernels / tiles of every layer by timing them at plan build (default on); False: the rules only"""
+        self._chk(self._L.rvc_set_plan_autotune(self._h, 1 if on else 0))
+
+    def plan_autotune_info(self) -> dict:
+        """the last plan build: layers tuned by trials / changed against the rules / served from the process cache, ms in trials, ms in all"""
+        t, c, h = C.c_int(), C.c_int(), C.c_int()
+        tm, bm = C.c_double(), C.c_double()
+        self._chk(self._L.rvc_plan_autotune_info(self._h, C.byref(t), C.byref(c), C.byref(h), C.byref(tm), C.byref(bm)))
+        return {"tuned": t.value, "changed": c.value, "cache_hits": h.value, "tune_ms": tm.value, "build_ms": bm.value}
+
     def plan_cache_info(self) -> dict:
         cap, cached, builds = C.c_int(), C.c_int(), C.c_longlong()
         self._L.rvc_plan_cache_info(self._h, C.byref(cap), C.byref(cached), C.byref(builds))

@@ -190,3 +190,35 @@ def test_weight_slabs_are_per_device_and_plan_copies_have_their_own():
     e1.close(); e2.close()
     n4, _ = slabs()
     assert n4 == n0, (n0, n4)          # everything returned
+
+
+@pytest.mark.parametrize("S", [8, 24])
+def test_autotuned_plan_matches_the_oracle_and_the_rule_based_plan(S):
+    # above 4 streams the plan times the eligible kernels / tiles of every layer on this device and keeps the fastest (rvc_set_plan_autotune,
+    # default on).  Whatever it picks is a parity-tested kernel: the autotuned plan and the rule-based plan of the same engine both match the oracle, and
+    # each other far inside the tolerance (fp32 summation order is all that can differ).  The first build measures, later builds of the same layers come from
+    # the process cache; a plan build stays interactive.
+    z = zoo("full")
+    eng = _engine(z, S, (8, 500))
+    xin = np.stack([voice_signal(g.input_buffer_16k_size, seed=300 + s) for s in range(S)])
+    outs = {}
+    for on in (True, False, True):
+        eng.set_plan_autotune(on)
+        eng.reset_state(); eng.set_noise_seed(8, 500)
+        y = eng.infer_batch(xin, g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+        info = eng.plan_autotune_info()
+        if on and True not in outs:
+            assert info["tuned"] + info["cache_hits"] > 20, info          # (an earlier test of this process may have filled the cache)
+            assert info["build_ms"] < 3000.0, info
+            first = info
+        elif on:
+            assert info["tuned"] == 0 and info["cache_hits"] > 20, info      # everything from the cache: nothing is measured twice
+            assert info["build_ms"] < 1000.0, info
+        else:
+            assert info["tuned"] == 0 and info["cache_hits"] == 0, info
+        outs.setdefault(on, y)
+    assert rms(outs[True] - outs[False]) < 5e-5
+    for s in (0, S - 1):
+        yo = _oracle(z, 8, 500 + s).infer(xin[s], g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
+        assert rms(outs[True][s] - yo) < PCM_TOL and rms(outs[False][s] - yo) < PCM_TOL, (s, rms(outs[True][s] - yo))
+    eng.close()
