@@ -118,8 +118,11 @@ class BoxProbe:
     key, never an error.  The leg's CLOCK of record is the in-kernel monitor's (rvc_clock_monitor_*), these are the box's own view next to it."""
 
     def __init__(self, local_rank=0, bdf=None):
-        self.smi = self.h = self.hwmon = None
+        self.smi = self.h = self.hwmon = self.uuid = None
         self.bdf = (bdf or "").lower()
+        self.source = None
+        if bdf == "none":
+            return
         try:
             import amdsmi
             amdsmi.amdsmi_init()
@@ -135,6 +138,10 @@ class BoxProbe:
                 pick = hs[local_rank] if local_rank < len(hs) else hs[0]
             if pick is not None:
                 self.smi, self.h = amdsmi, pick
+                try:
+                    self.uuid = str(amdsmi.amdsmi_get_gpu_device_uuid(pick))
+                except Exception:
+                    pass
         except Exception:
             pass
         if self.smi is None:
@@ -774,7 +781,7 @@ def main(argv=None):
         bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
     except Exception:
         pass
-    CTX["box"] = BoxProbe(job.local_rank, bdf)
+    CTX["box"] = BoxProbe(job.local_rank, bdf if CTX["calib"] else "none")      # (--no-calibration: no sensor library is loaded at all)
     box_idle = CTX["box"].sample()
     calib = []
     if CTX["calib"]:
@@ -903,7 +910,7 @@ def main(argv=None):
             gpu_name = job.torch.cuda.get_device_name(job.local_rank)
         except Exception:
             pass
-        box = {"gpu": gpu_name, "pci": bdf, "sensor_source": CTX["box"].source, "host_cpus": os.cpu_count(), "idle": box_idle, "headline_under_load": head.get("box_under_load")}
+        box = {"gpu": gpu_name, "pci": bdf, "uuid": CTX["box"].uuid, "sensor_source": CTX["box"].source, "host_cpus": os.cpu_count(), "idle": box_idle, "headline_under_load": head.get("box_under_load")}
         # ---- the verbose record: everything, with notes and sources (file + optionally stderr)
         full_rec = {
             "metric": "audio frames/sec (10 ms hops of new input, 160 ms chunks @16 kHz)", "value": head["frames_per_s"], "unit": "frames/s",
@@ -958,7 +965,7 @@ def main(argv=None):
         out["cpu_baseline"] = cpu
         out["peak_measured"] = [{k: c[k] for k in ("when", "mfma_f32_tflops", "mfma_sclk_mhz", "hbm_read_tbs", "error") if k in c} for c in calib] or None
         hl = head.get("box_under_load") or {}
-        out["box"] = {"gpu": gpu_name, "pci": bdf, "sensors": CTX["box"].source, "idle": box_idle, "headline": {"sclk": hl.get("sclk_mhz"), "sclk_min_xcd": hl.get("sclk_mhz_min_xcd"), **{k: v for k, v in (hl.get("sensors") or {}).items() if k != "samples"}}}
+        out["box"] = {"gpu": gpu_name, "pci": bdf, "uuid": CTX["box"].uuid, "sensors": CTX["box"].source, "idle": box_idle, "headline": {"sclk": hl.get("sclk_mhz"), "sclk_min_xcd": hl.get("sclk_mhz_min_xcd"), **{k: v for k, v in (hl.get("sensors") or {}).items() if k != "samples"}}}
         out["sub_configs"] = {k: compact_sub(v) for k, v in sub.items()} or None
         if job.world > 1 and sub.get("streams64"):
             c4 = sub["streams64"]

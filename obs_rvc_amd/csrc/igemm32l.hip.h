@@ -26,8 +26,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G32Occ<MT, 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wm = wave / WN, wn = wave % WN;
-    const int tid_x = p.m_fast == 1 ? xcd_tile_id((int)blockIdx.x, (int)gridDim.x, (int)(blockIdx.y * gridDim.x)) : (int)blockIdx.x;
-    const int tn = p.m_fast ? tid_x / p.ntm : tid_x % p.ntn, tm = p.m_fast ? tid_x % p.ntm : tid_x / p.ntn;
+    int tn, tm;
+    if (p.m_fast == 3) {
+        // Panel order (round 6; tall table-free panels with streams folded into N -- ContentVec's 2304- / 3072-row projections): the launch's n-tiles are dealt
+        // to the 8 XCDs as contiguous ranges, and INSIDE an XCD the tiles run panel by panel: mp m-tiles (a weight panel that fits the XCD's L2 next to the
+        // activation tiles) x all of the XCD's n-tiles, n-tile major, before the next panel.  With m fastest over all m-tiles (m_fast = 1) every n-tile streamed
+        // the WHOLE weight matrix (7-9 MB > the 4 MB L2) through the cache: 480 MB of fabric reads per 2304 x 768 launch for 29 MB of operands.  The grid is
+        // padded to 8 x (most tiles any XCD owns); surplus workgroups leave at once.  Block x runs on XCD x % 8 (dispatch order, tests/tools/xcd_probe.hip).
+        const int c = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3;
+        const int nb = p.ntn >> 3, nr = p.ntn & 7;
+        const int nx = nb + (c < nr ? 1 : 0), n0 = c * nb + (c < nr ? c : nr);
+        const int mp = p.pad2_, np = p.ntm / mp, mr = p.ntm - np * mp;
+        if (i >= nx * p.ntm) return;
+        const int full = np * mp * nx;
+        if (i < full) { const int g = i / (mp * nx), r = i - g * mp * nx; tn = n0 + r / mp; tm = g * mp + r % mp; }
+        else { const int r = i - full; tn = n0 + r / mr; tm = np * mp + r % mr; }
+    } else {
+        const int tid_x = p.m_fast == 1 ? xcd_tile_id((int)blockIdx.x, (int)gridDim.x, (int)(blockIdx.y * gridDim.x)) : (int)blockIdx.x;
+        tn = p.m_fast ? tid_x / p.ntm : tid_x % p.ntn; tm = p.m_fast ? tid_x % p.ntm : tid_x / p.ntn;
+    }
     const int b = blockIdx.y;
     const PhaseD &ph = p.ph0;
     const int nchunks = ph.nchunks;

@@ -7,7 +7,7 @@
 namespace rvc {
 
 static const char *const kTestHooks[] = {"RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_NO_LN_FUSE", "RVC_NO_CONV0_MULTI", "RVC_KNN_NO_GEMM",
-                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB", "RVC_CONV32S_BUF"};
+                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB", "RVC_CONV32S_BUF", "RVC_FORCE_CHOICE", "RVC_G32L_PANEL"};
 std::atomic<unsigned> g_opt_gen{0};       // bumped by every rvc_debug_option call: plans built under another generation are dropped (engine.hip get_plan)
 static std::mutex g_opt_mu;
 static std::map<std::string, std::string> g_opts;
@@ -792,6 +792,17 @@ static void queue_igemm_impl(Plan &pl, IgemmP p, int B, const std::vector<int> &
         const bool g32l = ((lc == 3 || lc == 7 || lc == 8) && g32l_on && !(lc == 3 && p.m_fast == 2)) || g32t;
         const int g32l_mode = g32t ? (pre ? 2 : 1) : 0;
         const size_t lds_l = (size_t)2 * bn * 20 * 4;
+        // panel order inside the XCDs (igemm32l.hip.h, m_fast = 3) for tall table-free panels whose weights exceed an L2: mp m-tiles = the largest panel of
+        // <= 2.5 MB; test hook RVC_G32L_PANEL = 0: the orders of round 4 (m fastest over XCD-local ids / the raw block index)
+        if (g32l && !g32t && p.fold_n && B == 1 && (lc == 7 || lc == 8) && p.ntm >= 8 && p.ntn >= 16 && test_opt_int("RVC_G32L_PANEL", 1) != 0) {
+            const size_t per_tile = (size_t)bm * (size_t)ksum * sizeof(float);
+            const int mp = (int)std::max<size_t>(1, ((size_t)5 << 19) / per_tile);
+            if ((size_t)p.M * (size_t)ksum * sizeof(float) > ((size_t)5 << 19) && mp < p.ntm) {
+                p.m_fast = 3; p.pad2_ = mp;
+                const int nx_max = (p.ntn + 7) / 8;
+                grid = dim3((unsigned)(8 * nx_max * p.ntm), 1u);
+            }
+        }
         { char d[160]; snprintf(d, sizeof d, "%s M=%d N=%d K=%d B=%d nph=%d tile=%dx%d grid=%ux%u", g32t ? "g32t" : g32l ? "g32l" : (lds_cfg >= 3 && lds_cfg != 6) ? "g32" : "lds", p.M, p.N, p.K, B, p.nphase, bm, bn, grid.x, grid.y); pl.descs.push_back(d); note_kernel(d); }
         const int desc_id = (int)pl.descs.size() - 1;
         if (final_out) pl.final_out_honoured = true;
@@ -930,7 +941,7 @@ hipStream_t tune_stream()
 }
 bool planner_hook_set()
 {
-    static const char *const names[] = {"RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_FORCE_G2W", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB", "RVC_CONV32S_BUF"};
+    static const char *const names[] = {"RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_FORCE_G2W", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB", "RVC_CONV32S_BUF", "RVC_FORCE_CHOICE", "RVC_G32L_PANEL"};
     for (const char *n : names) if (test_opt(n)) return true;
     return false;
 }
@@ -979,6 +990,14 @@ static double tune_trial(const Plan &pl, const IgemmP &p, int B, const std::vect
 
 void queue_igemm(Plan &pl, IgemmP p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases, bool final_out)
 {
+    if (const char *f = test_opt("RVC_FORCE_CHOICE")) {          // test hook "kind,a,b": every layer built under ONE of the choices the tuner can make (tests/test_gpu_tiles.py)
+        Choice c; if (sscanf(f, "%d,%d,%d", &c.kind, &c.a, &c.b) < 1) c = Choice();
+        const Choice saved = t_choice;
+        t_choice = c;
+        try { queue_igemm_impl(pl, p, B, koff, phases, final_out); } catch (...) { t_choice = saved; throw; }
+        t_choice = saved;
+        return;
+    }
     if (!pl.autotune || B <= 4 || pl.bf3 || p.bf3 || p.ln_wsum || p.ln_stats_in || p.ln_stats_out || planner_hook_set() || t_choice.kind != 0) return queue_igemm_impl(pl, p, B, koff, phases, final_out);
     // layer signature: everything the kernels' speed depends on (shape, strides, taps, epilogue class), not the tensors
     std::string key;

@@ -178,7 +178,13 @@ rvc_status rvc_session_process(rvc_session *s, const float *input_sample, size_t
             size_t got = 0;
             // with retrieval on, the chunk is synchronised before the post-processing chain: a hand-off time-out of the one-launch retrieval is
             // recovered inside infer_common (the SOLA / envelope state behind it must only ever see the recovered chunk)
-            const bool sync_infer = e->d_index && e->index_rate > 0.f;
+            // (only plans that CAN be recovered pay for that -- the one-launch retrieval of up to 11 streams, whose plan carries the fallback launches;
+            //  many-stream plans search through the distance GEMM and hand nothing over inside a launch: their chain stays asynchronous)
+            bool sync_infer = false;
+            if (e->d_index && e->index_rate > 0.f) {
+                Plan *peek = get_plan(e, 0, (size_t)s->input_buffer_16k_size, (size_t)s->sample_frame_16k, (uint32_t)s->skip_head, (uint32_t)s->model_return_length, 0);
+                sync_infer = !peek->knn_fallback.empty();
+            }
             rvc_status rc = infer_common(e, ring16, true, (size_t)s->input_buffer_16k_size, (size_t)s->sample_frame_16k, 0, (uint32_t)s->skip_head,
                                          (uint32_t)s->model_return_length, s->d_model, true, (size_t)s->model_return_size, &got, sync_infer, s->pitch_shift.data());
             if (rc != RVC_OK) return rc;

@@ -721,100 +721,3 @@ def test_pipelined_chunks_equal_serial_chunks():
     assert np.isfinite(ys).all() and np.array_equal(ys, yp) and np.array_equal(cs, cp)
 
 
-def test_every_tile_configuration_computes_the_same_convolution():
-    # the planner picks one of 5 tile shapes x 4 in-workgroup K splits (+ the two workgroup-tiled kernels at many streams) per layer;
-    # the model-level tests only ever see its choices.  Here every combination is forced onto small convolutions -- table-free 1x1
-    # layers (LIN), dilated multi-tap layers with the fused input LeakyReLU, K shorter and longer than the prefetch depth, ragged M / N
-    # -- and compared with a double-precision host evaluation (rvc_debug_conv_check)
-    import ctypes as C
-    from obs_rvc_amd import _native
-    L = _native.lib()
-    L.rvc_debug_conv_check.restype = C.c_double
-    L.rvc_debug_conv_check.argtypes = [C.c_void_p] + [C.c_int] * 7
-    h = C.c_void_p()
-    assert L.rvc_create(b"/tmp", 0, C.byref(h)) == 0
-    shapes = [(48, 48, 1, 1, 111, 0), (144, 48, 1, 1, 111, 0), (96, 384, 1, 1, 37, 0), (40, 32, 7, 3, 300, 1), (64, 512, 3, 1, 50, 0), (33, 16, 11, 1, 130, 1)]
-    try:
-        for cfg in range(5):
-            for ks in (1, 4, 8, 16):
-                set_opt("RVC_FORCE_CFG", "%d,%d" % (cfg, ks))
-                for (M, Cin, KW, dil, N, pre) in shapes:
-                    if ks > 1 and (Cin * KW + 15) // 16 < ks:
-                        continue                           # fewer K chunks than waves: the planner never splits that far
-                    e1 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, 1, pre)
-                    assert 0 <= e1 < 2e-5, (cfg, ks, M, Cin, KW, dil, N, pre, e1)
-        set_opt("RVC_FORCE_CFG", None)
-        # igemm2w_kernel (round 5: register-direct 32x32x2 tiles for the table-free 1x1 layers at a few streams): every wave tile x K split, one stream
-        # and streams folded into N, ragged M / N, K shorter and longer than the register ring, K splits that leave waves without a chunk
-        for tile in range(3):
-            for ks in (1, 2, 3, 4, 6, 8):
-                set_opt("RVC_FORCE_G2W", "%d,%d" % (tile, ks))
-                for streams in (1, 3, 8):
-                    for (M, Cin, N) in [(48, 48, 111), (144, 48, 111), (96, 384, 37), (768, 256, 111), (100, 1040, 70), (64, 16, 33)]:
-                        e5 = L.rvc_debug_conv_check(h, M, Cin, 1, 1, N, streams, 0)
-                        assert 0 <= e5 < 2e-5, ("igemm2w", tile, ks, streams, M, Cin, N, e5)
-        set_opt("RVC_FORCE_G2W", None)
-        # conv_tile_kernel (one stream, stride-1 1-D convolutions whose input channels come in 16s: input tile staged once per workgroup, K walked
-        # tap-major from repacked weights): every tile shape, with one and two K shares, forced onto short and long layers alike
-        for tile128 in ("0",):
-            for ks in ("1", "2"):
-                set_opt("RVC_CONV_TILE", "2"); set_opt("RVC_CONV_TILE_KS", ks)
-                for (M, Cin, KW, dil, N, pre) in [(40, 32, 7, 3, 300, 1), (64, 512, 3, 1, 50, 0), (33, 16, 11, 1, 130, 1), (100, 48, 5, 2, 1000, 0), (128, 128, 7, 3, 2520, 1),
-                                                  (128, 128, 11, 5, 700, 1), (32, 32, 11, 1, 10080, 1), (64, 64, 7, 1, 5040, 0), (16, 16, 1, 1, 40, 0), (256, 64, 3, 1, 97, 1)]:
-                    e3 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, 1, pre)
-                    assert 0 <= e3 < 2e-5, ("conv_tile", tile128, ks, M, Cin, KW, dil, N, pre, e3)
-        for k in ("RVC_CONV_TILE", "RVC_CONV_TILE_KS"):
-            set_opt(k, None)
-        # conv32s_kernel (round 5: stride-1 1-D convolutions at five streams and more -- input rows of a 32-channel block staged once per workgroup,
-        # taps walked from LDS, 32x32x2 MFMAs, K walked (block, tap, group)-major from repacked weights): every tile forced onto one, three and eight
-        # streams; ragged M / N, one to eight channel blocks, reach of the taps from 0 to 50 columns, N shorter than a tile
-        set_opt("RVC_CONV32S", "2")
-        for tile in range(3):
-            set_opt("RVC_CONV32S_TILE", str(tile))
-            for streams in (1, 3, 8):
-                for (M, Cin, KW, dil, N, pre) in [(32, 32, 11, 1, 1000, 1), (64, 64, 7, 3, 520, 0), (128, 128, 11, 5, 700, 1), (40, 32, 7, 3, 300, 1), (256, 64, 3, 1, 97, 1),
-                                                  (100, 96, 5, 2, 333, 0), (32, 32, 1, 1, 256, 0), (256, 256, 3, 1, 252, 1)]:
-                    e6 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, streams, pre)
-                    assert 0 <= e6 < 2e-5, ("conv32s", tile, streams, M, Cin, KW, dil, N, pre, e6)
-        # (the 64 x 128 tile exists in both kernels -- conv32s_buf_kernel below 24 streams, conv32s_kernel from there: each forced with the other's stream counts)
-        set_opt("RVC_CONV32S_TILE", "1")
-        for buf in ("0", "2"):
-            set_opt("RVC_CONV32S_BUF", buf)
-            for (M, Cin, KW, dil, N, pre, streams) in [(64, 64, 7, 3, 520, 1, 3), (64, 64, 11, 5, 700, 0, 8), (40, 32, 3, 1, 300, 1, 1)]:
-                e9 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, streams, pre)
-                assert 0 <= e9 < 2e-5, ("conv32s 64x128", buf, M, Cin, KW, dil, N, pre, streams, e9)
-        for k in ("RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_CONV32S_BUF"):
-            set_opt(k, None)
-        for streams in (3, 20):                            # folded streams; 20 streams reach the workgroup-tiled kernels on the wide layers
-            # (+ a 48-row panel wide enough for the 48 x 256 workgroup tile, a 32-row and a 64-row panel for the narrow 32x32x2 tiles)
-            for (M, Cin, KW, dil, N, pre) in shapes + [(128, 128, 7, 3, 2520, 1), (768, 256, 1, 1, 111, 0), (48, 48, 15, 1, 5000, 0), (32, 32, 11, 1, 10080, 1), (64, 64, 7, 1, 5040, 0)]:
-                e2 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, streams, pre)
-                assert 0 <= e2 < 2e-5, (streams, M, Cin, KW, dil, N, pre, e2)
-        # tall panels with few streams: the 64 x 64 tile of the 32x32x2 kernel (250-500 workgroups of 128 x 64) at 8 streams, the 128 x 64 tile at 16
-        for streams in (8, 16):
-            for (M, Cin, KW, dil, N, pre) in [(3072, 32, 1, 1, 111, 0), (2304, 48, 1, 1, 111, 1), (600, 32, 3, 1, 500, 0)]:
-                e4 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, streams, pre)
-                assert 0 <= e4 < 2e-5, ("tall", streams, M, Cin, KW, dil, N, pre, e4)
-        # igemm32l_kernel (round 5: igemm32_kernel's 128 x 128 / 128 x 64 / 64 x 64 tiles for table-free 1x1 layers, buffer loads with scalar row offsets, no
-        # offset table): the planner sends the tall panels above to its 64-column tiles; here a 2304-row panel wide enough for the 128 x 128 tile and a 3072-row
-        # panel (eight-fold m-tile count: moved to the 128 x 64 tile) at 64 streams, ragged M, and the old kernel on the same shapes (test hook RVC_G32L = 0)
-        for g32l in ("1", "0"):
-            set_opt("RVC_G32L", g32l)
-            for (M, Cin, N) in [(2304, 48, 111), (3072, 32, 111), (2300, 64, 111)]:
-                e7 = L.rvc_debug_conv_check(h, M, Cin, 1, 1, N, 64, 0)
-                assert 0 <= e7 < 2e-5, ("igemm32l", g32l, M, Cin, N, e7)
-        set_opt("RVC_G32L", None)
-        # ... and its table variant (one-phase 1-D layers WITH an offset table: table entries as scalar loads): the strided-stem shape class (three taps, 512 rows)
-        # and a dilated layer with the fused input activation on the 64-column tiles, hook on and off
-        for tab in ("1", "0"):
-            set_opt("RVC_G32L_TAB", tab)
-            for (M, Cin, KW, dil, N, pre, streams) in [(512, 64, 3, 1, 700, 0, 16), (600, 32, 3, 1, 500, 0, 8), (256, 64, 3, 2, 252, 1, 64), (512, 32, 5, 1, 3000, 0, 6)]:
-                e8 = L.rvc_debug_conv_check(h, M, Cin, KW, dil, N, streams, pre)
-                assert 0 <= e8 < 2e-5, ("igemm32l table", tab, M, Cin, KW, dil, N, pre, streams, e8)
-        set_opt("RVC_G32L_TAB", None)
-    finally:
-        for k in ("RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_FORCE_G2W", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_CONV32S_BUF", "RVC_G32L", "RVC_G32L_TAB"):
-            set_opt(k, None)
-        L.rvc_destroy(h)
-
-
