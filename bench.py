@@ -70,6 +70,9 @@ def parse_args(argv=None):
                     "(test hook RVC_SERIAL_BRANCHES through rvc_debug_option; the product reads no such variable from the environment), so that a "
                     "rocprofv3 kernel trace of many streams shows every kernel's own duration")
     ap.add_argument("--preset", default="full")
+    ap.add_argument("--hook", action="append", default=[], metavar="NAME=VALUE", help="measurement aid: set a test hook of the library (rvc_debug_option) before any engine exists, "
+                    "e.g. --hook RVC_G32L_PANEL=0 for an A/B under rocprofv3; recorded in the line as `hooks`")
+    ap.add_argument("--no-autotune", action="store_true", help="measurement aid: plans by the planner's rules only (rvc_set_plan_autotune(e, 0))")
     ap.add_argument("--verbose-line", action="store_true", help="also print the verbose record (gpurun_out/bench_full.json) to stderr")
     ap.add_argument("--no-calibration", action="store_true", help="skip rvc_calibrate and the per-leg clock probes")
     return ap.parse_args(argv)
@@ -507,6 +510,8 @@ def run_config(job, z, g, S, with_index, steps, warmup, graph, index_vecs, want_
     eng = RvcInfer(z["data"], device=job.local_rank)
     eng.load_contentvec(version); eng.load_f0(1); eng.load_model(z["model"])
     eng.set_streams(S)
+    if not CTX["autotune"]:
+        eng.set_plan_autotune(False)
     if gemm_precision:
         eng.set_gemm_precision(gemm_precision)
     # stream s of this rank is stream (s * world + rank) of the job: round-robin sharding
@@ -569,7 +574,7 @@ def run_config(job, z, g, S, with_index, steps, warmup, graph, index_vecs, want_
     return rec, eng, rings, d_rings
 
 
-CTX = {"peaks": None, "box": None, "calib": True}
+CTX = {"peaks": None, "box": None, "calib": True, "autotune": True}
 
 
 def compact_roofline(r):
@@ -768,6 +773,10 @@ def main(argv=None):
     if args.serial_branches:
         from common import set_opt
         set_opt("RVC_SERIAL_BRANCHES", "1")
+    for hk in args.hook:
+        from common import set_opt
+        set_opt(*hk.split("=", 1))
+    CTX["autotune"] = not args.no_autotune
     index_vecs = W.make_index() if (job.rank == 0 and full) else None      # only rank 0 ever holds the host copy
 
     # ---- the box: sensor probe + in-run calibration (what this GPU's matrix cores and HBM sustain right now; every rank calibrates its own GPU)
@@ -972,6 +981,9 @@ def main(argv=None):
             out["config4"] = dict(compact_sub(c4), streams_total=c4.get("streams_total"), n_gpus=c4.get("n_gpus"), per_rank_frames_per_s=c4.get("per_rank_frames_per_s"),
                                   index_broadcast={k: v for k, v in (c4.get("index_broadcast") or {}).items() if k != "via"})
         out["serial_branches"] = bool(args.serial_branches)
+        out["plan_autotune"] = bool(CTX["autotune"])
+        if args.hook:
+            out["hooks"] = args.hook
         out["keys"] = "sub_configs: ms per step, frames/s, p50 / p99 ms, GPU ms of the last chunk, sclk MHz / W / C while the leg ran, frac (events, nominal peak), frac_wall, frac_meas (vs peak_measured[0]), frac_clk (nominal peak at the leg's clock)"
         out["full_record"] = full_path
         summ = {"headline": head["ms_per_step"]}

@@ -1207,26 +1207,37 @@ double rvc_debug_conv_check(rvc_engine *e, int M, int Cin, int KW, int dil, int 
         for (auto &op : pl.ops.v) op(e->stream);
         HIPCHK(hipStreamSynchronize(e->stream));
         HIPCHK(hipGetLastError());
-        std::vector<float> hy((size_t)N);
-        double err = 0.0, ss = 0.0; size_t cnt = 0;
-        std::vector<double> ref((size_t)N);
+        // host evaluation in double, the (stream, output row) pairs dealt to the host's threads (a test aid: the full-size shapes are 1e9 MACs each)
+        std::vector<float> hy((size_t)streams * M * N);
         for (int b = 0; b < streams; b++)
-            for (int m = 0; m < M; m++) {
-                HIPCHK(hipMemcpy(hy.data(), y.p + (long long)b * y.bs + (long long)m * y.ld, (size_t)N * 4, hipMemcpyDeviceToHost));
-                for (int n = 0; n < N; n++) {
-                    double a = bias[m];
-                    for (int c = 0; c < Cin; c++)
-                        for (int k = 0; k < KW; k++) {
-                            const int t = n + k * dil - pad;
-                            if (t < 0 || t >= N) continue;
-                            double v = hx[((size_t)b * Cin + c) * N + t];
-                            if (pre_act && v < 0) v *= 0.1f;
-                            a += (double)w[((size_t)m * Cin + c) * KW + k] * v;
-                        }
-                    ref[n] = a; ss += a * a; cnt++;
+            HIPCHK(hipMemcpy2D(&hy[(size_t)b * M * N], (size_t)N * 4, y.p + (long long)b * y.bs, (size_t)y.ld * 4, (size_t)N * 4, M, hipMemcpyDeviceToHost));
+        const int nthr = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<double> errs(nthr, 0.0), sss(nthr, 0.0);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthr; t++)
+            pool.emplace_back([&, t]() {
+                std::vector<double> ref((size_t)N);
+                for (long long bm = t; bm < (long long)streams * M; bm += nthr) {
+                    const int b = (int)(bm / M), m = (int)(bm % M);
+                    for (int n = 0; n < N; n++) {
+                        double a = bias[m];
+                        for (int c = 0; c < Cin; c++)
+                            for (int k = 0; k < KW; k++) {
+                                const int tt = n + k * dil - pad;
+                                if (tt < 0 || tt >= N) continue;
+                                double v = hx[((size_t)b * Cin + c) * N + tt];
+                                if (pre_act && v < 0) v *= 0.1f;
+                                a += (double)w[((size_t)m * Cin + c) * KW + k] * v;
+                            }
+                        ref[n] = a; sss[t] += a * a;
+                    }
+                    const float *row = &hy[((size_t)b * M + m) * N];
+                    for (int n = 0; n < N; n++) errs[t] = std::max(errs[t], std::fabs((double)row[n] - ref[n]));
                 }
-                for (int n = 0; n < N; n++) err = std::max(err, std::fabs((double)hy[n] - ref[n]));
-            }
+            });
+        for (auto &th : pool) th.join();
+        double err = 0.0, ss = 0.0; const size_t cnt = (size_t)streams * M * N;
+        for (int t = 0; t < nthr; t++) { err = std::max(err, errs[t]); ss += sss[t]; }
         worst = err / (std::sqrt(ss / (double)std::max<size_t>(cnt, 1)) + 1e-12);
         free_conv(cw);
         return RVC_OK;

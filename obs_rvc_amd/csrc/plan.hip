@@ -794,7 +794,7 @@ static void queue_igemm_impl(Plan &pl, IgemmP p, int B, const std::vector<int> &
         const size_t lds_l = (size_t)2 * bn * 20 * 4;
         // panel order inside the XCDs (igemm32l.hip.h, m_fast = 3) for tall table-free panels whose weights exceed an L2: mp m-tiles = the largest panel of
         // <= 2.5 MB; test hook RVC_G32L_PANEL = 0: the orders of round 4 (m fastest over XCD-local ids / the raw block index)
-        if (g32l && !g32t && p.fold_n && B == 1 && (lc == 7 || lc == 8) && p.ntm >= 8 && p.ntn >= 16 && test_opt_int("RVC_G32L_PANEL", 1) != 0) {
+        if (g32l && !g32t && p.fold_n && B == 1 && (lc == 7 || lc == 8) && p.ntm >= 8 && p.ntn >= 64 && test_opt_int("RVC_G32L_PANEL", 1) != 0) {          // (from ~37 streams: at 16 streams -- 28 n-tiles, 3.5 per XCD -- the padded grid costs 2.4 %)
             const size_t per_tile = (size_t)bm * (size_t)ksum * sizeof(float);
             const int mp = (int)std::max<size_t>(1, ((size_t)5 << 19) / per_tile);
             if ((size_t)p.M * (size_t)ksum * sizeof(float) > ((size_t)5 << 19) && mp < p.ntm) {

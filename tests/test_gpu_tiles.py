@@ -126,7 +126,7 @@ def test_igemm32l_panel_order(conv, panel):
     # round 6: tall table-free panels whose weights exceed an L2 run panel by panel inside every XCD (m_fast = 3: padded grid, surplus workgroups leave at once);
     # m-tile counts that divide into panels and that leave a remainder, n-tile counts that do not divide over the 8 XCDs, ragged M -- hook on and off
     set_opt("RVC_G32L_PANEL", panel)
-    for (M, Cin, N, streams) in [(2304, 320, 111, 64), (3072, 256, 111, 40), (2300, 320, 111, 24), (1792, 384, 57, 33)]:
+    for (M, Cin, N, streams) in [(2304, 320, 111, 64), (3072, 256, 111, 40), (2300, 320, 74, 56), (1792, 384, 57, 74)]:
         e = conv(M, Cin, 1, 1, N, streams, 0)
         assert 0 <= e < TOL and conv.kernel() == "g32l", (panel, M, Cin, N, streams, e, conv.kernel())
 
@@ -153,8 +153,8 @@ def test_every_choice_of_the_autotuner(conv, choice):
     # shapes: the families' own (1x1 tall / short panels, multi-tap with dilation and fused input activation, 32-channel blocks), at 6 and 20 streams
     # (the tuner works above 4 streams), ragged M and N.
     set_opt("RVC_FORCE_CHOICE", "%d,%d,%d" % choice)
-    shapes = SHAPES + [(768, 256, 1, 1, 111, 0), (3072, 32, 1, 1, 111, 0), (128, 128, 7, 3, 1260, 1), (64, 64, 11, 5, 700, 0), (32, 32, 3, 1, 2520, 1), (256, 64, 3, 1, 252, 1),
-                       (512, 64, 3, 1, 700, 0), (100, 96, 5, 2, 333, 0)]
+    shapes = SHAPES + [(768, 256, 1, 1, 111, 0), (3072, 32, 1, 1, 111, 0), (128, 128, 7, 3, 420, 1), (64, 64, 11, 5, 350, 0), (32, 32, 3, 1, 1260, 1), (256, 64, 3, 1, 252, 1),
+                       (512, 64, 3, 1, 350, 0), (100, 96, 5, 2, 333, 0)]
     seen = set()
     for streams in (6, 20):
         for (M, Cin, KW, dil, N, pre) in shapes:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Tuning aid: section timeline of one chunk (test hook RVC_STAMPS: device timestamps) for a given stream count / model version.
-usage: python tests/tools/timeline.py [streams] [version]"""
+usage: python tests/tools/timeline.py [streams] [version] [HOOK=VALUE ...]"""
 import ctypes
 import os
 import sys
@@ -17,6 +17,8 @@ from obs_rvc_amd.rvc import RvcInfer  # noqa: E402
 set_opt("RVC_STAMPS", "1")          # test hook (rvc_debug_option): device timestamps at the section boundaries
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 ver = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+for a in sys.argv[3:]:              # further test hooks: NAME=VALUE (set before the models are loaded: RVC_NO_LN_FUSE is read at load)
+    set_opt(*a.split("=", 1))
 z = zoo("full", ver)
 eng = RvcInfer(z["data"], device=0); eng.load_contentvec(ver); eng.load_f0(1); eng.load_model(z["model"]); eng.set_streams(S); eng.set_noise_seed(1, 0)
 L, chunk, N = g.input_buffer_16k_size, g.sample_frame_16k, g.model_return_size
