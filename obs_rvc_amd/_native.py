@@ -29,7 +29,7 @@ SYMBOLS = [
 ]
 
 
-SOURCES = ("engine.hip", "engine_int.h", "plan.hip", "model_cv.hip", "model_rmvpe.hip", "model_synth.hip", "retrieval.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "igemm2_inst.hip", "igemm_tiled_inst.hip", "igemm2w_inst.hip", "igemm_bf3_inst.hip", "conv_tile.hip.h", "conv_tile_inst.hip", "conv32s.hip.h", "conv32s_inst.hip", "igemm32l.hip.h", "igemm32l_inst.hip", "version.cpp", "calib.hip", "exports.map",
+SOURCES = ("engine.hip", "engine_int.h", "plan.hip", "model_cv.hip", "model_rmvpe.hip", "model_synth.hip", "retrieval.hip", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "igemm2_inst.hip", "igemm_tiled_inst.hip", "igemm2w_inst.hip", "igemm_bf3_inst.hip", "conv_tile.hip.h", "conv_tile_inst.hip", "conv32s.hip.h", "conv32s_inst.hip", "rmblock.hip.h", "igemm32l.hip.h", "igemm32l_inst.hip", "version.cpp", "calib.hip", "exports.map",
            "state.hip.h",
            "resample.hip.h", "session.hip.h", "rccl_bcast.hip.h", "blob.h", "rvc_rpc.cpp")
 
@@ -39,7 +39,7 @@ SOURCES = ("engine.hip", "engine_int.h", "plan.hip", "model_cv.hip", "model_rmvp
 _IGEMM_DEPS = ("igemm.hip.h", "igemm_launch.h")
 _INT_DEPS = ("engine_int.h", "kernels.hip.h", "igemm.hip.h", "igemm_launch.h", "blob.h", "state.hip.h")
 _ENGINE_DEPS = ("engine.hip", "resample.hip.h", "session.hip.h", "rccl_bcast.hip.h") + _INT_DEPS
-UNITS = [("engine.hip", [], _ENGINE_DEPS), ("calib.hip", [], ("calib.hip",))] + [(u, [], (u,) + _INT_DEPS) for u in ("plan.hip", "model_cv.hip", "model_rmvpe.hip", "model_synth.hip", "retrieval.hip")] + \
+UNITS = [("engine.hip", [], _ENGINE_DEPS), ("calib.hip", [], ("calib.hip",))] + [(u, [], (u,) + _INT_DEPS + (("rmblock.hip.h",) if u == "model_rmvpe.hip" else ())) for u in ("plan.hip", "model_cv.hip", "model_rmvpe.hip", "model_synth.hip", "retrieval.hip")] + \
         [("igemm2_inst.hip", ["-DRVC_IGEMM2_CFG=%d" % c], ("igemm2_inst.hip",) + _IGEMM_DEPS) for c in range(5)] + \
         [("igemm_tiled_inst.hip", ["-DRVC_TILED_PART=%d" % c], ("igemm_tiled_inst.hip",) + _IGEMM_DEPS) for c in range(4)] + \
         [("igemm2w_inst.hip", ["-DRVC_G2W_PART=%d" % c], ("igemm2w_inst.hip",) + _IGEMM_DEPS) for c in range(3)] + \

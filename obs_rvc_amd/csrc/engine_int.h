@@ -233,6 +233,7 @@ struct Plan {
     int T = 0, Tm = 0, C = 0; size_t N = 0;
     bool with_index = false, with_taps = false;
     bool bucket = false;          // a plan of rvc_infer_batch_g: built for a subset of the streams on the gathered state block (rvc_engine::d_state_bucket)
+    bool rm_fuse = false;         // RMVPE's shallow ConvBlockRes as one launch each (model_rmvpe.hip; decided per plan from the engine's f0 partition)
     bool bf3 = false;             // built under rvc_set_gemm_precision(e, 1): ContentVec's 1x1 GEMMs on the split-bf16 kernel (exploratory)
     bool autotune = false;        // rvc_set_plan_autotune: layers with several eligible kernels / tiles are chosen by timing them at plan build (plan.hip queue_igemm)
     double tune_ms = 0; int tuned_layers = 0, tune_changed = 0, tune_hits = 0;      // time spent in trials, layers tuned here / changed against the rules / taken from the process cache
@@ -397,7 +398,27 @@ struct ModelCV {
     }
 };
 
-struct ResBlockW { ConvW c1, c2, sc; bool has_sc = false; int ci = 0, co = 0; float *pair_bias = nullptr; };    // pair_bias: [c1.bias; sc.bias] for the fused c1 + shortcut launch
+struct ResBlockW {
+    ConvW c1, c2, sc; bool has_sc = false; int ci = 0, co = 0; float *pair_bias = nullptr;      // pair_bias: [c1.bias; sc.bias] for the fused c1 + shortcut launch
+    // rm_block_kernel (rmblock.hip.h; blocks with 16 / 32 / 64 output channels): the three weight panels in its fragment order
+    // [tap][Cin16 / 4][Cout / 16][64 lanes] (lane (li, kq) = W[16 mt + li][4 c4 + kq][tap], zero beyond Cin), packed once at model load
+    // (one allocation [w1 | w2 | wsc]: the kernel touches every 128-byte line of it once at its start -- the panels are cold in HBM at every chunk)
+    float *f_w1 = nullptr, *f_w2 = nullptr, *f_sc = nullptr; int f_lines = 0;
+};
+// -> fragment-order panel of a [co][ci * taps] convolution weight for rm_block_kernel
+static inline std::vector<float> rm_block_panel(const float *w, int co, int ci, int taps)
+{
+    const int c16 = (ci + 15) / 16 * 16, steps = c16 / 4, MT = co / 16;
+    std::vector<float> pk((size_t)taps * steps * MT * 64, 0.f);
+    for (int t = 0; t < taps; t++)
+        for (int c4 = 0; c4 < steps; c4++)
+            for (int mt = 0; mt < MT; mt++)
+                for (int l = 0; l < 64; l++) {
+                    const int m = mt * 16 + (l & 15), c = c4 * 4 + (l >> 4);
+                    if (c < ci) pk[(((size_t)t * steps + c4) * MT + mt) * 64 + l] = w[(size_t)m * ci * taps + (size_t)c * taps + t];
+                }
+    return pk;
+}
 struct ModelRM {
     int en_out, levels, n_blocks, inter_layers, n_mels, gru_hidden, n_out;
     float bn_scale, bn_shift;
@@ -416,6 +437,15 @@ struct ModelRM {
             std::vector<float> pb(b.w(pre + "c1.b"), b.w(pre + "c1.b") + co);
             pb.insert(pb.end(), b.w(pre + "sc.b"), b.w(pre + "sc.b") + co);
             r.pair_bias = upload_f(pb);
+        }
+        if ((co == 16 || co == 32) && ci <= 64) {
+            std::vector<float> all = rm_block_panel(b.w(pre + "c1.w"), co, ci, 9);
+            const size_t o2 = all.size();
+            { std::vector<float> t = rm_block_panel(b.w(pre + "c2.w"), co, co, 9); all.insert(all.end(), t.begin(), t.end()); }
+            const size_t o3 = all.size();
+            if (r.has_sc) { std::vector<float> t = rm_block_panel(b.w(pre + "sc.w"), co, ci, 1); all.insert(all.end(), t.begin(), t.end()); }
+            all.resize((all.size() + 31) / 32 * 32, 0.f);
+            r.f_w1 = upload_f(all); r.f_w2 = r.f_w1 + o2; r.f_sc = r.has_sc ? r.f_w1 + o3 : nullptr; r.f_lines = (int)(all.size() / 32);
         }
         return r;
     }
@@ -468,7 +498,7 @@ struct ModelRM {
     }
     ~ModelRM()
     {
-        auto fb = [](std::vector<std::vector<ResBlockW>> &vv) { for (auto &v : vv) for (auto &r : v) { free_conv(r.c1); free_conv(r.c2); free_conv(r.sc); if (r.pair_bias) wfree(r.pair_bias); } };
+        auto fb = [](std::vector<std::vector<ResBlockW>> &vv) { for (auto &v : vv) for (auto &r : v) { free_conv(r.c1); free_conv(r.c2); free_conv(r.sc); if (r.pair_bias) wfree(r.pair_bias); if (r.f_w1) wfree(r.f_w1); } };
         fb(enc); fb(inter); fb(dec);
         for (auto &u : up) free_conv(u);
         free_conv(cnn); free_conv(gru_ih); free_conv(fc);

@@ -23,12 +23,32 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_GELU = 3, ACT_TANH = 4, ACT_SIGMOID = 5 };
 
+// GELU(erf) in ONE place (every kernel's epilogue and the fused ContentVec stem round the same way).
+#ifdef RVC_FAST_GELU
+// (round-6 experiment, never the default: erf as the 13 / 9-term rational polynomial of Eigen / XLA -- 15 vector instructions against libm's ~34 with both of its
+//  branches taken inside a wave -- at 4e-7 absolute error instead of 3e-8)
+__device__ __forceinline__ float erf_dev(float x)
+{
+    x = fminf(fmaxf(x, -4.f), 4.f);
+    const float x2 = x * x;
+    float p = -2.72614225801306e-10f;
+    p = fmaf(p, x2, 2.77068142495902e-08f); p = fmaf(p, x2, -2.10102402082508e-06f); p = fmaf(p, x2, -5.69250639462346e-05f);
+    p = fmaf(p, x2, -7.34990630326855e-04f); p = fmaf(p, x2, -2.95459980854025e-03f); p = fmaf(p, x2, -1.60960333262415e-02f);
+    float q = -1.45660718464996e-05f;
+    q = fmaf(q, x2, -2.13374055278905e-04f); q = fmaf(q, x2, -1.68282697438203e-03f); q = fmaf(q, x2, -7.37332916720468e-03f); q = fmaf(q, x2, -1.42647390514189e-02f);
+    return x * p * __builtin_amdgcn_rcpf(q);
+}
+#else
+__device__ __forceinline__ float erf_dev(float x) { return erff(x); }
+#endif
+__device__ __forceinline__ float gelu_dev(float v) { return 0.5f * v * (1.0f + erf_dev(v * 0.70710678118654752440f)); }
+
 __device__ __forceinline__ float apply_act(float v, int act, float slope)
 {
     switch (act) {
     case ACT_RELU: return v > 0.f ? v : 0.f;
     case ACT_LRELU: return v > 0.f ? v : v * slope;
-    case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case ACT_GELU: return gelu_dev(v);
     case ACT_TANH: return tanhf(v);
     case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
     default: return v;
@@ -475,7 +495,7 @@ template <int ACT> __device__ __forceinline__ float act_t(float v, float slope)
 {
     if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
     if (ACT == ACT_LRELU) return v > 0.f ? v : v * slope;
-    if (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (ACT == ACT_GELU) return gelu_dev(v);
     if (ACT == ACT_TANH) return tanhf(v);
     if (ACT == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
     return v;
@@ -1060,9 +1080,14 @@ typedef float f32x16w __attribute__((ext_vector_type(16)));
 // clocks: half the instructions per matrix-pipe clock, and an fp32 MFMA hides none of them (tests/tools/mfma_overlap_probe.hip).
 // Operand order inside a 16-deep chunk: MFMA (u, j) takes k = (2u + ks) * 4 + j, ks = lane >> 5 -- the weights come straight from the
 // 16-row fragment packing (lane (row r, k-slot ks) reads the float4 of fragment r >> 4, quad 2u + ks), as in igemm32_kernel.
-template <int MT, int NT, int KS>
+// LNB (round 6; 32 x 32 tile, K split only): the layer consumes a NOT yet normalised tensor -- igemm2_kernel's folded LayerNorm (IgemmP::ln_wsum) on this
+// kernel, for the one-stream QKV / first FFN projections (isolated 12.4 / 13.4 -> 9.5 / 10.0 us against igemm2_kernel's LNB tiles).  A lane adds up its
+// operand values relative to the column's first element (2 of the 4 k rows of every MFMA are this lane's, the partner lane holds the others), the K shares
+// meet in LDS next to the partial tiles in wave order, and the correction rstd * (acc - mean * wsum[m]) is applied in front of the epilogue.
+template <int MT, int NT, int KS, bool LNB = false>
 __global__ __launch_bounds__(KS * 64) void igemm2w_kernel(IgemmP p)
 {
+    static_assert(!LNB || (MT == 1 && NT == 1 && KS > 1), "LayerNorm-consumer instantiations: 32 x 32 wave tile with the in-workgroup K split");
     constexpr int D = MT * NT >= 4 ? 2 : 3;             // chunks in flight per wave
     constexpr int TE = MT * NT * 1024;                  // elements of the wave tile
     constexpr int PE = KS > 1 ? (TE + KS * 64 - 1) / (KS * 64) : 1;     // elements a thread finishes after the reduction
@@ -1121,6 +1146,20 @@ __global__ __launch_bounds__(KS * 64) void igemm2w_kernel(IgemmP p)
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
+    // LNB: sums of (value - first element of the column) and of its square over this lane's k rows (a buffer load like every other load of the kernel)
+    float ln_s = 0.f, ln_ss = 0.f, ln_c = 0.f;
+    float ln_ws[LNB ? PE : 1];                      // wsum of the rows this thread finishes: requested now, consumed behind the reduction
+    if (LNB) {
+        ln_c = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)(xo[0][0] - (unsigned)(c0 * 16 + ks * 4) * lin1), 0, 0));
+        const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.ln_wsum + ph.bias_off), 0, 0x7ffff000, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < PE; q++) {
+            const int e = (int)threadIdx.x + q * KS * 64;
+            int m_ = tm * 32 + ((e >> 6) & 3) + 8 * (((e >> 6) & 15) >> 2) + 4 * ((e & 63) >> 5);
+            m_ = m_ < p.M ? m_ : p.M - 1;
+            ln_ws[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, m_ * 4, 0, 0));
+        }
+    }
     f32x4 a_st[D][MT][2];
     float b_st[D][NT][8];
     auto load = [&](f32x4 (&a)[MT][2], float (&b)[NT][8], const int c) {
@@ -1136,6 +1175,10 @@ __global__ __launch_bounds__(KS * 64) void igemm2w_kernel(IgemmP p)
             for (int q = 0; q < 8; q++) b[nt][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (int)xo[nt][q], so, 0));
     };
     auto compute = [&](const f32x4 (&a)[MT][2], const float (&b)[NT][8]) {
+        if (LNB) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) { const float d_ = b[0][q] - ln_c; ln_s += d_; ln_ss = fmaf(d_, d_, ln_ss); }
+        }
 #pragma unroll
         for (int u = 0; u < 2; u++)
 #pragma unroll
@@ -1183,7 +1226,25 @@ __global__ __launch_bounds__(KS * 64) void igemm2w_kernel(IgemmP p)
             for (int nt = 0; nt < NT; nt++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) s_red[wave * TE + ((mt * NT + nt) * 16 + r) * 64 + lane] = acc[mt][nt][r];
+        float *lst = s_red + KS * TE;               // LNB: [KS][32 columns][2] sums of this wave's K share
+        if (LNB) {
+            const float s_ = ln_s + __shfl_xor(ln_s, 32, 64), q_ = ln_ss + __shfl_xor(ln_ss, 32, 64);        // the partner lane holds the other two k rows of every MFMA
+            if (ks == 0) { lst[(wave * 32 + c32) * 2] = s_; lst[(wave * 32 + c32) * 2 + 1] = q_; }
+        }
         __syncthreads();
+        // LNB: statistics of this thread's column -- every element a thread finishes lies in column threadIdx.x & 31 = this lane's operand column --, the
+        // K shares summed in wave order; the tm == 0 workgroups publish (mean, rstd) for the later layer whose residual is LayerNorm(y)
+        float ln_mean = 0.f, ln_rstd = 0.f;
+        if (LNB) {
+            float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+            for (int w = 0; w < KS; w++) { s_ += lst[(w * 32 + c32) * 2]; q_ += lst[(w * 32 + c32) * 2 + 1]; }
+            const float msh = s_ * p.ln_inv_rows;
+            const float var = fmaxf(q_ * p.ln_inv_rows - msh * msh, 0.f);
+            ln_mean = ln_c + msh; ln_rstd = 1.0f / sqrtf(var + p.ln_eps);
+            const int n_ = tn * 32 + c32;
+            if (p.ln_stats_out && tm == 0 && threadIdx.x < 32 && n_ < p.N) { p.ln_stats_out[2 * n_] = ln_mean; p.ln_stats_out[2 * n_ + 1] = ln_rstd; }
+        }
         // (batches of eight: a whole-share batch of 32 elements took the 64 x 64 tile with two waves to 288 registers)
         constexpr int EB = PE < 8 ? PE : 8;
         RVC_ACT_DISPATCH(
@@ -1197,8 +1258,9 @@ __global__ __launch_bounds__(KS * 64) void igemm2w_kernel(IgemmP p)
                     if (in) {
                         _Pragma("unroll") for (int w = 0; w < KS; w++) sum += s_red[w * TE + e];
                     }
-                    v[qq] = sum;
                     const int l = e & 63; const int r = (e >> 6) & 15; const int f = e >> 10; const int mt = f / NT; const int nt = f - mt * NT;
+                    if (LNB && in) sum = ln_rstd * (sum - ln_mean * ln_ws[LNB ? q0 + qq : 0]);          // the folded LayerNorm: out = rstd[n] * (acc - mean[n] * wsum[m]) (+ the folded bias in the epilogue)
+                    v[qq] = sum;
                     ep[qq] = in ? epi2_prefetch(p, ph, resb, yb, (tm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), (tn * NT + nt) * 32 + (l & 31)) : epi2_none();
                 }
                 _Pragma("unroll") for (int qq = 0; qq < EB; qq++) epi2_finish<A_>(p, yb, v[qq], ep[qq]);
@@ -1564,7 +1626,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G32Occ<MT, 
     // purpose: a whole-tile batch took the kernel from 164 to 268 registers (3 -> 1 waves per SIMD, 1.5x slower overall).
     const bool has_aux = resb != nullptr || p.accumulate;
     const bool full_m = row0 - ks * 4 + MT * 32 <= p.M;          // every row of this wave's tile exists (wave-uniform)
-    if (!p.accumulate && full_m) {
+    if (full_m) {
         // The common case, kept small on purpose: straight-line code per element is what the 64-element unrolled epilogue costs
         // in instruction-cache footprint (the general version below is ~10x larger; with every workgroup of the chip walking
         // through it at a different point the epilogue took 43 us per wave, most of it instruction fetch).  One predicate per
@@ -1587,8 +1649,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G32Occ<MT, 
                             _Pragma("unroll") for (int r = 0; r < 16; r++) rr[r] = rp[((r & 3) + 8 * (r >> 2)) * rcs];
                         }
                         float *yc = yb + cols[nt].yo + (long long)(m0 + ph.y_c0) * cs;
+                        float yo_[16];          // (round 6: accumulating launches take this path too -- the previous output as one more store-free batch)
+                        _Pragma("unroll") for (int r = 0; r < 16; r++) yo_[r] = 0.f;
+                        if (p.accumulate) { _Pragma("unroll") for (int r = 0; r < 16; r++) yo_[r] = yc[((r & 3) + 8 * (r >> 2)) * cs]; }
                         _Pragma("unroll") for (int r = 0; r < 16; r++)
-                            yc[((r & 3) + 8 * (r >> 2)) * cs] = epi2_value<A_>(acc[mt][nt][r], bias_r[r], rr[r], 0.f, slope, scale);
+                            yc[((r & 3) + 8 * (r >> 2)) * cs] = epi2_value<A_>(acc[mt][nt][r], bias_r[r], rr[r], yo_[r], slope, scale);
                     }
                 }
             }

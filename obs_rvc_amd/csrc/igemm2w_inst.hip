@@ -32,8 +32,20 @@ template <int KS> static void g2w_attr()
 }
 void G2W_FN(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
 {
-    if (ks < 0) { g2w_attr<2>(); g2w_attr<3>(); g2w_attr<4>(); g2w_attr<6>(); g2w_attr<8>(); return; }      // once per device (igemm2w_prepare_device)
+    if (ks < 0) {      // once per device (igemm2w_prepare_device)
+        g2w_attr<2>(); g2w_attr<3>(); g2w_attr<4>(); g2w_attr<6>(); g2w_attr<8>();
+#if RVC_G2W_PART == 0
+        g2w_attr<12>(); g2w_attr<16>();
+#endif
+        return;
+    }
     switch (ks) {
+#if RVC_G2W_PART == 0
+    // round 6 (one-stream experiment, VERDICT r5 #6b): 12 / 16 waves splitting K on the 32 x 32 tile -- 96 tiles of a 768-row panel at one stream are
+    // 768 waves with eight shares, fewer than the 896 SIMDs of the ContentVec partition
+    case 12: launch_k(igemm2w_kernel<G2W_MT, G2W_NT, 12>, p, grid, dim3(768), lds, s, ea, eb); return;
+    case 16: launch_k(igemm2w_kernel<G2W_MT, G2W_NT, 16>, p, grid, dim3(1024), lds, s, ea, eb); return;
+#endif
     case 1: launch_k(igemm2w_kernel<G2W_MT, G2W_NT, 1>, p, grid, dim3(64), lds, s, ea, eb); return;
     case 2: launch_k(igemm2w_kernel<G2W_MT, G2W_NT, 2>, p, grid, dim3(128), lds, s, ea, eb); return;
     case 3: launch_k(igemm2w_kernel<G2W_MT, G2W_NT, 3>, p, grid, dim3(192), lds, s, ea, eb); return;

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G32Occ<MT, 
     for (int nt = 0; nt < NT; nt++) cols[nt] = col_locate(p, ph, tn * BN + (wn * NT + nt) * 32 + c32);
     const int row0 = (tm * WM + wm) * MT * 32 + ks * 4;
     const bool full_m = row0 - ks * 4 + MT * 32 <= p.M;
-    if (!p.accumulate && full_m) {
+    if (full_m) {
         const float slope = p.slope, scale = p.scale;
         const long long cs = p.y_cs, rcs = p.res_cs;
         RVC_ACT_DISPATCH(
@@ -178,8 +178,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G32Occ<MT, 
                             _Pragma("unroll") for (int r = 0; r < 16; r++) rr[r] = rp[((r & 3) + 8 * (r >> 2)) * rcs];
                         }
                         float *yc = yb + cols[nt].yo + (long long)(m0 + ph.y_c0) * cs;
+                        float yo_[16];          // (round 6: accumulating launches take this path too -- the previous output as one more store-free batch)
+                        _Pragma("unroll") for (int r = 0; r < 16; r++) yo_[r] = 0.f;
+                        if (p.accumulate) { _Pragma("unroll") for (int r = 0; r < 16; r++) yo_[r] = yc[((r & 3) + 8 * (r >> 2)) * cs]; }
                         _Pragma("unroll") for (int r = 0; r < 16; r++)
-                            yc[((r & 3) + 8 * (r >> 2)) * cs] = epi2_value<A_>(acc[mt][nt][r], bias_r[r], rr[r], 0.f, slope, scale);
+                            yc[((r & 3) + 8 * (r >> 2)) * cs] = epi2_value<A_>(acc[mt][nt][r], bias_r[r], rr[r], yo_[r], slope, scale);
                     }
                 }
             }

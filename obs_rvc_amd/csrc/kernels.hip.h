@@ -580,14 +580,14 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnP p)
 #pragma unroll
         for (int c = 0; c < NC; c++) vv[c] = (wave * 16 < HD && c * 4 + kq < T) ? vr[c * 4] : 0.f;
     }
-    for (int qt = qt_first; qt < qt_last; qt++) {
-    const int t1 = qt * 16;
-    if (qt != qt_first) __syncthreads();         // the previous tile's probabilities / statistics have been consumed
     {
-        const int tq = t1 + li < T ? t1 + li : T - 1;
+        const int tq = qt_first * 16 + li < T ? qt_first * 16 + li : T - 1;
 #pragma unroll
         for (int c = 0; c < HD / 4; c++) qa[c] = qb[(long long)(c * 4 + kq) * p.cs + tq];
     }
+    for (int qt = qt_first; qt < qt_last; qt++) {
+    const int t1 = qt * 16;
+    if (qt != qt_first) __syncthreads();         // the previous tile's probabilities / statistics have been consumed
     f32x4 sacc[KF];
 #pragma unroll
     for (int f = 0; f < KF; f++) sacc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -596,6 +596,13 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnP p)
         const float a = qa[c] * p.scale;
 #pragma unroll
         for (int f = 0; f < KF; f++) sacc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, kv[c][f], sacc[f], 0, 0, 0);
+    }
+    // (round 6) the NEXT query tile's rows are requested as soon as this tile's products have consumed the registers: the walk over the query tiles of a
+    // (head, stream) paid one memory round trip per tile in front of its first MFMA (7 per workgroup at T = 111)
+    if (qt + 1 < qt_last) {
+        const int tq = t1 + 16 + li < T ? t1 + 16 + li : T - 1;
+#pragma unroll
+        for (int c = 0; c < HD / 4; c++) qa[c] = qb[(long long)(c * 4 + kq) * p.cs + tq];
     }
     // row statistics: this lane holds rows kq*4 + r, column li of each of its key fragments
     float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};

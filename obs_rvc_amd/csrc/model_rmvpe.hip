@@ -1,7 +1,61 @@
 // model_rmvpe.hip -- RMVPE f0 estimator (mel front end, U-Net, BiGRU, salience) and the decode / pitch-cache step as a plan (reference: rvc/src/f0/rmvpe.rs:118-133, 225-248; rvc/src/rvc.rs:111-131, 167-180)
 #include "engine_int.h"
+#include "rmblock.hip.h"
 
 namespace rvc {
+
+// One launch per ConvBlockRes on the shallow levels (rm_block_kernel, rmblock.hip.h): few streams only -- there the f0 branch is a chain of dependent
+// 5-8 us launches on its own CU partition and the block's halo recomputation costs nothing that matters; with many streams folded into a launch the two
+// convolutions fill the chip by themselves and keep the implicit-GEMM kernels.  Test hook RVC_RM_FUSE = 0: never, 2: at any stream count.  false = not taken.
+static bool add_rm_block_fused(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &out, const ResBlockW *next)
+{
+    const int mode = test_opt_int("RVC_RM_FUSE", 1);
+    if (!w.f_w1 || mode == 0 || (!pl.rm_fuse && mode != 2)) return false;
+    if (x.C != w.ci || out.C != w.co || out.H != x.H || out.W != x.W || (!w.has_sc && w.ci != w.co)) return false;
+    const int MT = w.co / 16;
+    RmBlockP q{};
+    q.x = x.p; q.y = out.p; q.Cin = w.ci; q.Cin4 = (w.ci + 15) / 16 * 4; q.Cout = w.co;
+    q.H = x.H; q.W = x.W;
+    // output tile per workgroup: 128 / 32 / 8 pixels for 16 / 32 / 64 channels (32 workgroups per stream at the 32 x 128 mel image: one per CU of the
+    // f0 partition); the y1 tile must fit the waves' n-tiles: ceil((TH + 2)(TW + 2) / 16) <= 4 * (4 / MT)
+    q.TH = MT == 1 ? 8 : (MT == 2 ? 4 : 2); q.TW = MT == 1 ? 16 : (MT == 2 ? 8 : 4);
+    q.TH = std::min(q.TH, x.H); q.TW = std::min(q.TW, x.W);
+    // n-tiles per wave of the two convolutions (template parameters of the kernel): 3 / 2 for 16 channels (12 and 8 tiles over four waves), 2 / 1 for 32 and 64
+    const int NT1 = MT == 1 ? 3 : 2, NT2 = MT == 1 ? 2 : 1, NWN = 4 / MT;
+    if (MT > 2) return false;          // (64 channels: every workgroup would stream 2 x 147 KB of weights for 8 output pixels -- measured 19 us against 11.6 for the two launches)
+    if (((q.TH + 2) * (q.TW + 2) + 15) / 16 > NT1 * NWN || (q.TH * q.TW + 15) / 16 > NT2 * NWN || (q.TH + 4) * (q.TW + 4) > 256) return false;      // (the staging gives every tile position a thread)
+    q.tiles_x = (x.W + q.TW - 1) / q.TW;
+    const int tiles = q.tiles_x * ((x.H + q.TH - 1) / q.TH);
+    q.x_ld = x.ld; q.x_cs = x.cs; q.x_bs = x.bs; q.y_ld = out.ld; q.y_cs = out.cs; q.y_bs = out.bs;
+    q.w1 = w.f_w1; q.w2 = w.f_w2; q.wsc = w.has_sc ? w.f_sc : nullptr;
+    q.b1 = w.c1.bias; q.b2 = w.c2.bias; q.bsc = w.has_sc ? w.sc.bias : nullptr;
+    q.wlines = w.f_lines; q.wnext = next ? next->f_w1 : nullptr; q.wnext_lines = next ? next->f_lines : 0;
+    if (q.wlines > 1536 || q.wnext_lines > 1536) return false;
+    auto stride = [](int n) { int v = n / 32 * 32 + 16; return v < n ? v + 32 : v; };      // >= n and 16 mod 32: the k-slots of a read alternate between the two bank halves
+    q.XS = stride((q.TH + 4) * (q.TW + 4)); q.YS = stride((q.TH + 2) * (q.TW + 2));
+    const size_t lds = ((size_t)q.Cin4 * 4 * q.XS + (size_t)q.Cout * q.YS) * sizeof(float);
+    if (lds > 64 * 1024) return false;
+    const dim3 grid((unsigned)tiles, (unsigned)x.B);
+    const double flops = 2.0 * w.co * (double)x.H * x.W * (9.0 * w.ci + 9.0 * w.co + (w.has_sc ? w.ci : 0)) * x.B;
+    pl.igemm_flops += flops; pl.n_igemm++;
+    Plan *plp = &pl;
+    { char d[176]; snprintf(d, sizeof d, "rmb M=%d N=%d K=%d B=%d nph=1 tile=%dx%d grid=%ux%u lds=%zu sc=%d", w.co, x.H * x.W, 9 * w.ci + 9 * w.co + (w.has_sc ? w.ci : 0), x.B, q.TH, q.TW, grid.x, grid.y, lds, (int)w.has_sc); pl.descs.push_back(d); }
+    const int desc_id = (int)pl.descs.size() - 1;
+    pl.ops.push_back([=](hipStream_t s) {
+        ProfEvent *pe = nullptr;
+        if (plp->profile) {
+            if (plp->prof_used == plp->prof.size()) { ProfEvent e; HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b)); e.flops = 0; e.bytes = 0; plp->prof.push_back(e); }
+            pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
+        }
+        hipEvent_t ea = pe ? pe->a : nullptr, eb = pe ? pe->b : nullptr;
+#define RVC_RMB_LAUNCH(MT_, N1_, N2_)                                                                                         \
+        { if (ea) hipExtLaunchKernelGGL((rm_block_kernel<MT_, N1_, N2_>), grid, dim3(256), (uint32_t)lds, s, ea, eb, 0, q);  \
+          else hipLaunchKernelGGL((rm_block_kernel<MT_, N1_, N2_>), grid, dim3(256), lds, s, q); }
+        if (MT == 1) RVC_RMB_LAUNCH(1, 3, 2) else if (MT == 2) RVC_RMB_LAUNCH(2, 2, 1) else RVC_RMB_LAUNCH(4, 2, 1)
+#undef RVC_RMB_LAUNCH
+    });
+    return true;
+}
 
 static void add_conv2d_with_shortcut(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &y1, const T2 &out)
 {
@@ -50,9 +104,10 @@ static void add_conv2d_with_shortcut(Plan &pl, const ResBlockW &w, const T2 &x, 
     queue_igemm(pl, p, x.B, koff, ph);
 }
 
-static T2 res_block(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &out)
+static T2 res_block(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &out, const ResBlockW *next = nullptr)
 {
     Arena &A = pl.arena;
+    if (add_rm_block_fused(pl, w, x, out, (next && next->f_w1) ? next : nullptr)) return out;
     T2 y1 = make_t2(A, x.B, w.co, x.H, x.W);
     // few streams: the 3x3 convolution and the 1x1 shortcut read the same input -- one launch with two phases (own K, own output tensor,
     // own activation) instead of two dependent launches (11 blocks of RMVPE have a shortcut: 11 launches off the f0 branch)
@@ -75,6 +130,10 @@ T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k, bool u
 {
     ModelRM &m = *e->rm;
     Arena &A = pl.arena;
+    // fused shallow blocks (rm_block_kernel): where the f0 branch runs on its own single-XCD partition -- up to four streams, and not the v1 engines of up to
+    // three streams, whose branch has two XCDs (the kernel's 32 workgroups per stream and its L2 warming are sized for one: v1 at one stream measured 1.92 ->
+    // 1.94 ms with it, v2 1.99 -> 1.965)
+    pl.rm_fuse = e->partitioned && (g_ncu - e->cv_cus) * 8 == g_ncu && B <= 4;
     const size_t fr = 5120 * ((frame16k + 800 - 1) / 5120 + 1) - 160;     // rmvpe.rs:256
     if (fr > L) throw PanicError("input shorter than f0_extractor_frame");
     const int Tm = (int)(1 + fr / 160);
@@ -108,7 +167,7 @@ T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k, bool u
         const int co = m.enc[lv][0].co;
         for (int j = 0; j < m.n_blocks; j++) {
             T2 out = (j == m.n_blocks - 1) ? cat[lv].chans(co, co) : make_t2(A, B, co, H, W);
-            x = res_block(pl, m.enc[lv][j], x, out);
+            x = res_block(pl, m.enc[lv][j], x, out, j + 1 < m.n_blocks ? &m.enc[lv][j + 1] : (lv + 1 < m.levels ? &m.enc[lv + 1][0] : nullptr));
         }
         if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "rm.enc%d", lv); add_tap2(pl, nm, x); }
         T2 p = make_t2(A, B, co, H / 2, W / 2);
@@ -129,7 +188,7 @@ T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k, bool u
         H *= 2; W *= 2;
         { ConvOpts o; o.act = ACT_RELU; add_convT2d(pl, m.up[lv], x, cat[sl].chans(0, co), o); }
         x = cat[sl];
-        for (int j = 0; j < m.n_blocks; j++) { T2 out = make_t2(A, B, co, H, W); x = res_block(pl, m.dec[lv][j], x, out); }
+        for (int j = 0; j < m.n_blocks; j++) { T2 out = make_t2(A, B, co, H, W); x = res_block(pl, m.dec[lv][j], x, out, j + 1 < m.n_blocks ? &m.dec[lv][j + 1] : (lv + 1 < m.levels ? &m.dec[lv + 1][0] : nullptr)); }
         if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "rm.dec%d", lv); add_tap2(pl, nm, x); }
     }
     T2 cn = make_t2(A, B, 3, H, W);

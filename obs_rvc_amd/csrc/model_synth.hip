@@ -209,9 +209,14 @@ void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T1 &src,
             }
             for (int j = 0; j < nr; j++) finals.push_back(fin.rows(j * co, co));
         }
+        // Chains issued one after the other (many streams): the average is taken by the chains' last convolutions themselves -- chain j's
+        // epilogue stores (j = 0) or adds (j > 0) its output x 1 / n_rb -- instead of three stored tensors and an averaging launch per
+        // stage (round 6: 4 launches and ~1 GB of reads + writes per 64-stream step).  The split-bf16 kernels have no accumulating
+        // epilogue: those plans keep the averaging launch.
+        const bool mean_in_epilogue = !fused && !pl.bf3 && test_opt_int("RVC_MEAN3", 0) == 0;     // (test hook RVC_MEAN3 = 1: the averaging launch)
         for (int j = 0; j < m.n_rb && !fused; j++) {
             const int k = m.rb_k[j];
-            T1 ra = make_t1(A, B, co, Tn, DH), rb = make_t1(A, B, co, Tn, DH), tt = make_t1(A, B, co, Tn, DH), fin = make_t1(A, B, co, Tn, 0);
+            T1 ra = make_t1(A, B, co, Tn, DH), rb = make_t1(A, B, co, Tn, DH), tt = make_t1(A, B, co, Tn, DH), fin = mean_in_epilogue ? xs : make_t1(A, B, co, Tn, 0);
             T1 cur = u;
             for (int q = 0; q < m.n_rbd; q++) {
                 const int d = m.rb_d[q];
@@ -219,12 +224,13 @@ void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T1 &src,
                 const bool last = q == m.n_rbd - 1;
                 T1 dst = last ? fin : (cur.p == ra.p ? rb : ra);
                 ConvOpts o; o.res = cur.p; o.res_cs = cur.ld; o.res_bs = cur.bs;
+                if (last && mean_in_epilogue) { o.scale = 1.0f / (float)m.n_rb; o.accumulate = j > 0; }
                 add_conv1d(pl, m.rbs[i][j][q].second, tt, dst, 1, (k - 1) / 2, 1, o);
                 cur = dst;
             }
             finals.push_back(fin);
         }
-        {
+        if (!mean_in_epilogue) {
             // xs = (r0 + r1 + ...) / n_rb, summed in chain order as in the reference definition
             const int nrb = m.n_rb; const float inv = 1.0f / (float)m.n_rb;
             const float *f0 = finals[0].p, *f1 = nrb > 1 ? finals[1].p : nullptr, *f2 = nrb > 2 ? finals[2].p : nullptr;

@@ -7,7 +7,7 @@
 namespace rvc {
 
 static const char *const kTestHooks[] = {"RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_NO_LN_FUSE", "RVC_NO_CONV0_MULTI", "RVC_KNN_NO_GEMM",
-                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB", "RVC_CONV32S_BUF", "RVC_FORCE_CHOICE", "RVC_G32L_PANEL"};
+                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB", "RVC_CONV32S_BUF", "RVC_FORCE_CHOICE", "RVC_G32L_PANEL", "RVC_MEAN3", "RVC_RM_FUSE"};
 std::atomic<unsigned> g_opt_gen{0};       // bumped by every rvc_debug_option call: plans built under another generation are dropped (engine.hip get_plan)
 static std::mutex g_opt_mu;
 static std::map<std::string, std::string> g_opts;
@@ -714,8 +714,8 @@ static void queue_igemm_impl(Plan &pl, IgemmP p, int B, const std::vector<int> &
         else if (const char *f = test_opt("RVC_FORCE_G2W")) { if (sscanf(f, "%d,%d", &gt, &gk) < 1) gt = -1; }
         else g2w_rule(p, nchunks, gt, gk);
         if (g2w_ok && gt >= 0 && gt <= 2) {
-            if (gk != 1 && gk != 2 && gk != 3 && gk != 4 && gk != 6 && gk != 8) gk = gk > 8 ? 8 : 4;
-            while (gk > 1 && nchunks < gk) gk = gk == 8 ? 6 : (gk == 6 ? 4 : gk - 1);
+            if (!(gt == 0 && (gk == 12 || gk == 16)) && gk != 1 && gk != 2 && gk != 3 && gk != 4 && gk != 6 && gk != 8) gk = gk > 8 ? 8 : 4;
+            while (gk > 1 && nchunks < gk) gk = gk == 16 ? 12 : (gk == 12 ? 8 : (gk == 8 ? 6 : (gk == 6 ? 4 : gk - 1)));
             const int bm = 32 * kG2wMT[gt], bn = 32 * kG2wNT[gt];
             p.ksplit = 1; p.chunks_per_split = nchunks;
             p.ntm = (p.M + bm - 1) / bm; p.ntn = (p.N + bn - 1) / bn;
@@ -951,10 +951,12 @@ bool planner_hook_set()
 static double tune_trial(const Plan &pl, const IgemmP &p, int B, const std::vector<int> &koff, const std::vector<PhaseD> &phases, const Choice &c, int reps, std::string *desc)
 {
     // one scratch plan per thread, rewound between trials (its arena holds a layer's tables only)
-    static thread_local std::unique_ptr<Plan> scratch;
+    // (a plain pointer, never freed at thread / process exit: a destructor that calls hipFree behind the runtime's own teardown crashed the process
+    //  at exit under rocprofv3 -- round 6, profiles of the first autotuned build)
+    static thread_local Plan *scratch = nullptr;
     static thread_local int scratch_dev = -1;
     int dev = 0; HIPCHK(hipGetDevice(&dev));
-    if (!scratch || scratch_dev != dev) { scratch.reset(new Plan()); scratch->arena.set_chunk_min((size_t)8 << 20); scratch_dev = dev; }
+    if (!scratch || scratch_dev != dev) { delete scratch; scratch = new Plan(); scratch->arena.set_chunk_min((size_t)8 << 20); scratch_dev = dev; }
     Plan &tp = *scratch;
     HIPCHK(hipStreamSynchronize(tune_stream()));          // (the previous trial's launches still read the tables that are about to be overwritten)
     tp.ops = OpList(); tp.descs.clear(); tp.arena.rewind();

@@ -16,7 +16,7 @@ h = C.c_void_p()
 assert L.rvc_create(b"/tmp", 0, C.byref(h)) == 0
 SHAPES = [("ffn1 3072x768", 3072, 768, 111, 3), ("qkv 2304x768", 2304, 768, 111, 0), ("ffn2 768x3072", 768, 3072, 111, 0), ("out 768x768", 768, 768, 111, 0),
           ("proj 768x512", 768, 512, 111, 0)]
-VAR = [("auto", None)] + [("%dx%d k%d" % (32 * (1, 2, 2)[t], 32 * (1, 1, 2)[t], k), "%d,%d" % (t, k)) for t in (0, 1, 2) for k in (1, 2, 3, 4, 6, 8)]
+VAR = [("auto", None)] + [("%dx%d k%d" % (32 * (1, 2, 2)[t], 32 * (1, 1, 2)[t], k), "%d,%d" % (t, k)) for t in (0, 1, 2) for k in ((1, 2, 3, 4, 6, 8, 12, 16) if t == 0 else (1, 2, 3, 4, 6, 8))]
 for S in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8, 16, 32]:
     print("streams %d: us per variant (best marked *)" % S)
     print("%-16s" % "layer" + "".join("%-10s" % v[0] for v in VAR))

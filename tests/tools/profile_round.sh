@@ -6,7 +6,10 @@
 tag=${1:-r06}; rnd=${2:-r06}; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; raw=/tmp/prof_$tag; mkdir -p $out $raw
 cd /tmp; export TMPDIR=/tmp
 prof() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d $raw/ks_$name -- python $R/bench.py --only-headline --no-cpu "$@" > $out/bench_$name.json 2> $out/bench_$name.err
-         cp $raw/ks_$name/*/*kernel_stats.csv $out/${rnd}_kernel_stats_bench_$name.csv; }
+         cp $raw/ks_$name/*/*kernel_stats.csv $out/${rnd}_kernel_stats_bench_$name.csv
+         python $R/tests/tools/trace_stats.py $raw/ks_$name/*/*kernel_trace.csv $out/${rnd}_kernel_stats_bench_${name}_steps.csv; }
+# (two tables per pass since round 6: rocprofv3's own --stats table of the whole process, which includes the plan build's autotune trials, and the same trace
+#  restricted to whole steps -- tests/tools/trace_stats.py; the serial passes and every per-step figure use the second)
 if [ -z "$RVC_PROFILE_ONLY_SERIAL" ]; then
 prof 1stream --steps 100
 prof index100k --steps 100 --index
@@ -16,13 +19,15 @@ prof 64streams --steps 15 --warmup 3 --streams 64
 # next to its own in-run roofline.frac of a many-stream configuration (events / rocprof: the validation of the event method).
 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/ks_64serial -- python $R/bench.py --only-headline --no-cpu --steps 15 --warmup 3 --streams 64 --serial-branches > $out/bench_64streams_serial.json 2> $out/bench_64streams_serial.err
 cp $raw/ks_64serial/*/*kernel_stats.csv $out/${rnd}_kernel_stats_bench_64streams_serial_branches.csv
-python $R/tests/tools/serial_pass.py $out/${rnd}_kernel_stats_bench_64streams_serial_branches.csv 64 $out/${rnd}_serial_64streams.json ${rnd}_kernel_stats_bench_64streams_serial_branches.csv $out/bench_64streams_serial.json > /dev/null
+python $R/tests/tools/trace_stats.py $raw/ks_64serial/*/*kernel_trace.csv $out/${rnd}_kernel_stats_bench_64streams_serial_branches_steps.csv
+python $R/tests/tools/serial_pass.py $out/${rnd}_kernel_stats_bench_64streams_serial_branches_steps.csv 64 $out/${rnd}_serial_64streams.json ${rnd}_kernel_stats_bench_64streams_serial_branches_steps.csv $out/bench_64streams_serial.json > /dev/null
 fi
 # the same pass at the stream counts between the two regimes (validation of the event method at those counts); RVC_PROFILE_ONLY_SERIAL=1 stops here
 for S in 8 16 32; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $raw/ks_${S}serial -- python $R/bench.py --only-headline --no-cpu --steps 20 --warmup 3 --streams $S --serial-branches > $out/bench_${S}streams_serial.json 2> $out/bench_${S}streams_serial.err
     cp $raw/ks_${S}serial/*/*kernel_stats.csv $out/${rnd}_kernel_stats_bench_${S}streams_serial_branches.csv
-    python $R/tests/tools/serial_pass.py $out/${rnd}_kernel_stats_bench_${S}streams_serial_branches.csv $S $out/${rnd}_serial_${S}streams.json ${rnd}_kernel_stats_bench_${S}streams_serial_branches.csv $out/bench_${S}streams_serial.json > /dev/null
+    python $R/tests/tools/trace_stats.py $raw/ks_${S}serial/*/*kernel_trace.csv $out/${rnd}_kernel_stats_bench_${S}streams_serial_branches_steps.csv
+    python $R/tests/tools/serial_pass.py $out/${rnd}_kernel_stats_bench_${S}streams_serial_branches_steps.csv $S $out/${rnd}_serial_${S}streams.json ${rnd}_kernel_stats_bench_${S}streams_serial_branches_steps.csv $out/bench_${S}streams_serial.json > /dev/null
 done
 if [ -n "$RVC_PROFILE_ONLY_SERIAL" ]; then ls -la $out; exit 0; fi
 pmc() { name=$1; ctr=$2; shift 2; rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $raw/pmc_${name}_$ctr -- python $R/bench.py --only-headline --no-cpu "$@" > /dev/null 2>&1; }

@@ -17,7 +17,7 @@ if steps < 3:
 ig = [r for r in rows if any(k in r["Name"] for k in IGEMM)]
 tot_ns = sum(float(r["TotalDurationNs"]) for r in ig)
 launches = sum(int(r["Calls"]) for r in ig)
-out = {"source": "rocprofv3 --kernel-trace --stats of `bench.py --only-headline --no-cpu --streams %s --serial-branches` (tests/tools/profile_round.sh)" % sys.argv[2],
+out = {"source": "rocprofv3 --kernel-trace of `bench.py --only-headline --no-cpu --streams %s --serial-branches` (tests/tools/profile_round.sh)" % sys.argv[2],
        "csv": sys.argv[4] if len(sys.argv) > 4 else os.path.basename(sys.argv[1]), "build": _native.binary_hash(), "streams": int(sys.argv[2]),
        "steps_in_trace": steps, "igemm_launches_per_step": launches / steps, "sum_igemm_ms_per_step": tot_ns / steps * 1e-6,
        "kernel_class": ", ".join(IGEMM)}
