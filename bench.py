@@ -419,8 +419,8 @@ def committed_traffic(S, with_index=False, version=2, preset="full"):
 
 def committed_serial_pass(S, sum_kernel_ms):
     """Validation of the HIP-event figure, not a gate: profiles/<round>_serial_<S>streams.json records, for a serial-branch pass on the builder's box,
-    the rocprofv3 kernel-trace sum of the implicit-GEMM class per step AND the HIP-event sum of the same process (tests/tools/serial_pass.py).  Their
-    ratio is a property of the measurement method (box-independent); this run's `frac` is its own HIP-event figure.  -> record"""
+    the rocprofv3 kernel-trace sum of the implicit-GEMM class per step (tests/tools/serial_pass.py).  This run's `frac` is its own HIP-event figure; the
+    event sum of this (unprofiled) run over that rocprofv3 sum is quoted next to it: 1.00 on the same build and box, the box's speed ratio elsewhere.  -> record"""
     from obs_rvc_amd import _native
     import glob
     have = _native.binary_hash()
@@ -435,14 +435,14 @@ def committed_serial_pass(S, sum_kernel_ms):
     rec = {"serial_pass": os.path.relpath(f, ROOT), "serial_pass_csv": d.get("csv"), "serial_pass_build": d.get("build"), "library_build": have,
            "serial_pass_same_build": d.get("build") == have,
            "serial_pass_rocprof_ms_per_step": d.get("sum_igemm_ms_per_step"), "serial_pass_events_ms_per_step": d.get("events_sum_igemm_ms_per_step")}
-    if d.get("sum_igemm_ms_per_step") and d.get("events_sum_igemm_ms_per_step"):
-        rec["events_over_rocprof_builder_box"] = round(float(d["events_sum_igemm_ms_per_step"]) / float(d["sum_igemm_ms_per_step"]), 4)
+    # (the pass's own event sum was taken while rocprofv3 traced the process -- the tool adds ~4 us to every event pair -- so it is kept for the record only;
+    #  the validation of the event method is THIS unprofiled run's event sum over the pass's rocprofv3 sum, below: 1.00 on the same build and box)
     if d.get("sum_igemm_ms_per_step"):
         rec["this_run_events_over_committed_rocprof"] = round(sum_kernel_ms / float(d["sum_igemm_ms_per_step"]), 4)
     return rec
 
 
-KERNEL_CLASS = "implicit-GEMM class: rvc::igemm2 / igemm2w / conv_tile / igemm32 / igemm32l / conv32s(_buf) / igemm_lds kernels, all instantiations"
+KERNEL_CLASS = "implicit-GEMM class: rvc::igemm2 / igemm2w / conv_tile / igemm32 / igemm32l / conv32s(_buf) / igemm_lds / rm_block kernels, all instantiations"
 
 
 def roofline_of(eng, step, S, reps=5, with_index=False, version=2, preset="full"):
@@ -583,7 +583,7 @@ def compact_roofline(r):
         return None
     keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_launch_us", "sum_kernel_ms", "flops_per_step", "frac_by_wall",
             "peak_measured", "frac_vs_measured_peak", "leg_sclk_mhz", "frac_at_leg_clock", "traffic_bytes_per_step", "algorithmic_weight_bytes_per_step",
-            "algorithmic_bytes_per_step_estimate", "events_over_rocprof_builder_box", "this_run_events_over_committed_rocprof", "serial_pass_same_build")
+            "algorithmic_bytes_per_step_estimate", "this_run_events_over_committed_rocprof", "serial_pass_same_build")
     out = {k: r[k] for k in keep if r.get(k) is not None or k in ("frac", "traffic")}
     out["kernel"] = "implicit-GEMM class (igemm2/2w/32/32l, conv_tile, conv32s), all launches"
     if r.get("traffic_source"):
@@ -939,7 +939,7 @@ def main(argv=None):
                 "frac_vs_measured_peak": "the same achieved figure against peak_measured[0].mfma_f32_tflops: a bare v_mfma_f32_32x32x2_f32 stream timed on this GPU at the start of this run (rvc_calibrate)",
                 "frac_at_leg_clock": "against 157.3 TF/s x (effective shader clock while the leg ran / 2400 MHz); the clock is counted by sleeping waves inside the GPU (s_memtime cycles per s_memrealtime tick, rvc_clock_monitor_*) during >= 0.6 s of the leg's own load, outside the timed region",
                 "box": "sclk / W / C per leg: shader clock from that monitor; socket power (W, against power_cap_w) and hotspot temperature from the SMU (amdsmi, device matched by PCI bus id) sampled every 100 ms during the same probe steps",
-                "serial_pass": "profiles/<round>_serial_<S>streams.json: rocprofv3 kernel-trace sum and HIP-event sum of one serial-branch process on the builder's box; their ratio validates the event method and is box-independent",
+                "serial_pass": "profiles/<round>_serial_<S>streams.json: rocprofv3 kernel-trace sum of the implicit-GEMM class per step of one serial-branch process on the builder's box (whole steps behind the plan build's autotune trials: tests/tools/trace_stats.py); this_run_events_over_committed_rocprof = this unprofiled run's HIP-event sum over it (1.00 on the same build and box)",
             },
         }
         if args.index and head.get("index_broadcast"):

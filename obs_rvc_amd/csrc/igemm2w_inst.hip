@@ -56,6 +56,17 @@ void G2W_FN(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEv
 }
 
 #if RVC_G2W_PART == 0
+// LayerNorm-consumer instantiations (32 x 32 wave tile, four or eight waves splitting K): the one-stream QKV / first FFN projections of ContentVec
+void launch_igemm2w_ln(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
+{
+    if (ks < 0) {
+        (void)hipFuncSetAttribute((const void *)igemm2w_kernel<1, 1, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        (void)hipFuncSetAttribute((const void *)igemm2w_kernel<1, 1, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        return;
+    }
+    if (ks == 4) launch_k(igemm2w_kernel<1, 1, 4, true>, p, grid, dim3(256), lds, s, ea, eb);
+    else launch_k(igemm2w_kernel<1, 1, 8, true>, p, grid, dim3(512), lds, s, ea, eb);
+}
 void launch_igemm2w(int tile, int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb)
 {
     if (tile == 0) launch_igemm2w_t0(ks, p, grid, lds, s, ea, eb);
@@ -66,6 +77,7 @@ void igemm2w_prepare_device()
 {
     IgemmP p{};
     for (int t = 0; t < 3; t++) launch_igemm2w(t, -1, p, dim3(1), 0, nullptr, nullptr, nullptr);
+    launch_igemm2w_ln(-1, p, dim3(1), 0, nullptr, nullptr, nullptr);
 }
 #endif
 

@@ -36,6 +36,7 @@ void launch_conv_tile(int tile, int kshares, const IgemmP &p, dim3 grid, size_t 
 static const int kG2wMT[3] = {1, 2, 2}, kG2wNT[3] = {1, 1, 2};
 void igemm2w_prepare_device();
 void launch_igemm2w(int tile, int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
+void launch_igemm2w_ln(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);      // LayerNorm-consumer variant: tile 0, ks 4 / 8
 void launch_igemm2w_t0(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 void launch_igemm2w_t1(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);
 void launch_igemm2w_t2(int ks, const IgemmP &p, dim3 grid, size_t lds, hipStream_t s, hipEvent_t ea, hipEvent_t eb);

@@ -7,7 +7,9 @@ namespace rvc {
 // One launch per ConvBlockRes on the shallow levels (rm_block_kernel, rmblock.hip.h): few streams only -- there the f0 branch is a chain of dependent
 // 5-8 us launches on its own CU partition and the block's halo recomputation costs nothing that matters; with many streams folded into a launch the two
 // convolutions fill the chip by themselves and keep the implicit-GEMM kernels.  Test hook RVC_RM_FUSE = 0: never, 2: at any stream count.  false = not taken.
-static bool add_rm_block_fused(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &out, const ResBlockW *next)
+// pool_src != nullptr: the block's input is AvgPool2d(2, 2) of that tensor, averaged while the tile is staged (the pooling launch in front of the block disappears);
+// dry: eligibility only, nothing queued
+static bool add_rm_block_fused(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &out, const ResBlockW *next, const T2 *pool_src = nullptr, bool dry = false)
 {
     const int mode = test_opt_int("RVC_RM_FUSE", 1);
     if (!w.f_w1 || mode == 0 || (!pl.rm_fuse && mode != 2)) return false;
@@ -27,6 +29,7 @@ static bool add_rm_block_fused(Plan &pl, const ResBlockW &w, const T2 &x, const 
     q.tiles_x = (x.W + q.TW - 1) / q.TW;
     const int tiles = q.tiles_x * ((x.H + q.TH - 1) / q.TH);
     q.x_ld = x.ld; q.x_cs = x.cs; q.x_bs = x.bs; q.y_ld = out.ld; q.y_cs = out.cs; q.y_bs = out.bs;
+    if (pool_src) { q.x = pool_src->p; q.x_ld = pool_src->ld; q.x_cs = pool_src->cs; q.x_bs = pool_src->bs; q.pool = 1; }
     q.w1 = w.f_w1; q.w2 = w.f_w2; q.wsc = w.has_sc ? w.f_sc : nullptr;
     q.b1 = w.c1.bias; q.b2 = w.c2.bias; q.bsc = w.has_sc ? w.sc.bias : nullptr;
     q.wlines = w.f_lines; q.wnext = next ? next->f_w1 : nullptr; q.wnext_lines = next ? next->f_lines : 0;
@@ -35,7 +38,9 @@ static bool add_rm_block_fused(Plan &pl, const ResBlockW &w, const T2 &x, const 
     q.XS = stride((q.TH + 4) * (q.TW + 4)); q.YS = stride((q.TH + 2) * (q.TW + 2));
     const size_t lds = ((size_t)q.Cin4 * 4 * q.XS + (size_t)q.Cout * q.YS) * sizeof(float);
     if (lds > 64 * 1024) return false;
-    const dim3 grid((unsigned)tiles, (unsigned)x.B);
+    if (dry) return true;
+    q.tiles = tiles;
+    const dim3 grid((unsigned)(tiles + (q.wnext ? 1 : 0)), (unsigned)x.B);
     const double flops = 2.0 * w.co * (double)x.H * x.W * (9.0 * w.ci + 9.0 * w.co + (w.has_sc ? w.ci : 0)) * x.B;
     pl.igemm_flops += flops; pl.n_igemm++;
     Plan *plp = &pl;
@@ -104,10 +109,11 @@ static void add_conv2d_with_shortcut(Plan &pl, const ResBlockW &w, const T2 &x, 
     queue_igemm(pl, p, x.B, koff, ph);
 }
 
-static T2 res_block(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &out, const ResBlockW *next = nullptr)
+static T2 res_block(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &out, const ResBlockW *next = nullptr, const T2 *pool_src = nullptr)
 {
     Arena &A = pl.arena;
-    if (add_rm_block_fused(pl, w, x, out, (next && next->f_w1) ? next : nullptr)) return out;
+    if (add_rm_block_fused(pl, w, x, out, (next && next->f_w1) ? next : nullptr, pool_src)) return out;
+    if (pool_src) throw std::runtime_error("RMVPE: pooled input without the fused block");
     T2 y1 = make_t2(A, x.B, w.co, x.H, x.W);
     // few streams: the 3x3 convolution and the 1x1 shortcut read the same input -- one launch with two phases (own K, own output tensor,
     // own activation) instead of two dependent launches (11 blocks of RMVPE have a shortcut: 11 launches off the f0 branch)
@@ -163,15 +169,20 @@ T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k, bool u
     }
     T2 x = img;
     int H = H0, W = W0;
+    T2 pool_from; bool pooled_in_block = false;         // the previous level's output when its pooling is folded into this level's first (fused) block
     for (int lv = 0; lv < m.levels; lv++) {
         const int co = m.enc[lv][0].co;
         for (int j = 0; j < m.n_blocks; j++) {
             T2 out = (j == m.n_blocks - 1) ? cat[lv].chans(co, co) : make_t2(A, B, co, H, W);
-            x = res_block(pl, m.enc[lv][j], x, out, j + 1 < m.n_blocks ? &m.enc[lv][j + 1] : (lv + 1 < m.levels ? &m.enc[lv + 1][0] : nullptr));
+            x = res_block(pl, m.enc[lv][j], x, out, j + 1 < m.n_blocks ? &m.enc[lv][j + 1] : (lv + 1 < m.levels ? &m.enc[lv + 1][0] : nullptr), (j == 0 && pooled_in_block) ? &pool_from : nullptr);
         }
         if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "rm.enc%d", lv); add_tap2(pl, nm, x); }
         T2 p = make_t2(A, B, co, H / 2, W / 2);
-        {
+        // the next level's first block stages AvgPool2d(2, 2) of this level's output itself when it is a fused block (one more launch off the f0 branch)
+        pooled_in_block = lv + 1 < m.levels && (H % 2) == 0 && (W % 2) == 0 && test_opt_int("RVC_RM_FUSE", 1) != 3 &&
+                          [&]() { T2 o = p; o.C = m.enc[lv + 1][0].co; return add_rm_block_fused(pl, m.enc[lv + 1][0], p, o, nullptr, &x, true); }();
+        if (pooled_in_block) pool_from = x;
+        else {
             T2 xi = x;
             dim3 grid((co * (H / 2) * (W / 2) + 255) / 256, B);
             pl.ops.push_back([=](hipStream_t s) {

@@ -7,7 +7,7 @@
 namespace rvc {
 
 static const char *const kTestHooks[] = {"RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_NO_LN_FUSE", "RVC_NO_CONV0_MULTI", "RVC_KNN_NO_GEMM",
-                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB", "RVC_CONV32S_BUF", "RVC_FORCE_CHOICE", "RVC_G32L_PANEL", "RVC_MEAN3", "RVC_RM_FUSE"};
+                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB", "RVC_CONV32S_BUF", "RVC_FORCE_CHOICE", "RVC_G32L_PANEL", "RVC_MEAN3", "RVC_RM_FUSE", "RVC_G2W_LN"};
 std::atomic<unsigned> g_opt_gen{0};       // bumped by every rvc_debug_option call: plans built under another generation are dropped (engine.hip get_plan)
 static std::mutex g_opt_mu;
 static std::map<std::string, std::string> g_opts;
@@ -707,12 +707,18 @@ static void queue_igemm_impl(Plan &pl, IgemmP p, int B, const std::vector<int> &
     // igemm2w_kernel: register-direct 32x32x2 tiles for the table-free 1x1 layers at a few streams (igemm.hip.h).  Test hook RVC_FORCE_G2W = "tile,ks"
     // (tile 0 = 32 x 32 per wave, 1 = 64 x 32, 2 = 64 x 64; ks = 1 / 2 / 3 / 4 / 6 / 8 waves splitting K) forces it wherever it is eligible.
     {
-        const bool g2w_ok = p.lin_cs4 != 0 && p.nphase == 1 && !pre && !p.glu && !ln_fold && B == 1 && nchunks >= 1;
+        // (round 6) a layer that consumes a not yet normalised tensor (IgemmP::ln_wsum) can take the kernel's LayerNorm-consumer variant: 32 x 32 wave tile, four or
+        // eight K shares.  One stream, tests/tools/g2w_sweep.py: the 2304- / 3072-row projections 12.4 / 13.4 -> 9.5 / 10.0 us against igemm2_kernel's LNB tiles;
+        // the 768-row layers (output projection, second FFN layer, feature projection) stay: 6.0 / 13.5 / 5.0 vs 6.3 / 15.0 / 5.4.  Test hook RVC_G2W_LN = 0: never.
+        const bool g2w_ln = p.ln_wsum && !p.ln_stats_in && !phase_epi;
+        const bool g2w_ok = p.lin_cs4 != 0 && p.nphase == 1 && !pre && !p.glu && (!ln_fold || g2w_ln) && B == 1 && nchunks >= 1;
         int gt = -1, gk = 1;
         if (t_choice.kind == 2) { gt = t_choice.a; gk = t_choice.b; }
         else if (t_choice.kind != 0) gt = -1;
         else if (const char *f = test_opt("RVC_FORCE_G2W")) { if (sscanf(f, "%d,%d", &gt, &gk) < 1) gt = -1; }
+        else if (g2w_ln) { if (streams == 1 && p.M >= 2048 && nchunks >= 32 && test_opt_int("RVC_G2W_LN", 1) != 0) { gt = 0; gk = 8; } }
         else g2w_rule(p, nchunks, gt, gk);
+        if (g2w_ln && (gt != 0 || (gk != 4 && gk != 8) || nchunks < gk)) gt = -1;          // (only those two instantiations exist)
         if (g2w_ok && gt >= 0 && gt <= 2) {
             if (!(gt == 0 && (gk == 12 || gk == 16)) && gk != 1 && gk != 2 && gk != 3 && gk != 4 && gk != 6 && gk != 8) gk = gk > 8 ? 8 : 4;
             while (gk > 1 && nchunks < gk) gk = gk == 16 ? 12 : (gk == 12 ? 8 : (gk == 8 ? 6 : (gk == 6 ? 4 : gk - 1)));
@@ -726,12 +732,12 @@ static void queue_igemm_impl(Plan &pl, IgemmP p, int B, const std::vector<int> &
             const dim3 grid(gx, (unsigned)(wh ? p.ntn : p.ntm), 1);
             if (grid.y > 65535) throw ShapeError("implicit GEMM grid too large");
             p.nbatch = 1;
-            const size_t lds = gk > 1 ? (size_t)gk * kG2wMT[gt] * kG2wNT[gt] * 1024 * sizeof(float) : 0;
+            const size_t lds = gk > 1 ? (size_t)gk * kG2wMT[gt] * kG2wNT[gt] * 1024 * sizeof(float) + (g2w_ln ? (size_t)gk * 32 * 2 * sizeof(float) : 0) : 0;
             g_last_wgs = (int)(grid.x * grid.y); g_last_waves = gk;
             const double flops = 2.0 * p.M * (double)p.N * ksum;
             pl.igemm_flops += flops; pl.n_igemm++;
             Plan *plp = &pl;
-            { char d[176]; snprintf(d, sizeof d, "g2w M=%d N=%d K=%d B=1 nph=1 tile=%dx%d ks=%d grid=%ux%u", p.M, p.N, p.K, bm, bn, gk, grid.x, grid.y); pl.descs.push_back(d); note_kernel(d); }
+            { char d[176]; snprintf(d, sizeof d, "g2w M=%d N=%d K=%d B=1 nph=1 tile=%dx%d ks=%d grid=%ux%u%s", p.M, p.N, p.K, bm, bn, gk, grid.x, grid.y, g2w_ln ? " ln=1" : ""); pl.descs.push_back(d); note_kernel(d); }
             const int desc_id = (int)pl.descs.size() - 1;
             if (final_out) pl.final_out_honoured = true;
             pl.ops.push_back([=](hipStream_t s) {
@@ -741,7 +747,8 @@ static void queue_igemm_impl(Plan &pl, IgemmP p, int B, const std::vector<int> &
                     pe = &plp->prof[plp->prof_used++]; pe->flops = flops; pe->bytes = 0; pe->desc = desc_id;
                 }
                 hipEvent_t ea = pe ? pe->a : nullptr, eb = pe ? pe->b : nullptr;
-                if (final_out && plp->cur_out) { IgemmP q = p; q.y = plp->cur_out; q.y_bs = plp->cur_out_bs; launch_igemm2w(gt, gk, q, grid, lds, s, ea, eb); }
+                if (g2w_ln) launch_igemm2w_ln(gk, p, grid, lds, s, ea, eb);
+                else if (final_out && plp->cur_out) { IgemmP q = p; q.y = plp->cur_out; q.y_bs = plp->cur_out_bs; launch_igemm2w(gt, gk, q, grid, lds, s, ea, eb); }
                 else launch_igemm2w(gt, gk, p, grid, lds, s, ea, eb);
             });
             return;

@@ -23,12 +23,13 @@ namespace rvc {
 struct RmBlockP {
     const float *x; float *y;
     int Cin, Cin4, Cout;              // Cin4 = (Cin padded to 16) / 4: K steps per tap of the first convolution and of the shortcut
-    int H, W, TH, TW, tiles_x;
+    int H, W, TH, TW, tiles_x, tiles;      // tiles: workgroups that compute (one more, of stream 0, only warms the next block's panels)
     int x_ld, x_cs; long long x_bs;
     int y_ld, y_cs; long long y_bs;
     const float *w1, *w2, *wsc;       // fragment-order panels (wsc == nullptr: identity shortcut, Cin == Cout)
     const float *b1, *b2, *bsc;
     int XS, YS;                       // LDS channel strides of the input tile and of the y1 tile (floats, 16 mod 32)
+    int pool;                         // 1: x is the previous level's output at twice the resolution (H, W are this block's): the staging averages 2 x 2 pixels
     int wlines;                       // 128-byte lines of the [w1 | w2 | wsc] allocation (<= 1536)
     const float *wnext; int wnext_lines;      // the NEXT fused block's panels (or nullptr): requested into the L2 while this block computes
 };
@@ -95,18 +96,22 @@ __global__ __launch_bounds__(256) void rm_block_kernel(RmBlockP p)
     float *ys = smem + (size_t)p.Cin4 * 4 * XS;                  // [Cout][YS]      y1 tile, one-pixel halo, zero outside the image
     // --- warm the weight panels: they were last read one chunk (~850 MB of weight traffic) ago, i.e. they are in HBM.  The K walks below keep twelve steps in
     //     flight per wave: enough against an L2 hit, not against HBM (the first version of this kernel spent 3 + 3 memory round trips per block on a 9 KB panel).
-    //     Every workgroup of the launch requests every line once, up front, next to the input tile's loads: one round trip for the whole block.  The next fused
-    //     block's panels are requested too (consumed nowhere: they only have to reach the L2 of this XCD while this block computes).
+    //     Every workgroup of the launch requests every line once, up front, next to the input tile's loads: one round trip for the whole block -- and an L2 hit
+    //     when the previous fused block's extra workgroup has requested them already (they only have to reach the L2 of this XCD while that block computes).
     float warm = 0.f;
+    if ((int)blockIdx.x >= p.tiles) {
+        // the launch's extra workgroup: requests the NEXT block's panels and ends (loads return in order: inside a computing workgroup these HBM reads would sit
+        // in front of every later wait of its weight stream)
+        const char *wn_ = reinterpret_cast<const char *>(p.wnext);
+#pragma unroll
+        for (int u = 0; u < 6; u++) { int l = (int)threadIdx.x + u * 256; l = l < p.wnext_lines ? l : p.wnext_lines - 1; warm += *reinterpret_cast<const float *>(wn_ + (size_t)l * 128); }
+        asm volatile("" :: "v"(warm));
+        return;
+    }
     {
         const char *wl = reinterpret_cast<const char *>(p.w1);
 #pragma unroll
         for (int u = 0; u < 6; u++) { int l = (int)threadIdx.x + u * 256; l = l < p.wlines ? l : p.wlines - 1; warm += *reinterpret_cast<const float *>(wl + (size_t)l * 128); }
-        if (p.wnext) {
-            const char *wn_ = reinterpret_cast<const char *>(p.wnext);
-#pragma unroll
-            for (int u = 0; u < 6; u++) { int l = (int)threadIdx.x + u * 256; l = l < p.wnext_lines ? l : p.wnext_lines - 1; warm += *reinterpret_cast<const float *>(wn_ + (size_t)l * 128); }
-        }
     }
     // --- stage the input tile: a thread owns one tile position r for every G-th channel (two integer divisions per thread, none per element); all loads of a
     //     batch are requested before the first LDS write (one memory round trip per batch of sixteen)
@@ -116,13 +121,26 @@ __global__ __launch_bounds__(256) void rm_block_kernel(RmBlockP p)
         const int g = (int)threadIdx.x / plane, r = (int)threadIdx.x - g * plane;
         const int iy = r / XW, ix = r - iy * XW, gy = ty0 - 2 + iy, gx = tx0 - 2 + ix;
         const bool active = g < G, inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        const float *xp = xg + gy * p.x_ld + gx;
+        const float *xp = p.pool ? xg + 2 * gy * p.x_ld + 2 * gx : xg + gy * p.x_ld + gx;
         for (int c0 = 0; c0 < Ctot; c0 += 16 * G) {
             float v[16];
+            if (p.pool) {          // AvgPool2d(2, 2) of the previous level's output, taken here
+                float t[16][4];
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int c = c0 + u * G + g;
+                    const bool ok = active && inside && c < p.Cin;
+                    const float *q4 = xp + (long long)c * p.x_cs;
+                    t[u][0] = ok ? q4[0] : 0.f; t[u][1] = ok ? q4[1] : 0.f; t[u][2] = ok ? q4[p.x_ld] : 0.f; t[u][3] = ok ? q4[p.x_ld + 1] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u++) v[u] = (t[u][0] + t[u][1] + t[u][2] + t[u][3]) * 0.25f;          // (avgpool2_kernel's order)
+            } else {
 #pragma unroll
             for (int u = 0; u < 16; u++) {
                 const int c = c0 + u * G + g;
                 v[u] = (active && inside && c < p.Cin) ? xp[(long long)c * p.x_cs] : 0.f;
+            }
             }
 #pragma unroll
             for (int u = 0; u < 16; u++) {

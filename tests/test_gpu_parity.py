@@ -278,8 +278,18 @@ def test_folded_layernorm_every_tile_and_split():
                     e1 = L.rvc_debug_ln_fold_check(h, M, K, N, 0.3)
                     assert 0 <= e1 < 2e-5, (cfg, ks, M, K, N, e1)
             set_opt("RVC_FORCE_CFG", None)
+            # round 6: igemm2w_kernel's LayerNorm-consumer variant (32 x 32 wave tile, four / eight waves splitting K) for the consuming layer
+            for ks in (4, 8):
+                if (K // 16) < ks:
+                    continue
+                set_opt("RVC_FORCE_G2W", "0,%d" % ks)
+                e2 = L.rvc_debug_ln_fold_check(h, M, K, N, 0.3)
+                assert 0 <= e2 < 2e-5, ("g2w", ks, M, K, N, e2)
+                e3 = L.rvc_debug_ln_fold_check(h, M, K, N, 100.0)
+                assert 0 <= e3 < 2e-3, ("g2w", ks, M, K, N, e3)
+            set_opt("RVC_FORCE_G2W", None)
     finally:
-        set_opt("RVC_FORCE_CFG", None)
+        set_opt("RVC_FORCE_CFG", None); set_opt("RVC_FORCE_G2W", None)
         L.rvc_destroy(h)
 
 

@@ -70,5 +70,5 @@ if json_out:
                "tflops": round(tot_gf / tot_us * 1e3, 2), "wall_ms_per_chunk_median": round(float(np.median(ts[5:]) * 1e3), 4),
                "kernel_names": {"reg": "igemm2_kernel (register-direct, 16x16x4 MFMA)", "g32": "igemm32_kernel (LDS-staged activations, 32x32x2 MFMA)",
                                 "g32l": "igemm32l_kernel (igemm32 tiles for table-free 1x1 layers, buffer loads with scalar row offsets)", "g32t": "igemm32l_kernel, table variant (offset-table entries as scalar loads)", "c32s": "conv32s_kernel / conv32s_buf_kernel (input rows staged once per workgroup and 32-channel block, 32x32x2 MFMA)", "g32w": "igemm32w_kernel (wide register tiles, 32x32x2 MFMA)", "lds": "igemm_lds_kernel (16x16x4 MFMA)", "ct": "conv_tile_kernel", "g2w": "igemm2w_kernel (register-direct 32x32x2 MFMA, K split in the workgroup)",
-                                "bf3": "igemm_bf3_kernel (exploratory: three bf16 MFMAs per fp32 product)"},
+                                "bf3": "igemm_bf3_kernel (exploratory: three bf16 MFMAs per fp32 product)", "rmb": "rm_block_kernel (one ConvBlockRes of RMVPE's 16- / 32-channel levels per launch, 16x16x4 MFMA; K = both convolutions + shortcut)"},
                "layers": layers}, open(json_out, "w"), indent=1)

@@ -28,7 +28,7 @@ def per_class(rows):
     n_chunks = len(ends) - 2
     acc = collections.defaultdict(lambda: [0, 0.0])
     for _, name, v, _g in body:
-        key = "igemm_all_instantiations" if ("igemm_kernel" in name or "igemm_lds_kernel" in name or "igemm2_kernel" in name or "igemm32_kernel" in name or "igemm32l_kernel" in name or "igemm32w_kernel" in name or "conv_tile_kernel" in name or "igemm2w_kernel" in name or "conv32s_kernel" in name or "conv32s_buf_kernel" in name) else ("knn_scan_select_kernel" if "knn_scan_select_kernel" in name else None)
+        key = "igemm_all_instantiations" if ("igemm_kernel" in name or "igemm_lds_kernel" in name or "igemm2_kernel" in name or "igemm32_kernel" in name or "igemm32l_kernel" in name or "igemm32w_kernel" in name or "conv_tile_kernel" in name or "igemm2w_kernel" in name or "conv32s_kernel" in name or "conv32s_buf_kernel" in name or "rm_block_kernel" in name) else ("knn_scan_select_kernel" if "knn_scan_select_kernel" in name else None)
         if key:
             acc[key][0] += 1; acc[key][1] += v
     return n_chunks, acc
@@ -57,7 +57,7 @@ out = {"source": (sys.argv[4] if len(sys.argv) > 4 else "") + " rocprofv3 --pmc 
        # the library the counters were taken on: bench.py puts these figures into roofline.traffic only when its own library carries the same hash
        "build": _native.binary_hash(),
        "config": (json.loads(sys.argv[5]) if len(sys.argv) > 5 and sys.argv[5] else None),
-       "kernel_class": "igemm_all_instantiations = igemm_kernel + igemm2_kernel + igemm2w_kernel + igemm_lds_kernel + igemm32_kernel + igemm32l_kernel + conv_tile_kernel + conv32s_kernel + conv32s_buf_kernel (the launches roofline.launches_per_step counts)"}
+       "kernel_class": "igemm_all_instantiations = igemm_kernel + igemm2_kernel + igemm2w_kernel + igemm_lds_kernel + igemm32_kernel + igemm32l_kernel + conv_tile_kernel + conv32s_kernel + conv32s_buf_kernel + rm_block_kernel (the launches roofline.launches_per_step counts)"}
 for key, (n, kib) in fa.items():
     d = {"launches_per_chunk": n / nf, "fetch_size_kib_per_chunk": kib / nf, "hbm_read_bytes_per_chunk": 2 * 1024 * kib / nf,
          "hbm_read_bytes_per_launch": 2 * 1024 * kib / n}
