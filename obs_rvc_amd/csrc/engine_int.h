@@ -195,6 +195,7 @@ struct ConvOpts {
     bool no_bias = false;
     bool glu = false;            // GLU-packed weight rows, gate fused into the epilogue (ModelSY flows)
     bool bf3 = false;            // exploratory: this 1x1 layer may run its products as three bf16 MFMAs (rvc_set_gemm_precision; igemm_bf3_kernel)
+    int y_ws = 0;                // add_conv2d: output column stride in floats (0 = 1); with y.ld = 1 the layer writes its image transposed (RMVPE's head -> GRU input layout)
     bool final_out = false;      // the chunk's last convolution: writes the caller's device buffer when the call provides one (Plan::cur_out)
     // LayerNorm folded into its neighbours (IgemmP::ln_*): this layer consumes a not-yet-normalised tensor (weights pre-scaled, wsum
     // per output row, optional (mean, rstd) output) / this layer's residual is LayerNorm(stored tensor) with published statistics

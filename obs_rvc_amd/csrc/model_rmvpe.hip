@@ -9,7 +9,7 @@ namespace rvc {
 // convolutions fill the chip by themselves and keep the implicit-GEMM kernels.  Test hook RVC_RM_FUSE = 0: never, 2: at any stream count.  false = not taken.
 // pool_src != nullptr: the block's input is AvgPool2d(2, 2) of that tensor, averaged while the tile is staged (the pooling launch in front of the block disappears);
 // dry: eligibility only, nothing queued
-static bool add_rm_block_fused(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &out, const ResBlockW *next, const T2 *pool_src = nullptr, bool dry = false)
+static bool add_rm_block_fused(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &out, const ResBlockW *next, const T2 *pool_src = nullptr, bool dry = false, const T2 *pool_dst = nullptr)
 {
     const int mode = test_opt_int("RVC_RM_FUSE", 1);
     if (!w.f_w1 || mode == 0 || (!pl.rm_fuse && mode != 2)) return false;
@@ -38,6 +38,10 @@ static bool add_rm_block_fused(Plan &pl, const ResBlockW &w, const T2 &x, const 
     q.XS = stride((q.TH + 4) * (q.TW + 4)); q.YS = stride((q.TH + 2) * (q.TW + 2));
     const size_t lds = ((size_t)q.Cin4 * 4 * q.XS + (size_t)q.Cout * q.YS) * sizeof(float);
     if (lds > 64 * 1024) return false;
+    if (pool_dst) {          // second output: the pooled tensor (tiles of eight columns; even image and tile sizes)
+        if (q.TW != 8 || (q.TH & 1) || (x.H & 1) || (x.W & 1) || pool_dst->H * 2 != x.H || pool_dst->W * 2 != x.W || pool_dst->C != w.co) return false;
+        q.ypool = pool_dst->p; q.p_ld = pool_dst->ld; q.p_cs = pool_dst->cs; q.p_bs = pool_dst->bs;
+    }
     if (dry) return true;
     q.tiles = tiles;
     const dim3 grid((unsigned)(tiles + (q.wnext ? 1 : 0)), (unsigned)x.B);
@@ -109,11 +113,11 @@ static void add_conv2d_with_shortcut(Plan &pl, const ResBlockW &w, const T2 &x, 
     queue_igemm(pl, p, x.B, koff, ph);
 }
 
-static T2 res_block(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &out, const ResBlockW *next = nullptr, const T2 *pool_src = nullptr)
+static T2 res_block(Plan &pl, const ResBlockW &w, const T2 &x, const T2 &out, const ResBlockW *next = nullptr, const T2 *pool_src = nullptr, const T2 *pool_dst = nullptr)
 {
     Arena &A = pl.arena;
-    if (add_rm_block_fused(pl, w, x, out, (next && next->f_w1) ? next : nullptr, pool_src)) return out;
-    if (pool_src) throw std::runtime_error("RMVPE: pooled input without the fused block");
+    if (add_rm_block_fused(pl, w, x, out, (next && next->f_w1) ? next : nullptr, pool_src, false, pool_dst)) return out;
+    if (pool_src || pool_dst) throw std::runtime_error("RMVPE: pooled input without the fused block");
     T2 y1 = make_t2(A, x.B, w.co, x.H, x.W);
     // few streams: the 3x3 convolution and the 1x1 shortcut read the same input -- one launch with two phases (own K, own output tensor,
     // own activation) instead of two dependent launches (11 blocks of RMVPE have a shortcut: 11 launches off the f0 branch)
@@ -172,17 +176,24 @@ T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k, bool u
     T2 pool_from; bool pooled_in_block = false;         // the previous level's output when its pooling is folded into this level's first (fused) block
     for (int lv = 0; lv < m.levels; lv++) {
         const int co = m.enc[lv][0].co;
+        T2 p = make_t2(A, B, co, H / 2, W / 2);
+        // ... and a level whose LAST block is a fused block with eight-column tiles writes the pooled tensor as a second output of that block
+        const bool next_takes_pool = lv + 1 < m.levels && (H % 2) == 0 && (W % 2) == 0 && test_opt_int("RVC_RM_FUSE", 1) != 3 &&
+                                     [&]() { T2 o = p; o.C = m.enc[lv + 1][0].co; return add_rm_block_fused(pl, m.enc[lv + 1][0], p, o, nullptr, &x, true); }();
+        bool pooled_by_block = false;
         for (int j = 0; j < m.n_blocks; j++) {
             T2 out = (j == m.n_blocks - 1) ? cat[lv].chans(co, co) : make_t2(A, B, co, H, W);
-            x = res_block(pl, m.enc[lv][j], x, out, j + 1 < m.n_blocks ? &m.enc[lv][j + 1] : (lv + 1 < m.levels ? &m.enc[lv + 1][0] : nullptr), (j == 0 && pooled_in_block) ? &pool_from : nullptr);
+            const bool last = j == m.n_blocks - 1;
+            const T2 xin = x;
+            pooled_by_block = last && !next_takes_pool && test_opt_int("RVC_RM_FUSE", 1) != 3 && add_rm_block_fused(pl, m.enc[lv][j], xin, out, nullptr, (j == 0 && pooled_in_block) ? &pool_from : nullptr, true, &p);
+            x = res_block(pl, m.enc[lv][j], xin, out, j + 1 < m.n_blocks ? &m.enc[lv][j + 1] : (lv + 1 < m.levels ? &m.enc[lv + 1][0] : nullptr), (j == 0 && pooled_in_block) ? &pool_from : nullptr,
+                          pooled_by_block ? &p : nullptr);
         }
         if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "rm.enc%d", lv); add_tap2(pl, nm, x); }
-        T2 p = make_t2(A, B, co, H / 2, W / 2);
         // the next level's first block stages AvgPool2d(2, 2) of this level's output itself when it is a fused block (one more launch off the f0 branch)
-        pooled_in_block = lv + 1 < m.levels && (H % 2) == 0 && (W % 2) == 0 && test_opt_int("RVC_RM_FUSE", 1) != 3 &&
-                          [&]() { T2 o = p; o.C = m.enc[lv + 1][0].co; return add_rm_block_fused(pl, m.enc[lv + 1][0], p, o, nullptr, &x, true); }();
+        pooled_in_block = next_takes_pool;
         if (pooled_in_block) pool_from = x;
-        else {
+        else if (!pooled_by_block) {
             T2 xi = x;
             dim3 grid((co * (H / 2) * (W / 2) + 255) / 256, B);
             pl.ops.push_back([=](hipStream_t s) {
@@ -202,11 +213,17 @@ T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k, bool u
         for (int j = 0; j < m.n_blocks; j++) { T2 out = make_t2(A, B, co, H, W); x = res_block(pl, m.dec[lv][j], x, out, j + 1 < m.n_blocks ? &m.dec[lv][j + 1] : (lv + 1 < m.levels ? &m.dec[lv + 1][0] : nullptr)); }
         if (pl.with_taps) { char nm[32]; snprintf(nm, sizeof nm, "rm.dec%d", lv); add_tap2(pl, nm, x); }
     }
-    T2 cn = make_t2(A, B, 3, H, W);
-    add_conv2d(pl, m.cnn, x, cn);
     const int Hg = m.gru_hidden, I = 3 * m.n_mels;
     T1 feat = make_t1(A, B, I, Tm, 0), gi = make_t1(A, B, 6 * Hg, Tm, 0), gout = make_t1(A, B, 2 * Hg, Tm, 0), sal = make_t1(A, B, m.n_out, Tm, 0);
-    {
+    if (H == Tm && W == m.n_mels && test_opt_int("RVC_RM_FUSE", 1) != 0) {
+        // (round 6) the head convolution writes the GRU's input layout itself -- feat[c * n_mels + mel][t] = conv[c][t][mel]: channel stride n_mels rows, image row
+        // (time) stride 1, image column (mel) stride one row of `feat` -- instead of an image and a transposing launch behind it
+        T2 ft; ft.p = feat.p; ft.B = B; ft.C = 3; ft.H = H; ft.W = W; ft.cs = m.n_mels * feat.ld; ft.ld = 1; ft.bs = feat.bs;
+        ConvOpts o; o.y_ws = feat.ld;
+        add_conv2d(pl, m.cnn, x, ft, o);
+    } else {
+        T2 cn = make_t2(A, B, 3, H, W);
+        add_conv2d(pl, m.cnn, x, cn);
         dim3 grid((3 * m.n_mels * Tm + 255) / 256, B); int nm = m.n_mels;
         pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(gru_input_kernel, grid, dim3(256), 0, s, cn.p, cn.ld, cn.cs, cn.bs, feat.p, feat.ld, feat.bs, Tm, nm); });
     }

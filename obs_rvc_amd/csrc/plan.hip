@@ -1252,7 +1252,7 @@ void add_conv2d(Plan &pl, const ConvW &cw, const T2 &x, const T2 &y, ConvOpts o)
     IgemmP p{};
     p.x = x.p; p.w = cw.w; p.y = y.p;
     p.M = cw.M; p.N = x.H * x.W; p.K = cw.Kp;
-    p.NW = x.W; p.x_hs = x.ld; p.x_ws = 1; p.y_hm = 1; p.y_ws = 1; p.OW = y.W;
+    p.NW = x.W; p.x_hs = x.ld; p.x_ws = 1; p.y_hm = 1; p.y_ws = o.y_ws > 0 ? o.y_ws : 1; p.OW = o.y_ws > 0 ? y.W * o.y_ws : y.W;      // (OW bounds the column OFFSET)
     p.x_bs = x.bs; p.y_bs = y.bs; p.y_cs = y.cs; p.y_rs = y.ld;
     fill_epilogue(p, cw, o);
     std::vector<int> koff;

@@ -29,6 +29,7 @@ struct RmBlockP {
     const float *w1, *w2, *wsc;       // fragment-order panels (wsc == nullptr: identity shortcut, Cin == Cout)
     const float *b1, *b2, *bsc;
     int XS, YS;                       // LDS channel strides of the input tile and of the y1 tile (floats, 16 mod 32)
+    float *ypool; int p_ld, p_cs; long long p_bs;      // second output (or nullptr): AvgPool2d(2, 2) of y -- tiles of 8 columns only
     int pool;                         // 1: x is the previous level's output at twice the resolution (H, W are this block's): the staging averages 2 x 2 pixels
     int wlines;                       // 128-byte lines of the [w1 | w2 | wsc] allocation (<= 1536)
     const float *wnext; int wnext_lines;      // the NEXT fused block's panels (or nullptr): requested into the L2 while this block computes
@@ -210,14 +211,28 @@ __global__ __launch_bounds__(256) void rm_block_kernel(RmBlockP p)
         {
             const int n = (wn + i * NWN) * 16 + li;
             const int gy = ty0 + oy2[i], gx = tx0 + ox2[i];
-            if (n < N2 && gy < p.H && gx < p.W) {
+            const bool ok = n < N2 && gy < p.H && gx < p.W;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = wm * 16 + kq * 4 + r;
+                float t = acc2[i][r] + bias2[r];
+                t = t > 0.f ? t : 0.f;
+                t += p.wsc ? accs[i][r] + biass[r] : xs[(m - kq) * XS + coff[i]];
+                v[r] = t;
+                if (ok) yg[(long long)m * p.y_cs + gy * p.y_ld + gx] = t;
+            }
+            if (p.ypool) {
+                // AvgPool2d(2, 2) of this block's output as a second result (the encoder level's last block: the pooling launch behind it disappears).  Tiles of
+                // eight columns: an n-tile of 16 pixels is two tile rows, lanes li and li + 8 are vertical neighbours, li and li ^ 1 horizontal ones -- a 2 x 2 block
+                // is summed with two shuffles inside the 16-lane group (H, W and the tile origin are even: a block is never cut by the image edge)
+                float *pg = p.ypool + (long long)b * p.p_bs;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int m = wm * 16 + kq * 4 + r;
-                    float v = acc2[i][r] + bias2[r];
-                    v = v > 0.f ? v : 0.f;
-                    v += p.wsc ? accs[i][r] + biass[r] : xs[(m - kq) * XS + coff[i]];
-                    yg[(long long)m * p.y_cs + gy * p.y_ld + gx] = v;
+                    float t = ok ? v[r] : 0.f;
+                    t += __shfl_xor(t, 1, 64);
+                    t += __shfl_xor(t, 8, 64);
+                    if (ok && (li & 9) == 0) pg[(long long)(wm * 16 + kq * 4 + r) * p.p_cs + (gy >> 1) * p.p_ld + (gx >> 1)] = t * 0.25f;
                 }
             }
         }
