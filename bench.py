@@ -32,6 +32,7 @@ in the environment) or, without those variables, bench.py spawns the N ranks its
 touching a GPU (CPU test of the multi-rank plumbing).
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -368,6 +369,11 @@ def timed_leg(job, eng, d_rings, d_out, g, steps, warmup):
 
     for i in range(warmup):
         step(i)
+    # The interpreter's cyclic collector is the measuring host's business, not the path's: with torch imported a full collection walks ~10^6 objects --
+    # 10 ms pauses that landed inside 20 timed steps of 2 ms twice in this round's driver-style runs (p99 12 ms on a leg whose p50 was 2.04).  Everything alive
+    # now is frozen out of the collector's reach and the collector stays off while the timed region and the latency soak behind it run (run_config turns it
+    # back on).
+    gc.collect(); gc.freeze(); gc.disable()
     job.barrier()
     lat = []
     t0 = time.perf_counter()
@@ -541,6 +547,7 @@ def run_config(job, z, g, S, with_index, steps, warmup, graph, index_vecs, want_
     soak_lat = []                              # tells a slow GPU from a slow submitting thread
     for i in range(soak):                        # latency distribution: more synchronised chunks behind the timed region
         t1 = time.perf_counter(); step(i); soak_lat.append(time.perf_counter() - t1)
+    gc.enable()
     lat_all = job.gather(lat)
     soak_all = job.gather(soak_lat) if soak else []
     per_rank = [FRAMES_PER_CHUNK * steps * S / float(np.sum(l)) for l in lat_all]
