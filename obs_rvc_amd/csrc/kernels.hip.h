@@ -933,7 +933,7 @@ static __global__ __launch_bounds__(1024) void gru_kernel(const float *gi, int g
 // whose 96 KB slice of W_hh stays in LDS for all steps.  After every step the 8 slices exchange their 32 new h values through
 // 8-byte {epoch, value} granules (cdna_hip_programming.md guideline 16, form R2: the data is the flag; relaxed agent-scope
 // stores / loads, no fences, placement independent).  Two granule slots alternate by step parity; the granule buffer is zeroed
-// by a memset node before every launch.  Every spin is bounded: on timeout the stream's status word is raised instead of hanging.
+// by a memset node before every launch of a captured graph, and once per plan for eager launches (GruMultiP::epoch).  Every spin is bounded: on timeout the stream's status word is raised instead of hanging.
 struct GruMultiP {
     const float *gi; int gi_cs; long long gi_bs;
     const float *whh;          // [2][3H][H] row-major
@@ -943,6 +943,8 @@ struct GruMultiP {
     int *status;               // per stream, stride status_stride ints
     int status_stride;
     int Tm;
+    unsigned epoch;            // tags of this launch are epoch + 1 ... epoch + Tm (round 6: the host advances it by Tm per launch, so stale granules of earlier
+                               // chunks never match and the buffer needs no memset in front of every launch -- a 5 us fill kernel on the f0 chain)
 };
 // Round 3: the 96 x 256 slice of W_hh lives in REGISTERS (thread (row r, quarter q) keeps its 64 weights for all steps: the matvec
 // reads only h from LDS, 16 broadcast b128 reads per thread, instead of streaming 96 KB of weights through LDS every step), the
@@ -983,7 +985,7 @@ static __global__ __launch_bounds__(384) void gru_multi_kernel(GruMultiP p)
                 unsigned spins = 0;
                 while (!dead) {
                     x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((unsigned)(x >> 32) == (unsigned)step) break;
+                    if ((unsigned)(x >> 32) == p.epoch + (unsigned)step) break;
                     if (++spins > (1u << 22)) { dead = true; atomicOr(&p.status[b * p.status_stride], (int)ST_HANDOFF); }
                     __builtin_amdgcn_s_sleep(1);
                 }
@@ -1015,7 +1017,7 @@ static __global__ __launch_bounds__(384) void gru_multi_kernel(GruMultiP p)
             const float ng = tanhf(in_ + rg * gh[2 * U + tid]);
             const float hn = (1.f - zg) * ng + zg * hs[unit];
             ob[(long long)unit * p.o_cs + t] = hn;
-            __hip_atomic_store(gr + (step & 1) * H + unit, ((unsigned long long)(unsigned)(step + 1) << 32) | (unsigned long long)__float_as_uint(hn),
+            __hip_atomic_store(gr + (step & 1) * H + unit, ((unsigned long long)(p.epoch + (unsigned)(step + 1)) << 32) | (unsigned long long)__float_as_uint(hn),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // (no barrier here: hs[unit] of the own slice is rewritten only after this thread's granule has been polled back, gh only

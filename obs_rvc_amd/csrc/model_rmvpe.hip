@@ -242,9 +242,19 @@ T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k, bool u
             gp.gran = (unsigned long long *)pl.arena.alloc(gbytes);
             const size_t lds3 = (size_t)(256 + 96 + (size_t)Tm * 96) * sizeof(float);      // h, gate pre-activations, this slice's input gates for all steps
             const dim3 g3(8, 2, B);
+            // eager launches: the tags advance by Tm per launch (host-side counter of this plan), so the granules of earlier chunks are stale by construction and
+            // the buffer is zeroed only in front of the plan's first launch (and when the 32-bit tag space runs out); a captured graph bakes its arguments and keeps the
+            // memset node + epoch 0
+            auto next_epoch = std::make_shared<unsigned>(0u);
+            auto dirty = std::make_shared<bool>(true);
             pl.ops.push_back([=](hipStream_t s) {
-                HIPCHK(hipMemsetAsync(gp.gran, 0, gbytes, s));
-                hipLaunchKernelGGL(gru_multi_kernel, g3, dim3(384), lds3, s, gp);
+                GruMultiP g2 = gp;
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                (void)hipStreamIsCapturing(s, &cs);
+                if (cs != hipStreamCaptureStatusNone) { HIPCHK(hipMemsetAsync(g2.gran, 0, gbytes, s)); g2.epoch = 0; *dirty = true; }
+                else if (*dirty || *next_epoch > 0xFFF00000u) { HIPCHK(hipMemsetAsync(g2.gran, 0, gbytes, s)); g2.epoch = 0; *next_epoch = (unsigned)Tm; *dirty = false; }
+                else { g2.epoch = *next_epoch; *next_epoch += (unsigned)Tm; }
+                hipLaunchKernelGGL(gru_multi_kernel, g3, dim3(384), lds3, s, g2);
             });
         } else {
             pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(gru_kernel, grid, dim3(threads), lds, s, gi.p, gi.ld, gi.bs, wt, bh, gout.p, gout.ld, gout.bs, Hg, Tm); });
