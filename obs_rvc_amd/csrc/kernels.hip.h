@@ -92,28 +92,55 @@ static __global__ __launch_bounds__(256) void mel_frontend_kernel(MelP p)
     const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const float *sig = p.audio + (long long)b * p.audio_bs + (p.n - p.frame);
     const int L = p.frame;
-    // frame t covers padded[t*160 .. t*160+1024), padded = reflect(sig, 512); natural order (the Stockham passes sort as they go)
+    const int lane = tid & 63, wave = tid >> 6, sub = lane >> 4, l16 = lane & 15;
+    // Round 6: EVERY table value this thread will need is requested here, next to the signal -- its twelve twiddles (they depend on tid only), the bands of its eight
+    // mel filters and, behind those, the first four basis values per filter.  The tables are cold at every chunk (853 MB of weights pass between two uses) and
+    // were read where they were needed: a memory round trip in front of each of four FFT passes and two per mel filter group -- most of the kernel's 20 us, which is
+    // the head of the f0 branch, the critical path of the chunk's front.  Same arithmetic in the same order.
+    float sg[4], wn[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int j = tid + r * 256;
         int q = t * 160 + j - 512;            // index into the unpadded signal
         if (q < 0) q = -q;                     // left reflect: padded[512-i-1] = sig[i+1]
         if (q >= L) q = 2 * L - 2 - q;         // right reflect: padded[L+512+i] = sig[L-i-2]
-        bufr[0][j] = sig[q] * p.window[j];
-        bufi[0][j] = 0.f;
+        sg[r] = sig[q]; wn[r] = p.window[j];
     }
+    float twc[4][3], tws[4][3];                // passes Ns = 4, 16, 64, 256; r = 1..3
+    {
+        int pi = 0;
+#pragma unroll
+        for (int Ns = 4; Ns < 1024; Ns *= 4, pi++) {
+            const int estep = (tid & (Ns - 1)) * (256 / Ns);
+#pragma unroll
+            for (int r = 1; r < 4; r++) tw1024(p.twiddle, estep * r, twc[pi][r - 1], tws[pi][r - 1]);
+        }
+    }
+    int blo[8], bhi[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) { const int m = wave * 32 + it * 4 + sub; blo[it] = p.band[2 * m]; bhi[it] = p.band[2 * m + 1]; }
+    float bpre[8][4];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const float *br = p.basis + (wave * 32 + it * 4 + sub) * 513;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int k = blo[it] + l16 + 16 * j; bpre[it][j] = k < bhi[it] ? br[k] : 0.f; }
+    }
+    // frame t covers padded[t*160 .. t*160+1024), padded = reflect(sig, 512); natural order (the Stockham passes sort as they go)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int j = tid + r * 256; bufr[0][j] = sg[r] * wn[r]; bufi[0][j] = 0.f; }
     __syncthreads();
     int cur = 0;
+    int pass = -1;
 #pragma unroll
-    for (int Ns = 1; Ns < 1024; Ns *= 4) {
+    for (int Ns = 1; Ns < 1024; Ns *= 4, pass++) {
         const int k = tid & (Ns - 1);
-        const int estep = k * (256 / Ns);                         // exponent of the unit twiddle of this butterfly, in 1024ths of a turn
         float vr[4], vi[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const float xr = bufr[cur][tid + r * 256], xi = bufi[cur][tid + r * 256];
             if (r == 0 || Ns == 1) { vr[r] = xr; vi[r] = xi; }
-            else { float c, sn; tw1024(p.twiddle, estep * r, c, sn); vr[r] = xr * c - xi * sn; vi[r] = xr * sn + xi * c; }
+            else { const float c = twc[Ns == 1 ? 0 : pass][r - 1], sn = tws[Ns == 1 ? 0 : pass][r - 1]; vr[r] = xr * c - xi * sn; vi[r] = xr * sn + xi * c; }
         }
         const float a0r = vr[0] + vr[2], a0i = vi[0] + vi[2], a1r = vr[0] - vr[2], a1i = vi[0] - vi[2];
         const float a2r = vr[1] + vr[3], a2i = vi[1] + vi[3];
@@ -130,14 +157,15 @@ static __global__ __launch_bounds__(256) void mel_frontend_kernel(MelP p)
     for (int k = tid; k < 513; k += 256) { const float xr = bufr[cur][k], xi = bufi[cur][k]; mag[k] = sqrtf(xr * xr + xi * xi); }
     __syncthreads();
     // mel projection: filter m = wave * 32 + it * 4 + (lane >> 4); its 16 lanes stride over the band [lo, hi), xor-shuffle fold
-    const int lane = tid & 63, wave = tid >> 6, sub = lane >> 4, l16 = lane & 15;
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const int m = wave * 32 + it * 4 + sub;
-        const int lo = p.band[2 * m], hi = p.band[2 * m + 1];
+        const int lo = blo[it], hi = bhi[it];
         const float *br = p.basis + m * 513;
         float s = 0.f;
-        for (int k = lo + l16; k < hi; k += 16) s += br[k] * mag[k];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int k = lo + l16 + 16 * j; if (k < hi) s += bpre[it][j] * mag[k]; }
+        for (int k = lo + l16 + 64; k < hi; k += 16) s += br[k] * mag[k];          // (bands wider than 64 bins: none at 16 kHz / 1024 points)
         s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
         if (l16 == 0) {
             const float lm = logf(fmaxf(s, 1e-5f));
