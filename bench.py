@@ -827,9 +827,6 @@ def main(argv=None):
             informational("offline_pipelined_frames_per_s", lambda: pipelined_leg(job, eng, d_rings, g, S, args.steps))
         if full and not args.index:
             informational("plugin_chain", lambda: chain_leg(eng, S, g))
-    cpu = None
-    if job.rank == 0 and job.world == 1 and not args.no_cpu:
-        cpu = cpu_baseline_leg(z, rings, g, args.index and full, index_vecs)
     del eng, d_rings
     job.torch.cuda.empty_cache()
 
@@ -913,8 +910,14 @@ def main(argv=None):
         if job.world == 1:
             leg("streams64_bf16x3", streams64_bf16x3)
 
+    # the CPU baseline runs LAST (round 6): behind it the process keeps the oracle's OpenMP team, and the GPU legs issued after it measured 5-9 % slower on their
+    # latency-bound configurations (the v1 leg 2.12-2.19 ms against 1.94-1.96 in every run without the team) -- the baseline is a separate measurement and must not
+    # sit in front of anything it can disturb
     if CTX["calib"]:
         calib.append(calibrate(job, "end"))
+    cpu = None
+    if job.rank == 0 and job.world == 1 and not args.no_cpu:
+        cpu = cpu_baseline_leg(z, rings, g, args.index and full, index_vecs)
     if job.rank == 0:
         if args.serial_branches:
             head["serial_branches"] = True

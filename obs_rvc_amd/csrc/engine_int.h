@@ -234,6 +234,9 @@ struct Plan {
     int T = 0, Tm = 0, C = 0; size_t N = 0;
     bool with_index = false, with_taps = false;
     bool bucket = false;          // a plan of rvc_infer_batch_g: built for a subset of the streams on the gathered state block (rvc_engine::d_state_bucket)
+    // gather tables by content (round 6): the 3x3 layers of one RMVPE level have identical k -> offset tables; with one device copy per distinct table the second
+    // and later layers of a level find it in the L2 instead of fetching a cold 6 KB table from HBM in front of their first operand gather
+    std::map<std::vector<int>, const int *> koff_tabs;
     bool rm_fuse = false;         // RMVPE's shallow ConvBlockRes as one launch each (model_rmvpe.hip; decided per plan from the engine's f0 partition)
     bool bf3 = false;             // built under rvc_set_gemm_precision(e, 1): ContentVec's 1x1 GEMMs on the split-bf16 kernel (exploratory)
     bool autotune = false;        // rvc_set_plan_autotune: layers with several eligible kernels / tiles are chosen by timing them at plan build (plan.hip queue_igemm)

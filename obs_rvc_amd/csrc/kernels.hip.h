@@ -994,9 +994,20 @@ static __global__ __launch_bounds__(384) void gru_multi_kernel(GruMultiP p)
     for (int i = 0; i < 16; i++) w[i] = *reinterpret_cast<const f32x4 *>(wsrc + i * 4);
     const float bias = p.bhh[dir * 3 * H + gate * H + g * U + u];
     const float *gib = p.gi + (long long)b * p.gi_bs + (long long)dir * 3 * H * p.gi_cs;
-    for (int i = tid; i < p.Tm * ROWS; i += NT) {
-        const int rr = i / p.Tm, t = i - rr * p.Tm, gg = rr / U, uu = rr - gg * U;      // coalesced along time
-        gis[t * ROWS + rr] = gib[(long long)(gg * H + g * U + uu) * p.gi_cs + t];
+    // (round 6: in batches of eight requests -- one memory round trip per batch instead of one per element of the strided copy loop)
+    for (int i0 = tid; i0 < p.Tm * ROWS; i0 += 8 * NT) {
+        float v8[8]; int d8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = i0 + k * NT;
+            const bool ok = i < p.Tm * ROWS;
+            const int ii = ok ? i : 0;
+            const int rr = ii / p.Tm, t = ii - rr * p.Tm, gg = rr / U, uu = rr - gg * U;      // coalesced along time
+            v8[k] = gib[(long long)(gg * H + g * U + uu) * p.gi_cs + t];
+            d8[k] = ok ? t * ROWS + rr : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (d8[k] >= 0) gis[d8[k]] = v8[k];
     }
     if (tid < H) hs[tid] = 0.f;
     float *ob = p.out + (long long)b * p.o_bs + (long long)dir * H * p.o_cs;

@@ -559,7 +559,11 @@ static void queue_igemm_impl(Plan &pl, IgemmP p, int B, const std::vector<int> &
     for (int &v : kb) v = (v - kmin) * 4;
     p.koff_bias = -kmin * 4;
     const bool pre = p.pre_act != ACT_NONE;
-    p.koff = pl.arena.upload(kb);
+    {
+        auto it = pl.koff_tabs.find(kb);
+        if (it == pl.koff_tabs.end()) it = pl.koff_tabs.emplace(kb, pl.arena.upload(kb)).first;
+        p.koff = it->second;
+    }
     std::vector<PhaseD> phv(phases);
     double ksum = 0;   // sum of the phases' K (phases of a fused launch may differ; p.K is the maximum)
     for (PhaseD &q : phv) { if (q.nchunks == 0) q.nchunks = p.K / 16; ksum += q.nchunks * 16.0; }
@@ -966,7 +970,7 @@ static double tune_trial(const Plan &pl, const IgemmP &p, int B, const std::vect
     if (!scratch || scratch_dev != dev) { delete scratch; scratch = new Plan(); scratch->arena.set_chunk_min((size_t)8 << 20); scratch_dev = dev; }
     Plan &tp = *scratch;
     HIPCHK(hipStreamSynchronize(tune_stream()));          // (the previous trial's launches still read the tables that are about to be overwritten)
-    tp.ops = OpList(); tp.descs.clear(); tp.arena.rewind();
+    tp.ops = OpList(); tp.descs.clear(); tp.koff_tabs.clear(); tp.arena.rewind();
     tp.B = pl.B; tp.bf3 = pl.bf3; tp.autotune = false; tp.profile = false; tp.igemm_flops = 0; tp.n_igemm = 0;
     const Choice saved = t_choice;
     t_choice = c;
