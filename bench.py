@@ -910,9 +910,9 @@ def main(argv=None):
         if job.world == 1:
             leg("streams64_bf16x3", streams64_bf16x3)
 
-    # the CPU baseline runs LAST (round 6): behind it the process keeps the oracle's OpenMP team, and the GPU legs issued after it measured 5-9 % slower on their
-    # latency-bound configurations (the v1 leg 2.12-2.19 ms against 1.94-1.96 in every run without the team) -- the baseline is a separate measurement and must not
-    # sit in front of anything it can disturb
+    # the CPU baseline runs LAST (round 6): behind it the process keeps the oracle's OpenMP team, and in four driver-style runs the latency-bound GPU legs issued
+    # after it were up to 9 % slower (the v1 leg 2.12-2.19 ms; 2.05 with the baseline behind it in the same kind of run, 1.94-1.96 in runs without it) -- the baseline
+    # is a separate measurement and must not sit in front of anything it can disturb
     if CTX["calib"]:
         calib.append(calibrate(job, "end"))
     cpu = None
