@@ -74,10 +74,11 @@ void build_synth(rvc_engine *e, Plan &pl, int B, const T1 &phone, const T1 &src,
             AttnP ap{}; ap.qkv = qkv.p; ap.out = att.p; ap.E = H; ap.T = R; ap.heads = m.heads; ap.cs = qkv.ld; ap.bs = qkv.bs; ap.o_cs = att.ld; ap.o_bs = att.bs;
             ap.scale = 1.0f / sqrtf((float)kc); ap.rel_k = Ly.rel_k; ap.rel_v = Ly.rel_v; ap.window = m.window;
             const size_t small_lds = ((size_t)2 * kc * Tp + 2 * (2 * m.window + 1) * kc + 4 * kc + 4 * 64) * sizeof(float);
-            // one stream: the matrix-core form (VALU form: 12.4 us per layer of dependent LDS reads)
+            // the matrix-core form (VALU form at one stream: 12.4 us per layer of dependent LDS reads; round 6: at every stream count -- 21.5 -> ~12 us per launch at 64
+            // streams, step 5 / 8 / 16 / 64 streams 4.585 / 6.156 / 11.03 / 34.24 -> 4.577 / 6.145 / 11.00 / 34.20 ms; test hook RVC_RELPOS_MFMA_MAX = 4: the round-5 rule)
             const int a_tp = R | 1, a_nr = 2 * m.window + 1, a_jf = (R + 15) / 16, a_pw = (a_nr + 15) / 16 * 16, a_nrp = (a_nr + 3) / 4 * 4;
             const size_t mfma_lds = ((size_t)kc * 16 + 2 * (size_t)kc * a_tp + (size_t)a_pw * kc + (size_t)a_nrp * kc + 16 * a_jf * 16 + 2 * 16 * a_pw + 64) * sizeof(float);
-            if (B <= 4 && R <= 64 && kc % 16 == 0 && mfma_lds <= 160 * 1024 && !tune_env("RVC_NO_SMALL_ATTN") && !tune_env("RVC_ATTN_VALU") && !tune_env("RVC_NO_SMALL_ATTN_MFMA")) {
+            if (B <= test_opt_int("RVC_RELPOS_MFMA_MAX", 1 << 20) && R <= 64 && kc % 16 == 0 && mfma_lds <= 160 * 1024 && !tune_env("RVC_NO_SMALL_ATTN") && !tune_env("RVC_ATTN_VALU") && !tune_env("RVC_NO_SMALL_ATTN_MFMA")) {
                 dim3 ag(m.heads * a_jf, B);
                 pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(relpos_attention_mfma_kernel, ag, dim3(256), mfma_lds, s, ap); });
             } else if (R <= 64 && small_lds <= 160 * 1024 && !tune_env("RVC_NO_SMALL_ATTN")) {
