@@ -957,51 +957,6 @@ static __global__ __launch_bounds__(1024) void gru_kernel(const float *gi, int g
     }
 }
 
-// The same recurrence for FOUR streams per workgroup (round 6; many streams): a step's matvec streams the 768 KB transposed W_hh of the direction from the L2 --
-// 3.2 GB per 64-stream launch with one stream per workgroup, i.e. the launch was bound by L2 bandwidth (297 us) -- so every weight a thread loads now serves four
-// streams' hidden vectors (h as [j][4] in LDS: one b128 broadcast per j).  Per stream the arithmetic and its order are gru_kernel's.
-static __global__ __launch_bounds__(1024) void gru4_kernel(const float *gi, int gi_cs, long long gi_bs, const float *whhT, const float *bhh,
-                                                    float *out, int o_cs, long long o_bs, int H, int Tm, int B)
-{
-    constexpr int NS = 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *hs = smem;                  // [H][NS]
-    float *gh = smem + NS * H;         // [NS][3H]
-    const int dir = blockIdx.x, b0 = blockIdx.y * NS, r = threadIdx.x, nthr = blockDim.x;
-    const float *wt = whhT + (long long)dir * H * 3 * H;
-    const float *bh = bhh + dir * 3 * H;
-    for (int i = r; i < NS * H; i += nthr) hs[i] = 0.f;
-    __syncthreads();
-    for (int step = 0; step < Tm; step++) {
-        const int t = dir == 0 ? step : Tm - 1 - step;
-        if (r < 3 * H) {
-            float a0 = bh[r], a1 = a0, a2 = a0, a3 = a0;
-            for (int j = 0; j < H; j++) {
-                const float w = wt[(long long)j * 3 * H + r];
-                const f32x4 hv = *reinterpret_cast<const f32x4 *>(hs + j * NS);
-                a0 += w * hv[0]; a1 += w * hv[1]; a2 += w * hv[2]; a3 += w * hv[3];
-            }
-            gh[r] = a0; gh[3 * H + r] = a1; gh[6 * H + r] = a2; gh[9 * H + r] = a3;
-        }
-        __syncthreads();
-        for (int idx = r; idx < NS * H; idx += nthr) {
-            const int s_ = idx / H, u = idx - s_ * H, b = b0 + s_;
-            if (b < B) {
-                const float *gib = gi + (long long)b * gi_bs + (long long)dir * 3 * H * gi_cs;
-                const float *g3 = gh + s_ * 3 * H;
-                const float ir = gib[(long long)u * gi_cs + t], iz = gib[(long long)(H + u) * gi_cs + t], in_ = gib[(long long)(2 * H + u) * gi_cs + t];
-                const float rg = 1.0f / (1.0f + expf(-(ir + g3[u])));
-                const float zg = 1.0f / (1.0f + expf(-(iz + g3[H + u])));
-                const float ng = tanhf(in_ + rg * g3[2 * H + u]);
-                const float hn = (1.f - zg) * ng + zg * hs[u * NS + s_];
-                hs[u * NS + s_] = hn;
-                out[(long long)b * o_bs + (long long)(dir * H + u) * o_cs + t] = hn;
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // Multi-CU recurrence for few streams (B <= 8): 8 workgroups per direction, each owning 32 hidden units = 96 gate rows
 // whose 96 KB slice of W_hh stays in LDS for all steps.  After every step the 8 slices exchange their 32 new h values through
 // 8-byte {epoch, value} granules (cdna_hip_programming.md guideline 16, form R2: the data is the flag; relaxed agent-scope

@@ -257,14 +257,6 @@ T1 build_rmvpe(rvc_engine *e, Plan &pl, int B, size_t L, size_t frame16k, bool u
                 hipLaunchKernelGGL(gru_multi_kernel, g3, dim3(384), lds3, s, g2);
             });
         } else {
-            if ((B >= 48 && test_opt_int("RVC_GRU4", 1) != 0) || test_opt_int("RVC_GRU4", 1) == 2) {
-                // many streams: four streams per workgroup share every weight they stream (gru4_kernel).  From 48 streams: with fewer the launch has too few
-                // workgroups left (12 streams: 6) and each walks four streams' gates per step -- same process, one stream per workgroup -> four: 12 / 16 / 32 / 64
-                // streams 8.75 / 11.02 / 18.91 / 34.55 -> 8.82 / 11.06 / 18.91 / 34.41 ms.  Test hook RVC_GRU4 = 0: never, 2: at any count.
-                const dim3 grid4(2, (B + 3) / 4);
-                const size_t lds4 = (size_t)16 * Hg * sizeof(float);
-                pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(gru4_kernel, grid4, dim3(threads), lds4, s, gi.p, gi.ld, gi.bs, wt, bh, gout.p, gout.ld, gout.bs, Hg, Tm, B); });
-            } else
             pl.ops.push_back([=](hipStream_t s) { hipLaunchKernelGGL(gru_kernel, grid, dim3(threads), lds, s, gi.p, gi.ld, gi.bs, wt, bh, gout.p, gout.ld, gout.bs, Hg, Tm); });
         }
     }

@@ -7,7 +7,7 @@
 namespace rvc {
 
 static const char *const kTestHooks[] = {"RVC_FORCE_CFG", "RVC_CONV_TILE", "RVC_CONV_TILE_KS", "RVC_NO_LN_FUSE", "RVC_NO_CONV0_MULTI", "RVC_KNN_NO_GEMM",
-                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB", "RVC_CONV32S_BUF", "RVC_FORCE_CHOICE", "RVC_G32L_PANEL", "RVC_MEAN3", "RVC_RM_FUSE", "RVC_G2W_LN", "RVC_GRU4", "RVC_RELPOS_MFMA_MAX"};
+                                         "RVC_KNN_EXHAUSTIVE", "RVC_STAMPS", "RVC_SERIAL_BRANCHES", "RVC_NO_WN_COMPOSE", "RVC_KNN_LOSE_TICKET", "RVC_FORCE_G2W", "RVC_F0_XCDS", "RVC_CONV32S", "RVC_CONV32S_TILE", "RVC_G32L", "RVC_G32L_TALL", "RVC_G32L_TAB", "RVC_CONV32S_BUF", "RVC_FORCE_CHOICE", "RVC_G32L_PANEL", "RVC_MEAN3", "RVC_RM_FUSE", "RVC_G2W_LN", "RVC_RELPOS_MFMA_MAX"};
 std::atomic<unsigned> g_opt_gen{0};       // bumped by every rvc_debug_option call: plans built under another generation are dropped (engine.hip get_plan)
 static std::mutex g_opt_mu;
 static std::map<std::string, std::string> g_opts;

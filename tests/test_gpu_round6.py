@@ -286,29 +286,3 @@ def test_rmvpe_shallow_blocks_in_one_launch(S, fuse, geo):
     finally:
         set_opt("RVC_RM_FUSE", None)
 
-
-def test_gru_four_streams_per_workgroup():
-    # Round 6: from 48 streams the GRU recurrence runs four streams per workgroup (gru4_kernel: every weight streamed from the L2 serves four hidden vectors).  Forced
-    # here at 9 streams -- three workgroups per direction, the last one with a single live stream -- against the oracle: the recurrence's tap of stream 0 and the PCM
-    # of the first and the last stream (the 64-stream tests run it by the planner's choice).
-    from common import rel_rms, set_opt
-    z = zoo("full")
-    S = 9
-    set_opt("RVC_GRU4", 2)
-    try:
-        eng = _engine(z, S, (6, 0))
-        eng.enable_taps(2)
-        xin = np.stack([voice_signal(g.input_buffer_16k_size, seed=270 + s) for s in range(S)])
-        ye = eng.infer_batch(xin, g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
-        o = _oracle(z, 6, 0); o.enable_taps(True)
-        yo = o.infer(xin[0], g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
-        Tm = 32
-        for oname, ename in (("rm.gru", "rm.gru_ct"), ("rm.sal", "rm.sal_ct")):
-            a = o.tap(oname); b = eng.tap(ename).reshape(-1, Tm).T.reshape(-1)
-            assert a.size == b.size and rel_rms(b, a) < 1e-4, (oname, rel_rms(b, a))
-        assert rms(ye[0] - yo) < PCM_TOL
-        y8 = _oracle(z, 6, S - 1).infer(xin[S - 1], g.sample_frame_16k, 12, g.skip_head, g.model_return_length)
-        assert rms(ye[S - 1] - y8) < PCM_TOL
-        eng.close()
-    finally:
-        set_opt("RVC_GRU4", None)
